@@ -1,0 +1,103 @@
+"""ctypes binding of libarp_hip.so (the C ABI in include/arp_hip.h).
+
+There is no CPU fallback: if the shared library is missing the import of any compute module
+raises, and if no HIP device is present every compute call fails with the library's error.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarp_hip.so")
+
+MODE_F32, MODE_BF16 = 0, 1
+ACT_NONE, ACT_QGELU, ACT_RELU, ACT_TANH, ACT_GELU_TANH = 0, 1, 2, 3, 4
+
+
+class ArpError(RuntimeError):
+    pass
+
+
+class ClipCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "patch", "width", "layers", "heads", "embed", "img_res", "txt_width", "txt_layers", "txt_heads", "ctx",
+        "vocab", "mode", "device", "max_batch", "attn_impl")]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `make -C arp_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_fp = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); also the list tests check against include/arp_hip.h
+SIGNATURES = {
+    "arp_last_error": (C.c_char_p, []),
+    "arp_version": (_i, []),
+    "arp_device_count": (_i, []),
+    "arp_dev_malloc": (_i, [C.POINTER(_vp), C.c_size_t]),
+    "arp_dev_free": (_i, [_vp]),
+    "arp_memcpy_h2d": (_i, [_vp, _vp, C.c_size_t]),
+    "arp_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
+    "arp_set_device": (_i, [_i]),
+    "arp_clip_create": (_i, [C.POINTER(ClipCfg), C.POINTER(_vp)]),
+    "arp_clip_destroy": (_i, [_vp]),
+    "arp_clip_load_weight": (_i, [_vp, C.c_char_p, _fp, _i64p, _i]),
+    "arp_clip_finalize_weights": (_i, [_vp]),
+    "arp_clip_set_text": (_i, [_vp, _i32p, _i]),
+    "arp_clip_get_text_features": (_i, [_vp, _fp]),
+    "arp_clip_label": (_i, [_vp, _u8p, _i, _i, _i, _i, _fp]),
+    "arp_clip_label_dev_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "arp_clip_sync": (_i, [_vp]),
+    "arp_clip_encode_image": (_i, [_vp, _u8p, _i, _i, _i, _i, _i, _fp]),
+    "arp_preprocess": (_i, [_u8p, _i, _i, _i, _i, _i, _fp]),
+    "arp_bicubic_coeffs": (_i, [_i, _i, _i32p, _i32p, _i32p, _i]),
+    "arp_clip_profile_enable": (_i, [_vp, _i]),
+    "arp_clip_profile_reset": (_i, [_vp]),
+    "arp_clip_profile_json": (_i, [_vp, C.c_char_p, _i]),
+    "arp_event_create": (_i, [C.POINTER(_vp)]),
+    "arp_event_destroy": (_i, [_vp]),
+    "arp_clip_event_record": (_i, [_vp, _vp]),
+    "arp_event_elapsed_ms": (_i, [_vp, _vp, _fp]),
+    "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
+    "arp_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f]),
+    "arp_op_attention": (_i, [_i, _i, _fp, _fp, _i, _i, _i, _i, _i]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    s = lib.arp_last_error()
+    return s.decode("utf-8", "replace") if s else ""
+
+
+def check(rc):
+    if rc < 0:
+        raise ArpError(last_error())
+    return rc
+
+
+def device_count():
+    return lib.arp_device_count()
+
+
+def require_gpu():
+    if device_count() <= 0:
+        raise ArpError("no HIP device visible: libarp_hip.so has no CPU fallback")
+
+
+def as_ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))

@@ -1,0 +1,929 @@
+// Path (1): CLIP reward labelling on MI355X -- host orchestration + C ABI.
+// Reference seam: compute_reward, /root/reference/arp_dt/label_reward.py:132-146.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/arp_hip.h"
+#include "attention.h"
+#include "common.h"
+#include "gemm.h"
+#include "preprocess.h"
+#include "rowops.h"
+#include "runtime.h"
+
+namespace arp {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(const std::string& msg) {
+    g_err = msg;
+    return -1;
+}
+
+// ---- Pillow resample table ------------------------------------------------------------------------
+static inline double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+void build_bicubic_table(int in_size, int out_size, ResampleTable& t) {
+    const double scale = (double)in_size / out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    t.ksize = ksize;
+    t.kmax = 0;
+    t.xmin.assign(out_size, 0);
+    t.cnt.assign(out_size, 0);
+    t.w.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x) {
+            if (ww != 0.0) k[x] /= ww;
+            const double v = k[x] * (double)(1 << 22);
+            t.w[(size_t)xx * ksize + x] = (k[x] < 0) ? (int)(-0.5 + v) : (int)(0.5 + v);
+        }
+        t.xmin[xx] = xmin;
+        t.cnt[xx] = xmax;
+        t.kmax = std::max(t.kmax, xmax);
+    }
+}
+
+// python round() / torchvision CenterCrop offset: round-half-to-even
+static inline int round_half_even(double v) { return (int)std::nearbyint(v); }
+
+struct ResizePlan {
+    int H = 0, W = 0, use_crop = 0, R = 0;
+    int cy = 0, cx = 0, ch = 0, cw = 0;
+    int kmax_h = 0, kmax_v = 0;
+    int TR = 32, max_rows = 0;
+    size_t lds_bytes = 0;
+    DevBuf h_tab, v_tab;
+};
+
+// Packs rows [first, first + R) of a table as [R][1 + kmax]: (xmin | cnt << 16), weights...
+static void pack_table(const ResampleTable& t, int first, int R, std::vector<int>& out) {
+    const int stride = 1 + t.kmax;
+    out.assign((size_t)R * stride, 0);
+    for (int o = 0; o < R; ++o) {
+        const int src = first + o;
+        out[(size_t)o * stride] = t.xmin[src] | (t.cnt[src] << 16);
+        for (int k = 0; k < t.cnt[src]; ++k) out[(size_t)o * stride + 1 + k] = t.w[(size_t)src * t.ksize + k];
+    }
+}
+
+static int build_plan(int H, int W, int use_crop, int R, ResizePlan& p) {
+    if (H <= 0 || W <= 0 || R <= 0 || (R & 3)) return fail("preprocess: bad geometry");
+    p.H = H; p.W = W; p.use_crop = use_crop; p.R = R;
+    int top = 0, left = 0;  // CenterCrop(R) offsets after the resize (non-crop transform)
+    int oh = R, ow = R;
+    if (use_crop) {
+        // label_reward.py:92-104: CenterCrop(image_size // 2), image_size = frame width, then Resize(R)
+        const int crop = W / 2;
+        if (crop <= 0 || crop > H) return fail("preprocess: use_crop needs H >= W/2");
+        p.ch = p.cw = crop;
+        p.cy = round_half_even((H - crop) / 2.0);
+        p.cx = round_half_even((W - crop) / 2.0);
+    } else {
+        p.cy = p.cx = 0; p.ch = H; p.cw = W;
+        // torchvision Resize(int): shorter side -> R, long side int(R * long / short); then CenterCrop(R)
+        if (H <= W) { oh = R; ow = (int)((double)R * W / H); } else { ow = R; oh = (int)((double)R * H / W); }
+        top = round_half_even((oh - R) / 2.0);
+        left = round_half_even((ow - R) / 2.0);
+    }
+    ResampleTable th, tv;
+    build_bicubic_table(p.cw, ow, th);
+    build_bicubic_table(p.ch, oh, tv);
+    std::vector<int> hp, vp;
+    pack_table(th, left, R, hp);
+    pack_table(tv, top, R, vp);
+    p.kmax_h = th.kmax; p.kmax_v = tv.kmax;
+    // rows of input needed by a tile of TR output rows; shrink TR until the LDS carve fits 64 KiB
+    const int row_bytes = p.cw * 3;
+    for (p.TR = 32; p.TR >= 1; p.TR >>= 1) {
+        int need = 0;
+        for (int o0 = 0; o0 < R; o0 += p.TR) {
+            const int o1 = std::min(o0 + p.TR, R) - 1;
+            const int lo = vp[(size_t)o0 * (1 + tv.kmax)] & 0xffff;
+            const int e = vp[(size_t)o1 * (1 + tv.kmax)];
+            need = std::max(need, (e & 0xffff) + (e >> 16) - lo);
+        }
+        p.max_rows = need;
+        p.lds_bytes = (size_t)((R * (1 + th.kmax) * 4 + 15) & ~15) + 768 * 4 + (size_t)((need * row_bytes + 15) & ~15) +
+                      (size_t)need * R * 3 + 16;
+        if (p.lds_bytes <= 64 * 1024) break;
+    }
+    if (p.TR < 1) return fail("preprocess: frame too wide for the LDS tile");
+    ARP_TRY(p.h_tab.ensure(hp.size() * 4));
+    ARP_TRY(p.v_tab.ensure(vp.size() * 4));
+    ARP_HIP_OK(hipMemcpy(p.h_tab.p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+    ARP_HIP_OK(hipMemcpy(p.v_tab.p, vp.data(), vp.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void build_lut(float* lut /* [3][256] */) {
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};  // label_reward.py:117
+    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    for (int c = 0; c < 3; ++c)
+        for (int v = 0; v < 256; ++v) {
+            volatile float x = (float)v / 255.0f;  // ToTensor: uint8 -> f32, div 255
+            volatile float y = x - mean[c];        // Normalize: (x - mean) / std, f32
+            lut[c * 256 + v] = y / stdv[c];
+        }
+}
+
+template <typename T, int LAYOUT>
+static int launch_preprocess(const ResizePlan& p, const uint8_t* frames, int n, int P, const float* lut, void* out,
+                             hipStream_t stream) {
+    PreprocArgs a;
+    a.frames = frames; a.out = out;
+    a.h_tab = p.h_tab.as<int>(); a.v_tab = p.v_tab.as<int>(); a.lut = lut;
+    a.n = n; a.H = p.H; a.W = p.W; a.cy = p.cy; a.cx = p.cx; a.ch = p.ch; a.cw = p.cw;
+    a.R = p.R; a.P = P; a.kmax_h = p.kmax_h; a.kmax_v = p.kmax_v; a.TR = p.TR; a.max_rows = p.max_rows;
+    auto kern = preprocess_kernel<T, LAYOUT>;
+    ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p.lds_bytes));
+    const int tiles = (p.R + p.TR - 1) / p.TR;
+    hipLaunchKernelGGL(kern, dim3(n * tiles), dim3(256), p.lds_bytes, stream, a);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---- model ---------------------------------------------------------------------------------------
+enum Site { SITE_PATCH = 0, SITE_QKV = 1, SITE_OUT = 2, SITE_FC1 = 3, SITE_FC2 = 4, SITE_PROJ = 5, SITE_OP = 6 };
+
+struct LayerW {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
+    void *w_in, *w_out, *w_fc, *w_proj;
+};
+struct TowerW {
+    int width = 0, layers = 0, heads = 0;
+    std::vector<LayerW> L;
+};
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+}  // namespace arp
+
+using namespace arp;
+
+struct arp_clip {
+    arp_clip_cfg cfg;
+    hipStream_t stream = nullptr;
+    std::map<std::string, HostTensor> staged;
+    bool finalized = false;
+    std::vector<void*> owned;  // every device allocation holding weights
+
+    TowerW vis, txt;
+    void* conv_w = nullptr;  // T [D, 3PP]
+    float *cls = nullptr, *pos = nullptr, *lnpre_w = nullptr, *lnpre_b = nullptr, *lnpost_w = nullptr, *lnpost_b = nullptr;
+    void* proj_t = nullptr;  // T [E, D]
+    float *tok_emb = nullptr, *tpos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
+    void* tproj_t = nullptr;  // T [E, Tw]
+    float logit_scale = 0.f;
+    float* lut = nullptr;
+
+    DevBuf txt_feat;
+    int n_prompts = 0;
+
+    // workspace for `ws_frames` frames
+    int ws_frames = 0;
+    DevBuf patches, pe, x, h, qkv, ao, fc, cls_h, feat, frames_in, rewards;
+    std::map<long long, ResizePlan*> plans;
+    Profiler prof;
+
+    int ntok() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
+    size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
+};
+
+namespace arp {
+
+static int upload_f32(arp_clip* c, const std::vector<float>& v, float** out) {
+    void* p = nullptr;
+    ARP_HIP_OK(hipMalloc(&p, std::max<size_t>(v.size() * 4, 16)));
+    ARP_HIP_OK(hipMemcpy(p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    c->owned.push_back(p);
+    *out = static_cast<float*>(p);
+    return 0;
+}
+
+// uploads a [rows, cols] matrix in the handle's GEMM operand type (bf16 RNE or f32); optional transpose
+static int upload_mat(arp_clip* c, const float* src, int rows, int cols, bool transpose, void** out) {
+    const size_t n = (size_t)rows * cols;
+    std::vector<float> tmp;
+    const float* s = src;
+    if (transpose) {  // src is [rows, cols]; result is [cols, rows]
+        tmp.resize(n);
+        for (int r = 0; r < rows; ++r)
+            for (int q = 0; q < cols; ++q) tmp[(size_t)q * rows + r] = src[(size_t)r * cols + q];
+        s = tmp.data();
+    }
+    void* p = nullptr;
+    ARP_HIP_OK(hipMalloc(&p, std::max<size_t>(n * c->esz(), 16)));
+    if (c->cfg.mode == ARP_MODE_BF16) {
+        std::vector<bf16_t> hb(n);
+        for (size_t i = 0; i < n; ++i) hb[i] = host_f2bf(s[i]);
+        ARP_HIP_OK(hipMemcpy(p, hb.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        ARP_HIP_OK(hipMemcpy(p, s, n * 4, hipMemcpyHostToDevice));
+    }
+    c->owned.push_back(p);
+    *out = p;
+    return 0;
+}
+
+static int get_staged(arp_clip* c, const std::string& name, std::vector<int64_t> shape, const HostTensor** out) {
+    auto it = c->staged.find(name);
+    if (it == c->staged.end()) return fail("missing weight: " + name);
+    if (it->second.shape != shape) {
+        std::string s = "weight " + name + " has shape [";
+        for (auto d : it->second.shape) s += std::to_string(d) + ",";
+        s += "], expected [";
+        for (auto d : shape) s += std::to_string(d) + ",";
+        return fail(s + "]");
+    }
+    *out = &it->second;
+    return 0;
+}
+
+static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers, int heads, TowerW& tw) {
+    tw.width = d; tw.layers = layers; tw.heads = heads;
+    tw.L.resize(layers);
+    for (int i = 0; i < layers; ++i) {
+        const std::string p = prefix + "resblocks." + std::to_string(i) + ".";
+        LayerW& L = tw.L[i];
+        const HostTensor* t;
+        ARP_TRY(get_staged(c, p + "ln_1.weight", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.ln1_w));
+        ARP_TRY(get_staged(c, p + "ln_1.bias", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.ln1_b));
+        ARP_TRY(get_staged(c, p + "ln_2.weight", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.ln2_w));
+        ARP_TRY(get_staged(c, p + "ln_2.bias", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.ln2_b));
+        ARP_TRY(get_staged(c, p + "attn.in_proj_weight", {3 * d, d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), 3 * d, d, false, &L.w_in));
+        ARP_TRY(get_staged(c, p + "attn.in_proj_bias", {3 * d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_in));
+        ARP_TRY(get_staged(c, p + "attn.out_proj.weight", {d, d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), d, d, false, &L.w_out));
+        ARP_TRY(get_staged(c, p + "attn.out_proj.bias", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_out));
+        ARP_TRY(get_staged(c, p + "mlp.c_fc.weight", {4 * d, d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), 4 * d, d, false, &L.w_fc));
+        ARP_TRY(get_staged(c, p + "mlp.c_fc.bias", {4 * d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_fc));
+        ARP_TRY(get_staged(c, p + "mlp.c_proj.weight", {d, 4 * d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), d, 4 * d, false, &L.w_proj));
+        ARP_TRY(get_staged(c, p + "mlp.c_proj.bias", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_proj));
+    }
+    return 0;
+}
+
+template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+static int gemm(arp_clip* c, const char* site, const void* A, const void* W, const float* bias, const float* resid, void* out,
+                int M, int N, int K) {
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = bias; g.resid = resid; g.out = out;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
+    ProfScope ps(c->prof, c->stream, site);
+    return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, c->stream);
+}
+
+template <typename OutT>
+static int layernorm(arp_clip* c, const char* site, const float* in, size_t in_stride, OutT* out, int out_stride,
+                     const float* w, const float* b, int rows, int D, float eps) {
+    if (D % 4 || D > ROW_MAX_V4 * 256) return fail("layernorm: unsupported width " + std::to_string(D));
+    ProfScope ps(c->prof, c->stream, site);
+#define ARP_LN_CALL(NV)                                                                                                   \
+    hipLaunchKernelGGL((layernorm_kernel<OutT, NV>), dim3((rows + 3) / 4), dim3(256), 0, c->stream, in, in_stride, out, \
+                       out_stride, w, b, rows, D, eps)
+    ARP_NV_DISPATCH(D, ARP_LN_CALL);
+#undef ARP_LN_CALL
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, int B, int N, int D, int heads, int causal) {
+    const int hd = D / heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    if constexpr (sizeof(T) == 2) {
+        if (impl == 0 && hd == 64) {
+            const int NT = ((N + 31) / 32) * 2;
+#define ARP_ATTN_CASE(nt)                                                                                                   \
+    case nt: {                                                                                                              \
+        auto kern = attn_mfma_kernel<nt>;                                                                                   \
+        const int lds = nt * 16 * 128 + 64 * (nt * 32 + 8);                                                                 \
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal);              \
+        ARP_HIP_OK(hipGetLastError());                                                                                      \
+        return 0;                                                                                                           \
+    }
+            switch (NT) {
+                ARP_ATTN_CASE(2)
+                ARP_ATTN_CASE(4)
+                ARP_ATTN_CASE(6)
+                ARP_ATTN_CASE(8)
+                ARP_ATTN_CASE(14)
+                ARP_ATTN_CASE(18)
+                default: break;  // fall through to the VALU kernel
+            }
+#undef ARP_ATTN_CASE
+        }
+    }
+    const size_t lds = (size_t)2 * N * hd * 4;
+    if (lds > 160 * 1024) return fail("attention: sequence too long for the LDS-resident kernel");
+    const int threads = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
+    if (hd == 64) {
+        auto kern = attn_valu_kernel<T, 64>;
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal);
+    } else if (hd == 32) {
+        auto kern = attn_valu_kernel<T, 32>;
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal);
+    } else if (hd == 16) {
+        auto kern = attn_valu_kernel<T, 16>;
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal);
+    } else {
+        return fail("attention: unsupported head_dim " + std::to_string(hd));
+    }
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// 12 x ResidualAttentionBlock (arp_dt/models/openai/layers.py:235-271) on the f32 residual stream x.
+template <typename T>
+static int run_blocks(arp_clip* c, const TowerW& tw, const char* tag, float* x, T* h, T* qkv, T* ao, T* fc, int B, int N,
+                      int causal) {
+    const int D = tw.width, M = B * N;
+    const std::string t(tag);
+    const std::string s_ln1 = t + ".ln_1", s_qkv = t + ".qkv", s_attn = t + ".attn", s_out = t + ".out_proj", s_ln2 = t + ".ln_2",
+                      s_fc1 = t + ".c_fc", s_fc2 = t + ".c_proj";
+    for (int i = 0; i < tw.layers; ++i) {
+        const LayerW& L = tw.L[i];
+        ARP_TRY(layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, 1e-5f));
+        ARP_TRY((gemm<T, T, ACT_NONE, false, SITE_QKV>(c, s_qkv.c_str(), h, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, D)));
+        {
+            ProfScope ps(c->prof, c->stream, s_attn.c_str());
+            ARP_TRY(launch_attention<T>(c->stream, c->cfg.attn_impl, qkv, ao, B, N, D, tw.heads, causal));
+        }
+        ARP_TRY((gemm<T, float, ACT_NONE, true, SITE_OUT>(c, s_out.c_str(), ao, L.w_out, L.b_out, x, x, M, D, D)));
+        ARP_TRY(layernorm<T>(c, s_ln2.c_str(), x, D, h, D, L.ln2_w, L.ln2_b, M, D, 1e-5f));
+        ARP_TRY((gemm<T, T, ACT_QGELU, false, SITE_FC1>(c, s_fc1.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, M, 4 * D, D)));
+        ARP_TRY((gemm<T, float, ACT_NONE, true, SITE_FC2>(c, s_fc2.c_str(), fc, L.w_proj, L.b_proj, x, x, M, D, 4 * D)));
+    }
+    return 0;
+}
+
+static int ensure_workspace(arp_clip* c, int frames) {
+    if (frames <= c->ws_frames) return 0;
+    const arp_clip_cfg& k = c->cfg;
+    const size_t e = c->esz();
+    const int G = k.img_res / k.patch, N = c->ntok(), D = k.width;
+    const size_t B = frames, M = B * N;
+    ARP_TRY(c->patches.ensure(B * G * G * 3 * k.patch * k.patch * e));
+    ARP_TRY(c->pe.ensure(B * G * G * D * 4));
+    ARP_TRY(c->x.ensure(M * D * 4));
+    ARP_TRY(c->h.ensure(M * D * e));
+    ARP_TRY(c->qkv.ensure(M * 3 * D * e));
+    ARP_TRY(c->ao.ensure(M * D * e));
+    ARP_TRY(c->fc.ensure(M * 4 * D * e));
+    ARP_TRY(c->cls_h.ensure(B * D * e));
+    ARP_TRY(c->feat.ensure(B * k.embed * 4));
+    c->ws_frames = frames;
+    return 0;
+}
+
+static int get_plan(arp_clip* c, int H, int W, int use_crop, ResizePlan** out) {
+    const long long key = ((long long)H << 32) | ((long long)W << 1) | (use_crop ? 1 : 0);
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) {
+        *out = it->second;
+        return 0;
+    }
+    ResizePlan* p = new ResizePlan();
+    const int r = build_plan(H, W, use_crop, c->cfg.img_res, *p);
+    if (r != 0) {
+        delete p;
+        return r;
+    }
+    c->plans[key] = p;
+    *out = p;
+    return 0;
+}
+
+// frames (device) -> un-normalised image features in c->feat [nb, embed]
+template <typename T>
+static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizePlan* plan) {
+    const arp_clip_cfg& k = c->cfg;
+    const int G = k.img_res / k.patch, N = c->ntok(), D = k.width, KP = 3 * k.patch * k.patch;
+    {
+        ProfScope ps(c->prof, c->stream, "preprocess");
+        ARP_TRY((launch_preprocess<T, PRE_PATCH>(*plan, frames_dev, nb, k.patch, c->lut, c->patches.p, c->stream)));
+    }
+    ARP_TRY((gemm<T, float, ACT_NONE, false, SITE_PATCH>(c, "vit.patch_embed", c->patches.p, c->conv_w, nullptr, nullptr, c->pe.p,
+                                                         nb * G * G, D, KP)));
+    {
+        ProfScope ps(c->prof, c->stream, "vit.assemble_ln_pre");
+#define ARP_ASM_CALL(NV)                                                                                                      \
+    hipLaunchKernelGGL((vit_assemble_lnpre_kernel<NV>), dim3((nb * N + 3) / 4), dim3(256), 0, c->stream, c->pe.as<float>(), \
+                       c->cls, c->pos, c->lnpre_w, c->lnpre_b, c->x.as<float>(), nb* N, N, D, 1e-5f)
+        ARP_NV_DISPATCH(D, ARP_ASM_CALL);
+#undef ARP_ASM_CALL
+        ARP_HIP_OK(hipGetLastError());
+    }
+    ARP_TRY(run_blocks<T>(c, c->vis, "vit", c->x.as<float>(), c->h.as<T>(), c->qkv.as<T>(), c->ao.as<T>(), c->fc.as<T>(), nb, N, 0));
+    // ln_post on the CLS rows only, then proj (arp_dt/models/openai/layers.py:330-332)
+    ARP_TRY(layernorm<T>(c, "vit.ln_post", c->x.as<float>(), (size_t)N * D, c->cls_h.as<T>(), D, c->lnpost_w, c->lnpost_b, nb, D, 1e-5f));
+    ARP_TRY((gemm<T, float, ACT_NONE, false, SITE_PROJ>(c, "vit.proj", c->cls_h.p, c->proj_t, nullptr, nullptr, c->feat.p, nb, k.embed, D)));
+    return 0;
+}
+
+static int forward_chunk_dispatch(arp_clip* c, const uint8_t* frames_dev, int nb, ResizePlan* plan) {
+    if (c->cfg.mode == ARP_MODE_BF16) return forward_chunk<bf16_t>(c, frames_dev, nb, plan);
+    return forward_chunk<float>(c, frames_dev, nb, plan);
+}
+
+template <typename T> static int run_text(arp_clip* c, const int32_t* tokens, int np) {
+    const arp_clip_cfg& k = c->cfg;
+    const int Tw = k.txt_width, ctx = k.ctx, M = np * ctx;
+    const size_t e = sizeof(T);
+    DevBuf tok, eot, x, h, qkv, ao, fc, hs;
+    int rc = 0;
+    std::vector<int> eot_rows(np);
+    for (int p = 0; p < np; ++p) {
+        int best = 0;
+        for (int t = 1; t < ctx; ++t)
+            if (tokens[p * ctx + t] > tokens[p * ctx + best]) best = t;  // argmax, first max wins (EOT is the largest id)
+        eot_rows[p] = p * ctx + best;
+        for (int t = 0; t < ctx; ++t)
+            if (tokens[p * ctx + t] < 0 || tokens[p * ctx + t] >= k.vocab) return fail("set_text: token id out of range");
+    }
+    auto body = [&]() -> int {
+        ARP_TRY(tok.ensure((size_t)M * 4)); ARP_TRY(eot.ensure((size_t)np * 4));
+        ARP_TRY(x.ensure((size_t)M * Tw * 4)); ARP_TRY(h.ensure((size_t)M * Tw * e)); ARP_TRY(qkv.ensure((size_t)M * 3 * Tw * e));
+        ARP_TRY(ao.ensure((size_t)M * Tw * e)); ARP_TRY(fc.ensure((size_t)M * 4 * Tw * e)); ARP_TRY(hs.ensure((size_t)np * Tw * e));
+        ARP_TRY(c->txt_feat.ensure((size_t)np * k.embed * 4));
+        ARP_HIP_OK(hipMemcpyAsync(tok.p, tokens, (size_t)M * 4, hipMemcpyHostToDevice, c->stream));
+        ARP_HIP_OK(hipMemcpyAsync(eot.p, eot_rows.data(), (size_t)np * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(text_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, c->stream, tok.as<int>(), c->tok_emb, c->tpos,
+                           x.as<float>(), M, ctx, Tw);
+        ARP_HIP_OK(hipGetLastError());
+        ARP_TRY(run_blocks<T>(c, c->txt, "text", x.as<float>(), h.as<T>(), qkv.as<T>(), ao.as<T>(), fc.as<T>(), np, ctx, 1));
+        // ln_final, EOT row, text_projection (arp_dt/models/openai/layers.py:367-369)
+#define ARP_LNG_CALL(NV)                                                                                                     \
+    hipLaunchKernelGGL((layernorm_gather_kernel<T, NV>), dim3((np + 3) / 4), dim3(256), 0, c->stream, x.as<float>(), (size_t)Tw, \
+                       eot.as<int>(), hs.as<T>(), Tw, c->lnf_w, c->lnf_b, np, Tw, 1e-5f)
+        ARP_NV_DISPATCH(Tw, ARP_LNG_CALL);
+#undef ARP_LNG_CALL
+        ARP_HIP_OK(hipGetLastError());
+        ARP_TRY((gemm<T, float, ACT_NONE, false, SITE_PROJ>(c, "text.proj", hs.p, c->tproj_t, nullptr, nullptr, c->txt_feat.p, np,
+                                                            k.embed, Tw)));
+        hipLaunchKernelGGL(l2_normalize_kernel, dim3((np + 3) / 4), dim3(256), 0, c->stream, c->txt_feat.as<float>(), np, k.embed);
+        ARP_HIP_OK(hipGetLastError());
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+        return 0;
+    };
+    rc = body();
+    tok.release(); eot.release(); x.release(); h.release(); qkv.release(); ao.release(); fc.release(); hs.release();
+    if (rc == 0) c->n_prompts = np;
+    return rc;
+}
+
+static int check_ready(arp_clip* c, bool need_text) {
+    if (!c) return fail("null handle");
+    if (!c->finalized) return fail("weights not finalized: call arp_clip_finalize_weights first");
+    if (need_text && c->n_prompts <= 0) return fail("no prompt set: call arp_clip_set_text first");
+    return 0;
+}
+
+static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev) {
+    ARP_TRY(check_ready(c, true));
+    if (n < 0) return fail("negative frame count");
+    if (n == 0) return 0;
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ResizePlan* plan;
+    ARP_TRY(get_plan(c, H, W, use_crop, &plan));
+    const int mb = c->cfg.max_batch;
+    ARP_TRY(ensure_workspace(c, std::min(n, mb)));
+    const float scale = expf(c->logit_scale);
+    for (int off = 0; off < n; off += mb) {
+        const int nb = std::min(mb, n - off);
+        ARP_TRY(forward_chunk_dispatch(c, frames_dev + (size_t)off * H * W * 3, nb, plan));
+        ProfScope ps(c->prof, c->stream, "reward");
+        hipLaunchKernelGGL(reward_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, c->feat.as<float>(), c->txt_feat.as<float>(),
+                           scale, rewards_dev + off, nb, c->cfg.embed);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace arp
+
+// =================================== C ABI ==========================================================
+extern "C" {
+
+const char* arp_last_error(void) { return g_err.c_str(); }
+int arp_version(void) { return 100; }
+
+int arp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int arp_dev_malloc(void** out, size_t bytes) {
+    if (!out) return fail("null out");
+    ARP_HIP_OK(hipMalloc(out, bytes ? bytes : 16));
+    return 0;
+}
+int arp_dev_free(void* p) {
+    if (p) ARP_HIP_OK(hipFree(p));
+    return 0;
+}
+int arp_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    ARP_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int arp_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    ARP_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int arp_set_device(int device) {
+    ARP_HIP_OK(hipSetDevice(device));
+    return 0;
+}
+
+int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
+    if (!cfg || !out) return fail("null argument");
+    const arp_clip_cfg& k = *cfg;
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16) return fail("bad mode");
+    if (k.patch <= 0 || k.img_res % k.patch || k.patch % 4 || k.img_res % 4) return fail("bad patch / img_res");
+    if (k.width % k.heads || k.txt_width % k.txt_heads) return fail("width not divisible by heads");
+    const int kq = (k.mode == ARP_MODE_BF16) ? 64 : 32;
+    if (k.width % kq || k.txt_width % kq || (3 * k.patch * k.patch) % kq)
+        return fail("width / txt_width / 3*patch^2 must be multiples of " + std::to_string(kq));
+    if (k.embed % 4) return fail("embed must be a multiple of 4");
+    int ndev = 0;
+    ARP_HIP_OK(hipGetDeviceCount(&ndev));
+    if (k.device < 0 || k.device >= ndev) return fail("no such HIP device: " + std::to_string(k.device));
+    ARP_HIP_OK(hipSetDevice(k.device));
+    arp_clip* c = new arp_clip();
+    c->cfg = k;
+    if (c->cfg.max_batch <= 0) c->cfg.max_batch = 1024;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail("hipStreamCreate failed");
+    }
+    *out = c;
+    return 0;
+}
+
+int arp_clip_destroy(arp_clip* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipStreamSynchronize(c->stream);
+    c->prof.destroy();
+    for (void* p : c->owned) (void)hipFree(p);
+    for (auto& kv : c->plans) {
+        kv.second->h_tab.release();
+        kv.second->v_tab.release();
+        delete kv.second;
+    }
+    DevBuf* bufs[] = {&c->txt_feat, &c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->cls_h, &c->feat, &c->frames_in, &c->rewards};
+    for (auto* b : bufs) b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int arp_clip_load_weight(arp_clip* c, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!c || !name || !data || (ndim > 0 && !shape)) return fail("null argument");
+    if (c->finalized) return fail("weights already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail("negative dimension");
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(data, data + n);
+    c->staged[name] = std::move(t);
+    return 0;
+}
+
+int arp_clip_finalize_weights(arp_clip* c) {
+    if (!c) return fail("null handle");
+    if (c->finalized) return 0;
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    const arp_clip_cfg& k = c->cfg;
+    const int D = k.width, P = k.patch, E = k.embed, Tw = k.txt_width, N = c->ntok();
+    const HostTensor* t;
+    ARP_TRY(get_staged(c, "visual.conv1.weight", {D, 3, P, P}, &t)); ARP_TRY(upload_mat(c, t->data.data(), D, 3 * P * P, false, &c->conv_w));
+    ARP_TRY(get_staged(c, "visual.class_embedding", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->cls));
+    ARP_TRY(get_staged(c, "visual.positional_embedding", {N, D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->pos));
+    ARP_TRY(get_staged(c, "visual.ln_pre.weight", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpre_w));
+    ARP_TRY(get_staged(c, "visual.ln_pre.bias", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpre_b));
+    ARP_TRY(get_staged(c, "visual.ln_post.weight", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpost_w));
+    ARP_TRY(get_staged(c, "visual.ln_post.bias", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpost_b));
+    ARP_TRY(get_staged(c, "visual.proj", {D, E}, &t)); ARP_TRY(upload_mat(c, t->data.data(), D, E, true, &c->proj_t));
+    ARP_TRY(load_tower(c, "visual.transformer.", D, k.layers, k.heads, c->vis));
+    ARP_TRY(get_staged(c, "token_embedding.weight", {k.vocab, Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->tok_emb));
+    ARP_TRY(get_staged(c, "positional_embedding", {k.ctx, Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->tpos));
+    ARP_TRY(get_staged(c, "ln_final.weight", {Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnf_w));
+    ARP_TRY(get_staged(c, "ln_final.bias", {Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnf_b));
+    ARP_TRY(get_staged(c, "text_projection", {Tw, E}, &t)); ARP_TRY(upload_mat(c, t->data.data(), Tw, E, true, &c->tproj_t));
+    ARP_TRY(load_tower(c, "transformer.", Tw, k.txt_layers, k.txt_heads, c->txt));
+    if (c->staged.count("logit_scale") && c->staged["logit_scale"].shape == std::vector<int64_t>{1}) c->staged["logit_scale"].shape.clear();
+    ARP_TRY(get_staged(c, "logit_scale", {}, &t));
+    c->logit_scale = t->data[0];
+    std::vector<float> lut(768);
+    build_lut(lut.data());
+    ARP_TRY(upload_f32(c, lut, &c->lut));
+    c->staged.clear();
+    c->finalized = true;
+    return 0;
+}
+
+int arp_clip_set_text(arp_clip* c, const int32_t* tokens, int n_prompts) {
+    ARP_TRY(check_ready(c, false));
+    if (!tokens || n_prompts <= 0) return fail("set_text: need at least one prompt");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_BF16) return run_text<bf16_t>(c, tokens, n_prompts);
+    return run_text<float>(c, tokens, n_prompts);
+}
+
+int arp_clip_get_text_features(arp_clip* c, float* out) {
+    ARP_TRY(check_ready(c, true));
+    if (!out) return fail("null out");
+    ARP_HIP_OK(hipMemcpy(out, c->txt_feat.p, (size_t)c->n_prompts * c->cfg.embed * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int arp_clip_label_dev_async(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev) {
+    if (n > 0 && (!frames_dev || !rewards_dev)) return fail("null buffer");
+    return label_dev(c, frames_dev, n, H, W, use_crop, rewards_dev);
+}
+
+int arp_clip_sync(arp_clip* c) {
+    if (!c) return fail("null handle");
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_clip_label(arp_clip* c, const uint8_t* frames, int n, int H, int W, int use_crop, float* rewards) {
+    ARP_TRY(check_ready(c, true));
+    if (n < 0) return fail("negative frame count");
+    if (n == 0) return 0;
+    if (!frames || !rewards) return fail("null buffer");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    const size_t fb = (size_t)H * W * 3;
+    const int mb = c->cfg.max_batch;
+    ARP_TRY(c->frames_in.ensure((size_t)std::min(n, mb) * fb));
+    ARP_TRY(c->rewards.ensure((size_t)std::min(n, mb) * 4));
+    for (int off = 0; off < n; off += mb) {
+        const int nb = std::min(mb, n - off);
+        ARP_HIP_OK(hipMemcpyAsync(c->frames_in.p, frames + (size_t)off * fb, (size_t)nb * fb, hipMemcpyHostToDevice, c->stream));
+        ARP_TRY(label_dev(c, c->frames_in.as<uint8_t>(), nb, H, W, use_crop, c->rewards.as<float>()));
+        ARP_HIP_OK(hipMemcpyAsync(rewards + off, c->rewards.p, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int arp_clip_encode_image(arp_clip* c, const uint8_t* frames, int n, int H, int W, int use_crop, int normalize, float* out) {
+    ARP_TRY(check_ready(c, false));
+    if (n < 0) return fail("negative frame count");
+    if (n == 0) return 0;
+    if (!frames || !out) return fail("null buffer");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ResizePlan* plan;
+    ARP_TRY(get_plan(c, H, W, use_crop, &plan));
+    const size_t fb = (size_t)H * W * 3;
+    const int mb = c->cfg.max_batch, E = c->cfg.embed;
+    ARP_TRY(c->frames_in.ensure((size_t)std::min(n, mb) * fb));
+    ARP_TRY(ensure_workspace(c, std::min(n, mb)));
+    for (int off = 0; off < n; off += mb) {
+        const int nb = std::min(mb, n - off);
+        ARP_HIP_OK(hipMemcpyAsync(c->frames_in.p, frames + (size_t)off * fb, (size_t)nb * fb, hipMemcpyHostToDevice, c->stream));
+        ARP_TRY(forward_chunk_dispatch(c, c->frames_in.as<uint8_t>(), nb, plan));
+        if (normalize) {
+            hipLaunchKernelGGL(l2_normalize_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, c->feat.as<float>(), nb, E);
+            ARP_HIP_OK(hipGetLastError());
+        }
+        ARP_HIP_OK(hipMemcpyAsync(out + (size_t)off * E, c->feat.p, (size_t)nb * E * 4, hipMemcpyDeviceToHost, c->stream));
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int arp_bicubic_coeffs(int in_size, int out_size, int32_t* xmin, int32_t* cnt, int32_t* weights, int ksize_cap) {
+    if (in_size <= 0 || out_size <= 0 || !xmin || !cnt || !weights) return fail("bad argument");
+    ResampleTable t;
+    build_bicubic_table(in_size, out_size, t);
+    if (t.kmax > ksize_cap) return fail("ksize_cap too small, need " + std::to_string(t.kmax));
+    for (int o = 0; o < out_size; ++o) {
+        xmin[o] = t.xmin[o];
+        cnt[o] = t.cnt[o];
+        for (int k = 0; k < ksize_cap; ++k) weights[(size_t)o * ksize_cap + k] = k < t.cnt[o] ? t.w[(size_t)o * t.ksize + k] : 0;
+    }
+    return t.kmax;
+}
+
+int arp_preprocess(const uint8_t* frames, int n, int H, int W, int use_crop, int res, float* out) {
+    if (n < 0) return fail("negative frame count");
+    if (n == 0) return 0;
+    if (!frames || !out) return fail("null buffer");
+    ResizePlan plan;
+    DevBuf in, o, lut;
+    int rc = 0;
+    auto body = [&]() -> int {
+        ARP_TRY(build_plan(H, W, use_crop, res, plan));
+        const size_t fb = (size_t)H * W * 3, ob = (size_t)3 * res * res * 4;
+        ARP_TRY(in.ensure((size_t)n * fb)); ARP_TRY(o.ensure((size_t)n * ob)); ARP_TRY(lut.ensure(768 * 4));
+        std::vector<float> l(768);
+        build_lut(l.data());
+        ARP_HIP_OK(hipMemcpy(lut.p, l.data(), 768 * 4, hipMemcpyHostToDevice));
+        ARP_HIP_OK(hipMemcpy(in.p, frames, (size_t)n * fb, hipMemcpyHostToDevice));
+        ARP_TRY((launch_preprocess<float, PRE_NCHW>(plan, in.as<uint8_t>(), n, 4, lut.as<float>(), o.p, nullptr)));
+        ARP_HIP_OK(hipDeviceSynchronize());
+        ARP_HIP_OK(hipMemcpy(out, o.p, (size_t)n * ob, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    rc = body();
+    in.release(); o.release(); lut.release(); plan.h_tab.release(); plan.v_tab.release();
+    return rc;
+}
+
+int arp_clip_profile_enable(arp_clip* c, int on) {
+    if (!c) return fail("null handle");
+    c->prof.on = on != 0;
+    return 0;
+}
+int arp_clip_profile_reset(arp_clip* c) {
+    if (!c) return fail("null handle");
+    c->prof.reset();
+    return 0;
+}
+int arp_clip_profile_json(arp_clip* c, char* buf, int buf_len) {
+    if (!c || !buf) return fail("null argument");
+    const std::string s = c->prof.json();
+    if ((int)s.size() + 1 > buf_len) return fail("profile buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+struct arp_event { hipEvent_t e; };
+int arp_event_create(arp_event** out) {
+    if (!out) return fail("null out");
+    arp_event* ev = new arp_event();
+    if (hipEventCreate(&ev->e) != hipSuccess) {
+        delete ev;
+        return fail("hipEventCreate failed");
+    }
+    *out = ev;
+    return 0;
+}
+int arp_event_destroy(arp_event* e) {
+    if (e) {
+        (void)hipEventDestroy(e->e);
+        delete e;
+    }
+    return 0;
+}
+int arp_clip_event_record(arp_clip* c, arp_event* e) {
+    if (!c || !e) return fail("null argument");
+    ARP_HIP_OK(hipEventRecord(e->e, c->stream));
+    return 0;
+}
+int arp_event_elapsed_ms(arp_event* a, arp_event* b, float* ms) {
+    if (!a || !b || !ms) return fail("null argument");
+    ARP_HIP_OK(hipEventSynchronize(b->e));
+    ARP_HIP_OK(hipEventElapsedTime(ms, a->e, b->e));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- single-operator entry points ------------------------------------------------------------------
+template <typename T> static int to_dev(const float* src, size_t n, DevBuf& d) {
+    ARP_TRY(d.ensure(std::max<size_t>(n * sizeof(T), 16)));
+    if constexpr (sizeof(T) == 2) {
+        std::vector<bf16_t> hb(n);
+        for (size_t i = 0; i < n; ++i) hb[i] = host_f2bf(src[i]);
+        ARP_HIP_OK(hipMemcpy(d.p, hb.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        ARP_HIP_OK(hipMemcpy(d.p, src, n * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+template <typename T> static int from_dev(float* dst, size_t n, const DevBuf& d) {
+    if constexpr (sizeof(T) == 2) {
+        std::vector<bf16_t> hb(n);
+        ARP_HIP_OK(hipMemcpy(hb.data(), d.p, n * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t u = (uint32_t)hb[i] << 16;
+            memcpy(&dst[i], &u, 4);
+        }
+    } else {
+        ARP_HIP_OK(hipMemcpy(dst, d.p, n * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+template <typename T> static int op_gemm(int act, const float* A, const float* W, const float* bias, const float* resid, float* out,
+                                         int M, int N, int K) {
+    DevBuf dA, dW, dB, dR, dO;
+    auto body = [&]() -> int {
+        ARP_TRY(to_dev<T>(A, (size_t)M * K, dA)); ARP_TRY(to_dev<T>(W, (size_t)N * K, dW));
+        if (bias) ARP_TRY(to_dev<float>(bias, N, dB));
+        ARP_TRY(dO.ensure((size_t)M * N * 4));
+        if (resid) ARP_TRY(to_dev<float>(resid, (size_t)M * N, dR));
+        GemmArgs g;
+        g.A = dA.p; g.W = dW.p; g.bias = bias ? dB.as<float>() : nullptr; g.resid = resid ? dR.as<float>() : nullptr; g.out = dO.p;
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
+        int rc = -1;
+#define ARP_OP_CASE(a)                                                                                            \
+    case a: rc = resid ? launch_gemm_nt<T, float, a, true, SITE_OP>(g, nullptr) : launch_gemm_nt<T, float, a, false, SITE_OP>(g, nullptr); break;
+        switch (act) {
+            ARP_OP_CASE(ACT_NONE) ARP_OP_CASE(ACT_QGELU) ARP_OP_CASE(ACT_RELU) ARP_OP_CASE(ACT_TANH) ARP_OP_CASE(ACT_GELU_TANH)
+            default: return fail("bad activation");
+        }
+#undef ARP_OP_CASE
+        ARP_TRY(rc);
+        ARP_HIP_OK(hipDeviceSynchronize());
+        return from_dev<float>(out, (size_t)M * N, dO);
+    };
+    const int rc = body();
+    dA.release(); dW.release(); dB.release(); dR.release(); dO.release();
+    return rc;
+}
+
+extern "C" {
+
+int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N,
+                   int K) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0) return fail("bad argument");
+    return mode == ARP_MODE_BF16 ? op_gemm<bf16_t>(act, A, W, bias, resid, out, M, N, K) : op_gemm<float>(act, A, W, bias, resid, out, M, N, K);
+}
+
+int arp_op_layernorm(const float* x, const float* w, const float* b, float* out, int rows, int D, float eps) {
+    if (!x || !w || !b || !out || rows <= 0 || D <= 0) return fail("bad argument");
+    if (D % 4 || D > ROW_MAX_V4 * 256) return fail("layernorm: unsupported width");
+    DevBuf dx, dw, db, dout;
+    auto body = [&]() -> int {
+        ARP_TRY(to_dev<float>(x, (size_t)rows * D, dx)); ARP_TRY(to_dev<float>(w, D, dw)); ARP_TRY(to_dev<float>(b, D, db));
+        ARP_TRY(dout.ensure((size_t)rows * D * 4));
+#define ARP_LN_CALL(NV)                                                                                                  \
+    hipLaunchKernelGGL((layernorm_kernel<float, NV>), dim3((rows + 3) / 4), dim3(256), 0, nullptr, dx.as<float>(), (size_t)D, \
+                       dout.as<float>(), D, dw.as<float>(), db.as<float>(), rows, D, eps)
+        ARP_NV_DISPATCH(D, ARP_LN_CALL);
+#undef ARP_LN_CALL
+        ARP_HIP_OK(hipGetLastError());
+        ARP_HIP_OK(hipDeviceSynchronize());
+        return from_dev<float>(out, (size_t)rows * D, dout);
+    };
+    const int rc = body();
+    dx.release(); dw.release(); db.release(); dout.release();
+    return rc;
+}
+
+}  // extern "C"
+
+template <typename T> static int op_attn(int impl, const float* qkv, float* out, int B, int N, int D, int heads, int causal) {
+    DevBuf dq, dout;
+    auto body = [&]() -> int {
+        ARP_TRY(to_dev<T>(qkv, (size_t)B * N * 3 * D, dq));
+        ARP_TRY(dout.ensure((size_t)B * N * D * sizeof(T)));
+        ARP_TRY(launch_attention<T>(nullptr, impl, dq.as<T>(), dout.as<T>(), B, N, D, heads, causal));
+        ARP_HIP_OK(hipDeviceSynchronize());
+        return from_dev<T>(out, (size_t)B * N * D, dout);
+    };
+    const int rc = body();
+    dq.release(); dout.release();
+    return rc;
+}
+
+extern "C" {
+
+int arp_op_attention(int mode, int impl, const float* qkv, float* out, int B, int N, int D, int heads, int causal) {
+    if (!qkv || !out || B <= 0 || N <= 0 || D <= 0 || heads <= 0 || D % heads) return fail("bad argument");
+    return mode == ARP_MODE_BF16 ? op_attn<bf16_t>(impl, qkv, out, B, N, D, heads, causal)
+                                 : op_attn<float>(impl, qkv, out, B, N, D, heads, causal);
+}
+
+}  // extern "C"

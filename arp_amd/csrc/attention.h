@@ -1,0 +1,189 @@
+// Short-sequence multi-head self-attention (N = 50 / 197 / 257 vision tokens, 77 text tokens,
+// 12 policy tokens).  K and V of one (sample, head) fit in LDS, so there is no flash-style
+// KV tiling: one workgroup per (sample, head) stages K/V once and produces every query row.
+//
+//   qkv : [B*N, 3*D]  (q | k | v along the last axis, head h at columns h*HD .. +HD of each third;
+//          torch nn.MultiheadAttention in-proj layout, arp_dt/models/openai/model.py:234-238;
+//          the policy's flax split "b n (h d)" is the same layout, arp_dt/layers.py:59-68)
+//   out : [B*N, D]
+//
+// Two kernels:
+//   attn_valu_kernel<T,HD>  : exact-f32 VALU kernel, one query row per lane, online softmax.
+//                             Parity mode (T=float), and the bit-simple fallback for T=bf16.
+//   attn_mfma_kernel        : bf16, HD = 64, QK^T and PV on v_mfma_f32_16x16x32_bf16; K staged
+//                             row-major (XOR-swizzled 16-B chunks), V staged TRANSPOSED so both
+//                             MFMA operand reads are contiguous; S is computed transposed
+//                             (S^T = K.Q^T) so that the softmax'd accumulator IS the B operand of
+//                             O^T = V^T.P^T with no cross-lane movement (cdna_hip_programming.md
+//                             section 3, "an accumulator tile as the next MFMA's operand").
+#pragma once
+#include "common.h"
+
+namespace arp {
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int D,
+                                                        int heads, float scale, int causal) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + (size_t)N * HD;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const size_t ld = 3 * (size_t)D;
+    const T* base = qkv + (size_t)b * N * ld + h * HD;
+    for (int i = threadIdx.x; i < N * HD; i += blockDim.x) {
+        const int t = i / HD, d = i - t * HD;
+        Ks[i] = Elem<T>::ld(base + t * ld + D + d);
+        Vs[i] = Elem<T>::ld(base + t * ld + 2 * D + d);
+    }
+    __syncthreads();
+    for (int qi = threadIdx.x; qi < N; qi += blockDim.x) {
+        float q[HD], acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            q[d] = Elem<T>::ld(base + qi * ld + d) * scale;
+            acc[d] = 0.f;
+        }
+        float m = -INFINITY, l = 0.f;
+        const int kend = causal ? qi + 1 : N;
+        for (int k = 0; k < kend; ++k) {
+            const float* kr = Ks + (size_t)k * HD;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) s = fmaf(q[d], kr[d], s);
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn);  // exp(-inf) = 0 on the first key
+            const float p = expf(s - mn);
+            const float* vr = Vs + (size_t)k * HD;
+            l = l * alpha + p;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, vr[d], acc[d] * alpha);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        T* o = out + ((size_t)b * N + qi) * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) store4(o + d, acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv);
+    }
+}
+
+// ---- MFMA kernel (bf16, head_dim 64) -------------------------------------------------------------
+// NT = number of 16-key tiles (keys padded to a multiple of 32, i.e. NT even).
+// LDS: K  [NT*16 keys][128 B]             (chunk-swizzled like the GEMM tiles)
+//      Vt [64 d][VT_STRIDE bytes]         (VT_STRIDE = NT*32 + 8: +8 B pad -> conflict-free b64 reads)
+template <int NT>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int D,
+                                                        int heads, float scale, int causal) {
+    constexpr int NP = NT * 16;
+    constexpr int VT_STRIDE = NP * 2 + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + NP * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const size_t ld = 3 * (size_t)D;
+    const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+
+    // stage K (row-major, swizzled) and V (transposed); pad keys are zero-filled
+    for (int i = tid; i < NP * 8; i += 256) {
+        const int key = i >> 3, ch = i & 7;
+        u32x4_v kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (key < N) {
+            kv = *reinterpret_cast<const u32x4_v*>(base + key * ld + D + ch * 8);
+            vv = *reinterpret_cast<const u32x4_v*>(base + key * ld + 2 * D + ch * 8);
+        }
+        *reinterpret_cast<u32x4_v*>(Ks + key * 128 + ((ch ^ (key & 7)) << 4)) = kv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d0 = ch * 8 + 2 * j;
+            *reinterpret_cast<uint16_t*>(Vt + d0 * VT_STRIDE + key * 2) = (uint16_t)(vv[j] & 0xffffu);
+            *reinterpret_cast<uint16_t*>(Vt + (d0 + 1) * VT_STRIDE + key * 2) = (uint16_t)(vv[j] >> 16);
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nqb = (N + 15) >> 4;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        // Q fragment as the B operand: lane (q = fr, group fg) holds Q[q][32*ks + 8*fg .. +7]
+        int qrow = qb * 16 + fr;
+        const int qvalid = qrow < N;
+        qrow = qvalid ? qrow : N - 1;
+        bf16x8_v qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const u32x4_v*>(base + qrow * ld + ks * 32 + fg * 8));
+
+        // S^T tile kt: rows = keys 16*kt + 4*fg + r, col = query fr
+        f32x4_v s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            s[kt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+            const int krow = kt * 16 + fr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_v kf = __builtin_bit_cast(
+                    bf16x8_v, *reinterpret_cast<const u32x4_v*>(Ks + krow * 128 + (((ks * 4 + fg) ^ (krow & 7)) << 4)));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+            }
+        }
+        // softmax over keys for query column fr: local over (kt, r), then across the 4 lane groups
+        const int qidx = qb * 16 + fr;
+        const int klim = causal ? (qidx < N ? qidx + 1 : N) : N;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + fg * 4 + r;
+                const float v = (key < klim) ? s[kt][r] * scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[kt][r] - mx);  // masked keys: exp(-inf) = 0
+                s[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        // O^T[d][q] = sum_key Vt[d][key] * P^T[key][q].  k-slot (fg, j) of step st <-> key
+        // 32*st + 16*(j>>2) + 4*fg + (j&3): B operand straight from s[2st], s[2st+1]; the A operand
+        // (Vt) reads the same permuted keys: two 8-byte reads per step.
+        f32x4_v o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < NT / 2; ++st) {
+            u32x4_v pb;
+            pb[0] = pack_bf2(s[2 * st][0], s[2 * st][1]);
+            pb[1] = pack_bf2(s[2 * st][2], s[2 * st][3]);
+            pb[2] = pack_bf2(s[2 * st + 1][0], s[2 * st + 1][1]);
+            pb[3] = pack_bf2(s[2 * st + 1][2], s[2 * st + 1][3]);
+            const bf16x8_v pf = __builtin_bit_cast(bf16x8_v, pb);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* vrow = Vt + (dt * 16 + fr) * VT_STRIDE + (32 * st + 4 * fg) * 2;
+                const u32x2_v lo = *reinterpret_cast<const u32x2_v*>(vrow);
+                const u32x2_v hi = *reinterpret_cast<const u32x2_v*>(vrow + 32);
+                const u32x4_v va = {lo[0], lo[1], hi[0], hi[1]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, va), pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (qvalid) {
+            bf16_t* orow = out + ((size_t)b * N + qidx) * D + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                store4(orow + dt * 16 + fg * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+        }
+    }
+}
+
+}  // namespace arp

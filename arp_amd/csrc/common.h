@@ -1,0 +1,110 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels of libarp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace arp {
+
+typedef uint16_t bf16_t;  // raw bf16 bits; arithmetic always happens in f32
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(4))) float f32x4_v;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_v;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_v;
+
+// Thread-local error string behind arp_last_error().
+void set_error(const std::string& msg);
+int fail(const std::string& msg);  // sets the error, returns -1
+
+#define ARP_HIP_OK(expr)                                                                        \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return ::arp::fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                               ":" + std::to_string(__LINE__) + ")");                           \
+    } while (0)
+
+#define ARP_TRY(expr)            \
+    do {                         \
+        int _r = (expr);         \
+        if (_r != 0) return _r;  \
+    } while (0)
+
+// ---- device-side scalar helpers -------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// f32 -> bf16, round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950.
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// store 4 consecutive values (16-B aligned for float, 8-B aligned for bf16)
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(a, b), pack_bf2(c, d));
+}
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+// 64-lane wavefront reductions (all lanes receive the result)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+enum Act { ACT_NONE = 0, ACT_QGELU = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_GELU_TANH = 4 };
+
+// FAST selects hardware-approximate exp/rcp (bf16 throughput mode); otherwise libm-accurate f32.
+template <int ACT, bool FAST = false> __device__ __forceinline__ float apply_act(float x) {
+    if constexpr (ACT == ACT_QGELU) {
+        // QuickGELU x*sigmoid(1.702x)  (reference: arp_dt/models/openai/layers.py:12-13)
+        if constexpr (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+        return x / (1.0f + expf(-1.702f * x));
+    } else if constexpr (ACT == ACT_RELU) {
+        return fmaxf(x, 0.0f);
+    } else if constexpr (ACT == ACT_TANH) {
+        return tanhf(x);
+    } else if constexpr (ACT == ACT_GELU_TANH) {
+        // flax nn.gelu default = tanh approximation (reference: arp_dt/layers.py:31)
+        const float c = 0.7978845608028654f;
+        return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+    } else {
+        return x;
+    }
+}
+
+// host-side f32 -> bf16 (RNE)
+static inline bf16_t host_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+}  // namespace arp

@@ -1,0 +1,213 @@
+// NT GEMM on the CDNA4 matrix cores:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)
+//
+// A (activations) and W (torch-Linear weight layout, [out, in]) are both K-contiguous, so both
+// LDS tiles are [rows][128 bytes] and every MFMA fragment is one ds_read_b128.
+//   * T = bf16_t : v_mfma_f32_16x16x32_bf16, BK = 64 elements  (throughput mode)
+//   * T = float  : v_mfma_f32_16x16x4_f32,  BK = 32 elements  (parity mode; exact f32 FMA chains)
+// Tile 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA fragments),
+// double-buffered LDS filled by global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), XOR
+// swizzle on the 16-byte chunk index (applied to the per-lane SOURCE address, because the LDS
+// destination of an LDS-DMA is lane-linear) so the ds_read_b128 fragment reads are
+// bank-conflict-free, and an XCD-aware block->tile map so the 32 CUs behind one L2 share panels.
+//
+// The MFMA is issued "swapped" (W fragment as the A operand): D[n][m], so each lane ends up with
+// 4 CONSECUTIVE n for one m -> the epilogue reads bias/residual and writes the output as 8/16-byte
+// vectors.
+//
+// Epilogue: (+bias[n]) -> activation -> (+residual[m,n], f32) -> OutT.
+#pragma once
+#include "common.h"
+
+namespace arp {
+
+struct GemmArgs {
+    const void* A;      // [M, lda] T
+    const void* W;      // [N, ldw] T
+    const float* bias;  // [N] or nullptr
+    const float* resid; // [M, ldr] f32 or nullptr (may alias out when OutT == float)
+    void* out;          // [M, ldo] OutT
+    int M, N, K;
+    int lda, ldw, ldr, ldo;
+};
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
+constexpr int GEMM_ROW_BYTES = 128;                                   // one LDS row = one K-tile of one row
+constexpr int GEMM_STAGE_BYTES = (GEMM_BM + GEMM_BN) * GEMM_ROW_BYTES;  // 32 KiB
+constexpr int GEMM_LDS_BYTES = 2 * GEMM_STAGE_BYTES;                  // 64 KiB -> 2 workgroups / CU
+
+// bijective XCD remap (cdna_hip_programming.md T1): blocks b, b+8, ... share an XCD (L2); give
+// each XCD a contiguous range of tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPB = GEMM_ROW_BYTES / (int)sizeof(T);  // elements per K-tile: 64 (bf16) / 32 (f32)
+    constexpr int EPC = 16 / (int)sizeof(T);              // elements per 16-byte chunk
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_tiles = (g.N + GEMM_BN - 1) / GEMM_BN;
+    const int m_tiles = (g.M + GEMM_BM - 1) / GEMM_BM;
+    const int tile = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    const int m0 = (tile / n_tiles) * GEMM_BM;
+    const int n0 = (tile % n_tiles) * GEMM_BN;
+
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ W = static_cast<const T*>(g.W);
+
+    // ---- LDS-DMA staging: each wave-instruction fills 1 KiB = 8 rows x 128 B -----------------
+    // lane -> (row-in-group = lane/8, physical chunk = lane%8); it fetches logical chunk
+    // (lane%8) ^ (row&7) so that a reader of logical chunk c finds it at physical c ^ (row&7).
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;  // (row & 7) == srow because groups start at multiples of 8
+    const T* a_src[4];
+    const T* w_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (i * 4 + wave) * 8 + srow;
+        int am = m0 + r;
+        am = am < g.M ? am : g.M - 1;  // clamp: rows past M are computed on valid memory and never stored
+        a_src[i] = A + (size_t)am * g.lda + schunk * EPC;
+        int wn = n0 + r;
+        wn = wn < g.N ? wn : g.N - 1;
+        w_src[i] = W + (size_t)wn * g.ldw + schunk * EPC;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * GEMM_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            char* dst = base + (i * 4 + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * EPB),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (size_t)kt * EPB),
+                                             (__attribute__((address_space(3))) void*)(dst + GEMM_BM * GEMM_ROW_BYTES), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing -------------------------------------------------------------------
+    const int wr = wave >> 1, wc = wave & 1;  // wave tile: rows (m) wr*64.., cols (n) wc*64..
+    const int fr = lane & 15, fg = lane >> 4;
+    // byte offset of (row, logical chunk c) inside a tile: row*128 + ((c ^ (row&7)) << 4)
+    int a_off[4], w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ar = wr * 64 + i * 16 + fr;
+        const int wrow = wc * 64 + i * 16 + fr;
+        a_off[i] = ar * GEMM_ROW_BYTES;
+        w_off[i] = GEMM_BM * GEMM_ROW_BYTES + wrow * GEMM_ROW_BYTES;
+    }
+    const int sw = fr & 7;  // (row & 7) for every fragment row of this lane (tile bases are multiples of 16)
+
+    f32x4_v acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / EPB;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* base = smem + cur * GEMM_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fg) ^ sw) << 4;
+            u32x4_v af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const u32x4_v*>(base + a_off[i] + coff);
+                wf[i] = *reinterpret_cast<const u32x4_v*>(base + w_off[i] + coff);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_v, wf[ni]), __builtin_bit_cast(bf16x8_v, af[mi]), acc[ni][mi], 0, 0, 0);
+                    } else {
+                        // 16 floats of K per (ks): lane group fg holds k = 16*ks + 4*fg + j in element j
+                        // of BOTH operands, so the four 16x16x4 MFMAs (j = 0..3) cover them all.
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                __uint_as_float(wf[ni][j]), __uint_as_float(af[mi][j]), acc[ni][mi], 0, 0, 0);
+                    }
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, per (ni, mi): m = .. + fr, n = .. + 4*fg + {0,1,2,3} ----------------
+    OutT* out = static_cast<OutT*>(g.out);  // may alias g.resid (in-place residual add)
+    const bool vec_ok = ((g.N | g.ldo | g.ldr) & 3) == 0;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wr * 64 + mi * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wc * 64 + ni * 16 + fg * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            if (vec_ok) {
+                if (g.bias) {
+                    const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                if constexpr (RESID) {
+                    const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                store4(out + (size_t)m * g.ldo + n, v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= g.N) break;
+                    float x = v[j] + (g.bias ? g.bias[n + j] : 0.f);
+                    x = apply_act<ACT, sizeof(T) == 2>(x);
+                    if constexpr (RESID) x += g.resid[(size_t)m * g.ldr + n + j];
+                    Elem<OutT>::st(out + (size_t)m * g.ldo + n + j, x);
+                }
+            }
+        }
+    }
+}
+
+// Host launcher.  Requirements: K % (128/sizeof(T)) == 0, lda/ldw multiples of 16/sizeof(T),
+// 16-byte aligned bases.  M and N are arbitrary (guarded; vector epilogue when N, ldo, ldr % 4 == 0).
+template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+inline int launch_gemm_nt(const GemmArgs& g, hipStream_t stream) {
+    constexpr int EPB = GEMM_ROW_BYTES / (int)sizeof(T);
+    if (g.M <= 0) return 0;
+    if (g.N <= 0 || g.K % EPB != 0 || g.K <= 0 || g.lda % (16 / (int)sizeof(T)) != 0 || g.ldw % (16 / (int)sizeof(T)) != 0)
+        return fail("gemm_nt: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) +
+                    " K=" + std::to_string(g.K));
+    auto kern = gemm_nt_kernel<T, OutT, ACT, RESID, SITE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       GEMM_LDS_BYTES));
+        attr_set = true;
+    }
+    const int m_tiles = (g.M + GEMM_BM - 1) / GEMM_BM;
+    const int n_tiles = (g.N + GEMM_BN - 1) / GEMM_BN;
+    hipLaunchKernelGGL(kern, dim3(m_tiles * n_tiles), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, g);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace arp

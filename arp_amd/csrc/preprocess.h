@@ -1,0 +1,136 @@
+// Fused frame preprocessing (HBM-bound integer/byte kernel):
+//   uint8 NHWC frame -> [center-crop] -> Pillow-exact antialiased bicubic resize (two passes,
+//   horizontal first, 22-bit fixed-point taps, uint8 round/clamp after EACH pass) -> x/255 ->
+//   (x - mean)/std -> written directly in the ViT's patch-major (im2col) layout so that the
+//   patch-embedding conv is a plain GEMM (or NCHW f32 for the parity-test entry point).
+//
+// Reference semantics: arp_dt/label_reward.py:109-121 (default) and :92-102 (use_crop); the resize
+// recipe is SURVEY.md Appendix A (verified bit-exact against PIL).  The /255 and normalise steps
+// are a 3x256-entry f32 lookup table computed on the host with the same IEEE f32 operations
+// torchvision's ToTensor/Normalize perform, so the f32 output is bit-identical by construction.
+//
+// One workgroup = one (frame, tile of TR output rows).  The input rows the tile needs (<= ~42 rows
+// of 768 B for 256->224, TR = 32) are fetched once with coalesced 16-byte loads into LDS, the
+// horizontal pass writes a uint8 intermediate to LDS, the vertical pass reads it back and streams
+// the normalised result out in 8/16-byte vectors.
+#pragma once
+#include "common.h"
+
+namespace arp {
+
+struct PreprocArgs {
+    const uint8_t* frames;  // [n, H, W, 3]
+    void* out;              // patch-major [n*G*G, 3*P*P] (T) or NCHW f32 [n,3,R,R]
+    const int* h_tab;       // [R][1 + kmax_h]: (xmin | cnt << 16), then kmax_h int32 weights
+    const int* v_tab;       // [R][1 + kmax_v]
+    const float* lut;       // [3][256]
+    int n, H, W;            // frame geometry
+    int cy, cx, ch, cw;     // crop window (full frame when not cropping)
+    int R, P;               // output resolution (224), patch size
+    int kmax_h, kmax_v;
+    int TR;                 // output rows per workgroup
+    int max_rows;           // LDS capacity in input rows
+};
+
+enum { PRE_PATCH = 0, PRE_NCHW = 1 };
+
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int tiles = (a.R + a.TR - 1) / a.TR;
+    const int frame = blockIdx.x / tiles;
+    const int oy0 = (blockIdx.x - frame * tiles) * a.TR;
+    const int oy1 = min(oy0 + a.TR, a.R);
+    const int hs = 1 + a.kmax_h, vs = 1 + a.kmax_v;
+    const int in_row_bytes = a.cw * 3;
+    const int mid_row_bytes = a.R * 3;
+
+    // LDS carve (every offset a multiple of 16)
+    int* hT = reinterpret_cast<int*>(smem);
+    float* lut = reinterpret_cast<float*>(smem + ((a.R * hs * 4 + 15) & ~15));
+    uint8_t* in_s = reinterpret_cast<uint8_t*>(lut + 768);
+    uint8_t* mid_s = in_s + ((a.max_rows * in_row_bytes + 15) & ~15);
+
+    for (int i = tid; i < a.R * hs; i += 256) hT[i] = a.h_tab[i];
+    for (int i = tid; i < 768; i += 256) lut[i] = a.lut[i];
+
+    const int v_first = a.v_tab[oy0 * vs];
+    const int v_last = a.v_tab[(oy1 - 1) * vs];
+    const int y_lo = v_first & 0xffff;
+    const int y_hi = (v_last & 0xffff) + (v_last >> 16);
+    const int rows = y_hi - y_lo;
+
+    // ---- stage input rows [cy + y_lo, cy + y_hi) x [cx, cx + cw) ---------------------------------
+    const uint8_t* fbase = a.frames + (size_t)frame * a.H * a.W * 3;
+    if (a.cx == 0 && a.cw == a.W && (in_row_bytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(fbase) & 15) == 0)) {
+        const uint4* src = reinterpret_cast<const uint4*>(fbase + (size_t)(a.cy + y_lo) * in_row_bytes);
+        uint4* dst = reinterpret_cast<uint4*>(in_s);
+        const int nvec = rows * in_row_bytes / 16;
+        for (int i = tid; i < nvec; i += 256) dst[i] = src[i];
+    } else {
+        for (int i = tid; i < rows * in_row_bytes; i += 256) {
+            const int r = i / in_row_bytes, cb = i - r * in_row_bytes;
+            in_s[i] = fbase[((size_t)(a.cy + y_lo + r) * a.W + a.cx) * 3 + cb];
+        }
+    }
+    __syncthreads();
+
+    // ---- horizontal pass: mid[r][ox][c] = clip8((2^21 + sum_k W[ox][k] * in[r][xmin+k][c]) >> 22) ----
+    const int quads = mid_row_bytes / 4;
+    for (int i = tid; i < rows * quads; i += 256) {
+        const int r = i / quads, j0 = (i - r * quads) * 4;
+        const uint8_t* irow = in_s + r * in_row_bytes;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            const int ox = j / 3, c = j - ox * 3;
+            const int* t = hT + ox * hs;
+            const int xmin = t[0] & 0xffff, cnt = t[0] >> 16;
+            int acc = 1 << 21;
+            for (int k = 0; k < cnt; ++k) acc += t[1 + k] * (int)irow[(xmin + k) * 3 + c];
+            acc >>= 22;
+            acc = acc < 0 ? 0 : (acc > 255 ? 255 : acc);
+            packed |= (uint32_t)acc << (8 * e);
+        }
+        *reinterpret_cast<uint32_t*>(mid_s + r * mid_row_bytes + j0) = packed;
+    }
+    __syncthreads();
+
+    // ---- vertical pass + normalise + layout -------------------------------------------------------
+    const int xg = a.R / 4;
+    const int items = (oy1 - oy0) * 3 * xg;
+    const int G = a.R / a.P;
+    for (int i = tid; i < items; i += 256) {
+        const int g4 = i % xg;
+        const int c = (i / xg) % 3;
+        const int oy = oy0 + i / (xg * 3);
+        const int* t = a.v_tab + oy * vs;
+        const int ymin = (t[0] & 0xffff) - y_lo, cnt = t[0] >> 16;
+        int acc[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+        const int ox = g4 * 4;
+        for (int k = 0; k < cnt; ++k) {
+            const int w = t[1 + k];
+            const uint8_t* mrow = mid_s + (ymin + k) * mid_row_bytes + ox * 3 + c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += w * (int)mrow[e * 3];
+        }
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int q = acc[e] >> 22;
+            q = q < 0 ? 0 : (q > 255 ? 255 : q);
+            v[e] = lut[c * 256 + q];
+        }
+        if constexpr (LAYOUT == PRE_PATCH) {
+            const size_t prow = ((size_t)frame * G + oy / a.P) * G + ox / a.P;
+            const int kidx = c * a.P * a.P + (oy % a.P) * a.P + (ox % a.P);
+            store4(static_cast<T*>(a.out) + prow * (size_t)(3 * a.P * a.P) + kidx, v[0], v[1], v[2], v[3]);
+        } else {
+            store4(static_cast<T*>(a.out) + (((size_t)frame * 3 + c) * a.R + oy) * a.R + ox, v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace arp

@@ -1,0 +1,228 @@
+"""Drop-in mirror of the reference's labelling entry point, with the CLIP forward on MI355X.
+
+Mirrors /root/reference/arp_dt/label_reward.py:
+  * ``label_reward(...)`` -- same positional/keyword signature as :44-60 (extra options are
+    keyword-only and default to the reference behaviour);
+  * the inner seam ``compute_reward(clip_model, images, text=text) -> float32[N]`` (:132-146) is
+    :func:`make_compute_reward`;
+  * ``discount_cumsum`` (:247-254) and ``stack_outputs`` (:232-245) are vectorised numpy with
+    bit-identical results (same f32 summation order);
+  * dataset key names ``"{img_key}_{model_type}_reward"`` / ``"..._pos_rtg"`` (+ ``_{inst_type}``),
+    gzip, chunks ``(1, num_frames)`` (:256-289).
+
+Differences that are forced by this image (documented in DESIGN.md): no BPE vocabulary offline, so
+the prompt is passed as token ids (``tokens=``) or through a ``tokenizer=`` callable
+(``clip.tokenize`` when the package exists); no pretrained checkpoint offline, so ``weights=`` (an
+openai/CLIP state dict) must be supplied; ``h5py`` is imported lazily and only for ``.hdf5`` paths --
+any mapping of numpy arrays (``store=``) works as the data file.
+
+Multi-GPU: labelling shards by contiguous trajectory ranges balanced by frame count, one process per
+GPU, no collective on the data path; rank 0 is the only writer.
+"""
+import os
+
+import numpy as np
+
+from .clip import MODELS, ClipLabeller
+from .data import get_clip_instruct, get_clip_special_instruct  # noqa: F401  (re-exported like the reference)
+
+
+def discount_cumsum(x, gamma=1.0):
+    """label_reward.py:247-254.  ``out[t] = x[t] + gamma * out[t+1]`` in x's dtype."""
+    x = np.asarray(x)
+    if x.ndim == 0:
+        x = x[None, ...]
+    if gamma == 1.0:
+        return np.cumsum(x[::-1], axis=0, dtype=x.dtype)[::-1].copy()
+    out = np.zeros_like(x)
+    out[-1] = x[-1]
+    for t in range(x.shape[0] - 2, -1, -1):
+        out[t] = x[t] + gamma * out[t + 1]
+    return out
+
+
+def stack_outputs(pos_outputs, num_frames):
+    """label_reward.py:232-245.  Row i = the last ``num_frames`` values up to i, first value left-padded."""
+    x = np.asarray(pos_outputs)
+    if x.ndim == 0:
+        x = x[None, ...]
+    idx = np.arange(len(x))[:, None] + np.arange(-num_frames + 1, 1)[None, :]
+    return x[np.clip(idx, 0, None)]
+
+
+def trajectory_bounds(store, done_key=None):
+    """label_reward.py:71-87.  Returns (len_data, num_frames, [traj start indices..., end])."""
+    if done_key is None:
+        for k in ("done", "rewards", "is_terminal"):
+            if k in store and store[k] is not None:
+                done_key = k
+                break
+        else:
+            raise ValueError
+    d = store[done_key]
+    len_data, num_frames = d.shape[:2]
+    idx = list(np.nonzero(np.asarray(d[:, -1]))[0] + 1)
+    idx.insert(0, 0)
+    return len_data, num_frames, idx
+
+
+def shard_trajectories(bounds, world):
+    """Contiguous trajectory ranges per rank, balanced by frame count.  Returns [(t0, t1)] * world."""
+    ntraj = len(bounds) - 1
+    lens = np.diff(np.asarray(bounds))
+    total = int(lens.sum())
+    cuts, acc, r = [0], 0, 1
+    for t in range(ntraj):
+        acc += int(lens[t])
+        while r < world and acc >= total * r / world:
+            cuts.append(t + 1)
+            r += 1
+    while len(cuts) < world:
+        cuts.append(ntraj)
+    cuts.append(ntraj)
+    return [(cuts[i], cuts[i + 1]) for i in range(world)]
+
+
+def make_compute_reward(model_type="clip"):
+    """The reference's ``compute_reward`` closures (label_reward.py:132-146 and :148-163)."""
+    if model_type == "clip":
+
+        def compute_reward(clip_model, images, text=None, use_crop=False):
+            # the prompt was tokenised + encoded once in clip_model.set_text (the reference re-runs
+            # the text tower per trajectory; same value).  Quirk Q1 kept: always prompt 0.
+            return clip_model.label(images, use_crop=use_crop)
+
+    elif model_type == "clip_goal_conditioned":
+
+        def compute_reward(clip_model, images, text=None, use_crop=False):
+            f = clip_model.encode_image(images, use_crop=use_crop, normalize=False)
+            return -1 * np.linalg.norm(f - f[-1], ord=2, axis=1).astype(np.float64)
+
+    else:
+        raise NotImplementedError(f"model_type {model_type!r} is outside the MI355X hot path (SURVEY.md section 8a, L12)")
+    return compute_reward
+
+
+def _open_store(data_path):
+    if data_path.endswith((".hdf5", ".h5")):
+        try:
+            import h5py
+        except ImportError as e:
+            raise ImportError("h5py is required to open HDF5 demonstration files (absent in this image)") from e
+        return h5py.File(data_path, "a"), True
+    raise ValueError(f"unsupported data file {data_path!r}: pass store=<mapping of arrays> instead")
+
+
+def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="clip", inst_type="none", use_crop=False,
+                rank=0, world=1, text=None):
+    """The per-trajectory loop (label_reward.py:256-289) over any mapping of arrays.
+
+    Returns ``{dataset_key: (first_row, float32 [rows, num_frames])}`` for this rank's shard."""
+    len_data, num_frames, bounds = trajectory_bounds(store)
+    target_keys = [f"{model_type}_reward", f"{model_type}_pos_rtg"]
+    if inst_type != "none":
+        target_keys = [f"{k}_{inst_type}" for k in target_keys]
+    t0, t1 = shard_trajectories(bounds, world)[rank]
+    out = {}
+    for img_key in image_keys.split(", "):
+        parts = {k: [] for k in target_keys}
+        for idx in range(t0, t1):
+            traj = list(range(bounds[idx], min(bounds[idx + 1], len_data)))
+            if not traj:
+                continue
+            images = np.asarray(store[img_key][traj[0] : traj[-1] + 1, -1])
+            r = np.asarray(compute_reward(clip_model, images, text=text, use_crop=use_crop))
+            parts[target_keys[0]].append(stack_outputs(r, num_frames))
+            parts[target_keys[1]].append(stack_outputs(discount_cumsum(r), num_frames))
+        first = bounds[t0] if t0 < len(bounds) else len_data
+        for k in target_keys:
+            rows = np.concatenate(parts[k], axis=0) if parts[k] else np.zeros((0, num_frames), np.float32)
+            out[f"{img_key}_{k}"] = (first, rows.astype(np.float32))
+    return out
+
+
+def write_results(store, results, is_hdf5, num_frames):
+    """label_reward.py:273-289: create (gzip, chunks (1,num_frames)) or overwrite in place."""
+    for key, (first, rows) in results.items():
+        existing = store.get(key) if hasattr(store, "get") else None
+        if existing is not None and getattr(existing, "shape", (0,))[0] >= first + rows.shape[0]:
+            existing[first : first + rows.shape[0]] = rows
+        elif is_hdf5:
+            if existing is None:
+                store.create_dataset(key, compression="gzip", chunks=(1, num_frames), maxshape=(None, num_frames), data=rows)
+            else:
+                existing.resize(first + rows.shape[0], axis=0)
+                existing[first:] = rows
+        else:
+            prev = np.asarray(existing) if existing is not None else np.zeros((0, num_frames), np.float32)
+            store[key] = np.concatenate([prev[:first], rows], axis=0)
+
+
+def label_reward(
+    env_name,
+    distribution_mode,
+    num_levels,
+    start_level,
+    text,
+    base_path,
+    data_path=None,
+    image_keys="ob",
+    num_demonstrations=500,
+    num_frames=8,
+    env_type=None,
+    model_type="clip",
+    model_ckpt_dir=None,
+    use_crop=False,
+    inst_type="none",
+    *,
+    store=None,
+    clip_model=None,
+    weights=None,
+    tokens=None,
+    tokenizer=None,
+    model_name="ViT-B/16",
+    mode="bf16",
+    device=0,
+    rank=0,
+    world=1,
+    gather=None,
+):
+    """Same call surface and side effect as the reference (label_reward.py:44-291): labels every
+    trajectory of the demonstration file and writes ``{img_key}_{model_type}_reward`` and
+    ``..._pos_rtg``.  Returns None.  ``gather(results) -> list of per-rank results`` merges shards
+    when ``world > 1`` (rank 0 writes)."""
+    is_hdf5 = False
+    if store is None:
+        if data_path is None:
+            dirname = f"{env_name}_{distribution_mode}_level{start_level}to{num_levels}_num{num_demonstrations}_frame{num_frames}"
+            if env_type != "none":
+                dirname += f"_{env_type}"
+            data_path = os.path.join(base_path, dirname, "data.hdf5")
+        store, is_hdf5 = _open_store(data_path)
+    _, num_frames, _ = trajectory_bounds(store)  # quirk Q2: the argument is overwritten from the file
+
+    compute_reward = make_compute_reward(model_type)
+    own_model = clip_model is None
+    if own_model:
+        if weights is None:
+            raise ValueError("no pretrained CLIP checkpoint is reachable offline: pass weights=<openai/CLIP state dict> "
+                             "or clip_model=<ClipLabeller>")
+        clip_model = ClipLabeller(MODELS[model_name], weights, mode=mode, device=device)
+    if model_type == "clip":
+        if tokens is None:
+            if tokenizer is None:
+                raise ValueError("no BPE vocabulary offline: pass tokens=<int32 [1,77]> or tokenizer=<callable>")
+            tokens = tokenizer([text] if not isinstance(text, list) else text)
+        clip_model.set_text(np.asarray(tokens, dtype=np.int32))
+
+    results = label_store(store, clip_model, compute_reward, image_keys=image_keys, model_type=model_type,
+                          inst_type=inst_type, use_crop=use_crop, rank=rank, world=world, text=text)
+    per_rank = gather(results) if (world > 1 and gather is not None) else [results]
+    if rank == 0:
+        for res in per_rank:
+            write_results(store, res, is_hdf5, num_frames)
+    if is_hdf5:
+        store.close()
+    if own_model:
+        clip_model.close()
+    return None

@@ -1,0 +1,122 @@
+/* arp_hip.h -- C ABI of libarp_hip.so: MI355X (gfx950) hot paths of ARP-DT.
+ *
+ * The reference (csmile-1006/ARP) is pure Python and has no FFI; the two hot paths are Python
+ * closures.  Each entry point below names the reference seam it replaces (paths relative to
+ * /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions: every function returns 0 on success and a negative value on error; the message is
+ * available from arp_last_error() (thread-local).  The caller owns every host buffer.  The library
+ * owns device memory behind opaque handles.  A handle is bound to one HIP device and one HIP
+ * stream and is NOT thread-safe (one host thread / process per GPU, as the reference's
+ * single-threaded callers).  Calls are synchronous on return unless the name ends in _async.
+ * There is NO CPU fallback: without a usable GPU every compute entry point fails.
+ */
+#ifndef ARP_HIP_H
+#define ARP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARP_MODE_F32 0  /* parity mode: f32 storage, f32-input MFMA (exact f32 FMA chains)        */
+#define ARP_MODE_BF16 1 /* throughput mode: bf16 GEMM operands, f32 accumulate/residual/LN/softmax */
+
+#define ARP_ACT_NONE 0
+#define ARP_ACT_QGELU 1
+#define ARP_ACT_RELU 2
+#define ARP_ACT_TANH 3
+#define ARP_ACT_GELU_TANH 4
+
+const char* arp_last_error(void);
+int arp_version(void);
+int arp_device_count(void); /* number of visible HIP devices; 0 when there is none (never fails) */
+
+/* ---- raw device memory + events (for HBM-resident benchmarking; no torch types anywhere) ------ */
+int arp_dev_malloc(void** out, size_t bytes);
+int arp_dev_free(void* p);
+int arp_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int arp_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int arp_set_device(int device);
+
+/* ---- path (1): CLIP reward labelling ------------------------------------------------------------
+ * Replaces clip.load(...) + the compute_reward closure, arp_dt/label_reward.py:125-146
+ * (third-party openai/CLIP forward; in-tree mirror arp_dt/models/openai/layers.py:274-449). */
+typedef struct arp_clip arp_clip;
+
+typedef struct arp_clip_cfg {
+    int32_t patch;      /* 32 (BASELINE headline) or 16 (what the reference loads, label_reward.py:126) */
+    int32_t width;      /* 768 */
+    int32_t layers;     /* 12  */
+    int32_t heads;      /* 12  */
+    int32_t embed;      /* 512 */
+    int32_t img_res;    /* 224 */
+    int32_t txt_width;  /* 512 */
+    int32_t txt_layers; /* 12  */
+    int32_t txt_heads;  /* 8   */
+    int32_t ctx;        /* 77  */
+    int32_t vocab;      /* 49408 */
+    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_BF16 */
+    int32_t device;     /* HIP device ordinal */
+    int32_t max_batch;  /* frames per internal pass (workspace size); <= 0 -> 1024 */
+    int32_t attn_impl;  /* 0 = auto (MFMA kernel where available), 1 = force the VALU kernel */
+} arp_clip_cfg;
+
+int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out);
+int arp_clip_destroy(arp_clip* h);
+
+/* One tensor of an openai/CLIP state dict (names and layouts: arp_dt/models/openai/model.py:220-314,
+ * SURVEY.md Appendix B), f32 host data, row-major.  Call arp_clip_finalize_weights() after the last. */
+int arp_clip_load_weight(arp_clip* h, const char* name, const float* data, const int64_t* shape, int ndim);
+int arp_clip_finalize_weights(arp_clip* h);
+
+/* clip.tokenize output [n_prompts, ctx] int32 -> runs the text tower ONCE and caches the normalised
+ * text features (the reference re-runs it per trajectory, label_reward.py:136-141). */
+int arp_clip_set_text(arp_clip* h, const int32_t* tokens, int n_prompts);
+int arp_clip_get_text_features(arp_clip* h, float* out /* [n_prompts, embed], L2-normalised */);
+
+/* compute_reward (label_reward.py:132-146): uint8 NHWC frames -> float32 rewards
+ * = exp(logit_scale) * cos(image, prompt 0).  use_crop selects the transform of label_reward.py:92-102. */
+int arp_clip_label(arp_clip* h, const uint8_t* frames_host, int n, int H, int W, int use_crop, float* rewards_host);
+/* Same, frames and rewards already in device memory; enqueued on the handle's stream. */
+int arp_clip_label_dev_async(arp_clip* h, const uint8_t* frames_dev, int n, int H, int W, int use_crop,
+                             float* rewards_dev);
+int arp_clip_sync(arp_clip* h);
+
+/* model.encode_image (label_reward.py:156, clip_goal_conditioned variant) */
+int arp_clip_encode_image(arp_clip* h, const uint8_t* frames_host, int n, int H, int W, int use_crop, int normalize,
+                          float* out /* [n, embed] */);
+
+/* The torchvision/PIL transform alone (label_reward.py:109-121 / :92-102), for PIL-parity tests:
+ * uint8 NHWC -> f32 NCHW [n,3,res,res]. */
+int arp_preprocess(const uint8_t* frames_host, int n, int H, int W, int use_crop, int res, float* out_nchw_host);
+/* Host-side resample table (Pillow precompute_coeffs + normalize_coeffs_8bpc); no GPU needed.
+ * xmin[out], cnt[out], weights[out*ksize_cap]; returns the max tap count or < 0. */
+int arp_bicubic_coeffs(int in_size, int out_size, int32_t* xmin, int32_t* cnt, int32_t* weights, int ksize_cap);
+
+/* Per-call-site HIP-event profile of the kernels launched on the handle's stream. */
+int arp_clip_profile_enable(arp_clip* h, int on);
+int arp_clip_profile_reset(arp_clip* h);
+/* JSON object {"site": {"ms": total_ms, "calls": n}, ...}; returns bytes written or < 0. */
+int arp_clip_profile_json(arp_clip* h, char* buf, int buf_len);
+
+/* HIP events on the handle's stream (bench timing) */
+typedef struct arp_event arp_event;
+int arp_event_create(arp_event** out);
+int arp_event_destroy(arp_event* e);
+int arp_clip_event_record(arp_clip* h, arp_event* e);
+int arp_event_elapsed_ms(arp_event* start, arp_event* stop, float* ms); /* synchronises on stop */
+
+/* ---- single-operator entry points (host buffers; used by the per-kernel parity tests) ---------- */
+/* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid), operands rounded to bf16 in ARP_MODE_BF16. */
+int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,
+                   float* out, int M, int N, int K);
+int arp_op_layernorm(const float* x, const float* w, const float* b, float* out, int rows, int D, float eps);
+/* qkv [B*N, 3*D] -> out [B*N, D]; impl 0 = MFMA (bf16 mode, head_dim 64 only), 1 = VALU. */
+int arp_op_attention(int mode, int impl, const float* qkv, float* out, int B, int N, int D, int heads, int causal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARP_HIP_H */

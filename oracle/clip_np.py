@@ -1,0 +1,150 @@
+"""Oracle (test infrastructure): CLIP ViT image tower + text tower + scaled cosine similarity, numpy.
+
+The reference's labelling pass (/root/reference/arp_dt/label_reward.py:132-146) calls the
+third-party PyTorch package ``clip`` (openai/CLIP, pinned at commit
+d50d76daa670286dd6cacf3bcd80b5e4823fc8e1 in /root/reference/requirements.txt:17), which is absent
+from /root/reference.  This file restates that package's published algorithm, following the
+reference's own in-tree Flax mirror of it line by line:
+
+  * LayerNorm eps 1e-5 ........................ arp_dt/models/openai/layers.py:9
+  * QuickGELU x*sigmoid(1.702x) ............... arp_dt/models/openai/layers.py:12-13
+  * MLP c_fc -> QuickGELU -> c_proj ........... arp_dt/models/openai/layers.py:223-232
+  * ResidualAttentionBlock (pre-LN) ........... arp_dt/models/openai/layers.py:235-250
+  * VisionTransformer (conv1 no bias, CLS,
+    pos-emb, ln_pre, blocks, ln_post(CLS), proj) arp_dt/models/openai/layers.py:274-336
+  * TextEncoder (embed + pos, causal blocks,
+    ln_final, EOT row = argmax(text), proj) ... arp_dt/models/openai/layers.py:339-370
+  * L2-normalise ............................... arp_dt/models/openai/layers.py:429-439
+  * reward = logits_per_text[0]
+           = exp(logit_scale) * <txt_n, img_n> . arp_dt/label_reward.py:140-146
+  * weight names / layouts (openai state dict) . arp_dt/models/openai/model.py:220-314
+
+Parity status: UNPINNED by reference-held vectors (the reference has none).  Pinned instead by
+``tests/test_oracle_clip.py`` against HuggingFace ``CLIPModel`` (quick_gelu) on the same weights.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class ClipConfig:
+    patch: int = 32
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    embed: int = 512
+    img_res: int = 224
+    txt_width: int = 512
+    txt_layers: int = 12
+    txt_heads: int = 8
+    ctx: int = 77
+    vocab: int = 49408
+
+    @property
+    def grid(self):
+        return self.img_res // self.patch
+
+    @property
+    def tokens(self):
+        return self.grid * self.grid + 1
+
+
+VIT_B32 = ClipConfig(patch=32)  # arp_dt/models/openai/model.py:60-69
+VIT_B16 = ClipConfig(patch=16)  # arp_dt/models/openai/model.py:70-79
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * w + b
+
+
+def quick_gelu(x):
+    return x * (1.0 / (1.0 + np.exp(-1.702 * x)))
+
+
+def _softmax(s):
+    s = s - s.max(-1, keepdims=True)
+    e = np.exp(s)
+    return e / e.sum(-1, keepdims=True)
+
+
+def mha(x, w_in, b_in, w_out, b_out, heads, causal):
+    """torch ``nn.MultiheadAttention`` self-attention: fused in-proj [3D, D], rows ordered q,k,v."""
+    n, t, d = x.shape
+    hd = d // heads
+    qkv = x @ w_in.T + b_in
+    q, k, v = np.split(qkv, 3, axis=-1)
+    sh = lambda a: a.reshape(n, t, heads, hd).transpose(0, 2, 1, 3)
+    q, k, v = sh(q), sh(k), sh(v)
+    s = (q * (hd ** -0.5)) @ k.transpose(0, 1, 3, 2)
+    if causal:
+        s = np.where(np.triu(np.ones((t, t), bool), 1), -np.inf, s)
+    p = _softmax(s)
+    o = (p @ v).transpose(0, 2, 1, 3).reshape(n, t, d)
+    return o @ w_out.T + b_out
+
+
+def resblock(x, W, pre, heads, causal):
+    g = lambda k: W[pre + k]
+    h = layer_norm(x, g("ln_1.weight"), g("ln_1.bias"))
+    x = x + mha(h, g("attn.in_proj_weight"), g("attn.in_proj_bias"), g("attn.out_proj.weight"),
+                g("attn.out_proj.bias"), heads, causal)
+    h = layer_norm(x, g("ln_2.weight"), g("ln_2.bias"))
+    h = quick_gelu(h @ g("mlp.c_fc.weight").T + g("mlp.c_fc.bias"))
+    return x + h @ g("mlp.c_proj.weight").T + g("mlp.c_proj.bias")
+
+
+def encode_image(W, cfg, x_nchw, return_tokens=False):
+    """x_nchw: float [n,3,R,R] already normalised.  Returns un-normalised features [n, embed]."""
+    n = x_nchw.shape[0]
+    P, G, D = cfg.patch, cfg.grid, cfg.width
+    # conv P x P stride P, no bias == GEMM over patches; k index = c*P*P + py*P + px
+    p = x_nchw.reshape(n, 3, G, P, G, P).transpose(0, 2, 4, 1, 3, 5).reshape(n, G * G, 3 * P * P)
+    x = p @ W["visual.conv1.weight"].reshape(D, -1).T
+    cls = np.broadcast_to(W["visual.class_embedding"], (n, 1, D))
+    x = np.concatenate([cls, x], axis=1) + W["visual.positional_embedding"]
+    x = layer_norm(x, W["visual.ln_pre.weight"], W["visual.ln_pre.bias"])
+    for i in range(cfg.layers):
+        x = resblock(x, W, f"visual.transformer.resblocks.{i}.", cfg.heads, causal=False)
+    if return_tokens:
+        return x
+    c = layer_norm(x[:, 0], W["visual.ln_post.weight"], W["visual.ln_post.bias"])
+    return c @ W["visual.proj"]
+
+
+def encode_text(W, cfg, tokens):
+    """tokens: int [p, ctx].  Returns un-normalised features [p, embed]."""
+    tokens = np.asarray(tokens)
+    x = W["token_embedding.weight"][tokens] + W["positional_embedding"]
+    for i in range(cfg.txt_layers):
+        x = resblock(x, W, f"transformer.resblocks.{i}.", cfg.txt_heads, causal=True)
+    x = layer_norm(x, W["ln_final.weight"], W["ln_final.bias"])
+    eot = tokens.argmax(-1)
+    return x[np.arange(x.shape[0]), eot] @ W["text_projection"]
+
+
+def l2n(x):
+    return x / np.linalg.norm(x, axis=-1, keepdims=True)
+
+
+def rewards_from_features(W, img_feat, txt_feat):
+    """``logits_per_text[0]`` of openai CLIP.forward (label_reward.py:141-145)."""
+    scale = np.exp(W["logit_scale"])
+    return (scale * (l2n(txt_feat) @ l2n(img_feat).T))[0]
+
+
+def cast_weights(W, dtype):
+    return {k: np.asarray(v, dtype=dtype) for k, v in W.items()}
+
+
+def compute_reward(W, cfg, frames_u8, tokens, use_crop=False, dtype=np.float64):
+    """The reference's ``compute_reward`` closure end to end (label_reward.py:132-146)."""
+    from . import preprocess as pp
+
+    Wd = cast_weights(W, dtype)
+    x = pp.preprocess(frames_u8, use_crop=use_crop).astype(dtype)
+    f = encode_image(Wd, cfg, x)
+    t = encode_text(Wd, cfg, tokens)
+    return rewards_from_features(Wd, f, t).astype(np.float32)

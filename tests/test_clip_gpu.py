@@ -1,0 +1,109 @@
+"""GPU parity of the whole labelling pass (preprocess -> ViT -> text tower -> reward) against the
+numpy oracle, through the C ABI.  Tolerances: north_star = cosine within 1e-4 in f32; the stored
+reward is exp(logit_scale) * cos = 100 * cos, so 1e-2 on the reward."""
+import numpy as np
+import pytest
+
+from conftest import TINY
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL_F32 = 1e-4   # north_star tolerance (parity mode)
+COS_TOL_BF16 = 3e-3  # throughput mode: bf16 GEMM operands; measured error is reported by bench.py
+
+
+def _setup(cfg_kw, n, seed, use_crop=False, H=256, W=256):
+    from arp_amd import synth
+    from oracle import clip_np as C
+    ocfg = C.ClipConfig(**cfg_kw)
+    Wt = synth.clip_weights(ocfg, seed=seed)
+    fr = synth.procgen_like_frames(n, H, W, seed=seed + 1)
+    tok = synth.prompt_tokens(2, [7, 3], ctx=ocfg.ctx, vocab=ocfg.vocab, seed=seed + 2)
+    ref = C.compute_reward(Wt, ocfg, fr, tok, use_crop=use_crop)
+    return ocfg, Wt, fr, tok, ref
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", COS_TOL_F32), ("bf16", COS_TOL_BF16)])
+@pytest.mark.parametrize("attn_impl", [0, 1])
+def test_tiny_end_to_end(gpu_lib, mode, tol, attn_impl):
+    from arp_amd import clip
+    ocfg, Wt, fr, tok, ref = _setup(TINY, 5, seed=11)
+    m = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode=mode, attn_impl=attn_impl).set_text(tok)
+    got = m.label(fr)
+    scale = float(np.exp(Wt["logit_scale"]))
+    err = np.abs(got - ref).max() / scale
+    assert err < tol, f"tiny {mode}: cosine err {err}; got {got}, ref {ref}"
+    m.close()
+
+
+def test_tiny_features_and_text(gpu_lib):
+    from arp_amd import clip
+    from oracle import clip_np as C, preprocess as P
+    ocfg, Wt, fr, tok, _ = _setup(TINY, 3, seed=5)
+    Wd = C.cast_weights(Wt, np.float64)
+    f_ref = C.encode_image(Wd, ocfg, P.preprocess(fr).astype(np.float64))
+    t_ref = C.l2n(C.encode_text(Wd, ocfg, tok))
+    m = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode="f32").set_text(tok)
+    f = m.encode_image(fr)
+    assert np.abs(f - f_ref).max() < 1e-4 * np.abs(f_ref).max()
+    fn = m.encode_image(fr, normalize=True)
+    assert np.abs(fn - C.l2n(f_ref)).max() < 1e-5
+    assert np.abs(m.text_features() - t_ref).max() < 1e-5
+    # goal-conditioned variant (label_reward.py:148-163): -||f_i - f_last||
+    goal_ref = -np.linalg.norm(f_ref - f_ref[-1], axis=1)
+    goal = -np.linalg.norm(f - f[-1], axis=1)
+    assert np.abs(goal - goal_ref).max() < 1e-3 * max(1.0, np.abs(goal_ref).max())
+    m.close()
+
+
+def test_chunking_and_crop(gpu_lib):
+    """max_batch smaller than n, ragged last chunk, use_crop transform, n = 1."""
+    from arp_amd import clip
+    ocfg, Wt, fr, tok, ref = _setup(TINY, 7, seed=21, use_crop=True)
+    m = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode="f32", max_batch=3).set_text(tok)
+    got = m.label(fr, use_crop=True)
+    scale = float(np.exp(Wt["logit_scale"]))
+    assert np.abs(got - ref).max() / scale < COS_TOL_F32
+    one = m.label(fr[:1], use_crop=True)
+    assert abs(one[0] - ref[0]) / scale < COS_TOL_F32
+    assert m.label(fr[:0]).shape == (0,)
+    m.close()
+
+
+@pytest.mark.parametrize("name,n", [("ViT-B/32", 4), ("ViT-B/16", 2)])
+def test_full_size_parity(gpu_lib, name, n):
+    """Full ViT-B geometry, seeded random-init weights: f32 mode within 1e-4 cosine of the oracle;
+    bf16 mode within its stated tolerance."""
+    from arp_amd import clip, synth
+    from oracle import clip_np as C
+    cfg = clip.MODELS[name]
+    ocfg = C.ClipConfig(patch=cfg.patch)
+    Wt = synth.clip_weights(ocfg, seed=0)
+    fr = synth.procgen_like_frames(n, seed=1)
+    tok = synth.prompt_tokens(1, 8, seed=2)
+    ref = C.compute_reward(Wt, ocfg, fr, tok)
+    scale = 100.0
+    for mode, tol in (("f32", COS_TOL_F32), ("bf16", COS_TOL_BF16)):
+        m = clip.ClipLabeller(cfg, Wt, mode=mode).set_text(tok)
+        got = m.label(fr)
+        err = np.abs(got - ref).max() / scale
+        print(f"{name} {mode}: cosine err {err:.3e}  got {got} ref {ref}")
+        assert err < tol, f"{name} {mode}: cosine err {err}"
+        m.close()
+
+
+def test_error_paths(gpu_lib):
+    from arp_amd import clip, synth, _ffi
+    from oracle import clip_np as C
+    ocfg = C.ClipConfig(**TINY)
+    Wt = synth.clip_weights(ocfg, seed=0)
+    bad = dict(Wt)
+    del bad["visual.proj"]
+    with pytest.raises(_ffi.ArpError, match="missing weight"):
+        clip.ClipLabeller(clip.ClipConfig(**TINY), bad, mode="f32")
+    m = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode="f32")
+    with pytest.raises(_ffi.ArpError, match="no prompt"):
+        m.label(np.zeros((1, 256, 256, 3), np.uint8))
+    with pytest.raises(ValueError):
+        m.label(np.zeros((1, 256, 256, 4), np.uint8))
+    m.close()
