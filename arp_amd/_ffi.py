@@ -49,6 +49,7 @@ SIGNATURES = {
     "arp_memcpy_h2d": (_i, [_vp, _vp, C.c_size_t]),
     "arp_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
     "arp_set_device": (_i, [_i]),
+    "arp_dev_synchronize": (_i, []),
     "arp_clip_create": (_i, [C.POINTER(ClipCfg), C.POINTER(_vp)]),
     "arp_clip_destroy": (_i, [_vp]),
     "arp_clip_load_weight": (_i, [_vp, C.c_char_p, _fp, _i64p, _i]),

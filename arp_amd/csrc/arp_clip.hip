@@ -567,6 +567,10 @@ int arp_set_device(int device) {
     ARP_HIP_OK(hipSetDevice(device));
     return 0;
 }
+int arp_dev_synchronize(void) {
+    ARP_HIP_OK(hipDeviceSynchronize());
+    return 0;
+}
 
 int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     if (!cfg || !out) return fail("null argument");

@@ -39,6 +39,7 @@ int arp_dev_free(void* p);
 int arp_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int arp_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int arp_set_device(int device);
+int arp_dev_synchronize(void); /* hipDeviceSynchronize on the current device */
 
 /* ---- path (1): CLIP reward labelling ------------------------------------------------------------
  * Replaces clip.load(...) + the compute_reward closure, arp_dt/label_reward.py:125-146

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 outputs of scripts/prof_r1.sh (gpurun_out/prof_<tag>_*) into the small
+files that are committed under profiles/:
+
+  profiles/<tag>_kernel_stats.csv   -- rocprofv3 --kernel-trace --stats summary (as emitted)
+  profiles/<tag>_pmc_summary.json   -- FETCH_SIZE / WRITE_SIZE per kernel and grid size (separate
+                                       --pmc passes), with the gfx950 corrections of
+                                       MI355X_MICROARCH.md (HBM section): counters are KiB;
+                                       FETCH_SIZE under-reports a wide coalesced read stream by 2x
+  profiles/pmc_traffic.json         -- per bench site: HBM bytes per launch (read by bench.py)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+out_dir = os.path.join(ROOT, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+
+# bench site -> kernel-name substring (template arguments ACT, RESID, SITE of gemm_nt_kernel)
+SITES = {
+    "vit.c_fc": "1, false, 3>",
+    "vit.c_proj": "0, true, 4>",
+    "vit.qkv": "0, false, 1>",
+    "vit.out_proj": "0, true, 2>",
+    "vit.patch_embed": "0, false, 0>",
+}
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    return g[0] if g else None
+
+
+stats = one(f"prof_{tag}_trace/*/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+
+summary = {}
+for counter, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    f = one(f"prof_{tag}_{d}/*/*_counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            agg[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    for (k, grid), v in agg.items():
+        e = summary.setdefault(f"{k} | grid={grid}", {"kernel": k, "grid_threads": grid})
+        e[counter + "_KiB_avg"] = sum(v) / len(v)
+        e[counter + "_launches"] = len(v)
+for e in summary.values():
+    rd = e.get("FETCH_SIZE_KiB_avg")
+    wr = e.get("WRITE_SIZE_KiB_avg")
+    if rd is not None and wr is not None:
+        e["hbm_bytes_per_launch_raw"] = (rd + wr) * 1024
+        e["hbm_bytes_per_launch"] = (2 * rd + wr) * 1024  # gfx950: FETCH_SIZE counts 128-B requests as 64 B
+json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+
+traffic = {}
+for site, sub in SITES.items():
+    cands = [e for e in summary.values() if sub in e["kernel"] and "gemm_" in e["kernel"] and "hbm_bytes_per_launch" in e]
+    if cands:
+        e = max(cands, key=lambda x: x["grid_threads"])
+        traffic[site] = {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "fetch_KiB": e["FETCH_SIZE_KiB_avg"],
+                         "write_KiB": e["WRITE_SIZE_KiB_avg"], "kernel": e["kernel"], "grid_threads": e["grid_threads"],
+                         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/{tag}_pmc_summary.json"}
+json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(traffic, indent=1))
