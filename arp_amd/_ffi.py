@@ -70,6 +70,7 @@ SIGNATURES = {
     "arp_clip_event_record": (_i, [_vp, _vp]),
     "arp_event_elapsed_ms": (_i, [_vp, _vp, _fp]),
     "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
+    "arp_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "arp_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f]),
     "arp_op_attention": (_i, [_i, _i, _fp, _fp, _i, _i, _i, _i, _i]),
 }

@@ -2,6 +2,7 @@
 // Reference seam: compute_reward, /root/reference/arp_dt/label_reward.py:132-146.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -11,6 +12,7 @@
 #include "attention.h"
 #include "common.h"
 #include "gemm.h"
+#include "gemm256.h"
 #include "preprocess.h"
 #include "rowops.h"
 #include "runtime.h"
@@ -213,6 +215,7 @@ struct arp_clip {
     DevBuf patches, pe, x, h, qkv, ao, fc, cls_h, feat, frames_in, rewards;
     std::map<long long, ResizePlan*> plans;
     Profiler prof;
+    int gemm_force = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (ARP_GEMM env)
 
     int ntok() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
     size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
@@ -298,7 +301,7 @@ static int gemm(arp_clip* c, const char* site, const void* A, const void* W, con
     g.A = A; g.W = W; g.bias = bias; g.resid = resid; g.out = out;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
     ProfScope ps(c->prof, c->stream, site);
-    return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, c->stream);
+    return launch_gemm_auto<T, OutT, ACT, RESID, SITE>(g, c->stream, c->gemm_force);
 }
 
 template <typename OutT>
@@ -589,6 +592,7 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     arp_clip* c = new arp_clip();
     c->cfg = k;
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 1024;
+    if (const char* e = getenv("ARP_GEMM")) c->gemm_force = atoi(e);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail("hipStreamCreate failed");
@@ -861,8 +865,10 @@ template <typename T> static int op_gemm(int act, const float* A, const float* W
         g.A = dA.p; g.W = dW.p; g.bias = bias ? dB.as<float>() : nullptr; g.resid = resid ? dR.as<float>() : nullptr; g.out = dO.p;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
         int rc = -1;
+        const char* fe = getenv("ARP_GEMM");
+        const int force = fe ? atoi(fe) : 0;
 #define ARP_OP_CASE(a)                                                                                            \
-    case a: rc = resid ? launch_gemm_nt<T, float, a, true, SITE_OP>(g, nullptr) : launch_gemm_nt<T, float, a, false, SITE_OP>(g, nullptr); break;
+    case a: rc = resid ? launch_gemm_auto<T, float, a, true, SITE_OP>(g, nullptr, force) : launch_gemm_auto<T, float, a, false, SITE_OP>(g, nullptr, force); break;
         switch (act) {
             ARP_OP_CASE(ACT_NONE) ARP_OP_CASE(ACT_QGELU) ARP_OP_CASE(ACT_RELU) ARP_OP_CASE(ACT_TANH) ARP_OP_CASE(ACT_GELU_TANH)
             default: return fail("bad activation");
@@ -883,6 +889,57 @@ int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const floa
                    int K) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0) return fail("bad argument");
     return mode == ARP_MODE_BF16 ? op_gemm<bf16_t>(act, A, W, bias, resid, out, M, N, K) : op_gemm<float>(act, A, W, bias, resid, out, M, N, K);
+}
+
+}  // extern "C"
+
+template <typename T> static int op_gemm_bench(int kernel, int act, int resid, int out_f32, int M, int N, int K, int iters, float* avg_ms) {
+    DevBuf dA, dW, dB, dR, dO;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto body = [&]() -> int {
+        std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N);
+        uint32_t s = 12345u;
+        auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+        for (auto& v : hA) v = rnd();
+        for (auto& v : hW) v = rnd() * 0.05f;
+        for (auto& v : hb) v = rnd();
+        ARP_TRY(to_dev<T>(hA.data(), hA.size(), dA)); ARP_TRY(to_dev<T>(hW.data(), hW.size(), dW)); ARP_TRY(to_dev<float>(hb.data(), N, dB));
+        ARP_TRY(dO.ensure((size_t)M * N * 4)); ARP_TRY(dR.ensure((size_t)M * N * 4));
+        ARP_HIP_OK(hipMemset(dR.p, 0, (size_t)M * N * 4));
+        GemmArgs g;
+        g.A = dA.p; g.W = dW.p; g.bias = dB.as<float>(); g.resid = resid ? dR.as<float>() : nullptr; g.out = resid ? dR.p : dO.p;
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
+        if (const char* fe = getenv("ARP_GEMM_FLAGS")) g.flags = atoi(fe);
+        auto run = [&]() -> int {
+            if (resid) return launch_gemm_auto<T, float, ACT_NONE, true, SITE_OP>(g, nullptr, kernel);
+            if (out_f32) return launch_gemm_auto<T, float, ACT_NONE, false, SITE_OP>(g, nullptr, kernel);
+            if (act == ACT_QGELU) return launch_gemm_auto<T, T, ACT_QGELU, false, SITE_OP>(g, nullptr, kernel);
+            return launch_gemm_auto<T, T, ACT_NONE, false, SITE_OP>(g, nullptr, kernel);
+        };
+        ARP_HIP_OK(hipEventCreate(&e0)); ARP_HIP_OK(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) ARP_TRY(run());
+        ARP_HIP_OK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) ARP_TRY(run());
+        ARP_HIP_OK(hipEventRecord(e1, nullptr));
+        ARP_HIP_OK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        ARP_HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / iters;
+        return 0;
+    };
+    const int rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dA.release(); dW.release(); dB.release(); dR.release(); dO.release();
+    return rc;
+}
+
+extern "C" {
+
+int arp_op_gemm_bench(int mode, int kernel, int act, int resid, int out_f32, int M, int N, int K, int iters, float* avg_ms) {
+    if (!avg_ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return fail("bad argument");
+    return mode == ARP_MODE_BF16 ? op_gemm_bench<bf16_t>(kernel, act, resid, out_f32, M, N, K, iters, avg_ms)
+                                 : op_gemm_bench<float>(kernel, act, resid, out_f32, M, N, K, iters, avg_ms);
 }
 
 int arp_op_layernorm(const float* x, const float* w, const float* b, float* out, int rows, int D, float eps) {

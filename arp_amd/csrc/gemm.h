@@ -28,6 +28,7 @@ struct GemmArgs {
     void* out;          // [M, ldo] OutT
     int M, N, K;
     int lda, ldw, ldr, ldo;
+    int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only)
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;

@@ -1,0 +1,414 @@
+// 256x256-tile NT GEMM for the big ViT GEMMs:  C[M,N] = epilogue(A[M,K] . W[N,K]^T)
+//
+// Structure (written for CDNA4, one 512-thread workgroup per CU, 128 KiB LDS):
+//   * 8 waves as 2 (M) x 4 (N); each wave owns a 128x64 output block = 2x2 "quadrants" of 64x32
+//     (4x2 MFMA fragments of 16x16), 128 accumulator VGPRs.
+//   * K is consumed in tiles of 128 bytes per row (64 bf16 / 32 f32).  A K-tile is processed in
+//     FOUR PHASES, one quadrant each, in the order (0,0) (0,1) (1,1) (1,0), so consecutive phases
+//     share either the A or the B register sub-tile.
+//   * Every phase is [load segment | s_barrier | MFMA segment | s_barrier].  The two wave groups
+//     (wr = 0 / 1; they sit pairwise on the same SIMDs) run ONE BARRIER OUT OF STEP, so while one
+//     group issues its 16 MFMAs the other issues its LDS reads and LDS-DMA: the SIMD's matrix pipe
+//     always has a wave to serve.
+//   * Operands reach LDS by global_load_lds_dwordx4 (LDS-DMA), 2 instructions per thread per phase
+//     ("unit" = 128 rows x 128 B = 16 KiB).  Units are ordered by FIRST USE, not by position:
+//       U0 = A rows of quadrant-row 0 (needed in phase 1)     U1 = W rows of quadrant-col 0 (phase 1)
+//       U2 = W rows of quadrant-col 1 (phase 2)               U3 = A rows of quadrant-row 1 (phase 3)
+//     and issued 5 units ahead of their first use into a 2-deep ring of K-tile buffers; the only
+//     waits are COUNTED s_waitcnt vmcnt(6) (three units stay in flight across every barrier).
+//     Hazards (unit g = 4*tile + u is issued in phase g-5, waited for in phase g-2 before that
+//     phase's first barrier, first read in phase g-1 or later; its LDS region was last read three
+//     phases before it is overwritten) are argued in DESIGN.md section 5.
+//   * 16-byte-chunk XOR swizzle applied on the LDS-DMA SOURCE address and on the ds_read_b128
+//     address (the LDS-DMA destination is lane-linear), as in gemm.h.
+//   * block -> tile map: XCD-contiguous ranges, then groups of GROUP_M tile-rows walked column by
+//     column, so the ~32 tiles resident on one XCD form a compact 2-D patch that shares panels in
+//     that XCD's L2.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+#include "gemm.h"
+
+namespace arp {
+
+constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
+constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * 128;  // one K-tile: 64 KiB
+static_assert(256 * (256 * 2 + 16) >= 2 * G2_BUF_BYTES && 256 * (256 * 2 + 16) >= 128 * (256 * 4 + 16), "epilogue tile must cover the K-tile ring");
+constexpr int G2_LDS_BYTES = 256 * (256 * 2 + 16);   // 132 KiB: 2 K-tile buffers (128 KiB) or the padded epilogue tile
+constexpr int G2_B_REGION = G2_BM * 128;             // W rows start here inside a buffer
+constexpr int G2_GROUP_M = 8;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+// units allowed to stay in flight -> counted wait (2 LDS-DMA instructions per unit per thread)
+__device__ __forceinline__ void wait_units(int allow) {
+    if (allow >= 3) wait_vmcnt<6>();
+    else if (allow == 2) wait_vmcnt<4>();
+    else if (allow == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+}
+
+template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPB = 128 / (int)sizeof(T);
+    constexpr int EPC = 16 / (int)sizeof(T);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- block -> tile ---------------------------------------------------------------------------
+    const int n_tiles = (g.N + G2_BN - 1) / G2_BN;
+    const int m_tiles = (g.M + G2_BM - 1) / G2_BM;
+    int t = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    const int per_group = G2_GROUP_M * n_tiles;
+    const int grp = t / per_group;
+    const int first_m = grp * G2_GROUP_M;
+    const int gsize = min(m_tiles - first_m, G2_GROUP_M);
+    t -= grp * per_group;
+    const int m0 = (first_m + t % gsize) * G2_BM;
+    const int n0 = (t / gsize) * G2_BN;
+
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ W = static_cast<const T*>(g.W);
+
+    // ---- LDS-DMA plan: unit u in {0:A q-row 0, 1:W q-col 0, 2:W q-col 1, 3:A q-row 1}, 2 instr / thread
+    const int srow = lane >> 3;
+    const int schunk = (lane & 7) ^ srow;
+    const T* src[4][2];
+    int dst[4][2];  // byte offset inside a K-tile buffer (wave-uniform)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr0 = (wave * 2 + i) * 8;  // first of the 8 unit-local rows this instruction fills
+            const bool isA = (u == 0 || u == 3);
+            const int q = (u == 0 || u == 1) ? 0 : 1;
+            const int row0 = isA ? ((lr0 >> 6) * 128 + q * 64 + (lr0 & 63)) : ((lr0 >> 5) * 64 + q * 32 + (lr0 & 31));
+            const int row = row0 + srow;
+            dst[u][i] = (isA ? 0 : G2_B_REGION) + row0 * 128;
+            if (isA) {
+                int am = m0 + row;
+                am = am < g.M ? am : g.M - 1;
+                src[u][i] = A + (size_t)am * g.lda + schunk * EPC;
+            } else {
+                int wn = n0 + row;
+                wn = wn < g.N ? wn : g.N - 1;
+                src[u][i] = W + (size_t)wn * g.ldw + schunk * EPC;
+            }
+        }
+    const int nk = g.K / EPB;
+    const int G = 4 * nk;  // total units
+    // issue unit index gi (tile gi>>2, unit U) if it exists; U is a compile-time constant per phase
+    auto issue = [&](int gi, auto U) {
+        constexpr int u = decltype(U)::value;
+        if (gi < G) {
+            const int tt = gi >> 2;
+            char* base = smem + (tt & 1) * G2_BUF_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u][i] + (size_t)tt * EPB),
+                                                 (__attribute__((address_space(3))) void*)(base + dst[u][i]), 16, 0, 0);
+        }
+    };
+    using U0 = std::integral_constant<int, 0>;
+    using U1 = std::integral_constant<int, 1>;
+    using U2 = std::integral_constant<int, 2>;
+    using U3 = std::integral_constant<int, 3>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- fragment addressing ----------------------------------------------------------------------
+    const int fr = lane & 15, fg = lane >> 4;
+    const int a_base = (wr * 128 + fr) * 128;
+    const int b_base = G2_B_REGION + (wc * 64 + fr) * 128;
+    const int coff0 = ((0 * 4 + fg) ^ (fr & 7)) << 4;
+    const int coff1 = ((1 * 4 + fg) ^ (fr & 7)) << 4;
+
+    f32x4_v acc[2][2][2][4];  // [mq][nq][ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    u32x4_v areg[4][2];  // [mi][ks]   A sub-tile of the current quadrant-row
+    u32x4_v breg[2][2][2];  // [nq][ni][ks]  both W sub-tiles of the K-tile stay in registers: quadrant (1,0) reuses
+                            // sub-tile 0 without re-reading LDS, so every LDS region is last read >= 3 phases before
+                            // the LDS-DMA that overwrites it is issued (WAR margin for the staggered wave groups)
+
+    auto load_a = [&](const char* buf, int mq) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const char* p = buf + a_base + (mq * 64 + mi * 16) * 128;
+            areg[mi][0] = *reinterpret_cast<const u32x4_v*>(p + coff0);
+            areg[mi][1] = *reinterpret_cast<const u32x4_v*>(p + coff1);
+        }
+    };
+    auto load_b = [&](const char* buf, auto NQ) {
+        constexpr int nq = decltype(NQ)::value;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const char* p = buf + b_base + (nq * 32 + ni * 16) * 128;
+            breg[nq][ni][0] = *reinterpret_cast<const u32x4_v*>(p + coff0);
+            breg[nq][ni][1] = *reinterpret_cast<const u32x4_v*>(p + coff1);
+        }
+    };
+    auto mfma_quadrant = [&](auto MQ, auto NQ) {
+        constexpr int mq = decltype(MQ)::value, nq = decltype(NQ)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[mq][nq][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_v, breg[nq][ni][ks]), __builtin_bit_cast(bf16x8_v, areg[mi][ks]),
+                            acc[mq][nq][ni][mi], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[mq][nq][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                __uint_as_float(breg[nq][ni][ks][j]), __uint_as_float(areg[mi][ks][j]), acc[mq][nq][ni][mi], 0, 0, 0);
+                    }
+                }
+    };
+    // one phase = [reads + LDS-DMA issue + counted wait] barrier [MFMAs] barrier
+    auto phase_tail = [&](int ph) {
+        int allow = G - 3 - ph;
+        allow = allow > 3 ? 3 : allow;
+        wait_units(allow);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](auto MQ, auto NQ) {
+        __builtin_amdgcn_s_setprio(1);
+        mfma_quadrant(MQ, NQ);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- prologue: units 0..4 in flight, units 0 and 1 landed and visible ---------------------------
+    issue(0, U0{});
+    issue(1, U1{});
+    issue(2, U2{});
+    issue(3, U3{});
+    issue(4, U0{});
+    {
+        const int last = G - 1 < 4 ? G - 1 : 4;
+        wait_units(last - 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) {  // stagger: group 1 runs one barrier behind group 0
+        __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* buf = smem + (kt & 1) * G2_BUF_BYTES;
+        const int ph = 4 * kt;
+        // phase 1: quadrant (0,0)
+        load_a(buf, 0);
+        load_b(buf, I0{});
+        issue(ph + 5, U1{});
+        phase_tail(ph);
+        compute(I0{}, I0{});
+        // phase 2: quadrant (0,1)
+        load_b(buf, I1{});
+        issue(ph + 6, U2{});
+        phase_tail(ph + 1);
+        compute(I0{}, I1{});
+        // phase 3: quadrant (1,1)
+        load_a(buf, 1);
+        issue(ph + 7, U3{});
+        phase_tail(ph + 2);
+        compute(I1{}, I1{});
+        // phase 4: quadrant (1,0) -- operands already in registers
+        issue(ph + 8, U0{});
+        phase_tail(ph + 3);
+        compute(I1{}, I0{});
+    }
+    if (wr == 0) {  // re-align the two groups
+        __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    OutT* out = static_cast<OutT*>(g.out);  // may alias g.resid (in-place residual add)
+    const bool vec_ok = ((g.N | g.ldo | g.ldr) & 3) == 0;
+    if (g.flags & 1) {  // ablation: keep the accumulators live, store (almost) nothing
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) sacc += acc[a][b][c][d][0] + acc[a][b][c][d][1] + acc[a][b][c][d][2] + acc[a][b][c][d][3];
+        if (sacc == 12345.678f) Elem<OutT>::st(out, sacc);
+        return;
+    }
+    // ---- staged epilogue: accumulators -> (bias, activation) -> LDS tile -> whole rows out --------------
+    // After the K loop every LDS byte is dead, so the 256x256 output tile is transposed through LDS and
+    // leaves the CU as 16-byte-per-lane stores of 512 B (bf16) / 1 KiB (f32) contiguous runs -- whole
+    // 128-B lines -- instead of 32 eight-byte stores per lane into 32-B row fragments; the residual is
+    // read the same way.  (Direct per-fragment stores measured 118 us of a 358 us c_fc launch.)
+    const bool staged = vec_ok && ((g.N | g.ldo) & 7) == 0 && !(g.flags & 2);
+    if (staged) {
+        if constexpr (sizeof(OutT) == 2) {
+            constexpr int RS = 256 * 2 + 16;  // +16 B pad: fragment rows land on different banks
+#pragma unroll
+            for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int row = wr * 128 + mq * 64 + mi * 16 + fr;
+                            const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
+                            const f32x4_v a4 = acc[mq][nq][ni][mi];
+                            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                            if (g.bias && n0 + col < g.N) {
+                                const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
+                                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                            *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        }
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 16 + wave * 2 + (lane >> 5);
+                const int m = m0 + r, n = n0 + (lane & 31) * 8;
+                if (m < g.M && n < g.N)
+                    *reinterpret_cast<uint4*>(out + (size_t)m * g.ldo + n) = *reinterpret_cast<const uint4*>(smem + r * RS + (lane & 31) * 16);
+            }
+        } else {
+            constexpr int RSF = 256 * 4 + 16;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (p) __syncthreads();
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int lrow = wr * 64 + mi * 16 + fr;
+                            const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
+                            const f32x4_v a4 = acc[p][nq][ni][mi];
+                            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                            if (g.bias && n0 + col < g.N) {
+                                const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
+                                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                            *reinterpret_cast<float4*>(smem + lrow * RSF + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                __syncthreads();
+#pragma unroll 4
+                for (int it = 0; it < 16; ++it) {
+                    const int lr = it * 8 + wave;
+                    const int m = m0 + (lr >> 6) * 128 + p * 64 + (lr & 63), n = n0 + lane * 4;
+                    if (m < g.M && n < g.N) {
+                        float4 v = *reinterpret_cast<const float4*>(smem + lr * RSF + lane * 16);
+                        if constexpr (RESID) {
+                            const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wr * 128 + mq * 64 + mi * 16 + fr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int n = n0 + wc * 64 + nq * 32 + ni * 16 + fg * 4;
+                    if (n >= g.N) continue;
+                    const f32x4_v a4 = acc[mq][nq][ni][mi];
+                    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                    if (vec_ok) {
+                        if (g.bias) {
+                            const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+                            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                        if constexpr (RESID) {
+                            const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+                            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                        }
+                        store4(out + (size_t)m * g.ldo + n, v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (n + j >= g.N) break;
+                            float x = v[j] + (g.bias ? g.bias[n + j] : 0.f);
+                            x = apply_act<ACT, sizeof(T) == 2>(x);
+                            if constexpr (RESID) x += g.resid[(size_t)m * g.ldr + n + j];
+                            Elem<OutT>::st(out + (size_t)m * g.ldo + n + j, x);
+                        }
+                    }
+                }
+        }
+}
+
+template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
+    constexpr int EPB = 128 / (int)sizeof(T);
+    if (g.M <= 0) return 0;
+    if (g.N <= 0 || g.K % EPB != 0 || g.K <= 0 || g.lda % (16 / (int)sizeof(T)) != 0 || g.ldw % (16 / (int)sizeof(T)) != 0)
+        return fail("gemm256_nt: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) +
+                    " K=" + std::to_string(g.K));
+    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G2_LDS_BYTES));
+        attr_set = true;
+    }
+    const int m_tiles = (g.M + G2_BM - 1) / G2_BM;
+    const int n_tiles = (g.N + G2_BN - 1) / G2_BN;
+    hipLaunchKernelGGL(kern, dim3(m_tiles * n_tiles), dim3(G2_THREADS), G2_LDS_BYTES, stream, g);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// Picks the 256x256 pipelined kernel when the grid fills the chip, else the 128x128 kernel.
+template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+inline int launch_gemm_auto(const GemmArgs& g, hipStream_t stream, int force = 0) {
+    const long tiles256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
+    const bool big = force == 2 || (force == 0 && tiles256 >= 192);
+    if (big) return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);
+    return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, stream);
+}
+
+}  // namespace arp

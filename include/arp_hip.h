@@ -113,6 +113,9 @@ int arp_event_elapsed_ms(arp_event* start, arp_event* stop, float* ms); /* synch
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid), operands rounded to bf16 in ARP_MODE_BF16. */
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,
                    float* out, int M, int N, int K);
+/* Times `iters` launches of the GEMM on device-resident random operands (HIP events); kernel: 1 = 128x128,
+ * 2 = 256x256 pipelined, 0 = auto.  act/resid/out_f32 select the epilogue.  Returns the average ms per launch. */
+int arp_op_gemm_bench(int mode, int kernel, int act, int resid, int out_f32, int M, int N, int K, int iters, float* avg_ms);
 int arp_op_layernorm(const float* x, const float* w, const float* b, float* out, int rows, int D, float eps);
 /* qkv [B*N, 3*D] -> out [B*N, D]; impl 0 = MFMA (bf16 mode, head_dim 64 only), 1 = VALU. */
 int arp_op_attention(int mode, int impl, const float* qkv, float* out, int B, int N, int D, int heads, int causal);

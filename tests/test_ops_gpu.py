@@ -33,9 +33,12 @@ GEMM_SHAPES = [  # M, N, K
 ]
 
 
+@pytest.mark.parametrize("kernel", ["128", "256"])
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
-def test_gemm_nt(gpu_lib, mode, shape):
+def test_gemm_nt(gpu_lib, mode, shape, kernel, monkeypatch):
+    """Both GEMM kernels (ARP_GEMM=1: 128x128 two-phase; ARP_GEMM=2: 256x256 four-phase pipelined)."""
+    monkeypatch.setenv("ARP_GEMM", "1" if kernel == "128" else "2")
     M, N, K = shape
     if mode == 1 and K % 64:
         pytest.skip("bf16 GEMM needs K % 64 == 0")
@@ -59,6 +62,28 @@ def test_gemm_nt(gpu_lib, mode, shape):
         err = np.abs(out - ref).max()
         tol = 2e-5 * np.sqrt(K / 64) if mode == 0 else 3e-4 * max(1.0, np.abs(ref).max())
         assert err < tol, f"gemm mode={mode} shape={shape} act={act} bias={use_b} resid={use_r}: max err {err} (tol {tol})"
+
+
+def test_gemm256_race_screen(gpu_lib, monkeypatch):
+    """The pipelined kernel's LDS hand-offs are ordered by counted vmcnt + barriers: repeated launches on
+    a chip-filling shape must be bit-identical to each other and correct (a race shows up as rare
+    wrong tiles)."""
+    monkeypatch.setenv("ARP_GEMM", "2")
+    rng = np.random.default_rng(5)
+    for (M, N, K) in ((8192, 1536, 768), (4100, 768, 3072), (2048, 2304, 64), (2048, 2304, 128)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        ref = bf16_round(A).astype(np.float64) @ bf16_round(W).astype(np.float64).T
+        first = None
+        for rep in range(6):
+            out = np.empty((M, N), np.float32)
+            gpu_lib.check(gpu_lib.lib.arp_op_gemm_nt(1, 0, _fp(A), _fp(W), None, None, _fp(out), M, N, K))
+            if first is None:
+                first = out
+                err = np.abs(out - ref).max()
+                assert err < 3e-4 * max(1.0, np.abs(ref).max()), f"gemm256 {M}x{N}x{K}: max err {err}"
+            else:
+                assert (out == first).all(), f"gemm256 {M}x{N}x{K}: launch {rep} differs from launch 0 in {(out != first).sum()} elements"
 
 
 @pytest.mark.parametrize("D", [64, 128, 512, 768, 1024])
