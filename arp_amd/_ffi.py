@@ -2,6 +2,13 @@
 
 There is no CPU fallback: if the shared library is missing the import of any compute module
 raises, and if no HIP device is present every compute call fails with the library's error.
+
+Process hygiene: PyTorch-ROCm wheels bundle their own libamdhip64.so and request it by its unversioned
+file name.  A process that uses the GPU through libarp_hip.so (bound to /opt/rocm's runtime) and imports
+torch AFTERWARDS ends up with two HIP runtimes and aborts in glibc at exit.  If a process needs both,
+import torch FIRST (libarp_hip.so then binds to the runtime torch already loaded: same SONAME) -- the
+tests, bench.py (N > 1) and __graft_entry__.smoke() do -- or keep torch in a child process (bench.py's
+cpu_baseline leg does).
 """
 import ctypes as C
 import os
@@ -21,6 +28,12 @@ class ClipCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "patch", "width", "layers", "heads", "embed", "img_res", "txt_width", "txt_layers", "txt_heads", "ctx",
         "vocab", "mode", "device", "max_batch", "attn_impl")]
+
+
+class DtCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "emb", "depth", "heads", "mlp_ratio", "n_actions", "window", "enc_tokens", "enc_dim", "use_adapter", "mode",
+        "device", "world", "rank")] + [(n, C.c_float) for n in ("lambda_ret", "weight_decay", "clip_norm", "b1", "b2", "eps")]
 
 
 def _load():
@@ -69,6 +82,27 @@ SIGNATURES = {
     "arp_event_destroy": (_i, [_vp]),
     "arp_clip_event_record": (_i, [_vp, _vp]),
     "arp_event_elapsed_ms": (_i, [_vp, _vp, _fp]),
+    "arp_dt_create": (_i, [C.POINTER(DtCfg), C.POINTER(_vp)]),
+    "arp_dt_destroy": (_i, [_vp]),
+    "arp_dt_num_params": (_i, [_vp, _i64p, _i32p]),
+    "arp_dt_param_info": (_i, [_vp, _i, C.c_char_p, _i, _i64p, _i32p]),
+    "arp_dt_set_tensor": (_i, [_vp, C.c_char_p, _i, _fp]),
+    "arp_dt_get_tensor": (_i, [_vp, C.c_char_p, _i, _fp]),
+    "arp_dt_set_step": (_i, [_vp, C.c_int64]),
+    "arp_dt_get_step": (_i, [_vp, _i64p]),
+    "arp_dt_set_batch": (_i, [_vp, _fp, _i32p, _fp, _i]),
+    "arp_dt_forward": (_i, [_vp, _fp, _fp, _fp]),
+    "arp_dt_backward": (_i, [_vp]),
+    "arp_dt_train_step": (_i, [_vp, _f, _fp]),
+    "arp_dt_train_step_async": (_i, [_vp, _f]),
+    "arp_dt_sync": (_i, [_vp]),
+    "arp_dt_event_record": (_i, [_vp, _vp]),
+    "arp_dt_comm_unique_id": (_i, [_vp]),
+    "arp_dt_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "arp_dt_broadcast_state": (_i, [_vp]),
+    "arp_dt_profile_enable": (_i, [_vp, _i]),
+    "arp_dt_profile_reset": (_i, [_vp]),
+    "arp_dt_profile_json": (_i, [_vp, C.c_char_p, _i]),
     "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
     "arp_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "arp_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f]),

@@ -795,7 +795,6 @@ int arp_clip_profile_json(arp_clip* c, char* buf, int buf_len) {
     return (int)s.size();
 }
 
-struct arp_event { hipEvent_t e; };
 int arp_event_create(arp_event** out) {
     if (!out) return fail("null out");
     arp_event* ev = new arp_event();

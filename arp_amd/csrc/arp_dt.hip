@@ -1,0 +1,793 @@
+// Path (2): the ARP-DT policy train step on MI355X -- host orchestration + C ABI.
+// Reference seam: create_train_step / train_step_fn, /root/reference/arp_dt/main_procgen.py:104-141
+// (model: arp_dt/ARPDT.py:152-261,413-486; arp_dt/layers.py; optimizer: main_procgen.py:490-507).
+//
+// Boundary this round: the frozen M3AE encoder output `enc` [B,T,tokens,dim] is an
+// INPUT (BASELINE.json configs[3]: "random-init M3AE encodings"); everything trainable is inside.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: librccl is dlopen'ed at arp_dt_comm_init, never linked (see rccl_api())
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/arp_hip.h"
+#include "attention.h"
+#include "common.h"
+#include "dtops.h"
+#include "gemm.h"
+#include "gemm256.h"
+#include "runtime.h"
+
+using namespace arp;
+
+namespace {
+
+// RCCL is bound at run time.  Linking it would make every process that loads libarp_hip.so also load
+// /opt/rocm's librccl next to the copy PyTorch-ROCm bundles (same SONAME, different file) -- two RCCLs in one
+// process abort in glibc at exit.  dlopen("librccl.so.1") returns whichever copy is already loaded, else the
+// system one.
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    bool ok = false;
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.ok ? &api : nullptr;
+    tried = true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return nullptr;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(h, "ncclBroadcast"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Broadcast;
+    return api.ok ? &api : nullptr;
+}
+
+enum { SITE_DT = 16 };
+
+struct ParamInfo {
+    std::string name;
+    std::vector<int64_t> shape;  // Flax shape
+    size_t off = 0, size = 0;
+    bool dense = false;  // 2-D Dense kernel: device layout is [out, in] (transposed from Flax [in, out])
+    int in = 0, out = 0;
+};
+
+inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+struct arp_dt {
+    arp_dt_cfg cfg;
+    hipStream_t stream = nullptr;
+    std::vector<ParamInfo> infos;
+    std::map<std::string, int> index;
+    size_t P = 0, n_decay = 0;  // total parameters; the first n_decay are the ndim > 1 ones (L2 penalty applies)
+    DevBuf params, grads, mu, nu;
+    long long step = 0;
+    bool shadows_stale = true;
+    // operand-type shadows of the big weights
+    DevBuf W1s, W2s, W2t, Wis, Wit;
+    // batch
+    int B = 0;
+    DevBuf enc32, action, rtg;
+    // activations (T = operand type)
+    DevBuf Xb, XbT, H1, H1T, A, Y, YT, dY, dApre, dApreT, G, dH1T, dzb, dzT, part, scal;
+    // f32 small tensors
+    std::vector<DevBuf> xs, ln0, qkv, att, hmid, ln1, u, gl;  // per block
+    DevBuf img, hf, a_in, r_in, ha, hr, logits, ret, metrics;
+    DevBuf dlogits, dret, dha, dhr, da_in, dr_in, dhf, dh, t1, t2, t3, dws, dbs, dimg, dz, dqkv;
+    ncclComm_t comm = nullptr;
+    bool has_comm = false;
+    Profiler prof;
+
+    size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
+    int R() const { return B * cfg.window; }
+    int L() const { return 3 * cfg.window; }
+    float* p(const std::string& n) { return params.as<float>() + infos[index.at(n)].off; }
+    float* g(const std::string& n) { return grads.as<float>() + infos[index.at(n)].off; }
+};
+
+namespace {
+
+int add_param(arp_dt* c, std::vector<ParamInfo>& v, const std::string& name, std::vector<int64_t> shape) {
+    ParamInfo pi;
+    pi.name = name;
+    pi.shape = shape;
+    pi.size = 1;
+    for (auto d : shape) pi.size *= (size_t)d;
+    const bool is_kernel = name.size() >= 7 && name.compare(name.size() - 7, 7, "/kernel") == 0;
+    if (shape.size() == 2 && is_kernel) {
+        pi.dense = true;
+        pi.in = (int)shape[0];
+        pi.out = (int)shape[1];
+    }
+    v.push_back(pi);
+    return 0;
+}
+
+void build_layout(arp_dt* c) {
+    const arp_dt_cfg& k = c->cfg;
+    const int E = k.emb, D = k.enc_dim, H = k.mlp_ratio * k.emb;
+    std::vector<ParamInfo> v;
+    if (k.use_adapter) {
+        for (int i = 0; i < 2; ++i) {
+            add_param(c, v, "AdapterMLP_0/Dense_" + std::to_string(i) + "/kernel", {D, D});
+            add_param(c, v, "AdapterMLP_0/Dense_" + std::to_string(i) + "/bias", {D});
+        }
+        add_param(c, v, "residual_weight", {1});
+    }
+    add_param(c, v, "image_text_input/kernel", {(int64_t)k.enc_tokens * D, E});
+    add_param(c, v, "image_text_input/bias", {E});
+    add_param(c, v, "action_input/embedding", {k.n_actions, E});
+    add_param(c, v, "rtg_input/kernel", {1, E});
+    for (int i = 0; i < k.depth; ++i) {
+        const std::string p = "policy/Block_" + std::to_string(i) + "/";
+        for (const char* ln : {"LayerNorm_0", "LayerNorm_1"}) {
+            add_param(c, v, p + ln + "/scale", {E});
+            add_param(c, v, p + ln + "/bias", {E});
+        }
+        add_param(c, v, p + "Attention_0/Dense_0/kernel", {E, 3 * E});
+        add_param(c, v, p + "Attention_0/Dense_0/bias", {3 * E});
+        add_param(c, v, p + "Attention_0/Dense_1/kernel", {E, E});
+        add_param(c, v, p + "Attention_0/Dense_1/bias", {E});
+        add_param(c, v, p + "FeedForward_0/fc1/kernel", {E, H});
+        add_param(c, v, p + "FeedForward_0/fc2/kernel", {H, E});
+    }
+    add_param(c, v, "policy/LayerNorm_0/scale", {E});
+    add_param(c, v, "policy/LayerNorm_0/bias", {E});
+    for (auto hn : {std::make_pair(std::string("action_outputs_0"), k.n_actions), std::make_pair(std::string("return_outputs_0"), 1)}) {
+        add_param(c, v, hn.first + "/layers_0/kernel", {E, E});
+        add_param(c, v, hn.first + "/layers_0/bias", {E});
+        add_param(c, v, hn.first + "/layers_2/kernel", {E, hn.second});
+    }
+    // flat order: every ndim > 1 parameter first (the explicit L2 term of main_procgen.py:114-117 covers
+    // exactly those), then the vectors; every offset a multiple of 4 floats
+    size_t off = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (auto& pi : v)
+            if ((pi.shape.size() > 1) == (pass == 0)) {
+                pi.off = off;
+                off += (pi.size + 3) & ~(size_t)3;
+                if (pass == 0) c->n_decay = off;
+            }
+    c->P = off;
+    c->infos = v;
+    for (size_t i = 0; i < v.size(); ++i) c->index[v[i].name] = (int)i;
+}
+
+template <typename T> int small_attention_fwd(arp_dt* c, const float* qkv, float* out, int B, int L, int E, int heads) {
+    const int hd = E / heads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const size_t lds = (size_t)2 * L * hd * 4;
+    const int threads = 64;
+#define ARP_DT_ATT(HD)                                                                                                   \
+    hipLaunchKernelGGL((attn_valu_kernel<float, HD>), dim3(B * heads), dim3(threads), lds, c->stream, qkv, out, L, E, heads, scale, 1)
+    if (hd == 16) ARP_DT_ATT(16);
+    else if (hd == 32) ARP_DT_ATT(32);
+    else if (hd == 64) ARP_DT_ATT(64);
+    else return fail("policy attention: unsupported head_dim " + std::to_string(hd));
+#undef ARP_DT_ATT
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sgemm(arp_dt* c, const float* A, int ta, const float* B, int tb, const float* bias, const float* resid, float* C, int M, int N, int K,
+          int lda, int ldb, int act = ACT_NONE, int accumulate = 0) {
+    SmallGemm g{A, B, bias, resid, C, M, N, K, lda, ldb, N, ta, tb, act, accumulate};
+    hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv(N, 32), cdiv(M, 32)), dim3(256), 0, c->stream, g);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+// Y[M,N] = act(X[M,K] . W[N,K]^T + b)   (W in device layout [out, in])
+int linear_fwd(arp_dt* c, const float* X, const float* W, const float* b, const float* resid, float* Y, int M, int N, int K, int act = ACT_NONE) {
+    return sgemm(c, X, 0, W, 1, b, resid, Y, M, N, K, K, K, act);
+}
+// dW[N,K] = dY[M,N]^T . X[M,K];  db[N] = colsum(dY);  dX[M,K] = dY . W
+int linear_bwd(arp_dt* c, const float* X, const float* W, const float* dY, float* dW, float* db, float* dX, int M, int N, int K) {
+    ARP_TRY(sgemm(c, dY, 1, X, 0, nullptr, nullptr, dW, N, K, M, N, K));
+    if (db) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, dY, M, N, db);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    if (dX) ARP_TRY(sgemm(c, dY, 0, W, 0, nullptr, nullptr, dX, M, K, N, N, K));
+    return 0;
+}
+int ln_fwd(arp_dt* c, const float* x, const float* w, const float* b, float* y, int rows, int D) {
+    hipLaunchKernelGGL(ln_fwd_f32_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, c->stream, x, w, b, y, rows, D, 1e-6f);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+int ln_bwd(arp_dt* c, const float* x, const float* w, const float* dy, float* dx, int accumulate, float* dscale, float* dbias, int rows, int D) {
+    hipLaunchKernelGGL(ln_bwd_f32_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, c->stream, x, w, dy, dx, accumulate, c->dws.as<float>(),
+                       c->dbs.as<float>(), rows, D, 1e-6f);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dws.as<float>(), rows, D, dscale);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dbs.as<float>(), rows, D, dbias);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+int ew_bwd(arp_dt* c, const float* gr, const float* ref, float* out, size_t n, int op) {
+    hipLaunchKernelGGL(ew_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, gr, ref, out, n, op);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// big NT GEMM on the MFMA kernels; OutT in {T, float}
+template <typename T, typename OutT, int ACT>
+int big_gemm(arp_dt* c, const char* site, const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo, int M, int N,
+             int K) {
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = bias; g.resid = nullptr; g.out = out;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = ldo; g.ldo = ldo;
+    ProfScope ps(c->prof, c->stream, site);
+    return launch_gemm_auto<T, OutT, ACT, false, SITE_DT>(g, c->stream, 0);
+}
+// split-K NT GEMM: f32 partials [S][M][N] then a fixed-order reduce (+bias, act) into OutT
+template <typename T, typename OutT>
+int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void* W, int ldw, const float* bias, int act, OutT* out, int M, int N,
+                int K) {
+    constexpr int EPB = 128 / (int)sizeof(T);
+    const int nk = K / EPB;
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    int S = std::max(1, std::min(nk, 1024 / std::max(tiles, 1)));
+    const int per = (nk + S - 1) / S;
+    S = (nk + per - 1) / per;  // every slice non-empty
+    ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = nullptr; g.resid = nullptr; g.out = c->part.p;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = N; g.ldo = N;
+    g.ksplit = S; g.slice_stride = (size_t)M * N;
+    ProfScope ps(c->prof, c->stream, site);
+    if (S == 1) g.ksplit = 1;
+    ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_DT + 1>(g, c->stream)));
+    const size_t MN = (size_t)M * N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 256)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename TI, typename TM, typename TO>
+int transpose_mask(arp_dt* c, const TI* in, int ldi, const TM* mask, const float* scale_ptr, float scale, TO* outN, int ldn, TO* outT, int ldt,
+                   int Rr, int Cc) {
+    hipLaunchKernelGGL((transpose_mask_kernel<TI, TM, TO>), dim3(cdiv(Cc, 64), cdiv(Rr, 64)), dim3(256), 0, c->stream, in, ldi, mask, scale_ptr,
+                       scale, outN, ldn, outT, ldt, Rr, Cc);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename T> int refresh_shadows(arp_dt* c) {
+    if (!c->shadows_stale) return 0;
+    const arp_dt_cfg& k = c->cfg;
+    const int D = k.enc_dim, E = k.emb;
+    const size_t Kin = (size_t)k.enc_tokens * D;
+    ProfScope ps(c->prof, c->stream, "dt.refresh_shadows");
+    if (k.use_adapter) {
+        // device layout of a Dense kernel is [out, in]
+        ARP_TRY((transpose_mask<float, float, T>(c, c->p("AdapterMLP_0/Dense_0/kernel"), D, nullptr, nullptr, 1.f, c->W1s.as<T>(), D, nullptr, 0, D, D)));
+        ARP_TRY((transpose_mask<float, float, T>(c, c->p("AdapterMLP_0/Dense_1/kernel"), D, nullptr, nullptr, 1.f, c->W2s.as<T>(), D, c->W2t.as<T>(), D, D, D)));
+    }
+    ARP_TRY((transpose_mask<float, float, T>(c, c->p("image_text_input/kernel"), (int)Kin, nullptr, nullptr, 1.f, c->Wis.as<T>(), (int)Kin,
+                                             c->Wit.as<T>(), E, E, (int)Kin)));
+    c->shadows_stale = false;
+    return 0;
+}
+
+int ensure_buffers(arp_dt* c, int B) {
+    if (B == c->B) return 0;
+    const arp_dt_cfg& k = c->cfg;
+    const size_t e = c->esz();
+    const int E = k.emb, D = k.enc_dim, H = k.mlp_ratio * E, T = k.window, NA = k.n_actions;
+    const size_t R = (size_t)B * T, Mx = R * k.enc_tokens, BL = R * 3, Kin = (size_t)k.enc_tokens * D;
+    const size_t Mxp = (Mx + 63) / 64 * 64, Rp = (R + 63) / 64 * 64;
+    ARP_TRY(c->enc32.ensure(Mx * D * 4)); ARP_TRY(c->action.ensure(R * 4)); ARP_TRY(c->rtg.ensure(R * 4));
+    DevBuf* tb[] = {&c->Xb, &c->H1, &c->A, &c->Y, &c->dY, &c->dApre, &c->G};
+    for (auto* b : tb) ARP_TRY(b->ensure(Mx * D * e));
+    DevBuf* tt[] = {&c->XbT, &c->H1T, &c->dApreT, &c->dH1T};
+    for (auto* b : tt) {
+        ARP_TRY(b->ensure((size_t)D * Mxp * e));
+        ARP_HIP_OK(hipMemsetAsync(b->p, 0, (size_t)D * Mxp * e, c->stream));  // K padding must read as zeros
+    }
+    ARP_TRY(c->YT.ensure(Kin * Rp * e)); ARP_HIP_OK(hipMemsetAsync(c->YT.p, 0, Kin * Rp * e, c->stream));
+    ARP_TRY(c->dzT.ensure((size_t)E * Rp * e)); ARP_HIP_OK(hipMemsetAsync(c->dzT.p, 0, (size_t)E * Rp * e, c->stream));
+    ARP_TRY(c->dzb.ensure(R * E * e));
+    ARP_TRY(c->scal.ensure(4096 * 4));
+    auto f32 = [&](DevBuf& b, size_t n) { return b.ensure(std::max<size_t>(n, 4) * 4); };
+    c->xs.resize(k.depth + 1); c->ln0.resize(k.depth); c->qkv.resize(k.depth); c->att.resize(k.depth); c->hmid.resize(k.depth);
+    c->ln1.resize(k.depth); c->u.resize(k.depth); c->gl.resize(k.depth);
+    for (int i = 0; i <= k.depth; ++i) ARP_TRY(f32(c->xs[i], BL * E));
+    for (int i = 0; i < k.depth; ++i) {
+        ARP_TRY(f32(c->ln0[i], BL * E)); ARP_TRY(f32(c->qkv[i], BL * 3 * E)); ARP_TRY(f32(c->att[i], BL * E)); ARP_TRY(f32(c->hmid[i], BL * E));
+        ARP_TRY(f32(c->ln1[i], BL * E)); ARP_TRY(f32(c->u[i], BL * H)); ARP_TRY(f32(c->gl[i], BL * H));
+    }
+    ARP_TRY(f32(c->img, R * E)); ARP_TRY(f32(c->hf, BL * E)); ARP_TRY(f32(c->a_in, R * E)); ARP_TRY(f32(c->r_in, R * E));
+    ARP_TRY(f32(c->ha, R * E)); ARP_TRY(f32(c->hr, R * E)); ARP_TRY(f32(c->logits, R * NA)); ARP_TRY(f32(c->ret, R)); ARP_TRY(f32(c->metrics, 16));
+    ARP_TRY(f32(c->dlogits, R * NA)); ARP_TRY(f32(c->dret, R)); ARP_TRY(f32(c->dha, R * E)); ARP_TRY(f32(c->dhr, R * E));
+    ARP_TRY(f32(c->da_in, R * E)); ARP_TRY(f32(c->dr_in, R * E)); ARP_TRY(f32(c->dhf, BL * E)); ARP_TRY(f32(c->dh, BL * E));
+    ARP_TRY(f32(c->t1, BL * std::max(H, 3 * E))); ARP_TRY(f32(c->t2, BL * std::max(H, 3 * E))); ARP_TRY(f32(c->t3, BL * E));
+    ARP_TRY(f32(c->dws, BL * E)); ARP_TRY(f32(c->dbs, BL * E)); ARP_TRY(f32(c->dimg, R * E)); ARP_TRY(f32(c->dz, R * E));
+    ARP_TRY(f32(c->dqkv, BL * 3 * E));
+    c->B = B;
+    return 0;
+}
+
+// ---- forward: everything up to the losses; leaves every activation the backward needs -----------------
+template <typename T> int forward(arp_dt* c) {
+    const arp_dt_cfg& k = c->cfg;
+    const int E = k.emb, D = k.enc_dim, H = k.mlp_ratio * E, NA = k.n_actions, depth = k.depth;
+    const int R = c->R(), L = c->L(), BL = c->B * L;
+    const size_t Mx = (size_t)R * k.enc_tokens;
+    const int Kin = k.enc_tokens * D;
+    const int Mxp = (int)((Mx + 63) / 64 * 64);
+    ARP_TRY(refresh_shadows<T>(c));
+    {   // enc f32 -> operand type, both layouts (the transposed one feeds the weight-gradient GEMM)
+        ProfScope ps(c->prof, c->stream, "dt.enc_convert");
+        ARP_TRY((transpose_mask<float, float, T>(c, c->enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D,
+                                                 k.use_adapter ? c->XbT.as<T>() : nullptr, Mxp, (int)Mx, D)));
+    }
+    const T* Yp = c->Xb.as<T>();
+    if (k.use_adapter) {
+        // AdapterMLP: relu(relu(x W1 + b1) W2 + b2)   (arp_dt/models/adapter/layers.py:19-30)
+        ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc1", c->Xb.p, D, c->W1s.p, D, c->p("AdapterMLP_0/Dense_0/bias"), c->H1.p, D, (int)Mx, D, D)));
+        ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc2", c->H1.p, D, c->W2s.p, D, c->p("AdapterMLP_0/Dense_1/bias"), c->A.p, D, (int)Mx, D, D)));
+        ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
+        hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->Xb.as<T>(),
+                           c->p("residual_weight"), c->Y.as<T>(), Mx * D);
+        ARP_HIP_OK(hipGetLastError());
+        Yp = c->Y.as<T>();
+    }
+    // image_text_input + tanh (arp_dt/ARPDT.py:475-484): [R, tokens*dim] x [tokens*dim, E], split over K
+    ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
+    {
+        ProfScope ps(c->prof, c->stream, "dt.policy_fwd");
+        hipLaunchKernelGGL(tokens_fwd_kernel, dim3(cdiv((size_t)R * E, 256)), dim3(256), 0, c->stream, c->img.as<float>(), c->rtg.as<float>(),
+                           c->action.as<int>(), c->p("rtg_input/kernel"), c->p("action_input/embedding"), c->xs[0].as<float>(), R, E);
+        ARP_HIP_OK(hipGetLastError());
+        for (int i = 0; i < depth; ++i) {
+            const std::string p = "policy/Block_" + std::to_string(i) + "/";
+            float* x = c->xs[i].as<float>();
+            ARP_TRY(ln_fwd(c, x, c->p(p + "LayerNorm_0/scale"), c->p(p + "LayerNorm_0/bias"), c->ln0[i].as<float>(), BL, E));
+            ARP_TRY(linear_fwd(c, c->ln0[i].as<float>(), c->p(p + "Attention_0/Dense_0/kernel"), c->p(p + "Attention_0/Dense_0/bias"), nullptr,
+                               c->qkv[i].as<float>(), BL, 3 * E, E));
+            ARP_TRY(small_attention_fwd<float>(c, c->qkv[i].as<float>(), c->att[i].as<float>(), c->B, L, E, k.heads));
+            ARP_TRY(linear_fwd(c, c->att[i].as<float>(), c->p(p + "Attention_0/Dense_1/kernel"), c->p(p + "Attention_0/Dense_1/bias"), x,
+                               c->hmid[i].as<float>(), BL, E, E));
+            ARP_TRY(ln_fwd(c, c->hmid[i].as<float>(), c->p(p + "LayerNorm_1/scale"), c->p(p + "LayerNorm_1/bias"), c->ln1[i].as<float>(), BL, E));
+            ARP_TRY(linear_fwd(c, c->ln1[i].as<float>(), c->p(p + "FeedForward_0/fc1/kernel"), nullptr, nullptr, c->u[i].as<float>(), BL, H, E));
+            hipLaunchKernelGGL(gelu_fwd_kernel, dim3(cdiv((size_t)BL * H, 256)), dim3(256), 0, c->stream, c->u[i].as<float>(), c->gl[i].as<float>(),
+                               (size_t)BL * H);
+            ARP_TRY(linear_fwd(c, c->gl[i].as<float>(), c->p(p + "FeedForward_0/fc2/kernel"), nullptr, c->hmid[i].as<float>(),
+                               c->xs[i + 1].as<float>(), BL, E, H));
+        }
+        ARP_TRY(ln_fwd(c, c->xs[depth].as<float>(), c->p("policy/LayerNorm_0/scale"), c->p("policy/LayerNorm_0/bias"), c->hf.as<float>(), BL, E));
+        hipLaunchKernelGGL(heads_gather_kernel, dim3(cdiv((size_t)R * E, 256)), dim3(256), 0, c->stream, c->hf.as<float>(), c->a_in.as<float>(),
+                           c->r_in.as<float>(), R, E);
+        ARP_TRY(linear_fwd(c, c->a_in.as<float>(), c->p("action_outputs_0/layers_0/kernel"), c->p("action_outputs_0/layers_0/bias"), nullptr,
+                           c->ha.as<float>(), R, E, E, ACT_RELU));
+        ARP_TRY(linear_fwd(c, c->ha.as<float>(), c->p("action_outputs_0/layers_2/kernel"), nullptr, nullptr, c->logits.as<float>(), R, NA, E));
+        ARP_TRY(linear_fwd(c, c->r_in.as<float>(), c->p("return_outputs_0/layers_0/kernel"), c->p("return_outputs_0/layers_0/bias"), nullptr,
+                           c->hr.as<float>(), R, E, E, ACT_RELU));
+        ARP_TRY(linear_fwd(c, c->hr.as<float>(), c->p("return_outputs_0/layers_2/kernel"), nullptr, nullptr, c->ret.as<float>(), R, 1, E));
+        hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, c->stream, c->logits.as<float>(), c->ret.as<float>(), c->action.as<int>(),
+                           c->rtg.as<float>(), R, NA, k.lambda_ret, c->metrics.as<float>(), c->dlogits.as<float>(), c->dret.as<float>());
+        ARP_HIP_OK(hipGetLastError());
+    }
+    return 0;
+}
+
+// ---- backward: fills c->grads (every entry written exactly once; no accumulation across calls) ----------
+template <typename T> int backward(arp_dt* c) {
+    const arp_dt_cfg& k = c->cfg;
+    const int E = k.emb, D = k.enc_dim, H = k.mlp_ratio * E, NA = k.n_actions, depth = k.depth;
+    const int R = c->R(), L = c->L(), BL = c->B * L;
+    const size_t Mx = (size_t)R * k.enc_tokens;
+    const int Kin = k.enc_tokens * D;
+    const int Mxp = (int)((Mx + 63) / 64 * 64), Rp = (R + 63) / 64 * 64;
+    float* dh = c->dh.as<float>();
+    {
+        ProfScope ps(c->prof, c->stream, "dt.policy_bwd");
+        // heads (arp_dt/ARPDT.py:94-99,206-220)
+        ARP_TRY(linear_bwd(c, c->ha.as<float>(), c->p("action_outputs_0/layers_2/kernel"), c->dlogits.as<float>(), c->g("action_outputs_0/layers_2/kernel"),
+                           nullptr, c->t1.as<float>(), R, NA, E));
+        ARP_TRY(ew_bwd(c, c->t1.as<float>(), c->ha.as<float>(), c->dha.as<float>(), (size_t)R * E, EW_RELU_BWD));
+        ARP_TRY(linear_bwd(c, c->a_in.as<float>(), c->p("action_outputs_0/layers_0/kernel"), c->dha.as<float>(), c->g("action_outputs_0/layers_0/kernel"),
+                           c->g("action_outputs_0/layers_0/bias"), c->da_in.as<float>(), R, E, E));
+        ARP_TRY(linear_bwd(c, c->hr.as<float>(), c->p("return_outputs_0/layers_2/kernel"), c->dret.as<float>(), c->g("return_outputs_0/layers_2/kernel"),
+                           nullptr, c->t1.as<float>(), R, 1, E));
+        ARP_TRY(ew_bwd(c, c->t1.as<float>(), c->hr.as<float>(), c->dhr.as<float>(), (size_t)R * E, EW_RELU_BWD));
+        ARP_TRY(linear_bwd(c, c->r_in.as<float>(), c->p("return_outputs_0/layers_0/kernel"), c->dhr.as<float>(), c->g("return_outputs_0/layers_0/kernel"),
+                           c->g("return_outputs_0/layers_0/bias"), c->dr_in.as<float>(), R, E, E));
+        hipLaunchKernelGGL(heads_scatter_kernel, dim3(cdiv((size_t)R * E, 256)), dim3(256), 0, c->stream, c->da_in.as<float>(), c->dr_in.as<float>(),
+                           c->dhf.as<float>(), R, E);
+        ARP_TRY(ln_bwd(c, c->xs[depth].as<float>(), c->p("policy/LayerNorm_0/scale"), c->dhf.as<float>(), dh, 0, c->g("policy/LayerNorm_0/scale"),
+                       c->g("policy/LayerNorm_0/bias"), BL, E));
+        for (int i = depth - 1; i >= 0; --i) {
+            const std::string p = "policy/Block_" + std::to_string(i) + "/";
+            // x_{i+1} = hmid + gelu(ln1 Wfc1) Wfc2
+            ARP_TRY(linear_bwd(c, c->gl[i].as<float>(), c->p(p + "FeedForward_0/fc2/kernel"), dh, c->g(p + "FeedForward_0/fc2/kernel"), nullptr,
+                               c->t1.as<float>(), BL, E, H));
+            ARP_TRY(ew_bwd(c, c->t1.as<float>(), c->u[i].as<float>(), c->t2.as<float>(), (size_t)BL * H, EW_GELU_BWD));
+            ARP_TRY(linear_bwd(c, c->ln1[i].as<float>(), c->p(p + "FeedForward_0/fc1/kernel"), c->t2.as<float>(), c->g(p + "FeedForward_0/fc1/kernel"),
+                               nullptr, c->t3.as<float>(), BL, H, E));
+            ARP_TRY(ln_bwd(c, c->hmid[i].as<float>(), c->p(p + "LayerNorm_1/scale"), c->t3.as<float>(), dh, 1, c->g(p + "LayerNorm_1/scale"),
+                           c->g(p + "LayerNorm_1/bias"), BL, E));
+            // hmid = x_i + att Wo + bo
+            ARP_TRY(linear_bwd(c, c->att[i].as<float>(), c->p(p + "Attention_0/Dense_1/kernel"), dh, c->g(p + "Attention_0/Dense_1/kernel"),
+                               c->g(p + "Attention_0/Dense_1/bias"), c->t3.as<float>(), BL, E, E));
+            {
+                const int hd = E / k.heads;
+                const size_t lds = ((size_t)4 * L * hd + 2 * L * L) * 4;
+                hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(c->B * k.heads), dim3(64), lds, c->stream, c->qkv[i].as<float>(), c->t3.as<float>(),
+                                   c->dqkv.as<float>(), L, E, k.heads, 1.0f / sqrtf((float)hd));
+                ARP_HIP_OK(hipGetLastError());
+            }
+            ARP_TRY(linear_bwd(c, c->ln0[i].as<float>(), c->p(p + "Attention_0/Dense_0/kernel"), c->dqkv.as<float>(), c->g(p + "Attention_0/Dense_0/kernel"),
+                               c->g(p + "Attention_0/Dense_0/bias"), c->t3.as<float>(), BL, 3 * E, E));
+            ARP_TRY(ln_bwd(c, c->xs[i].as<float>(), c->p(p + "LayerNorm_0/scale"), c->t3.as<float>(), dh, 1, c->g(p + "LayerNorm_0/scale"),
+                           c->g(p + "LayerNorm_0/bias"), BL, E));
+        }
+        hipLaunchKernelGGL(tokens_bwd_kernel, dim3(cdiv(E, 256)), dim3(256), 0, c->stream, dh, c->rtg.as<float>(), c->action.as<int>(),
+                           c->dimg.as<float>(), c->g("rtg_input/kernel"), c->g("action_input/embedding"), R, E, NA);
+        ARP_TRY(ew_bwd(c, c->dimg.as<float>(), c->img.as<float>(), c->dz.as<float>(), (size_t)R * E, EW_TANH_BWD));
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(E, 256)), dim3(256), 0, c->stream, c->dz.as<float>(), R, E, c->g("image_text_input/bias"));
+        ARP_HIP_OK(hipGetLastError());
+    }
+    // ---- image_text_input: dW[E, Kin] = dz^T Y ;  dY[R, Kin] = dz Wi -------------------------------------
+    const T* Yp = k.use_adapter ? c->Y.as<T>() : c->Xb.as<T>();
+    ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, 1.f, c->dzb.as<T>(), E, c->dzT.as<T>(), Rp, R, E)));
+    {
+        ProfScope ps(c->prof, c->stream, "dt.Y_transpose");
+        ARP_TRY((transpose_mask<T, T, T>(c, Yp, Kin, nullptr, nullptr, 1.f, nullptr, 0, c->YT.as<T>(), Rp, R, Kin)));
+    }
+    ARP_TRY((big_gemm<T, float, ACT_NONE>(c, "dt.image_text_input_dW", c->dzT.p, Rp, c->YT.p, Rp, nullptr, c->g("image_text_input/kernel"), Kin, E, Kin, Rp)));
+    if (!k.use_adapter) return 0;
+    ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.image_text_input_dX", c->dzb.p, E, c->Wit.p, E, nullptr, c->dY.p, Kin, R, Kin, E)));
+    // ---- adapter backward (y = res a + (1-res) x, x is stop_gradient'ed: arp_dt/ARPDT.py:462-472) --------
+    {
+        ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_elementwise");
+        const int nb = 1024;
+        hipLaunchKernelGGL((adapter_dres_kernel<T>), dim3(nb), dim3(256), 0, c->stream, c->dY.as<T>(), c->A.as<T>(), c->Xb.as<T>(),
+                           c->scal.as<float>() + 16, Mx * D);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, nb, 1.0f, c->scal.as<float>() + 8, 0);
+        hipLaunchKernelGGL(dres_to_drw_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 8, c->p("residual_weight"), c->g("residual_weight"));
+        // res = sigmoid(rw) as a device scalar for the masked transposes
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->p("residual_weight"), 1, 1.0f, c->scal.as<float>() + 9, 0);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    // dApre = res * dY * (A > 0), both layouts.  res is applied through scale_ptr after a sigmoid kernel:
+    {
+        ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
+        hipLaunchKernelGGL(sigmoid_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 9);
+        ARP_TRY((transpose_mask<T, T, T>(c, c->dY.as<T>(), D, c->A.as<T>(), c->scal.as<float>() + 9, 1.f, c->dApre.as<T>(), D, c->dApreT.as<T>(), Mxp,
+                                         (int)Mx, D)));
+        ARP_TRY((transpose_mask<T, T, T>(c, c->H1.as<T>(), D, nullptr, nullptr, 1.f, nullptr, 0, c->H1T.as<T>(), Mxp, (int)Mx, D)));
+    }
+    ARP_TRY((splitk_gemm<T, float>(c, "dt.adapter_fc2_dW", c->dApreT.p, Mxp, c->H1T.p, Mxp, nullptr, ACT_NONE, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp)));
+    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->dApreT.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_1/bias"), D);
+    ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.adapter_fc2_dX", c->dApre.p, D, c->W2t.p, D, nullptr, c->G.p, D, (int)Mx, D, D)));
+    {
+        ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
+        ARP_TRY((transpose_mask<T, T, T>(c, c->G.as<T>(), D, c->H1.as<T>(), nullptr, 1.f, nullptr, 0, c->dH1T.as<T>(), Mxp, (int)Mx, D)));
+    }
+    ARP_TRY((splitk_gemm<T, float>(c, "dt.adapter_fc1_dW", c->dH1T.p, Mxp, c->XbT.p, Mxp, nullptr, ACT_NONE, c->g("AdapterMLP_0/Dense_0/kernel"), D, D, Mxp)));
+    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->dH1T.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_0/bias"), D);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// weight_l2 = sum p^2 over ndim > 1 params -> scal[1];  grads += wd * p there (main_procgen.py:114-117)
+int l2_penalty(arp_dt* c) {
+    ProfScope ps(c->prof, c->stream, "dt.l2_penalty");
+    const int nb = 1024;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, c->stream, c->params.as<float>(), c->n_decay, c->scal.as<float>() + 16);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, nb, 1.0f, c->scal.as<float>() + 1, 0);
+    hipLaunchKernelGGL(add_scaled_kernel, dim3(cdiv(c->n_decay, 256)), dim3(256), 0, c->stream, c->grads.as<float>(), c->params.as<float>(),
+                       c->cfg.weight_decay, c->n_decay);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int apply_update(arp_dt* c, float lr) {
+    ProfScope ps(c->prof, c->stream, "dt.clip_adam");
+    const int nb = 1024;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, c->stream, c->grads.as<float>(), c->P, c->scal.as<float>() + 16);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, nb, 1.0f, c->scal.as<float>() + 0, 0);
+    const double t = (double)(c->step + 1);
+    const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
+    const float gscale = 1.0f / (float)std::max(c->cfg.world, 1);
+    hipLaunchKernelGGL(adam_kernel, dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(), c->mu.as<float>(),
+                       c->nu.as<float>(), c->scal.as<float>(), gscale, c->cfg.clip_norm, lr, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P);
+    ARP_HIP_OK(hipGetLastError());
+    c->step += 1;
+    c->shadows_stale = true;
+    return 0;
+}
+
+template <typename T> int step_impl(arp_dt* c, float lr, float* aux) {
+    ARP_TRY(forward<T>(c));
+    ARP_TRY(backward<T>(c));
+    ARP_TRY(l2_penalty(c));
+    if (c->has_comm && c->cfg.world > 1) {
+        // pmean of (loss, aux, grads) over devices (main_procgen.py:132): ONE all-reduce(sum) of the flat
+        // gradient plus one of the 8 scalars; the 1/world factor is folded into the update kernel
+        ProfScope ps(c->prof, c->stream, "dt.allreduce");
+        if (rccl_api()->AllReduce(c->grads.p, c->grads.p, c->P, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(grads) failed");
+        if (rccl_api()->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(metrics) failed");
+    }
+    const long long step_before = c->step;
+    ARP_TRY(apply_update(c, lr));
+    if (aux) {
+        float m[4], s[2];
+        ARP_HIP_OK(hipMemcpyAsync(m, c->metrics.p, 16, hipMemcpyDeviceToHost, c->stream));
+        ARP_HIP_OK(hipMemcpyAsync(s, c->scal.p, 8, hipMemcpyDeviceToHost, c->stream));
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+        const float inv = 1.0f / (float)std::max(c->cfg.world, 1);
+        const float l2 = s[1], pen = c->cfg.weight_decay * 0.5f * l2;
+        aux[0] = m[0] * inv + pen;   // loss (incl. the L2 penalty)
+        aux[1] = m[1] * inv * 100.f; // acc * 100
+        aux[2] = m[2] * inv;         // trans_loss
+        aux[3] = m[3] * inv;         // return_loss
+        aux[4] = pen;                // weight_penalty
+        aux[5] = l2;                 // weight_l2
+        aux[6] = (float)step_before; // train_state_step
+        aux[7] = lr;                 // learning_rate
+        aux[8] = sqrtf(s[0]) * inv;  // (extra) global gradient norm before clipping
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =================================== C ABI ===============================================================
+extern "C" {
+
+int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
+    if (!cfg || !out) return fail("null argument");
+    const arp_dt_cfg& k = *cfg;
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16) return fail("bad mode");
+    if (k.emb <= 0 || k.heads <= 0 || k.emb % k.heads || k.emb % 4) return fail("emb must be a positive multiple of heads and of 4");
+    const int hd = k.emb / k.heads;
+    if (hd != 16 && hd != 32 && hd != 64) return fail("head_dim must be 16, 32 or 64");
+    const int kq = k.mode == ARP_MODE_BF16 ? 64 : 32;
+    if (k.enc_dim % kq || k.emb % kq) return fail("enc_dim and emb must be multiples of " + std::to_string(kq));
+    if (k.window <= 0 || 3 * k.window > 64) return fail("window must be in 1..21");
+    if (k.depth <= 0 || k.n_actions <= 0 || k.enc_tokens <= 0 || k.mlp_ratio <= 0) return fail("bad geometry");
+    int ndev = 0;
+    ARP_HIP_OK(hipGetDeviceCount(&ndev));
+    if (k.device < 0 || k.device >= ndev) return fail("no such HIP device: " + std::to_string(k.device));
+    ARP_HIP_OK(hipSetDevice(k.device));
+    arp_dt* c = new arp_dt();
+    c->cfg = k;
+    if (c->cfg.world <= 0) c->cfg.world = 1;
+    build_layout(c);
+    auto body = [&]() -> int {
+        ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
+        for (auto* b : fb) {
+            ARP_TRY(b->ensure(c->P * 4));
+            ARP_HIP_OK(hipMemset(b->p, 0, c->P * 4));
+        }
+        const size_t e = c->esz(), D = k.enc_dim, Kin = (size_t)k.enc_tokens * D;
+        if (k.use_adapter) { ARP_TRY(c->W1s.ensure(D * D * e)); ARP_TRY(c->W2s.ensure(D * D * e)); ARP_TRY(c->W2t.ensure(D * D * e)); }
+        ARP_TRY(c->Wis.ensure(Kin * k.emb * e)); ARP_TRY(c->Wit.ensure(Kin * k.emb * e));
+        return 0;
+    };
+    if (body() != 0) { arp_dt_destroy(c); return -1; }
+    *out = c;
+    return 0;
+}
+
+int arp_dt_destroy(arp_dt* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
+    c->prof.destroy();
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->enc32, &c->action, &c->rtg, &c->Xb, &c->XbT,
+                     &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
+                     &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
+                     &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv};
+    for (auto* b : all) b->release();
+    for (auto* v : {&c->xs, &c->ln0, &c->qkv, &c->att, &c->hmid, &c->ln1, &c->u, &c->gl})
+        for (auto& b : *v) b.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int arp_dt_num_params(arp_dt* c, int64_t* total, int32_t* n_tensors) {
+    if (!c) return fail("null handle");
+    size_t n = 0;
+    for (auto& pi : c->infos) n += pi.size;
+    if (total) *total = (int64_t)n;
+    if (n_tensors) *n_tensors = (int32_t)c->infos.size();
+    return 0;
+}
+
+int arp_dt_param_info(arp_dt* c, int i, char* name_buf, int name_len, int64_t* shape4, int32_t* ndim) {
+    if (!c || i < 0 || i >= (int)c->infos.size() || !name_buf || !shape4 || !ndim) return fail("bad argument");
+    const ParamInfo& pi = c->infos[i];
+    if ((int)pi.name.size() + 1 > name_len) return fail("name buffer too small");
+    memcpy(name_buf, pi.name.c_str(), pi.name.size() + 1);
+    *ndim = (int32_t)pi.shape.size();
+    for (size_t d = 0; d < pi.shape.size() && d < 4; ++d) shape4[d] = pi.shape[d];
+    return 0;
+}
+
+// which: 0 = params, 1 = grads, 2 = adam mu, 3 = adam nu.  Host data is in the Flax layout ([in, out] kernels).
+static int tensor_io(arp_dt* c, const char* name, int which, float* host, int write) {
+    if (!c || !name || !host) return fail("null argument");
+    auto it = c->index.find(name);
+    if (it == c->index.end()) return fail(std::string("unknown parameter: ") + name);
+    const ParamInfo& pi = c->infos[it->second];
+    DevBuf* bufs[] = {&c->params, &c->grads, &c->mu, &c->nu};
+    if (which < 0 || which > 3) return fail("bad tensor selector");
+    float* dev = bufs[which]->as<float>() + pi.off;
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    std::vector<float> tmp(pi.size);
+    if (write) {
+        if (pi.dense) {
+            for (int i = 0; i < pi.in; ++i)
+                for (int o = 0; o < pi.out; ++o) tmp[(size_t)o * pi.in + i] = host[(size_t)i * pi.out + o];
+        } else {
+            memcpy(tmp.data(), host, pi.size * 4);
+        }
+        ARP_HIP_OK(hipMemcpy(dev, tmp.data(), pi.size * 4, hipMemcpyHostToDevice));
+        if (which == 0) c->shadows_stale = true;
+    } else {
+        ARP_HIP_OK(hipMemcpy(tmp.data(), dev, pi.size * 4, hipMemcpyDeviceToHost));
+        if (pi.dense) {
+            for (int i = 0; i < pi.in; ++i)
+                for (int o = 0; o < pi.out; ++o) host[(size_t)i * pi.out + o] = tmp[(size_t)o * pi.in + i];
+        } else {
+            memcpy(host, tmp.data(), pi.size * 4);
+        }
+    }
+    return 0;
+}
+int arp_dt_set_tensor(arp_dt* c, const char* name, int which, const float* data) { return tensor_io(c, name, which, const_cast<float*>(data), 1); }
+int arp_dt_get_tensor(arp_dt* c, const char* name, int which, float* out) { return tensor_io(c, name, which, out, 0); }
+int arp_dt_set_step(arp_dt* c, int64_t step) {
+    if (!c || step < 0) return fail("bad argument");
+    c->step = step;
+    return 0;
+}
+int arp_dt_get_step(arp_dt* c, int64_t* step) {
+    if (!c || !step) return fail("bad argument");
+    *step = c->step;
+    return 0;
+}
+
+int arp_dt_set_batch(arp_dt* c, const float* enc, const int32_t* action, const float* rtg, int B) {
+    if (!c || !enc || !action || !rtg || B <= 0) return fail("bad argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    const int R = B * c->cfg.window;
+    for (int i = 0; i < R; ++i)
+        if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
+    ARP_TRY(ensure_buffers(c, B));
+    const size_t Mx = (size_t)R * c->cfg.enc_tokens;
+    ARP_HIP_OK(hipMemcpyAsync(c->enc32.p, enc, Mx * c->cfg.enc_dim * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_dt_forward(arp_dt* c, float* action_logits, float* return_pred, float* metrics) {
+    if (!c) return fail("null handle");
+    if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : forward<float>(c));
+    const int R = c->R();
+    if (action_logits) ARP_HIP_OK(hipMemcpyAsync(action_logits, c->logits.p, (size_t)R * c->cfg.n_actions * 4, hipMemcpyDeviceToHost, c->stream));
+    if (return_pred) ARP_HIP_OK(hipMemcpyAsync(return_pred, c->ret.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
+    if (metrics) ARP_HIP_OK(hipMemcpyAsync(metrics, c->metrics.p, 16, hipMemcpyDeviceToHost, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_dt_backward(arp_dt* c) {
+    if (!c) return fail("null handle");
+    if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(forward<bf16_t>(c)); ARP_TRY(backward<bf16_t>(c)); }
+    else { ARP_TRY(forward<float>(c)); ARP_TRY(backward<float>(c)); }
+    ARP_TRY(l2_penalty(c));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_dt_train_step_async(arp_dt* c, float lr) {
+    if (!c) return fail("null handle");
+    if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, nullptr) : step_impl<float>(c, lr, nullptr);
+}
+
+int arp_dt_train_step(arp_dt* c, float lr, float* aux) {
+    if (!c || !aux) return fail("null argument");
+    if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, aux) : step_impl<float>(c, lr, aux);
+}
+
+int arp_dt_sync(arp_dt* c) {
+    if (!c) return fail("null handle");
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_dt_event_record(arp_dt* c, arp_event* e) {
+    if (!c || !e) return fail("null argument");
+    ARP_HIP_OK(hipEventRecord(e->e, c->stream));
+    return 0;
+}
+
+int arp_dt_comm_unique_id(void* id128) {
+    if (!id128) return fail("null argument");
+    if (!rccl_api()) return fail("librccl.so.1 could not be loaded");
+    ncclUniqueId id;
+    if (rccl_api()->GetUniqueId(&id) != ncclSuccess) return fail("ncclGetUniqueId failed");
+    static_assert(sizeof(ncclUniqueId) == 128, "unexpected ncclUniqueId size");
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+int arp_dt_comm_init(arp_dt* c, const void* id128, int world, int rank) {
+    if (!c || !id128 || world <= 0 || rank < 0 || rank >= world) return fail("bad argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    if (!rccl_api()) return fail("librccl.so.1 could not be loaded");
+    if (rccl_api()->CommInitRank(&c->comm, world, id, rank) != ncclSuccess) return fail("ncclCommInitRank failed");
+    c->has_comm = true;
+    c->cfg.world = world;
+    c->cfg.rank = rank;
+    return 0;
+}
+
+// sync_state_fn (main_procgen.py:94-101): every rank takes rank 0's params and optimizer state
+int arp_dt_broadcast_state(arp_dt* c) {
+    if (!c) return fail("null handle");
+    if (!c->has_comm) return 0;
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    DevBuf* fb[] = {&c->params, &c->mu, &c->nu};
+    for (auto* b : fb)
+        if (rccl_api()->Broadcast(b->p, b->p, c->P, ncclFloat, 0, c->comm, c->stream) != ncclSuccess) return fail("ncclBroadcast failed");
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    c->shadows_stale = true;
+    return 0;
+}
+
+int arp_dt_profile_enable(arp_dt* c, int on) {
+    if (!c) return fail("null handle");
+    c->prof.on = on != 0;
+    return 0;
+}
+int arp_dt_profile_reset(arp_dt* c) {
+    if (!c) return fail("null handle");
+    c->prof.reset();
+    return 0;
+}
+int arp_dt_profile_json(arp_dt* c, char* buf, int buf_len) {
+    if (!c || !buf) return fail("null argument");
+    const std::string s = c->prof.json();
+    if ((int)s.size() + 1 > buf_len) return fail("profile buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+}  // extern "C"

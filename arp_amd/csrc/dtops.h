@@ -1,0 +1,463 @@
+// Kernels of path (2), the ARP-DT policy train step (reference: arp_dt/ARPDT.py, arp_dt/layers.py,
+// arp_dt/main_procgen.py:104-141,490-507).  The big contractions (adapter MLP, image_text_input and
+// their weight/input gradients) run on the MFMA GEMM kernels of gemm.h / gemm256.h; everything here is
+// the glue around them: layout transposes, masks, the tiny 12-token transformer (f32, VALU), losses,
+// reductions and the fused clip + Adam update.  All reductions are fixed-order (no float atomics), so a
+// step is bitwise reproducible.
+#pragma once
+#include "common.h"
+
+namespace arp {
+
+// ---- generic small f32 GEMM:  C[M,N] (+)= act(opA(A) . opB(B) + bias)  (+ resid) -------------------
+// opA(A)[m,k] = ta ? A[k*lda + m] : A[m*lda + k];  opB(B)[k,n] = tb ? B[n*ldb + k] : B[k*ldb + n].
+// 32x32 output tile per 256-thread block (2x2 per thread), K in steps of 16 through LDS.  Used for the
+// policy transformer (M = B*12 rows, E = 128): a few MFLOP per call, latency- not throughput-bound.
+struct SmallGemm {
+    const float* A; const float* B; const float* bias; const float* resid; float* C;
+    int M, N, K, lda, ldb, ldc, ta, tb, act, accumulate;
+};
+
+__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
+    __shared__ float As[16][33];
+    __shared__ float Bs[16][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        for (int i = threadIdx.x; i < 512; i += 256) {
+            const int kk = i & 15, r = i >> 4;  // r: 0..31
+            const int m = m0 + r, n = n0 + r, k = k0 + kk;
+            float a = 0.f, b = 0.f;
+            if (k < g.K) {
+                if (m < g.M) a = g.ta ? g.A[(size_t)k * g.lda + m] : g.A[(size_t)m * g.lda + k];
+                if (n < g.N) b = g.tb ? g.B[(size_t)n * g.ldb + k] : g.B[(size_t)k * g.ldb + n];
+            }
+            As[kk][r] = a;
+            Bs[kk][r] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
+            const float b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + ty * 2 + i, n = n0 + tx * 2 + j;
+            if (m < g.M && n < g.N) {
+                float v = acc[i][j] + (g.bias ? g.bias[n] : 0.f);
+                if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (g.act == ACT_TANH) v = tanhf(v);
+                else if (g.act == ACT_GELU_TANH) v = apply_act<ACT_GELU_TANH>(v);
+                if (g.resid) v += g.resid[(size_t)m * g.ldc + n];
+                float* c = g.C + (size_t)m * g.ldc + n;
+                *c = g.accumulate ? *c + v : v;
+            }
+        }
+}
+
+// ---- split-K partial reduce:  out[m,n] = act(sum_s part[s,m,n] + bias[n]) ---------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t MN, int N,
+                                                            const float* __restrict__ bias, int act, OutT* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MN) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * MN + i];
+    if (bias) s += bias[i % N];
+    if (act == ACT_TANH) s = tanhf(s);
+    else if (act == ACT_RELU) s = fmaxf(s, 0.f);
+    Elem<OutT>::st(out + i, s);
+}
+
+// ---- f32 -> T conversion ----------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float v[4];
+        load4(in + i, v);
+        store4(out + i, v[0], v[1], v[2], v[3]);
+    } else {
+        for (size_t j = i; j < n; ++j) Elem<T>::st(out + j, in[j]);
+    }
+}
+
+// ---- tiled transpose with optional mask/scale:  ---------------------------------------------------------
+//   v[r,c] = scale * in[r,c] * (mask ? mask[r,c] > 0 : 1)
+//   outN[r*ldn + c] = v (if outN)        outT[c*ldt + r] = v (if outT)
+// 64x64 tiles through LDS; both the read and the two writes are row-contiguous.
+template <typename TI, typename TM, typename TO>
+__global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restrict__ in, int ldi, const TM* __restrict__ mask,
+                                                             const float* __restrict__ scale_ptr, float scale, TO* __restrict__ outN,
+                                                             int ldn, TO* __restrict__ outT, int ldt, int R, int Ccols) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const float s = scale_ptr ? scale * scale_ptr[0] : scale;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int lr = i >> 6, lc = i & 63;
+        const int r = r0 + lr, c = c0 + lc;
+        float v = 0.f;
+        if (r < R && c < Ccols) {
+            v = Elem<TI>::ld(in + (size_t)r * ldi + c) * s;
+            if (mask && !(Elem<TM>::ld(mask + (size_t)r * ldi + c) > 0.f)) v = 0.f;
+            if (outN) Elem<TO>::st(outN + (size_t)r * ldn + c, v);
+        }
+        tile[lr][lc] = v;
+    }
+    if (!outT) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int lc = i >> 6, lr = i & 63;  // consecutive threads -> consecutive r (contiguous in outT)
+        const int r = r0 + lr, c = c0 + lc;
+        if (r < R && c < Ccols) Elem<TO>::st(outT + (size_t)c * ldt + r, tile[lr][lc]);
+    }
+}
+
+// ---- adapter mix (arp_dt/ARPDT.py:466-472):  y = res*a + (1-res)*x,  res = sigmoid(residual_weight) -----
+template <typename T>
+__global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ a, const T* __restrict__ x, const float* __restrict__ rw,
+                                                          T* __restrict__ y, size_t n) {
+    const float res = 1.0f / (1.0f + expf(-rw[0]));
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float av[4], xv[4];
+        load4(a + i, av);
+        load4(x + i, xv);
+        store4(y + i, res * av[0] + (1.f - res) * xv[0], res * av[1] + (1.f - res) * xv[1], res * av[2] + (1.f - res) * xv[2],
+               res * av[3] + (1.f - res) * xv[3]);
+    } else {
+        for (size_t j = i; j < n; ++j) Elem<T>::st(y + j, res * Elem<T>::ld(a + j) + (1.f - res) * Elem<T>::ld(x + j));
+    }
+}
+
+// partial[b] = sum over the block's slice of dy * (a - x)      (d loss / d res; finished by reduce_sum)
+template <typename T>
+__global__ __launch_bounds__(256) void adapter_dres_kernel(const T* __restrict__ dy, const T* __restrict__ a, const T* __restrict__ x,
+                                                           float* __restrict__ partial, size_t n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        s += Elem<T>::ld(dy + i) * (Elem<T>::ld(a + i) - Elem<T>::ld(x + i));
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] (+)= scale * sum_i in[i]   -- single block, fixed order
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ in, int n, float scale, float* __restrict__ out,
+                                                         int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = scale * ((red[0] + red[1]) + (red[2] + red[3]));
+        out[0] = accumulate ? out[0] + v : v;
+    }
+}
+
+__global__ void sigmoid_scalar_kernel(float* x) { x[0] = 1.0f / (1.0f + expf(-x[0])); }
+
+// residual_weight gradient: d/d rw = dres * res * (1 - res)
+__global__ void dres_to_drw_kernel(const float* __restrict__ dres, const float* __restrict__ rw, float* __restrict__ grad) {
+    const float res = 1.0f / (1.0f + expf(-rw[0]));
+    grad[0] = dres[0] * res * (1.f - res);
+}
+
+// ---- row sums of a [R, ld] matrix (bias gradients from the TRANSPOSED gradient: one row per output unit)
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, int ld, int cols, float* __restrict__ out, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* r = in + (size_t)row * ld;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += Elem<T>::ld(r + c);
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+// column sums of a small [R, C] f32 matrix: out[c] = sum_r in[r, c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += in[(size_t)r * C + c];
+    out[c] = s;
+}
+
+// ---- LayerNorm forward (f32 in/out, saves nothing: backward recomputes the statistics) ------------------
+__global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* __restrict__ y, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    for (int c = lane; c < D; c += 64) y[(size_t)row * D + c] = (xr[c] - mean) * rstd * w[c] + b[c];
+}
+// LayerNorm backward: dx (written or accumulated), and per-row contributions to dscale / dbias
+// (dws[row, c] = dy*xhat, dbs[row, c] = dy; summed over rows by colsum_kernel).
+__global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+                                                         float* __restrict__ dx, int accumulate, float* __restrict__ dws,
+                                                         float* __restrict__ dbs, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    const float* dyr = dy + (size_t)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    float s1 = 0.f, s2 = 0.f;  // sum(g), sum(g * xhat), g = dy * w
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, gg = dyr[c] * w[c];
+        s1 += gg;
+        s2 += gg * xh;
+        dws[(size_t)row * D + c] = dyr[c] * xh;
+        dbs[(size_t)row * D + c] = dyr[c];
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, gg = dyr[c] * w[c];
+        const float v = rstd * (gg - s1 - xh * s2);
+        float* o = dx + (size_t)row * D + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+// ---- causal multi-head attention backward for the policy (L <= 64 tokens, head_dim <= 64), f32 ---------
+// qkv [B*L, 3E], dout [B*L, E] -> dqkv [B*L, 3E].  One workgroup per (sample, head); probabilities are
+// recomputed (arp_dt/layers.py:70-90: scale, masked fill, softmax).
+__global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                            float* __restrict__ dqkv, int L, int E, int heads, float scale) {
+    extern __shared__ float sm[];
+    const int hd = E / heads;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    float* q = sm;                // [L][hd]
+    float* k = q + L * hd;        // [L][hd]
+    float* v = k + L * hd;        // [L][hd]
+    float* dO = v + L * hd;       // [L][hd]
+    float* P = dO + L * hd;       // [L][L]
+    float* dS = P + L * L;        // [L][L]
+    const size_t ld = 3 * (size_t)E;
+    for (int i = threadIdx.x; i < L * hd; i += 64) {
+        const int t = i / hd, d = i - t * hd;
+        const size_t row = (size_t)b * L + t;
+        q[i] = qkv[row * ld + h * hd + d];
+        k[i] = qkv[row * ld + E + h * hd + d];
+        v[i] = qkv[row * ld + 2 * E + h * hd + d];
+        dO[i] = dout[row * E + h * hd + d];
+    }
+    __syncthreads();
+    // probabilities, one query row per thread
+    for (int i = threadIdx.x; i < L; i += 64) {
+        float mx = -INFINITY;
+        for (int j = 0; j <= i; ++j) {
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s = fmaf(q[i * hd + d], k[j * hd + d], s);
+            s *= scale;
+            P[i * L + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j <= i; ++j) { const float e = expf(P[i * L + j] - mx); P[i * L + j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        // dP = dO . V^T ; dS = P * (dP - sum_j P dP)
+        float dot = 0.f;
+        for (int j = 0; j <= i; ++j) {
+            const float p = P[i * L + j] * inv;
+            P[i * L + j] = p;
+            float dp = 0.f;
+            for (int d = 0; d < hd; ++d) dp = fmaf(dO[i * hd + d], v[j * hd + d], dp);
+            dS[i * L + j] = dp;
+            dot += p * dp;
+        }
+        for (int j = 0; j < L; ++j) {
+            if (j <= i) dS[i * L + j] = P[i * L + j] * (dS[i * L + j] - dot) * scale;
+            else { dS[i * L + j] = 0.f; P[i * L + j] = 0.f; }
+        }
+    }
+    __syncthreads();
+    // dq[i] = sum_j dS[i,j] k[j];  dk[j] = sum_i dS[i,j] q[i];  dv[j] = sum_i P[i,j] dO[i]
+    for (int idx = threadIdx.x; idx < L * hd; idx += 64) {
+        const int t = idx / hd, d = idx - t * hd;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < L; ++j) {
+            dq = fmaf(dS[t * L + j], k[j * hd + d], dq);
+            dk = fmaf(dS[j * L + t], q[j * hd + d], dk);
+            dv = fmaf(P[j * L + t], dO[j * hd + d], dv);
+        }
+        const size_t row = (size_t)b * L + t;
+        dqkv[row * ld + h * hd + d] = dq;
+        dqkv[row * ld + E + h * hd + d] = dk;
+        dqkv[row * ld + 2 * E + h * hd + d] = dv;
+    }
+}
+
+// ---- token assembly (arp_dt/ARPDT.py:159-172,278-293): per time step [image, rtg, action] -------------
+// tok[(b*T + t)*3 + 0] = img[b*T+t];  +1 = rtg[b*T+t] * Wr;  +2 = Emb[action[b*T+t]]
+__global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict__ img, const float* __restrict__ rtg,
+                                                         const int* __restrict__ action, const float* __restrict__ Wr,
+                                                         const float* __restrict__ emb, float* __restrict__ tok, int R, int E) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * E) return;
+    const int r = i / E, e = i - r * E;
+    tok[((size_t)r * 3 + 0) * E + e] = img[i];
+    tok[((size_t)r * 3 + 1) * E + e] = rtg[r] * Wr[e];
+    tok[((size_t)r * 3 + 2) * E + e] = emb[(size_t)action[r] * E + e];
+}
+// backward: dimg = dtok[.,0];  dWr[e] = sum_r rtg[r]*dtok[r,1,e];  dEmb[a,e] = sum_{r: action=a} dtok[r,2,e]
+__global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ rtg,
+                                                         const int* __restrict__ action, float* __restrict__ dimg,
+                                                         float* __restrict__ dWr, float* __restrict__ demb, int R, int E, int n_actions) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    float wr = 0.f;
+    for (int a = 0; a < n_actions; ++a) demb[(size_t)a * E + e] = 0.f;
+    for (int r = 0; r < R; ++r) {
+        dimg[(size_t)r * E + e] = dtok[((size_t)r * 3 + 0) * E + e];
+        wr += rtg[r] * dtok[((size_t)r * 3 + 1) * E + e];
+        demb[(size_t)action[r] * E + e] += dtok[((size_t)r * 3 + 2) * E + e];
+    }
+    dWr[e] = wr;
+}
+
+// gather / scatter of the head inputs (arp_dt/ARPDT.py:203-205): action head <- rtg-token rows (1::3),
+// return head <- image-token rows (0::3)
+__global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restrict__ hf, float* __restrict__ a_in, float* __restrict__ r_in,
+                                                           int R, int E) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * E) return;
+    const int r = i / E, e = i - r * E;
+    r_in[i] = hf[((size_t)r * 3 + 0) * E + e];
+    a_in[i] = hf[((size_t)r * 3 + 1) * E + e];
+}
+__global__ __launch_bounds__(256) void heads_scatter_kernel(const float* __restrict__ da_in, const float* __restrict__ dr_in,
+                                                            float* __restrict__ dhf, int R, int E) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * E) return;
+    const int r = i / E, e = i - r * E;
+    dhf[((size_t)r * 3 + 0) * E + e] = dr_in[i];
+    dhf[((size_t)r * 3 + 1) * E + e] = da_in[i];
+    dhf[((size_t)r * 3 + 2) * E + e] = 0.f;
+}
+
+// ---- elementwise backward helpers -----------------------------------------------------------------------
+enum { EW_RELU_BWD = 0, EW_TANH_BWD = 1, EW_GELU_BWD = 2 };
+// RELU_BWD: out = g * (y > 0)   (ref = activation output)
+// TANH_BWD: out = g * (1 - y^2) (ref = activation output)
+// GELU_BWD: out = g * gelu_tanh'(u) (ref = PRE-activation)
+__global__ __launch_bounds__(256) void ew_bwd_kernel(const float* __restrict__ g, const float* __restrict__ ref, float* __restrict__ out,
+                                                     size_t n, int op) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float r = ref[i];
+    float d;
+    if (op == EW_RELU_BWD) d = r > 0.f ? 1.f : 0.f;
+    else if (op == EW_TANH_BWD) d = 1.f - r * r;
+    else {
+        const float c = 0.7978845608028654f, a = 0.044715f;
+        const float t = tanhf(c * (r + a * r * r * r));
+        d = 0.5f * (1.f + t) + 0.5f * r * (1.f - t * t) * c * (1.f + 3.f * a * r * r);
+    }
+    out[i] = g[i] * d;
+}
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = apply_act<ACT_GELU_TANH>(u[i]);
+}
+
+// ---- losses (arp_dt/ARPDT.py:238-261,498-507), single block; also the gradients w.r.t. logits / return ---
+// metrics: [0] loss = trans + lambda*ret, [1] acc (fraction), [2] trans_loss, [3] return_loss
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ logits, const float* __restrict__ ret,
+                                                   const int* __restrict__ action, const float* __restrict__ rtg, int R, int NA,
+                                                   float lambda, float* __restrict__ metrics, float* __restrict__ dlogits,
+                                                   float* __restrict__ dret) {
+    __shared__ float red[3][4];
+    float ce = 0.f, hit = 0.f, se = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float* l = logits + (size_t)r * NA;
+        float mx = l[0];
+        int am = 0;
+        for (int c = 1; c < NA; ++c)
+            if (l[c] > mx) { mx = l[c]; am = c; }
+        float sum = 0.f;
+        for (int c = 0; c < NA; ++c) sum += expf(l[c] - mx);
+        const float lse = logf(sum) + mx;
+        const int lab = action[r];
+        ce += lse - l[lab];
+        hit += (am == lab) ? 1.f : 0.f;
+        for (int c = 0; c < NA; ++c) dlogits[(size_t)r * NA + c] = (expf(l[c] - lse) - (c == lab ? 1.f : 0.f)) / ((float)R * NA);
+        const float d = ret[r] - rtg[r];
+        se += d * d;
+        dret[r] = lambda * 2.f * d / (float)R;
+    }
+    ce = wave_sum(ce); hit = wave_sum(hit); se = wave_sum(se);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ce; red[1][threadIdx.x >> 6] = hit; red[2][threadIdx.x >> 6] = se; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tce = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float th = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const float tse = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        const float trans = tce / ((float)R * NA), rl = tse / (float)R;
+        metrics[0] = trans + lambda * rl;
+        metrics[1] = th / (float)R;
+        metrics[2] = trans;
+        metrics[3] = rl;
+    }
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------------------
+// partial[b] = sum of x^2 over the block's grid-stride slice of [begin, end)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// g += wd * p on a range (the explicit L2 term of main_procgen.py:114-117 differentiates to wd * p)
+__global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ g, const float* __restrict__ p, float wd, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g[i] += wd * p[i];
+}
+// scal: [0] = sum of squares of the (already averaged-over-ranks) gradient.
+// optax.clip_by_global_norm(c) then adam (b1, b2, eps outside the sqrt, bias correction with t = step+1);
+// the adamw decay mask of the reference is all-False, so no decoupled decay.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
+                                                   float* __restrict__ nu, const float* __restrict__ scal, float gscale, float clip,
+                                                   float lr, float b1, float b2, float eps, float bc1, float bc2, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gnorm = sqrtf(scal[0]) * gscale;
+    const float s = (gnorm < clip) ? gscale : gscale / gnorm * clip;
+    const float gi = g[i] * s;
+    const float m = b1 * mu[i] + (1.f - b1) * gi;
+    const float v = b2 * nu[i] + (1.f - b2) * gi * gi;
+    mu[i] = m;
+    nu[i] = v;
+    p[i] -= lr * (m / bc1) / (sqrtf(v / bc2) + eps);
+}
+
+}  // namespace arp

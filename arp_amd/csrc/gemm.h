@@ -29,6 +29,8 @@ struct GemmArgs {
     int M, N, K;
     int lda, ldw, ldr, ldo;
     int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only)
+    int ksplit = 1;     // split-K: gridDim.y slices of K; slice s writes to out + s * slice_stride (bias/resid ignored by callers)
+    size_t slice_stride = 0;
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
@@ -79,14 +81,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
         wn = wn < g.N ? wn : g.N - 1;
         w_src[i] = W + (size_t)wn * g.ldw + schunk * EPC;
     }
+    int kt0 = 0;
+    int nk = g.K / EPB;
+    if (g.ksplit > 1) {  // this block's K-tile range
+        const int per = (nk + g.ksplit - 1) / g.ksplit;
+        kt0 = blockIdx.y * per;
+        nk = min(per, nk - kt0);
+    }
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * GEMM_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             char* dst = base + (i * 4 + wave) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * EPB),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)(kt0 + kt) * EPB),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (size_t)kt * EPB),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + (size_t)(kt0 + kt) * EPB),
                                              (__attribute__((address_space(3))) void*)(dst + GEMM_BM * GEMM_ROW_BYTES), 16, 0, 0);
         }
     };
@@ -111,7 +120,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / EPB;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane holds, per (ni, mi): m = .. + fr, n = .. + 4*fg + {0,1,2,3} ----------------
-    OutT* out = static_cast<OutT*>(g.out);  // may alias g.resid (in-place residual add)
+    OutT* out = static_cast<OutT*>(g.out) + (size_t)blockIdx.y * g.slice_stride;  // may alias g.resid (in-place residual add)
     const bool vec_ok = ((g.N | g.ldo | g.ldr) & 3) == 0;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -206,7 +214,7 @@ inline int launch_gemm_nt(const GemmArgs& g, hipStream_t stream) {
     }
     const int m_tiles = (g.M + GEMM_BM - 1) / GEMM_BM;
     const int n_tiles = (g.N + GEMM_BN - 1) / GEMM_BN;
-    hipLaunchKernelGGL(kern, dim3(m_tiles * n_tiles), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL(kern, dim3(m_tiles * n_tiles, g.ksplit > 1 ? g.ksplit : 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, g);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }

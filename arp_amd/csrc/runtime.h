@@ -7,6 +7,11 @@
 
 #include "common.h"
 
+// the C ABI's opaque event (include/arp_hip.h)
+struct arp_event {
+    hipEvent_t e;
+};
+
 namespace arp {
 
 struct DevBuf {

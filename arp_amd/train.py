@@ -1,6 +1,237 @@
-"""Path (2): return-conditioned policy train step (mirror of create_train_step,
-/root/reference/arp_dt/main_procgen.py:104-141).  Under construction."""
+"""Path (2): the ARP-DT policy train step on MI355X, behind the reference's call surface.
+
+Mirrors /root/reference/arp_dt/main_procgen.py:
+  * ``create_train_step(model, learning_rate, weight_decay) -> train_step_fn`` (:104-141)
+  * ``train_step_fn(state, batch, rng) -> (new_state, aux, next_rng)`` with the reference's ``aux`` keys
+    (``loss, acc, trans_loss, return_loss, weight_penalty, weight_l2, train_state_step, learning_rate``)
+  * ``sync_state_fn`` (:94-101) = :meth:`PolicyTrainer.broadcast_state`
+and ARPDT.__call__ (arp_dt/ARPDT.py:152-236) = :meth:`PolicyTrainer.forward`.
+
+``model`` is the policy configuration (the reference passes an ``ARPDT`` flax module built from
+``FLAGS.model``; jax/flax do not exist here, so a :class:`PolicyConfig` or a dict of the same fields
+stands in).  ``state`` is a :class:`TrainState` wrapping the device-resident parameters, Adam moments and
+step counter; like the reference's donated state it is consumed by the call and the returned one must be
+used.  ``batch`` keeps the reference's keys: ``batch["image"]`` holds, per image key, the frozen encoder
+output ``[B, T, tokens, dim]`` (the boundary of this round: BASELINE.json configs[3] feeds pre-computed
+encodings), ``batch["action"]`` int ``[B, T]``, ``batch["rtg"]`` per key ``[B, T, 1]``.
+All compute is in libarp_hip.so; there is no CPU fallback.
+"""
+import ctypes as C
+import json
+from dataclasses import asdict, dataclass
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import MODE_BF16, MODE_F32, check, lib
+
+AUX_KEYS = ("loss", "acc", "trans_loss", "return_loss", "weight_penalty", "weight_l2", "train_state_step", "learning_rate")
 
 
-def smoke():
-    raise NotImplementedError
+@dataclass(frozen=True)
+class PolicyConfig:
+    """ARPDT.get_default_config fields that shape the shipped policy (arp_dt/ARPDT.py:27-66)."""
+    emb: int = 128
+    depth: int = 2
+    heads: int = 8
+    mlp_ratio: int = 4
+    n_actions: int = 15
+    window: int = 4
+    enc_tokens: int = 257
+    enc_dim: int = 768
+    use_adapter: bool = True
+    lambda_ret: float = 1.0
+    weight_decay: float = 5e-5
+    clip_norm: float = 10.0
+    b1: float = 0.9
+    b2: float = 0.999
+    eps: float = 1e-8
+
+
+class PolicyTrainer:
+    """Owns one GPU's copy of the policy: parameters, Adam state, activations, RCCL communicator."""
+
+    def __init__(self, cfg, mode="bf16", device=0):
+        _ffi.require_gpu()
+        self.cfg = cfg
+        c = _ffi.DtCfg(cfg.emb, cfg.depth, cfg.heads, cfg.mlp_ratio, cfg.n_actions, cfg.window, cfg.enc_tokens, cfg.enc_dim,
+                       int(cfg.use_adapter), {"bf16": MODE_BF16, "f32": MODE_F32}[mode], device, 1, 0, cfg.lambda_ret,
+                       cfg.weight_decay, cfg.clip_norm, cfg.b1, cfg.b2, cfg.eps)
+        h = C.c_void_p()
+        check(lib.arp_dt_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self.world, self.rank = 1, 0
+        self.shapes = {}
+        n = C.c_int32()
+        tot = C.c_int64()
+        check(lib.arp_dt_num_params(h, C.byref(tot), C.byref(n)))
+        self.num_params = tot.value
+        buf = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int32()
+        for i in range(n.value):
+            check(lib.arp_dt_param_info(h, i, buf, 256, shape, C.byref(nd)))
+            self.shapes[buf.value.decode()] = tuple(shape[d] for d in range(nd.value))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.arp_dt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- tensors (Flax tree path -> array, Flax layout) ---------------------------------------------
+    def set_tensors(self, tree, which=0):
+        for name, val in tree.items():
+            a = np.require(np.asarray(val, dtype=np.float32), requirements="C")
+            if tuple(a.shape) != self.shapes[name]:
+                raise ValueError(f"{name}: shape {a.shape}, expected {self.shapes[name]}")
+            check(lib.arp_dt_set_tensor(self._h, name.encode(), which, _ffi.as_ptr(a, C.c_float)))
+
+    def get_tensors(self, which=0, names=None):
+        out = {}
+        for name in (names or self.shapes):
+            a = np.empty(self.shapes[name], np.float32)
+            check(lib.arp_dt_get_tensor(self._h, name.encode(), which, _ffi.as_ptr(a, C.c_float)))
+            out[name] = a
+        return out
+
+    set_params = set_tensors
+
+    def get_params(self):
+        return self.get_tensors(0)
+
+    def get_grads(self):
+        return self.get_tensors(1)
+
+    @property
+    def step(self):
+        s = C.c_int64()
+        check(lib.arp_dt_get_step(self._h, C.byref(s)))
+        return s.value
+
+    @step.setter
+    def step(self, v):
+        check(lib.arp_dt_set_step(self._h, int(v)))
+
+    # -- compute --------------------------------------------------------------------------------------
+    def set_batch(self, enc, action, rtg):
+        enc = np.require(np.asarray(enc, dtype=np.float32), requirements="C")
+        action = np.require(np.asarray(action, dtype=np.int32), requirements="C")
+        rtg = np.require(np.asarray(rtg, dtype=np.float32), requirements="C")
+        B, T = action.shape
+        if enc.shape != (B, T, self.cfg.enc_tokens, self.cfg.enc_dim) or rtg.size != B * T or T != self.cfg.window:
+            raise ValueError(f"batch shapes: enc {enc.shape}, action {action.shape}, rtg {rtg.shape}")
+        check(lib.arp_dt_set_batch(self._h, _ffi.as_ptr(enc, C.c_float), _ffi.as_ptr(action, C.c_int32), _ffi.as_ptr(rtg, C.c_float), B))
+        self._B = B
+
+    def forward(self):
+        """ARPDT.__call__ (ARPDT.py:152-236) on the staged batch."""
+        B, T, NA = self._B, self.cfg.window, self.cfg.n_actions
+        logits = np.empty((B, T, NA), np.float32)
+        ret = np.empty((B, T, 1), np.float32)
+        m = np.empty(4, np.float32)
+        check(lib.arp_dt_forward(self._h, _ffi.as_ptr(logits, C.c_float), _ffi.as_ptr(ret, C.c_float), _ffi.as_ptr(m, C.c_float)))
+        return {"action_pred": logits, "return_pred": ret, "loss": float(m[0]), "acc": float(m[1]), "trans_loss": float(m[2]),
+                "return_loss": float(m[3])}
+
+    def backward(self):
+        check(lib.arp_dt_backward(self._h))
+
+    def train_step(self, lr):
+        aux = np.empty(9, np.float32)
+        check(lib.arp_dt_train_step(self._h, float(lr), _ffi.as_ptr(aux, C.c_float)))
+        d = {k: float(aux[i]) for i, k in enumerate(AUX_KEYS)}
+        d["train_state_step"] = int(aux[6])
+        d["grad_norm"] = float(aux[8])
+        return d
+
+    def train_step_async(self, lr):
+        check(lib.arp_dt_train_step_async(self._h, float(lr)))
+
+    def sync(self):
+        check(lib.arp_dt_sync(self._h))
+
+    def record(self, event):
+        check(lib.arp_dt_event_record(self._h, event.ptr))
+
+    # -- data parallelism (one process per GPU, RCCL over xGMI) ---------------------------------------
+    @staticmethod
+    def new_unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib.arp_dt_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, world, rank):
+        check(lib.arp_dt_comm_init(self._h, C.create_string_buffer(unique_id, 128), world, rank))
+        self.world, self.rank = world, rank
+
+    def broadcast_state(self):
+        """sync_state_fn (main_procgen.py:94-101)."""
+        check(lib.arp_dt_broadcast_state(self._h))
+
+    def profile(self, on=True):
+        check(lib.arp_dt_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        check(lib.arp_dt_profile_reset(self._h))
+
+    def profile_read(self):
+        buf = C.create_string_buffer(1 << 16)
+        check(lib.arp_dt_profile_json(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+
+class TrainState:
+    """The reference's flax ``TrainState`` (params + optax state + step), resident on the GPU."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+        self._live = True
+
+    @classmethod
+    def create(cls, model, params, mode="bf16", device=0):
+        cfg = model if isinstance(model, PolicyConfig) else PolicyConfig(**dict(model))
+        tr = PolicyTrainer(cfg, mode=mode, device=device)
+        tr.set_params(params)
+        return cls(tr)
+
+    @property
+    def step(self):
+        return self.trainer.step
+
+    @property
+    def params(self):
+        return self.trainer.get_params()
+
+
+def _batch_arrays(batch):
+    image = batch["image"]
+    enc = next(iter(image.values())) if isinstance(image, dict) else image
+    rtg = batch["rtg"]
+    rtg = np.mean(np.stack([np.asarray(v, np.float32) for v in rtg.values()]), axis=0) if isinstance(rtg, dict) else rtg
+    return np.asarray(enc), np.asarray(batch["action"]), np.asarray(rtg)
+
+
+def create_train_step(model, learning_rate, weight_decay):
+    """main_procgen.py:104-141.  ``learning_rate`` is the schedule ``step -> lr`` (``:135``)."""
+    cfg = model if isinstance(model, PolicyConfig) else PolicyConfig(**dict(model))
+    if abs(cfg.weight_decay - weight_decay) > 1e-12:
+        cfg = PolicyConfig(**{**asdict(cfg), "weight_decay": float(weight_decay)})
+
+    def train_step_fn(state, batch, rng):
+        if not state._live:
+            raise RuntimeError("this TrainState was donated to a previous train_step_fn call (donate_argnums=0)")
+        tr = state.trainer
+        if abs(tr.cfg.weight_decay - cfg.weight_decay) > 1e-12:
+            raise ValueError("state was created with a different weight_decay than create_train_step")
+        tr.set_batch(*_batch_arrays(batch))
+        aux = tr.train_step(learning_rate(tr.step))
+        state._live = False
+        return TrainState(tr), aux, rng  # dropout is 0 in the shipped config: the rng is carried through unused
+
+    return train_step_fn

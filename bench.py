@@ -52,6 +52,77 @@ def cpu_baseline(model, seconds):
         return {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
 
 
+def bench_policy(a):
+    """Secondary benchmark: ARPDT train_step (BASELINE.json configs[3]): B = 32 samples per GPU, T = 4, random-init
+    M3AE-shaped encodings [B,4,257,768] resident in HBM, forward + backward + RCCL all-reduce + clip + Adam."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arp_amd import _ffi, clip, synth_policy as S
+    from arp_amd.train import PolicyConfig, PolicyTrainer
+    _ffi.require_gpu()
+    _ffi.check(_ffi.lib.arp_set_device(local_rank))
+    cfg = PolicyConfig(lambda_ret=0.01)
+    tr = PolicyTrainer(cfg, mode=a.mode, device=local_rank)
+    tr.set_params(S.policy_params(cfg, seed=0))
+    if world > 1:
+        ids = [PolicyTrainer.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        tr.comm_init(ids[0], world, rank)
+        tr.broadcast_state()
+    tr.set_batch(*S.policy_batch(cfg, a.policy_batch, seed=100 + rank))
+    lr = 5e-4
+    for _ in range(a.warmup):
+        tr.train_step_async(lr)
+    tr.sync()
+    if dist is not None:
+        dist.barrier()
+    _ffi.check(_ffi.lib.arp_dev_synchronize())
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.train_step_async(lr)
+    tr.sync()
+    _ffi.check(_ffi.lib.arp_dev_synchronize())
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tr.profile(True)
+    tr.profile_reset()
+    for _ in range(a.steps):
+        tr.train_step_async(lr)
+    tr.sync()
+    prof = tr.profile_read()
+    aux = tr.train_step(lr)
+    if rank == 0:
+        Mx = a.policy_batch * cfg.window * cfg.enc_tokens
+        site = "dt.adapter_fc1"
+        flops = 2.0 * Mx * cfg.enc_dim * cfg.enc_dim
+        avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
+        peak = PEAK_TFLOPS[a.mode]
+        print(json.dumps({
+            "metric": "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
+            "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
+            "config": {"workload": f"ARPDT policy train_step, {a.policy_batch} samples/GPU x window 4, random-init encodings [B,4,257,768] f32 "
+                                   f"resident in HBM, 26.9 M trainable params (BASELINE.json configs[3])", "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                         "frac": flops / (avg_ms * 1e-3) / 1e12 / peak, "traffic": None, "kernel": f"gemm @ {site}", "flops_per_launch": flops,
+                         "avg_launch_ms": avg_ms},
+            "cpu_baseline": None, "final_aux": aux,
+            "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
+    tr.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,7 +133,12 @@ def main():
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--parity-frames", type=int, default=4, help="frames checked against the oracle before timing (rank 0)")
+    ap.add_argument("--path", default="label", choices=["label", "policy"],
+                    help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary)")
+    ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
     a = ap.parse_args()
+    if a.path == "policy":
+        return bench_policy(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

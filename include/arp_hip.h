@@ -109,6 +109,68 @@ int arp_event_destroy(arp_event* e);
 int arp_clip_event_record(arp_clip* h, arp_event* e);
 int arp_event_elapsed_ms(arp_event* start, arp_event* stop, float* ms); /* synchronises on stop */
 
+/* ---- path (2): ARP-DT policy train step ------------------------------------------------------------
+ * Replaces create_train_step(...) -> train_step_fn(state, batch, rng), arp_dt/main_procgen.py:104-141
+ * (model arp_dt/ARPDT.py:152-261,413-486 + arp_dt/layers.py; optimizer main_procgen.py:490-507).
+ * Boundary: the frozen (stop_gradient) M3AE encodings are an input; adapter, image_text_input, token
+ * embeddings, the causal transformer, both heads, losses, L2 term, gradient all-reduce, global-norm clip
+ * and Adam are inside.  Tensors cross the boundary under their Flax tree path flattened with '/'
+ * (e.g. "policy/Block_0/Attention_0/Dense_0/kernel"), in the Flax layout ([in, out] kernels). */
+typedef struct arp_dt arp_dt;
+
+typedef struct arp_dt_cfg {
+    int32_t emb;         /* 128 */
+    int32_t depth;       /* 2   */
+    int32_t heads;       /* 8   */
+    int32_t mlp_ratio;   /* 4   */
+    int32_t n_actions;   /* 15  */
+    int32_t window;      /* 4 time steps -> 12 tokens */
+    int32_t enc_tokens;  /* 257 (M3AE ViT-B/16 at 256x256) */
+    int32_t enc_dim;     /* 768 */
+    int32_t use_adapter; /* 1   */
+    int32_t mode;        /* ARP_MODE_F32 | ARP_MODE_BF16: operand type of the adapter / image_text_input GEMMs */
+    int32_t device;
+    int32_t world;       /* data-parallel degree (set again by arp_dt_comm_init) */
+    int32_t rank;
+    float lambda_ret;    /* lambda_return_pred */
+    float weight_decay;  /* coefficient of the explicit 0.5*wd*||p||^2 term (main_procgen.py:114-117) */
+    float clip_norm;     /* optax.clip_by_global_norm */
+    float b1, b2, eps;   /* adam */
+} arp_dt_cfg;
+
+int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out);
+int arp_dt_destroy(arp_dt* h);
+int arp_dt_num_params(arp_dt* h, int64_t* total, int32_t* n_tensors);
+int arp_dt_param_info(arp_dt* h, int i, char* name_buf, int name_len, int64_t* shape4, int32_t* ndim);
+/* which: 0 = params, 1 = gradients (of the last backward), 2 = adam mu, 3 = adam nu */
+int arp_dt_set_tensor(arp_dt* h, const char* name, int which, const float* data);
+int arp_dt_get_tensor(arp_dt* h, const char* name, int which, float* out);
+int arp_dt_set_step(arp_dt* h, int64_t step);
+int arp_dt_get_step(arp_dt* h, int64_t* step);
+/* Stages one per-device batch in HBM: enc f32 [B,T,enc_tokens,enc_dim], action int32 [B,T], rtg f32 [B,T,1]. */
+int arp_dt_set_batch(arp_dt* h, const float* enc, const int32_t* action, const float* rtg, int B);
+/* ARPDT.__call__ on the staged batch: logits [B,T,n_actions], return_pred [B,T,1],
+ * metrics[4] = loss, acc (fraction), trans_loss, return_loss (any pointer may be NULL). */
+int arp_dt_forward(arp_dt* h, float* action_logits, float* return_pred, float* metrics);
+/* forward + backward + L2 term; gradients readable with arp_dt_get_tensor(.., 1, ..) (parity tests) */
+int arp_dt_backward(arp_dt* h);
+/* train_step_fn on the staged batch: forward, backward, L2 term, RCCL all-reduce (when a communicator is
+ * attached), clip_by_global_norm, adam.  aux[9] = loss, acc*100, trans_loss, return_loss, weight_penalty,
+ * weight_l2, train_state_step, learning_rate, (extra) gradient norm. */
+int arp_dt_train_step(arp_dt* h, float lr, float* aux);
+int arp_dt_train_step_async(arp_dt* h, float lr); /* no read-back; pair with arp_dt_sync */
+int arp_dt_sync(arp_dt* h);
+int arp_dt_event_record(arp_dt* h, arp_event* e);
+/* Data parallelism: one process per GPU.  Rank 0 calls arp_dt_comm_unique_id, ships the 128 bytes to the
+ * others (any side channel), every rank calls arp_dt_comm_init, then arp_dt_broadcast_state
+ * (= sync_state_fn, main_procgen.py:94-101). */
+int arp_dt_comm_unique_id(void* id128);
+int arp_dt_comm_init(arp_dt* h, const void* id128, int world, int rank);
+int arp_dt_broadcast_state(arp_dt* h);
+int arp_dt_profile_enable(arp_dt* h, int on);
+int arp_dt_profile_reset(arp_dt* h);
+int arp_dt_profile_json(arp_dt* h, char* buf, int buf_len);
+
 /* ---- single-operator entry points (host buffers; used by the per-kernel parity tests) ---------- */
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid), operands rounded to bf16 in ARP_MODE_BF16. */
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,
