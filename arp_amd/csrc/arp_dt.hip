@@ -200,7 +200,7 @@ int linear_fwd(arp_dt* c, const float* X, const float* W, const float* b, const 
 int linear_bwd(arp_dt* c, const float* X, const float* W, const float* dY, float* dW, float* db, float* dX, int M, int N, int K) {
     ARP_TRY(sgemm(c, dY, 1, X, 0, nullptr, nullptr, dW, N, K, M, N, K));
     if (db) {
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, c->stream, dY, M, N, db);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, c->stream, dY, M, N, db);
         ARP_HIP_OK(hipGetLastError());
     }
     if (dX) ARP_TRY(sgemm(c, dY, 0, W, 0, nullptr, nullptr, dX, M, K, N, N, K));
@@ -214,8 +214,8 @@ int ln_fwd(arp_dt* c, const float* x, const float* w, const float* b, float* y, 
 int ln_bwd(arp_dt* c, const float* x, const float* w, const float* dy, float* dx, int accumulate, float* dscale, float* dbias, int rows, int D) {
     hipLaunchKernelGGL(ln_bwd_f32_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, c->stream, x, w, dy, dx, accumulate, c->dws.as<float>(),
                        c->dbs.as<float>(), rows, D, 1e-6f);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dws.as<float>(), rows, D, dscale);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 256)), dim3(256), 0, c->stream, c->dbs.as<float>(), rows, D, dbias);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->dws.as<float>(), rows, D, dscale);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->dbs.as<float>(), rows, D, dbias);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -254,7 +254,7 @@ int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void*
     if (S == 1) g.ksplit = 1;
     ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_DT + 1>(g, c->stream)));
     const size_t MN = (size_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 256)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out);
+    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -441,7 +441,7 @@ template <typename T> int backward(arp_dt* c) {
         hipLaunchKernelGGL(tokens_bwd_kernel, dim3(cdiv(E, 256)), dim3(256), 0, c->stream, dh, c->rtg.as<float>(), c->action.as<int>(),
                            c->dimg.as<float>(), c->g("rtg_input/kernel"), c->g("action_input/embedding"), R, E, NA);
         ARP_TRY(ew_bwd(c, c->dimg.as<float>(), c->img.as<float>(), c->dz.as<float>(), (size_t)R * E, EW_TANH_BWD));
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(E, 256)), dim3(256), 0, c->stream, c->dz.as<float>(), R, E, c->g("image_text_input/bias"));
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(E, 64)), dim3(256), 0, c->stream, c->dz.as<float>(), R, E, c->g("image_text_input/bias"));
         ARP_HIP_OK(hipGetLastError());
     }
     // ---- image_text_input: dW[E, Kin] = dz^T Y ;  dY[R, Kin] = dz Wi -------------------------------------
@@ -475,14 +475,14 @@ template <typename T> int backward(arp_dt* c) {
         ARP_TRY((transpose_mask<T, T, T>(c, c->H1.as<T>(), D, nullptr, nullptr, 1.f, nullptr, 0, c->H1T.as<T>(), Mxp, (int)Mx, D)));
     }
     ARP_TRY((splitk_gemm<T, float>(c, "dt.adapter_fc2_dW", c->dApreT.p, Mxp, c->H1T.p, Mxp, nullptr, ACT_NONE, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp)));
-    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->dApreT.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_1/bias"), D);
+    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(D), dim3(256), 0, c->stream, c->dApreT.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_1/bias"), D);
     ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.adapter_fc2_dX", c->dApre.p, D, c->W2t.p, D, nullptr, c->G.p, D, (int)Mx, D, D)));
     {
         ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
         ARP_TRY((transpose_mask<T, T, T>(c, c->G.as<T>(), D, c->H1.as<T>(), nullptr, 1.f, nullptr, 0, c->dH1T.as<T>(), Mxp, (int)Mx, D)));
     }
     ARP_TRY((splitk_gemm<T, float>(c, "dt.adapter_fc1_dW", c->dH1T.p, Mxp, c->XbT.p, Mxp, nullptr, ACT_NONE, c->g("AdapterMLP_0/Dense_0/kernel"), D, D, Mxp)));
-    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(cdiv(D, 4)), dim3(256), 0, c->stream, c->dH1T.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_0/bias"), D);
+    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(D), dim3(256), 0, c->stream, c->dH1T.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_0/bias"), D);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }

@@ -26,15 +26,16 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int k0 = 0; k0 < g.K; k0 += 16) {
         for (int i = threadIdx.x; i < 512; i += 256) {
-            const int kk = i & 15, r = i >> 4;  // r: 0..31
-            const int m = m0 + r, n = n0 + r, k = k0 + kk;
+            // consecutive threads walk the operand's CONTIGUOUS axis (k for a row-major operand, m/n for a
+            // transposed one) so both layouts load coalesced
+            const int ka = g.ta ? (i >> 5) : (i & 15), ra = g.ta ? (i & 31) : (i >> 4);
+            const int kb = g.tb ? (i & 15) : (i >> 5), rb = g.tb ? (i >> 4) : (i & 31);
+            const int m = m0 + ra, n = n0 + rb;
             float a = 0.f, b = 0.f;
-            if (k < g.K) {
-                if (m < g.M) a = g.ta ? g.A[(size_t)k * g.lda + m] : g.A[(size_t)m * g.lda + k];
-                if (n < g.N) b = g.tb ? g.B[(size_t)n * g.ldb + k] : g.B[(size_t)k * g.ldb + n];
-            }
-            As[kk][r] = a;
-            Bs[kk][r] = b;
+            if (k0 + ka < g.K && m < g.M) a = g.ta ? g.A[(size_t)(k0 + ka) * g.lda + m] : g.A[(size_t)m * g.lda + k0 + ka];
+            if (k0 + kb < g.K && n < g.N) b = g.tb ? g.B[(size_t)n * g.ldb + k0 + kb] : g.B[(size_t)(k0 + kb) * g.ldb + n];
+            As[ka][ra] = a;
+            Bs[kb][rb] = b;
         }
         __syncthreads();
 #pragma unroll
@@ -67,10 +68,17 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
 template <typename OutT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t MN, int N,
                                                             const float* __restrict__ bias, int act, OutT* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= MN) return;
+    // 64 outputs per block, 4 slice groups per output (fixed order: group partials are added 0..3)
+    __shared__ float red[4][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + x;
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[(size_t)k * MN + i];
+    if (i < MN)
+        for (int k = y; k < S; k += 4) s += part[(size_t)k * MN + i];
+    red[y][x] = s;
+    __syncthreads();
+    if (y != 0 || i >= MN) return;
+    s = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
     if (bias) s += bias[i % N];
     if (act == ACT_TANH) s = tanhf(s);
     else if (act == ACT_RELU) s = fmaxf(s, 0.f);
@@ -177,22 +185,43 @@ __global__ void dres_to_drw_kernel(const float* __restrict__ dres, const float* 
 // ---- row sums of a [R, ld] matrix (bias gradients from the TRANSPOSED gradient: one row per output unit)
 template <typename T>
 __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, int ld, int cols, float* __restrict__ out, int rows) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    __shared__ float red[4];
+    const int row = blockIdx.x;  // one workgroup per row; ld % 4 == 0 (rows are 8/16-byte aligned)
     const T* r = in + (size_t)row * ld;
     float s = 0.f;
-    for (int c = lane; c < cols; c += 64) s += Elem<T>::ld(r + c);
+    const int c4 = cols & ~3;
+    for (int c = threadIdx.x * 4; c < c4; c += 1024) {
+        float v[4];
+        load4(r + c, v);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (int c = c4 + threadIdx.x; c < cols; c += 256) s += Elem<T>::ld(r + c);
     s = wave_sum(s);
-    if (lane == 0) out[row] = s;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 // column sums of a small [R, C] f32 matrix: out[c] = sum_r in[r, c]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += in[(size_t)r * C + c];
-    out[c] = s;
+    // 64 columns per block (lane = column: coalesced rows), rows split over the 4 waves with 4 independent
+    // accumulators each, then a fixed-order combine
+    __shared__ float red[4][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int r = y;
+        for (; r + 12 < R; r += 16) {
+            s0 += in[(size_t)r * C + c];
+            s1 += in[(size_t)(r + 4) * C + c];
+            s2 += in[(size_t)(r + 8) * C + c];
+            s3 += in[(size_t)(r + 12) * C + c];
+        }
+        for (; r < R; r += 4) s0 += in[(size_t)r * C + c];
+    }
+    red[y][x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (y == 0 && c < C) out[c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
 }
 
 // ---- LayerNorm forward (f32 in/out, saves nothing: backward recomputes the statistics) ------------------
