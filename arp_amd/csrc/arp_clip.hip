@@ -2,6 +2,7 @@
 // Reference seam: compute_reward, /root/reference/arp_dt/label_reward.py:132-146.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -909,6 +910,7 @@ template <typename T> static int op_gemm_bench(int kernel, int act, int resid, i
         g.A = dA.p; g.W = dW.p; g.bias = dB.as<float>(); g.resid = resid ? dR.as<float>() : nullptr; g.out = resid ? dR.p : dO.p;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
         if (const char* fe = getenv("ARP_GEMM_FLAGS")) g.flags = atoi(fe);
+        if (const char* fe = getenv("ARP_GEMM_STAGGER")) sscanf(fe, "%d,%d", &g.stagger_groups, &g.stagger_cycles);
         auto run = [&]() -> int {
             if (resid) return launch_gemm_auto<T, float, ACT_NONE, true, SITE_OP>(g, nullptr, kernel);
             if (out_f32) return launch_gemm_auto<T, float, ACT_NONE, false, SITE_OP>(g, nullptr, kernel);

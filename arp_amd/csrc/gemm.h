@@ -31,6 +31,8 @@ struct GemmArgs {
     int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only)
     int ksplit = 1;     // split-K: gridDim.y slices of K; slice s writes to out + s * slice_stride (bias/resid ignored by callers)
     size_t slice_stride = 0;
+    int stagger_groups = 0;   // >1: the first wave of workgroups starts in `stagger_groups` phase groups spread over
+    int stagger_cycles = 0;   //     `stagger_cycles` shader cycles, so CUs do not all reach their store epilogue together
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
@@ -161,6 +163,72 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     // ---- epilogue: lane holds, per (ni, mi): m = .. + fr, n = .. + 4*fg + {0,1,2,3} ----------------
     OutT* out = static_cast<OutT*>(g.out) + (size_t)blockIdx.y * g.slice_stride;  // may alias g.resid (in-place residual add)
     const bool vec_ok = ((g.N | g.ldo | g.ldr) & 3) == 0;
+    // ---- staged epilogue (see gemm256.h): accumulators -> bias/activation -> LDS -> whole 256-B / 512-B rows.
+    // With two workgroups per CU one workgroup's store phase runs under the other's K loop.
+    const bool staged = vec_ok && ((g.N | g.ldo) & 7) == 0 && !(g.flags & 2);
+    if (staged) {
+        if constexpr (sizeof(OutT) == 2) {
+            constexpr int RS = 128 * 2 + 16;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int row = wr * 64 + mi * 16 + fr, col = wc * 64 + ni * 16 + fg * 4;
+                    float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+                    if (g.bias && n0 + col < g.N) {
+                        const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                    *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                }
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 16 + wave * 4 + (lane >> 4);
+                const int m = m0 + r, n = n0 + (lane & 15) * 8;
+                if (m < g.M && n < g.N)
+                    *reinterpret_cast<uint4*>(out + (size_t)m * g.ldo + n) = *reinterpret_cast<const uint4*>(smem + r * RS + (lane & 15) * 16);
+            }
+        } else {
+            constexpr int RSF = 128 * 4 + 16;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (p) __syncthreads();
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const int mi = 2 * p + mh;
+                        const int lrow = wr * 32 + mh * 16 + fr, col = wc * 64 + ni * 16 + fg * 4;
+                        float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+                        if (g.bias && n0 + col < g.N) {
+                            const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
+                            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                        *reinterpret_cast<float4*>(smem + lrow * RSF + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                __syncthreads();
+#pragma unroll 4
+                for (int it = 0; it < 8; ++it) {
+                    const int lr = it * 8 + wave * 2 + (lane >> 5);
+                    const int m = m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), n = n0 + (lane & 31) * 4;
+                    if (m < g.M && n < g.N) {
+                        float4 v = *reinterpret_cast<const float4*>(smem + lr * RSF + (lane & 31) * 16);
+                        if constexpr (RESID) {
+                            const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wr * 64 + mi * 16 + fr;

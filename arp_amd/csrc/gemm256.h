@@ -79,6 +79,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     const T* __restrict__ A = static_cast<const T*>(g.A);
     const T* __restrict__ W = static_cast<const T*>(g.W);
 
+    // De-phase the CUs: every tile costs the same, so without this all 256 CUs hit their (HBM-write-bound)
+    // epilogue in the same window and nobody computes meanwhile.  Only the first resident wave of workgroups
+    // waits; later workgroups inherit their CU's phase.
+    if (g.stagger_groups > 1 && blockIdx.x < 256) {
+        const int grp = (blockIdx.x >> 3) % g.stagger_groups;
+        if (grp) {
+            const unsigned long long target = (unsigned long long)g.stagger_cycles * grp / g.stagger_groups;
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < target) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+
     // ---- LDS-DMA plan: unit u in {0:A q-row 0, 1:W q-col 0, 2:W q-col 1, 3:A q-row 1}, 2 instr / thread
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;

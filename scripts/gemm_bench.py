@@ -13,6 +13,9 @@ SHAPES = {  # name: (M, N, K, act, resid, out_f32)
     "c_proj": (51200, 768, 3072, 0, 1, 1),
     "sq4096": (4096, 4096, 4096, 0, 0, 0),
     "sq8192": (8192, 8192, 8192, 0, 0, 0),
+    "k64_store_only": (51200, 3072, 64, 0, 0, 0),
+    "k64_f32out": (51200, 768, 64, 0, 0, 1),
+    "k64_resid": (51200, 768, 64, 0, 1, 1),
     "k768_noepi": (51200, 3072, 768, 0, 0, 0),
     "k1536": (51200, 3072, 1536, 0, 0, 0),
     "k3072": (51200, 3072, 3072, 0, 0, 0),
