@@ -103,6 +103,16 @@ def make_compute_reward(model_type="clip"):
     return compute_reward
 
 
+def get_torch_clip_reward(clip_model, obs, pos_text=None, use_crop=False):
+    """Online single-frame reward of the rollout loop (/root/reference/arp_dt/envs/vl_reward.py:11-23):
+    one uint8 frame [H,W,3] (or a stack [N,H,W,3]) -> float32 [N]; the prompt is the one cached by
+    ``clip_model.set_text``.  Same kernels as the offline path at N = 1."""
+    obs = np.asarray(obs)
+    if obs.ndim == 3:
+        obs = obs[None]
+    return clip_model.label(obs, use_crop=use_crop)
+
+
 def _open_store(data_path):
     if data_path.endswith((".hdf5", ".h5")):
         try:

@@ -142,6 +142,17 @@ class PolicyTrainer:
     def backward(self):
         check(lib.arp_dt_backward(self._h))
 
+    def greedy_action(self, enc, action, rtg):
+        """ARPDT.greedy_action (ARPDT.py:488-492): argmax of the LAST time step's action logits."""
+        self.set_batch(enc, action, rtg)
+        return self.forward()["action_pred"][:, -1, :].argmax(-1)
+
+    def greedy_return(self, enc, action, rtg):
+        """ARPDT.greedy_return (ARPDT.py:494-495): symexp(return_pred) (utils.py symexp = sign(x)(exp|x| - 1))."""
+        self.set_batch(enc, action, rtg)
+        r = self.forward()["return_pred"]
+        return np.sign(r) * (np.exp(np.abs(r)) - 1.0)
+
     def train_step(self, lr):
         aux = np.empty(9, np.float32)
         check(lib.arp_dt_train_step(self._h, float(lr), _ffi.as_ptr(aux, C.c_float)))

@@ -39,14 +39,17 @@ def gemm_sites(cfg, batch):
     }
 
 
-def cpu_baseline(model, seconds):
+def cpu_baseline(model, seconds, policy_batch=0):
     """Runs the oracle's torch-CPU port in a child process (before this process touches the GPU)."""
     try:
-        out = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--model", model, "--target-seconds", str(seconds)],
-                             cwd=ROOT, capture_output=True, text=True, timeout=600)
+        cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--model", model, "--target-seconds", str(seconds)]
+        if policy_batch:
+            cmd = [sys.executable, "-m", "oracle.cpu_baseline_policy", "--batch", str(policy_batch), "--target-seconds", str(seconds)]
+        out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         d.pop("checksum", None)
+        d.pop("final_loss", None)
         return d
     except Exception as e:  # the baseline is a reported extra, never the measured path
         return {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
@@ -58,6 +61,7 @@ def bench_policy(a):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu = cpu_baseline(a.model, a.cpu_seconds, a.policy_batch) if (rank == 0 and world == 1 and a.cpu_seconds > 0) else None
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -116,7 +120,7 @@ def bench_policy(a):
             "roofline": {"bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                          "frac": flops / (avg_ms * 1e-3) / 1e12 / peak, "traffic": None, "kernel": f"gemm @ {site}", "flops_per_launch": flops,
                          "avg_launch_ms": avg_ms},
-            "cpu_baseline": None, "final_aux": aux,
+            "cpu_baseline": cpu, "final_aux": aux,
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
     tr.close()
     if dist is not None:

@@ -146,7 +146,7 @@ def grads(P, cfg, enc, action, rtg):
     loss, aux, out = loss_and_aux(Pr, cfg, enc, action, rtg)
     loss.backward()
     g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in Pr.items()}
-    return g, {k: float(v) for k, v in aux.items()}, {k: v.detach() for k, v in out.items()}
+    return g, {k: float(v.detach()) for k, v in aux.items()}, {k: v.detach() for k, v in out.items()}
 
 
 def init_state(P):

@@ -64,7 +64,7 @@ json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w"), 
 
 traffic = {}
 for site, sub in SITES.items():
-    cands = [e for e in summary.values() if sub in e["kernel"] and "gemm_" in e["kernel"] and "hbm_bytes_per_launch" in e]
+    cands = [e for e in summary.values() if sub in e["kernel"] and "gemm" in e["kernel"] and "hbm_bytes_per_launch" in e]
     if cands:
         e = max(cands, key=lambda x: x["grid_threads"])
         traffic[site] = {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "fetch_KiB": e["FETCH_SIZE_KiB_avg"],

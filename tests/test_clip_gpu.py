@@ -107,3 +107,15 @@ def test_error_paths(gpu_lib):
     with pytest.raises(ValueError):
         m.label(np.zeros((1, 256, 256, 4), np.uint8))
     m.close()
+
+
+def test_online_single_frame_reward(gpu_lib):
+    """get_torch_clip_reward (envs/vl_reward.py:11-23): the N = 1 path equals the batched one."""
+    from arp_amd import clip, label_reward as L
+    ocfg, Wt, fr, tok, ref = _setup(TINY, 3, seed=31)
+    m = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode="f32").set_text(tok)
+    scale = float(np.exp(Wt["logit_scale"]))
+    for i in range(3):
+        r = L.get_torch_clip_reward(m, fr[i])
+        assert r.shape == (1,) and abs(r[0] - ref[i]) / scale < COS_TOL_F32
+    m.close()

@@ -144,3 +144,17 @@ def test_single_rank_comm(gpu_lib):
     pa, pb = a.get_params(), b.get_params()
     assert all((pa[k] == pb[k]).all() for k in pa)
     a.close(); b.close()
+
+
+def test_greedy_action_and_return(gpu_lib):
+    """ARPDT.greedy_action / greedy_return (ARPDT.py:488-495), batch 1 as in the rollout loop."""
+    from arp_amd.train import PolicyTrainer
+    from oracle import arpdt_torch as O
+    cfg, ocfg, P, (enc, act, rtg), Pt, tb = _setup(TINY, 1, 13)
+    ref = O.forward(Pt, ocfg, *tb)
+    tr = PolicyTrainer(cfg, mode="f32")
+    tr.set_params(P)
+    assert (tr.greedy_action(enc, act, rtg) == ref["action_pred"][:, -1].argmax(-1).numpy()).all()
+    r = ref["return_pred"].numpy()
+    assert np.abs(tr.greedy_return(enc, act, rtg) - np.sign(r) * (np.exp(np.abs(r)) - 1)).max() < 1e-5
+    tr.close()
