@@ -36,6 +36,11 @@ class DtCfg(C.Structure):
         "device", "world", "rank")] + [(n, C.c_float) for n in ("lambda_ret", "weight_decay", "clip_norm", "b1", "b2", "eps")]
 
 
+class EncCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("patch", "width", "layers", "heads", "mlp_ratio", "img_res", "mode", "device", "max_frames",
+                                          "attn_impl")]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -103,6 +108,15 @@ SIGNATURES = {
     "arp_dt_profile_enable": (_i, [_vp, _i]),
     "arp_dt_profile_reset": (_i, [_vp]),
     "arp_dt_profile_json": (_i, [_vp, C.c_char_p, _i]),
+    "arp_enc_create": (_i, [C.POINTER(EncCfg), C.POINTER(_vp)]),
+    "arp_enc_destroy": (_i, [_vp]),
+    "arp_enc_load_weight": (_i, [_vp, C.c_char_p, _fp, _i64p, _i]),
+    "arp_enc_finalize_weights": (_i, [_vp]),
+    "arp_enc_forward": (_i, [_vp, _fp, _i, _fp]),
+    "arp_enc_profile_enable": (_i, [_vp, _i]),
+    "arp_enc_profile_json": (_i, [_vp, C.c_char_p, _i]),
+    "arp_dt_attach_encoder": (_i, [_vp, _vp]),
+    "arp_dt_set_batch_images": (_i, [_vp, _fp, _i32p, _fp, _i]),
     "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
     "arp_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "arp_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f]),

@@ -19,6 +19,7 @@
 #include "attention.h"
 #include "common.h"
 #include "dtops.h"
+#include "enc_internal.h"
 #include "gemm.h"
 #include "gemm256.h"
 #include "runtime.h"
@@ -84,6 +85,9 @@ struct arp_dt {
     // batch
     int B = 0;
     DevBuf enc32, action, rtg;
+    arp_enc* enc = nullptr;   // optional frozen encoder in front (row N1)
+    DevBuf img32;             // raw frames [B*T, res, res, 3] f32 when the encoder is attached
+    bool use_images = false;
     // activations (T = operand type)
     DevBuf Xb, XbT, H1, H1T, A, Y, YT, dY, dApre, dApreT, G, dH1T, dzb, dzT, part, scal;
     // f32 small tensors
@@ -332,6 +336,9 @@ template <typename T> int forward(arp_dt* c) {
     const int Kin = k.enc_tokens * D;
     const int Mxp = (int)((Mx + 63) / 64 * 64);
     ARP_TRY(refresh_shadows<T>(c));
+    if (c->use_images) {  // frozen M3AE encoder under stop_gradient (arp_dt/ARPDT.py:418-462): frames -> encodings, on this stream
+        ARP_TRY(enc_forward_on(c->enc, c->stream, c->img32.as<float>(), R, c->enc32.as<float>()));
+    }
     {   // enc f32 -> operand type, both layouts (the transposed one feeds the weight-gradient GEMM)
         ProfScope ps(c->prof, c->stream, "dt.enc_convert");
         ARP_TRY((transpose_mask<float, float, T>(c, c->enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D,
@@ -595,7 +602,7 @@ int arp_dt_destroy(arp_dt* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->enc32, &c->action, &c->rtg, &c->Xb, &c->XbT,
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv};
@@ -679,10 +686,41 @@ int arp_dt_set_batch(arp_dt* c, const float* enc, const int32_t* action, const f
         if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
     ARP_TRY(ensure_buffers(c, B));
     const size_t Mx = (size_t)R * c->cfg.enc_tokens;
+    c->use_images = false;
     ARP_HIP_OK(hipMemcpyAsync(c->enc32.p, enc, Mx * c->cfg.enc_dim * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipMemcpyAsync(c->rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_dt_attach_encoder(arp_dt* c, arp_enc* enc) {
+    if (!c || !enc) return fail("null argument");
+    int tokens = 0, width = 0, res = 0, dev = 0;
+    ARP_TRY(enc_geometry(enc, &tokens, &width, &res, &dev));
+    if (tokens != c->cfg.enc_tokens || width != c->cfg.enc_dim) return fail("encoder geometry does not match enc_tokens / enc_dim");
+    if (dev != c->cfg.device) return fail("encoder lives on another device");
+    c->enc = enc;
+    return 0;
+}
+
+int arp_dt_set_batch_images(arp_dt* c, const float* images, const int32_t* action, const float* rtg, int B) {
+    if (!c || !images || !action || !rtg || B <= 0) return fail("bad argument");
+    if (!c->enc) return fail("no encoder attached: call arp_dt_attach_encoder first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    const int R = B * c->cfg.window;
+    for (int i = 0; i < R; ++i)
+        if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
+    int tokens = 0, width = 0, res = 0, dev = 0;
+    ARP_TRY(enc_geometry(c->enc, &tokens, &width, &res, &dev));
+    ARP_TRY(ensure_buffers(c, B));
+    const size_t fb = (size_t)res * res * 3 * 4;
+    ARP_TRY(c->img32.ensure((size_t)R * fb));
+    ARP_HIP_OK(hipMemcpyAsync(c->img32.p, images, (size_t)R * fb, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    c->use_images = true;
     return 0;
 }
 

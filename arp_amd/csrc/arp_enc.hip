@@ -1,0 +1,322 @@
+// Row N1: the frozen M3AE image encoder (forward_representation) on MI355X -- host orchestration + C ABI.
+// Reference: /root/reference/arp_dt/models/m3ae/model.py:471-496 (forward_representation), :200-312 (blocks),
+// :95-136 (sincos pos-emb), arp_dt/ARPDT.py:111-116,413-458 (patchify, call site under stop_gradient).
+// Same kernels as the CLIP image tower (tower.h) with tanh-GELU, LayerNorm eps 1e-6, a biased patch
+// embedding, fixed 2-D sincos position embedding + type embedding, no ln_pre and a final LN over all tokens.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/arp_hip.h"
+#include "enc_internal.h"
+#include "tower.h"
+
+using namespace arp;
+
+namespace {
+
+// images f32 NHWC -> patch matrix [n*G*G, P*P*3] (T), "b (h p1) (w p2) c -> b (h w) (p1 p2 c)"
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int n, int res, int P) {
+    const int G = res / P, K = P * P * 3;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (size_t)n * G * G * K) return;
+    const int k = (int)(i % K);
+    const size_t row = i / K;
+    const int px = (int)(row % G), py = (int)((row / G) % G);
+    const size_t b = row / ((size_t)G * G);
+    const int p1 = k / (P * 3), rem = k - p1 * P * 3;  // rem = p2*3 + c, contiguous in the source row
+    const float* src = img + ((b * res + (size_t)py * P + p1) * res + (size_t)px * P) * 3 + rem;
+    store4(out + i, src[0], src[1], src[2], src[3]);
+}
+
+// x[b, 0] = cls;  x[b, 1+p] = pe[b*GG + p] + pos[p]   (pos already holds sincos + type embedding)
+__global__ __launch_bounds__(256) void enc_assemble_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ x, int rows, int ntok,
+                                                           int D) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (size_t)rows * D) return;
+    const int c = (int)(i % D);
+    const size_t row = i / D;
+    const int t = (int)(row % ntok);
+    const size_t b = row / ntok;
+    float v[4];
+    if (t == 0) {
+        load4(cls + c, v);
+    } else {
+        float p4[4];
+        load4(pe + (b * (ntok - 1) + (t - 1)) * D + c, v);
+        load4(pos + (size_t)(t - 1) * D + c, p4);
+        v[0] += p4[0]; v[1] += p4[1]; v[2] += p4[2]; v[3] += p4[3];
+    }
+    store4(x + i, v[0], v[1], v[2], v[3]);
+}
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+}  // namespace
+
+struct arp_enc {
+    arp_enc_cfg cfg;
+    hipStream_t stream = nullptr;
+    std::map<std::string, HostTensor> staged;
+    std::vector<void*> owned;
+    bool finalized = false;
+    TowerW tower;
+    void* w_emb = nullptr;  // T [D, P*P*3]
+    float *b_emb = nullptr, *cls = nullptr, *pos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
+    int ws_frames = 0;
+    DevBuf patches, pe, x, h, qkv, ao, fc, img_in, out;
+    Profiler prof;
+    int gemm_force = 0;
+    int tokens() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
+    size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
+};
+
+namespace {
+
+int up_f32(arp_enc* c, const float* v, size_t n, float** out) {
+    void* p = nullptr;
+    ARP_HIP_OK(hipMalloc(&p, std::max<size_t>(n * 4, 16)));
+    ARP_HIP_OK(hipMemcpy(p, v, n * 4, hipMemcpyHostToDevice));
+    c->owned.push_back(p);
+    *out = static_cast<float*>(p);
+    return 0;
+}
+// Flax kernel [in, out] -> device [out, in] in the operand type
+int up_kernel(arp_enc* c, const float* src, int in, int out_, void** out) {
+    const size_t n = (size_t)in * out_;
+    std::vector<float> t(n);
+    for (int i = 0; i < in; ++i)
+        for (int o = 0; o < out_; ++o) t[(size_t)o * in + i] = src[(size_t)i * out_ + o];
+    void* p = nullptr;
+    ARP_HIP_OK(hipMalloc(&p, std::max<size_t>(n * c->esz(), 16)));
+    if (c->cfg.mode == ARP_MODE_BF16) {
+        std::vector<bf16_t> hb(n);
+        for (size_t i = 0; i < n; ++i) hb[i] = host_f2bf(t[i]);
+        ARP_HIP_OK(hipMemcpy(p, hb.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        ARP_HIP_OK(hipMemcpy(p, t.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    c->owned.push_back(p);
+    *out = p;
+    return 0;
+}
+int staged(arp_enc* c, const std::string& name, std::vector<int64_t> shape, const HostTensor** out) {
+    auto it = c->staged.find(name);
+    if (it == c->staged.end()) return fail("missing weight: " + name);
+    if (it->second.shape != shape) return fail("weight " + name + " has an unexpected shape");
+    *out = &it->second;
+    return 0;
+}
+
+int ensure_ws(arp_enc* c, int frames) {
+    if (frames <= c->ws_frames) return 0;
+    const arp_enc_cfg& k = c->cfg;
+    const size_t e = c->esz(), G = k.img_res / k.patch, D = k.width, N = c->tokens(), B = frames, M = B * N;
+    ARP_TRY(c->patches.ensure(B * G * G * k.patch * k.patch * 3 * e));
+    ARP_TRY(c->pe.ensure(B * G * G * D * 4));
+    ARP_TRY(c->x.ensure(M * D * 4)); ARP_TRY(c->h.ensure(M * D * e)); ARP_TRY(c->qkv.ensure(M * 3 * D * e));
+    ARP_TRY(c->ao.ensure(M * D * e)); ARP_TRY(c->fc.ensure(M * k.mlp_ratio * D * e));
+    c->ws_frames = frames;
+    return 0;
+}
+
+template <typename T> int forward_chunk(arp_enc* c, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
+    const arp_enc_cfg& k = c->cfg;
+    const int G = k.img_res / k.patch, N = c->tokens(), D = k.width, KP = k.patch * k.patch * 3;
+    TowerCtx t;
+    t.stream = stream; t.prof = &c->prof; t.attn_impl = k.attn_impl; t.gemm_force = c->gemm_force;
+    {
+        ProfScope ps(c->prof, stream, "m3ae.patchify");
+        const size_t tot = (size_t)nb * G * G * KP;
+        hipLaunchKernelGGL((patchify_kernel<T>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, c->patches.as<T>(), nb,
+                           k.img_res, k.patch);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    ARP_TRY((tower_gemm<T, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", c->patches.p, c->w_emb, c->b_emb, nullptr, c->pe.p,
+                                                                   nb * G * G, D, KP)));
+    {
+        ProfScope ps(c->prof, stream, "m3ae.assemble");
+        const size_t tot = (size_t)nb * N * D;
+        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, c->pe.as<float>(), c->cls, c->pos,
+                           c->x.as<float>(), nb * N, N, D);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    ARP_TRY((run_blocks<T, ACT_GELU_TANH, 8>(t, c->tower, "m3ae", c->x.as<float>(), c->h.as<T>(), c->qkv.as<T>(), c->ao.as<T>(), c->fc.as<T>(), nb, N, 0,
+                                             1e-6f)));
+    ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_final", c->x.as<float>(), (size_t)D, out_dev, D, c->lnf_w, c->lnf_b, nb * N, D, 1e-6f));
+    return 0;
+}
+
+}  // namespace
+
+namespace arp {
+
+int enc_forward_on(arp_enc* c, hipStream_t stream, const float* images_dev, int n, float* out_dev) {
+    if (!c || !c->finalized) return fail("encoder weights not finalized");
+    if (n <= 0) return 0;
+    const int mb = c->cfg.max_frames;
+    ARP_TRY(ensure_ws(c, std::min(n, mb)));
+    const size_t fi = (size_t)c->cfg.img_res * c->cfg.img_res * 3, fo = (size_t)c->tokens() * c->cfg.width;
+    for (int off = 0; off < n; off += mb) {
+        const int nb = std::min(mb, n - off);
+        if (c->cfg.mode == ARP_MODE_BF16) ARP_TRY(forward_chunk<bf16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
+        else ARP_TRY(forward_chunk<float>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
+    }
+    return 0;
+}
+int enc_geometry(arp_enc* c, int* tokens, int* width, int* img_res, int* device) {
+    if (!c) return fail("null encoder");
+    *tokens = c->tokens(); *width = c->cfg.width; *img_res = c->cfg.img_res; *device = c->cfg.device;
+    return 0;
+}
+
+}  // namespace arp
+
+extern "C" {
+
+int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
+    if (!cfg || !out) return fail("null argument");
+    const arp_enc_cfg& k = *cfg;
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16) return fail("bad mode");
+    if (k.patch <= 0 || k.img_res % k.patch || k.width % k.heads || k.width % 4) return fail("bad geometry");
+    const int kq = k.mode == ARP_MODE_BF16 ? 64 : 32;
+    if (k.width % kq || (k.patch * k.patch * 3) % kq) return fail("width and 3*patch^2 must be multiples of " + std::to_string(kq));
+    int ndev = 0;
+    ARP_HIP_OK(hipGetDeviceCount(&ndev));
+    if (k.device < 0 || k.device >= ndev) return fail("no such HIP device");
+    ARP_HIP_OK(hipSetDevice(k.device));
+    arp_enc* c = new arp_enc();
+    c->cfg = k;
+    if (c->cfg.max_frames <= 0) c->cfg.max_frames = 128;
+    if (const char* e = getenv("ARP_GEMM")) c->gemm_force = atoi(e);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail("hipStreamCreate failed");
+    }
+    *out = c;
+    return 0;
+}
+
+int arp_enc_destroy(arp_enc* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipDeviceSynchronize();
+    c->prof.destroy();
+    for (void* p : c->owned) (void)hipFree(p);
+    DevBuf* bufs[] = {&c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->img_in, &c->out};
+    for (auto* b : bufs) b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int arp_enc_load_weight(arp_enc* c, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!c || !name || !data || (ndim > 0 && !shape)) return fail("null argument");
+    if (c->finalized) return fail("weights already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(data, data + n);
+    c->staged[name] = std::move(t);
+    return 0;
+}
+
+int arp_enc_finalize_weights(arp_enc* c) {
+    if (!c) return fail("null handle");
+    if (c->finalized) return 0;
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    const arp_enc_cfg& k = c->cfg;
+    const int D = k.width, KP = k.patch * k.patch * 3, H = k.mlp_ratio * D, G = k.img_res / k.patch;
+    const HostTensor* t;
+    ARP_TRY(staged(c, "image_embedding/kernel", {KP, D}, &t)); ARP_TRY(up_kernel(c, t->data.data(), KP, D, &c->w_emb));
+    ARP_TRY(staged(c, "image_embedding/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->b_emb));
+    ARP_TRY(staged(c, "cls_token", {1, 1, D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->cls));
+    ARP_TRY(staged(c, "encoder_image_type_embedding", {1, 1, D}, &t));
+    {   // get_2d_sincos_pos_embed (m3ae/model.py:95-136, "w goes first") + the image type embedding
+        std::vector<float> pos((size_t)G * G * D);
+        const int q = D / 4;  // embed_dim/2 per axis, half sin half cos
+        for (int i = 0; i < G; ++i)
+            for (int j = 0; j < G; ++j) {
+                float* row = pos.data() + ((size_t)i * G + j) * D;
+                for (int half = 0; half < 2; ++half) {
+                    const double p = half == 0 ? (double)j : (double)i;  // first half encodes the w coordinate
+                    for (int d = 0; d < q; ++d) {
+                        const double omega = 1.0 / std::pow(10000.0, (double)d / (double)q);
+                        row[half * 2 * q + d] = (float)std::sin(p * omega);
+                        row[half * 2 * q + q + d] = (float)std::cos(p * omega);
+                    }
+                }
+                for (int d = 0; d < D; ++d) row[d] += t->data[d];
+            }
+        ARP_TRY(up_f32(c, pos.data(), pos.size(), &c->pos));
+    }
+    c->tower.width = D; c->tower.layers = k.layers; c->tower.heads = k.heads;
+    c->tower.L.resize(k.layers);
+    for (int i = 0; i < k.layers; ++i) {
+        const std::string p = "encoder/Block_" + std::to_string(i) + "/";
+        LayerW& L = c->tower.L[i];
+        ARP_TRY(staged(c, p + "LayerNorm_0/scale", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln1_w));
+        ARP_TRY(staged(c, p + "LayerNorm_0/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln1_b));
+        ARP_TRY(staged(c, p + "LayerNorm_1/scale", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln2_w));
+        ARP_TRY(staged(c, p + "LayerNorm_1/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln2_b));
+        ARP_TRY(staged(c, p + "Attention_0/Dense_0/kernel", {D, 3 * D}, &t)); ARP_TRY(up_kernel(c, t->data.data(), D, 3 * D, &L.w_in));
+        ARP_TRY(staged(c, p + "Attention_0/Dense_0/bias", {3 * D}, &t)); ARP_TRY(up_f32(c, t->data.data(), 3 * D, &L.b_in));
+        ARP_TRY(staged(c, p + "Attention_0/Dense_1/kernel", {D, D}, &t)); ARP_TRY(up_kernel(c, t->data.data(), D, D, &L.w_out));
+        ARP_TRY(staged(c, p + "Attention_0/Dense_1/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.b_out));
+        ARP_TRY(staged(c, p + "TransformerMLP_0/fc1/kernel", {D, H}, &t)); ARP_TRY(up_kernel(c, t->data.data(), D, H, &L.w_fc));
+        ARP_TRY(staged(c, p + "TransformerMLP_0/fc1/bias", {H}, &t)); ARP_TRY(up_f32(c, t->data.data(), H, &L.b_fc));
+        ARP_TRY(staged(c, p + "TransformerMLP_0/fc2/kernel", {H, D}, &t)); ARP_TRY(up_kernel(c, t->data.data(), H, D, &L.w_proj));
+        ARP_TRY(staged(c, p + "TransformerMLP_0/fc2/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.b_proj));
+    }
+    ARP_TRY(staged(c, "encoder/LayerNorm_0/scale", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->lnf_w));
+    ARP_TRY(staged(c, "encoder/LayerNorm_0/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->lnf_b));
+    c->staged.clear();
+    c->finalized = true;
+    return 0;
+}
+
+int arp_enc_forward(arp_enc* c, const float* images, int n, float* out) {
+    if (!c || !c->finalized) return fail("encoder weights not finalized");
+    if (n < 0) return fail("negative frame count");
+    if (n == 0) return 0;
+    if (!images || !out) return fail("null buffer");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    const size_t fi = (size_t)c->cfg.img_res * c->cfg.img_res * 3, fo = (size_t)c->tokens() * c->cfg.width;
+    const int mb = c->cfg.max_frames;
+    ARP_TRY(c->img_in.ensure((size_t)std::min(n, mb) * fi * 4));
+    ARP_TRY(c->out.ensure((size_t)std::min(n, mb) * fo * 4));
+    for (int off = 0; off < n; off += mb) {
+        const int nb = std::min(mb, n - off);
+        ARP_HIP_OK(hipMemcpyAsync(c->img_in.p, images + off * fi, nb * fi * 4, hipMemcpyHostToDevice, c->stream));
+        ARP_TRY(enc_forward_on(c, c->stream, c->img_in.as<float>(), nb, c->out.as<float>()));
+        ARP_HIP_OK(hipMemcpyAsync(out + off * fo, c->out.p, nb * fo * 4, hipMemcpyDeviceToHost, c->stream));
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int arp_enc_profile_enable(arp_enc* c, int on) {
+    if (!c) return fail("null handle");
+    c->prof.on = on != 0;
+    return 0;
+}
+int arp_enc_profile_json(arp_enc* c, char* buf, int buf_len) {
+    if (!c || !buf) return fail("null argument");
+    const std::string s = c->prof.json();
+    if ((int)s.size() + 1 > buf_len) return fail("profile buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+}  // extern "C"

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void vit_assemble_lnpre_kernel(const float* __
 }
 
 // Text token embedding (arp_dt/models/openai/layers.py:364-365): x[p*ctx + t] = tok_emb[tokens] + pos[t]
-__global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ emb,
+static __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ emb,
                                                          const float* __restrict__ pos, float* __restrict__ x, int rows, int ctx,
                                                          int D) {
     const int lane = threadIdx.x & 63;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__
 }
 
 // f[r, :] /= ||f[r, :]||   (arp_dt/models/openai/layers.py:429-439), in place, f32.
-__global__ __launch_bounds__(256) void l2_normalize_kernel(float* __restrict__ f, int rows, int E) {
+static __global__ __launch_bounds__(256) void l2_normalize_kernel(float* __restrict__ f, int rows, int E) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(float* __restrict__ f
 
 // reward[i] = exp(logit_scale) * < img[i]/||img[i]||, txt_n >  -- the "image x text GEMV"
 // (arp_dt/label_reward.py:140-146: logits_per_text[0]).  txt_n is already L2-normalised.
-__global__ __launch_bounds__(256) void reward_kernel(const float* __restrict__ img, const float* __restrict__ txt_n,
+static __global__ __launch_bounds__(256) void reward_kernel(const float* __restrict__ img, const float* __restrict__ txt_n,
                                                      float scale, float* __restrict__ reward, int rows, int E) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -129,6 +129,22 @@ class PolicyTrainer:
         check(lib.arp_dt_set_batch(self._h, _ffi.as_ptr(enc, C.c_float), _ffi.as_ptr(action, C.c_int32), _ffi.as_ptr(rtg, C.c_float), B))
         self._B = B
 
+    def attach_encoder(self, encoder):
+        """Put the frozen M3AE encoder (arp_amd.m3ae.M3AEEncoder) inside the step: the boundary then is the
+        reference's own -- batch["image"] holds frames, not encodings (ARPDT.py:413-462)."""
+        check(lib.arp_dt_attach_encoder(self._h, encoder._h))
+        self._encoder = encoder
+
+    def set_batch_images(self, images, action, rtg):
+        images = np.require(np.asarray(images, dtype=np.float32), requirements="C")
+        action = np.require(np.asarray(action, dtype=np.int32), requirements="C")
+        rtg = np.require(np.asarray(rtg, dtype=np.float32), requirements="C")
+        B, T = action.shape
+        if images.shape[:2] != (B, T) or rtg.size != B * T or T != self.cfg.window:
+            raise ValueError(f"batch shapes: images {images.shape}, action {action.shape}, rtg {rtg.shape}")
+        check(lib.arp_dt_set_batch_images(self._h, _ffi.as_ptr(images, C.c_float), _ffi.as_ptr(action, C.c_int32), _ffi.as_ptr(rtg, C.c_float), B))
+        self._B = B
+
     def forward(self):
         """ARPDT.__call__ (ARPDT.py:152-236) on the staged batch."""
         B, T, NA = self._B, self.cfg.window, self.cfg.n_actions

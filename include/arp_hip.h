@@ -171,6 +171,36 @@ int arp_dt_profile_enable(arp_dt* h, int on);
 int arp_dt_profile_reset(arp_dt* h);
 int arp_dt_profile_json(arp_dt* h, char* buf, int buf_len);
 
+/* ---- row N1: frozen M3AE image encoder (forward_representation) -----------------------------------
+ * arp_dt/models/m3ae/model.py:471-496 as called under stop_gradient by arp_dt/ARPDT.py:413-462.
+ * Weights cross under their Flax tree path ('/'-flattened, [in,out] kernels): "cls_token",
+ * "encoder_image_type_embedding", "image_embedding/{kernel,bias}", "encoder/Block_i/...", "encoder/LayerNorm_0/...". */
+typedef struct arp_enc arp_enc;
+typedef struct arp_enc_cfg {
+    int32_t patch;      /* 16  */
+    int32_t width;      /* 768 */
+    int32_t layers;     /* 12  */
+    int32_t heads;      /* 12  */
+    int32_t mlp_ratio;  /* 4   */
+    int32_t img_res;    /* 256 -> 257 tokens */
+    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_BF16 */
+    int32_t device;
+    int32_t max_frames; /* frames per internal pass; <= 0 -> 128 */
+    int32_t attn_impl;  /* 0 auto, 1 VALU */
+} arp_enc_cfg;
+int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out);
+int arp_enc_destroy(arp_enc* h);
+int arp_enc_load_weight(arp_enc* h, const char* name, const float* data, const int64_t* shape, int ndim);
+int arp_enc_finalize_weights(arp_enc* h);
+/* images f32 NHWC [n,res,res,3] (already normalised, as the training pipeline delivers them) -> f32 [n,tokens,width] */
+int arp_enc_forward(arp_enc* h, const float* images_host, int n, float* out_host);
+int arp_enc_profile_enable(arp_enc* h, int on);
+int arp_enc_profile_json(arp_enc* h, char* buf, int buf_len);
+/* Put the frozen encoder INSIDE the policy step: after attaching, arp_dt_set_batch_images stages raw frames
+ * [B,T,res,res,3] f32 and every forward / train step runs the encoder first (on the step's stream). */
+int arp_dt_attach_encoder(arp_dt* h, arp_enc* enc);
+int arp_dt_set_batch_images(arp_dt* h, const float* images, const int32_t* action, const float* rtg, int B);
+
 /* ---- single-operator entry points (host buffers; used by the per-kernel parity tests) ---------- */
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid), operands rounded to bf16 in ARP_MODE_BF16. */
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,
