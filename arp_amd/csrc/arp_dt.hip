@@ -96,6 +96,10 @@ struct arp_dt {
     DevBuf dlogits, dret, dha, dhr, da_in, dr_in, dhf, dh, t1, t2, t3, dws, dbs, dimg, dz, dqkv;
     ncclComm_t comm = nullptr;
     bool has_comm = false;
+    // forward + backward + L2 term captured once per batch geometry and replayed (about 120 short launches)
+    bool use_graph = true;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_B = 0, graph_images = -1, eager_steps = 0;
     Profiler prof;
 
     size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
@@ -522,10 +526,55 @@ int apply_update(arp_dt* c, float lr) {
     return 0;
 }
 
-template <typename T> int step_impl(arp_dt* c, float lr, float* aux) {
+template <typename T> int fwd_bwd(arp_dt* c) {
     ARP_TRY(forward<T>(c));
     ARP_TRY(backward<T>(c));
-    ARP_TRY(l2_penalty(c));
+    return l2_penalty(c);
+}
+
+// Replays forward + backward + L2 as one hipGraph (the chain is launch-bound: ~120 kernels of a few
+// microseconds).  The first steps of a geometry run eagerly (lazy workspace allocations must not happen under
+// capture); profiling and any capture failure fall back to eager launches.
+template <typename T> int fwd_bwd_graphed(arp_dt* c) {
+    const int images = c->use_images ? 1 : 0;
+    if (!c->use_graph || c->prof.on) return fwd_bwd<T>(c);
+    if (c->graph_exec && (c->graph_B != c->B || c->graph_images != images)) {
+        (void)hipGraphExecDestroy(c->graph_exec);
+        c->graph_exec = nullptr;
+        c->eager_steps = 0;
+    }
+    if (!c->graph_exec) {
+        if (c->eager_steps < 2) {
+            c->eager_steps++;
+            return fwd_bwd<T>(c);
+        }
+        c->shadows_stale = true;  // the captured chain always refreshes the operand shadows
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            c->use_graph = false;
+            return fwd_bwd<T>(c);
+        }
+        const int rc = fwd_bwd<T>(c);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc != 0 || e != hipSuccess || !g || hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+            if (g) (void)hipGraphDestroy(g);
+            c->graph_exec = nullptr;
+            c->use_graph = false;
+            (void)hipGetLastError();
+            c->shadows_stale = true;
+            return fwd_bwd<T>(c);
+        }
+        (void)hipGraphDestroy(g);
+        c->graph_B = c->B;
+        c->graph_images = images;
+    }
+    ARP_HIP_OK(hipGraphLaunch(c->graph_exec, c->stream));
+    c->shadows_stale = false;
+    return 0;
+}
+
+template <typename T> int step_impl(arp_dt* c, float lr, float* aux) {
+    ARP_TRY(fwd_bwd_graphed<T>(c));
     if (c->has_comm && c->cfg.world > 1) {
         // pmean of (loss, aux, grads) over devices (main_procgen.py:132): ONE all-reduce(sum) of the flat
         // gradient plus one of the 8 scalars; the 1/world factor is folded into the update kernel
@@ -578,6 +627,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     arp_dt* c = new arp_dt();
     c->cfg = k;
     if (c->cfg.world <= 0) c->cfg.world = 1;
+    if (const char* e = getenv("ARP_DT_GRAPH")) c->use_graph = atoi(e) != 0;
     build_layout(c);
     auto body = [&]() -> int {
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -600,6 +650,7 @@ int arp_dt_destroy(arp_dt* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
     c->prof.destroy();
     DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,

@@ -19,27 +19,42 @@ struct SmallGemm {
 };
 
 __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
-    __shared__ float As[16][33];
-    __shared__ float Bs[16][33];
+    // K in steps of 64 (a 12-token-transformer GEMM has K = 128..512: 2..8 steps), operands prefetched into
+    // registers one step ahead so the global-memory latency of step k+1 hides under the FMAs of step k.
+    constexpr int KS = 64;
+    __shared__ float As[KS][33];
+    __shared__ float Bs[KS][33];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
-        for (int i = threadIdx.x; i < 512; i += 256) {
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = threadIdx.x + e * 256;  // 0..2047
             // consecutive threads walk the operand's CONTIGUOUS axis (k for a row-major operand, m/n for a
             // transposed one) so both layouts load coalesced
-            const int ka = g.ta ? (i >> 5) : (i & 15), ra = g.ta ? (i & 31) : (i >> 4);
-            const int kb = g.tb ? (i & 15) : (i >> 5), rb = g.tb ? (i >> 4) : (i & 31);
-            const int m = m0 + ra, n = n0 + rb;
-            float a = 0.f, b = 0.f;
-            if (k0 + ka < g.K && m < g.M) a = g.ta ? g.A[(size_t)(k0 + ka) * g.lda + m] : g.A[(size_t)m * g.lda + k0 + ka];
-            if (k0 + kb < g.K && n < g.N) b = g.tb ? g.B[(size_t)n * g.ldb + k0 + kb] : g.B[(size_t)(k0 + kb) * g.ldb + n];
-            As[ka][ra] = a;
-            Bs[kb][rb] = b;
+            const int ka = g.ta ? (i >> 5) : (i & 63), rra = g.ta ? (i & 31) : (i >> 6);
+            const int kb = g.tb ? (i & 63) : (i >> 5), rrb = g.tb ? (i >> 6) : (i & 31);
+            const int m = m0 + rra, n = n0 + rrb;
+            ra[e] = (k0 + ka < g.K && m < g.M) ? (g.ta ? g.A[(size_t)(k0 + ka) * g.lda + m] : g.A[(size_t)m * g.lda + k0 + ka]) : 0.f;
+            rb[e] = (k0 + kb < g.K && n < g.N) ? (g.tb ? g.B[(size_t)n * g.ldb + k0 + kb] : g.B[(size_t)(k0 + kb) * g.ldb + n]) : 0.f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.K; k0 += KS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = threadIdx.x + e * 256;
+            const int ka = g.ta ? (i >> 5) : (i & 63), rra = g.ta ? (i & 31) : (i >> 6);
+            const int kb = g.tb ? (i & 63) : (i >> 5), rrb = g.tb ? (i >> 6) : (i & 31);
+            As[ka][rra] = ra[e];
+            Bs[kb][rrb] = rb[e];
         }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
+        if (k0 + KS < g.K) fetch(k0 + KS);
+#pragma unroll 16
+        for (int kk = 0; kk < KS; ++kk) {
             const float a0 = As[kk][ty * 2], a1 = As[kk][ty * 2 + 1];
             const float b0 = Bs[kk][tx * 2], b1 = Bs[kk][tx * 2 + 1];
             acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);

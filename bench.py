@@ -78,7 +78,17 @@ def bench_policy(a):
         dist.broadcast_object_list(ids, src=0)
         tr.comm_init(ids[0], world, rank)
         tr.broadcast_state()
-    tr.set_batch(*S.policy_batch(cfg, a.policy_batch, seed=100 + rank))
+    enc = None
+    if a.with_encoder:
+        from arp_amd import m3ae
+        ecfg = m3ae.EncoderConfig()
+        enc = m3ae.M3AEEncoder(ecfg, S.m3ae_params(ecfg, seed=0), mode=a.mode, device=local_rank, max_frames=a.policy_batch * cfg.window)
+        tr.attach_encoder(enc)
+        _, act_, rtg_ = S.policy_batch(PolicyConfig(enc_tokens=1, enc_dim=4), a.policy_batch, seed=100 + rank)
+        frames = S.normalized_frames(a.policy_batch * cfg.window, 256, seed=100 + rank).reshape(a.policy_batch, cfg.window, 256, 256, 3)
+        tr.set_batch_images(frames, act_, rtg_)
+    else:
+        tr.set_batch(*S.policy_batch(cfg, a.policy_batch, seed=100 + rank))
     lr = 5e-4
     for _ in range(a.warmup):
         tr.train_step_async(lr)
@@ -104,6 +114,11 @@ def bench_policy(a):
         tr.train_step_async(lr)
     tr.sync()
     prof = tr.profile_read()
+    if enc is not None:
+        enc.profile(True)
+        tr.train_step_async(lr)
+        tr.sync()
+        prof.update({k: {"ms": v["ms"] * a.steps, "calls": v["calls"] * a.steps} for k, v in enc.profile_read().items()})
     aux = tr.train_step(lr)
     if rank == 0:
         Mx = a.policy_batch * cfg.window * cfg.enc_tokens
@@ -112,7 +127,8 @@ def bench_policy(a):
         avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
         peak = PEAK_TFLOPS[a.mode]
         print(json.dumps({
-            "metric": "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
+            "metric": "samples/sec ARPDT train_step (frames in, frozen M3AE encoder inside)" if enc is not None else
+                      "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
             "config": {"workload": f"ARPDT policy train_step, {a.policy_batch} samples/GPU x window 4, random-init encodings [B,4,257,768] f32 "
@@ -140,6 +156,8 @@ def main():
     ap.add_argument("--path", default="label", choices=["label", "policy"],
                     help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary)")
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
+    ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
+                    "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
     a = ap.parse_args()
     if a.path == "policy":
         return bench_policy(a)
