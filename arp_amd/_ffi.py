@@ -27,7 +27,7 @@ class ArpError(RuntimeError):
 class ClipCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "patch", "width", "layers", "heads", "embed", "img_res", "txt_width", "txt_layers", "txt_heads", "ctx",
-        "vocab", "mode", "device", "max_batch", "attn_impl")]
+        "vocab", "mode", "device", "max_batch", "attn_impl", "n_streams")]
 
 
 class DtCfg(C.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "arp_clip_label": (_i, [_vp, _u8p, _i, _i, _i, _i, _fp]),
     "arp_clip_label_dev_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "arp_clip_sync": (_i, [_vp]),
+    "arp_clip_set_streams": (_i, [_vp, _i]),
     "arp_clip_encode_image": (_i, [_vp, _u8p, _i, _i, _i, _i, _i, _fp]),
     "arp_preprocess": (_i, [_u8p, _i, _i, _i, _i, _i, _fp]),
     "arp_bicubic_coeffs": (_i, [_i, _i, _i32p, _i32p, _i32p, _i]),

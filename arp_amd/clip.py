@@ -110,12 +110,12 @@ class ClipLabeller:
     operands, f32 accumulate / residual / LayerNorm / softmax) or "f32" (parity; f32-input MFMA).
     """
 
-    def __init__(self, cfg, state_dict, mode="bf16", device=0, max_batch=1024, attn_impl=0):
+    def __init__(self, cfg, state_dict, mode="bf16", device=0, max_batch=1024, attn_impl=0, n_streams=1):
         _ffi.require_gpu()
         self.cfg = cfg
         self.mode = {"bf16": MODE_BF16, "f32": MODE_F32}[mode]
         c = _ffi.ClipCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.embed, cfg.img_res, cfg.txt_width,
-                         cfg.txt_layers, cfg.txt_heads, cfg.ctx, cfg.vocab, self.mode, device, max_batch, attn_impl)
+                         cfg.txt_layers, cfg.txt_heads, cfg.ctx, cfg.vocab, self.mode, device, max_batch, attn_impl, n_streams)
         h = C.c_void_p()
         check(lib.arp_clip_create(C.byref(c), C.byref(h)))
         self._h = h
@@ -184,6 +184,9 @@ class ClipLabeller:
 
     def sync(self):
         check(lib.arp_clip_sync(self._h))
+
+    def set_streams(self, n_streams):
+        check(lib.arp_clip_set_streams(self._h, int(n_streams)))
 
     def record(self, event):
         check(lib.arp_clip_event_record(self._h, event.ptr))

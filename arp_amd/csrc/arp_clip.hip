@@ -207,6 +207,11 @@ struct arp_clip {
     DevBuf patches, pe, x, h, qkv, ao, fc, cls_h, feat, frames_in, rewards;
     std::map<long long, ResizePlan*> plans;
     Profiler prof;
+    // second stream: a shallow clone (shared weights, own workspace/stream/profiler) that labels the other half of a
+    // batch concurrently, so one half's memory-bound kernels and GEMM tails overlap the other half's GEMMs
+    arp_clip* sibling = nullptr;
+    bool is_sibling = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int gemm_force = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (ARP_GEMM env)
 
     int ntok() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
@@ -438,7 +443,7 @@ static int check_ready(arp_clip* c, bool need_text) {
     return 0;
 }
 
-static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev) {
+static int label_dev_single(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev) {
     ARP_TRY(check_ready(c, true));
     if (n < 0) return fail("negative frame count");
     if (n == 0) return 0;
@@ -456,6 +461,52 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
                            scale, rewards_dev + off, nb, c->cfg.embed);
         ARP_HIP_OK(hipGetLastError());
     }
+    return 0;
+}
+
+static int make_sibling(arp_clip* c) {
+    arp_clip* s = new arp_clip(*c);  // shares every weight pointer; owns nothing of them
+    s->is_sibling = true;
+    s->sibling = nullptr;
+    s->owned.clear();
+    s->staged.clear();
+    s->prof = Profiler();
+    s->prof.on = c->prof.on;
+    s->ws_frames = 0;
+    DevBuf* bufs[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards};
+    for (auto* b : bufs) *b = DevBuf();
+    s->stream = nullptr;
+    s->ev_fork = s->ev_join = nullptr;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete s;
+        return fail("hipStreamCreate failed");
+    }
+    ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    c->sibling = s;
+    return 0;
+}
+
+static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev) {
+    ARP_TRY(check_ready(c, true));
+    if (c->cfg.n_streams < 2 || n < 256) return label_dev_single(c, frames_dev, n, H, W, use_crop, rewards_dev);
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (!c->sibling) ARP_TRY(make_sibling(c));
+    arp_clip* s = c->sibling;
+    ResizePlan* plan;
+    ARP_TRY(get_plan(c, H, W, use_crop, &plan));
+    s->plans = c->plans;  // shared, owned by the primary
+    s->txt_feat = c->txt_feat;
+    s->n_prompts = c->n_prompts;
+    s->logit_scale = c->logit_scale;
+    s->prof.on = c->prof.on;
+    const int n0 = n / 2;
+    ARP_HIP_OK(hipEventRecord(c->ev_fork, c->stream));
+    ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_fork, 0));
+    ARP_TRY(label_dev_single(c, frames_dev, n0, H, W, use_crop, rewards_dev));
+    ARP_TRY(label_dev_single(s, frames_dev + (size_t)n0 * H * W * 3, n - n0, H, W, use_crop, rewards_dev + n0));
+    ARP_HIP_OK(hipEventRecord(c->ev_join, s->stream));
+    ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     return 0;
 }
 
@@ -529,6 +580,18 @@ int arp_clip_destroy(arp_clip* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->sibling) {
+        arp_clip* s = c->sibling;
+        (void)hipStreamSynchronize(s->stream);
+        s->prof.destroy();
+        DevBuf* sb[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards};
+        for (auto* b : sb) b->release();
+        (void)hipStreamDestroy(s->stream);
+        s->plans.clear();
+        delete s;
+        (void)hipEventDestroy(c->ev_fork);
+        (void)hipEventDestroy(c->ev_join);
+    }
     c->prof.destroy();
     for (void* p : c->owned) (void)hipFree(p);
     for (auto& kv : c->plans) {
@@ -701,18 +764,40 @@ int arp_preprocess(const uint8_t* frames, int n, int H, int W, int use_crop, int
     return rc;
 }
 
+int arp_clip_set_streams(arp_clip* c, int n_streams) {
+    if (!c || n_streams < 0 || n_streams > 2) return fail("n_streams must be 0, 1 or 2");
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    if (c->sibling) ARP_HIP_OK(hipStreamSynchronize(c->sibling->stream));
+    c->cfg.n_streams = n_streams;
+    return 0;
+}
+
 int arp_clip_profile_enable(arp_clip* c, int on) {
     if (!c) return fail("null handle");
     c->prof.on = on != 0;
+    if (c->sibling) c->sibling->prof.on = c->prof.on;
     return 0;
 }
 int arp_clip_profile_reset(arp_clip* c) {
     if (!c) return fail("null handle");
     c->prof.reset();
+    if (c->sibling) c->sibling->prof.reset();
     return 0;
 }
 int arp_clip_profile_json(arp_clip* c, char* buf, int buf_len) {
     if (!c || !buf) return fail("null argument");
+    if (c->sibling) {  // fold the second stream's launches into the primary's sites
+        Profiler& q = c->sibling->prof;
+        q.collect();
+        c->prof.collect();
+        for (size_t i = 0; i < q.names.size(); ++i) {
+            const int id = c->prof.site_id(q.names[i].c_str());
+            c->prof.ms[id] += q.ms[i];
+            c->prof.calls[id] += q.calls[i];
+            q.ms[i] = 0.0;
+            q.calls[i] = 0;
+        }
+    }
     const std::string s = c->prof.json();
     if ((int)s.size() + 1 > buf_len) return fail("profile buffer too small");
     memcpy(buf, s.c_str(), s.size() + 1);

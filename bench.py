@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--parity-frames", type=int, default=4, help="frames checked against the oracle before timing (rank 0)")
+    ap.add_argument("--streams", type=int, default=2, help="label path: 2 = the two halves of each batch run on two HIP streams of "
+                    "the same GPU (one half's LayerNorm/attention/GEMM tails overlap the other half's GEMMs); 1 = single stream")
     ap.add_argument("--path", default="label", choices=["label", "policy"],
                     help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary)")
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
@@ -188,7 +190,7 @@ def main():
     cfg = clip.MODELS[a.model]
     weights = synth.clip_weights(cfg, seed=0)
     tokens = synth.prompt_tokens(1, 8, seed=2)
-    model = clip.ClipLabeller(cfg, weights, mode=a.mode, device=local_rank, max_batch=a.batch).set_text(tokens)
+    model = clip.ClipLabeller(cfg, weights, mode=a.mode, device=local_rank, max_batch=a.batch, n_streams=a.streams).set_text(tokens)
 
     # parity gate on a few frames (rank 0): the thing timed below is the thing checked here
     parity = None
@@ -252,10 +254,23 @@ def main():
     model.sync()
     prof = model.profile_read()
     prof_ms = clip.elapsed_ms(e2, e3)
+    # isolated per-kernel figures: the same steps on ONE stream (no other kernel shares the chip with a launch)
+    iso = None
+    if a.streams >= 2 and a.batch >= 256:
+        model.set_streams(1)
+        step()
+        model.sync()
+        model.profile_reset()
+        for _ in range(max(a.steps // 2, 2)):
+            step()
+        model.sync()
+        iso = model.profile_read()
+        model.set_streams(a.streams)
     model.profile(False)
 
     if rank == 0:
-        sites = gemm_sites(cfg, a.batch)
+        nsplit = 2 if (a.streams >= 2 and a.batch >= 256) else 1  # launches per call site per layer (half batches)
+        sites = {k: v / nsplit for k, v in gemm_sites(cfg, a.batch).items()}
         dom = max(sites, key=lambda s: prof.get(s, {"ms": 0})["ms"])
         avg_ms = prof[dom]["ms"] / max(prof[dom]["calls"], 1)
         achieved = sites[dom] / (avg_ms * 1e-3) / 1e12
@@ -285,10 +300,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"CLIP {a.model} reward labelling, batch {a.batch} synthetic 256x256x3 uint8 frames per GPU resident in HBM "
                                    f"(BASELINE.json configs[1]), random-init weights, text tower cached", "frames_per_gpu_per_step": a.batch,
-                       "parallelism": f"shard{world} (no collective)"},
+                       "parallelism": f"shard{world} (no collective)", "streams_per_gpu": nsplit},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": f"gemm_nt_kernel @ {dom}", "flops_per_launch": sites[dom],
+                         "traffic": (traffic / nsplit if traffic else None), "kernel": f"gemm256_nt_kernel @ {dom}",
+                         "note": (f"each launch covers {a.batch // nsplit} frames; with --streams 2 two such launches (the two half batches) share "
+                                  "the chip, so a launch's HIP-event duration includes time it ran beside the other stream's kernels; "
+                                  "--streams 1 gives the isolated per-kernel figure") if nsplit > 1 else "single stream", "flops_per_launch": sites[dom],
                          "avg_launch_ms": avg_ms, "launches": prof[dom]["calls"]},
+            "roofline_isolated": (None if iso is None else {
+                "achieved": gemm_sites(cfg, a.batch)[dom] / (iso[dom]["ms"] / iso[dom]["calls"] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": gemm_sites(cfg, a.batch)[dom] / (iso[dom]["ms"] / iso[dom]["calls"] * 1e-3) / 1e12 / peak,
+                "avg_launch_ms": iso[dom]["ms"] / iso[dom]["calls"], "flops_per_launch": gemm_sites(cfg, a.batch)[dom],
+                "note": f"same kernel @ {dom}, whole {a.batch}-frame batch per launch on a single stream (nothing else resident)"}),
             "cpu_baseline": cpu,
             "whole_pass": {"gflop_per_frame": flops_frame / 1e9, "mfma_frac_of_peak": fps / world * flops_frame / (peak * 1e12),
                            "hip_event_ms_per_step": ev_ms / a.steps, "profiled_ms_per_step": prof_ms / a.steps},

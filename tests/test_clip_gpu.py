@@ -119,3 +119,23 @@ def test_online_single_frame_reward(gpu_lib):
         r = L.get_torch_clip_reward(m, fr[i])
         assert r.shape == (1,) and abs(r[0] - ref[i]) / scale < COS_TOL_F32
     m.close()
+
+
+def test_two_stream_split_matches_single_stream(gpu_lib):
+    """n_streams = 2 labels the two halves of a batch on two HIP streams; results are bit-identical to one stream."""
+    from arp_amd import clip, synth
+    from oracle import clip_np as C
+    ocfg = C.ClipConfig(**TINY)
+    Wt = synth.clip_weights(ocfg, seed=3)
+    tok = synth.prompt_tokens(1, 5, ctx=ocfg.ctx, vocab=ocfg.vocab, seed=4)
+    fr = synth.procgen_like_frames(301, 64, 64, seed=5)  # odd count: halves of 150 and 151
+    a = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode="bf16", n_streams=1).set_text(tok)
+    b = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode="bf16", n_streams=2).set_text(tok)
+    ra, rb = a.label(fr), b.label(fr)
+    assert (ra == rb).all()
+    b.profile(True)
+    rb2 = b.label(fr)
+    assert (rb2 == ra).all() and b.profile_read()["vit.qkv"]["calls"] == 2 * TINY["layers"]
+    ref = C.compute_reward(Wt, ocfg, fr[:6], tok)
+    assert np.abs(ra[:6] - ref).max() / float(np.exp(Wt["logit_scale"])) < COS_TOL_BF16
+    a.close(); b.close()
