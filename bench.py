@@ -279,7 +279,13 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch of the dominant kernel from committed rocprofv3 --pmc passes
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath)).get(dom, {})
+                traffic = rec.get("hbm_bytes_per_launch")
+                # the committed PMC run may have used a different launch size: scale by workgroup count
+                exp_grid = 512 * (-(-(a.batch * cfg.tokens // (2 if (a.streams >= 2 and a.batch >= 256) else 1)) // 256)) * {
+                    "vit.c_fc": 4 * cfg.width, "vit.qkv": 3 * cfg.width}.get(dom, cfg.width) // 256
+                if traffic and rec.get("grid_threads") and rec["grid_threads"] != exp_grid:
+                    traffic = traffic * exp_grid / rec["grid_threads"]
             except Exception:
                 traffic = None
         fps = world * a.batch * a.steps / elapsed
@@ -302,7 +308,7 @@ def main():
                                    f"(BASELINE.json configs[1]), random-init weights, text tower cached", "frames_per_gpu_per_step": a.batch,
                        "parallelism": f"shard{world} (no collective)", "streams_per_gpu": nsplit},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": (traffic / nsplit if traffic else None), "kernel": f"gemm256_nt_kernel @ {dom}",
+                         "traffic": traffic, "kernel": f"gemm256_nt_kernel @ {dom}",
                          "note": (f"each launch covers {a.batch // nsplit} frames; with --streams 2 two such launches (the two half batches) share "
                                   "the chip, so a launch's HIP-event duration includes time it ran beside the other stream's kernels; "
                                   "--streams 1 gives the isolated per-kernel figure") if nsplit > 1 else "single stream", "flops_per_launch": sites[dom],
