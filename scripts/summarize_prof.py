@@ -33,8 +33,8 @@ SITES = {
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern)), key=os.path.getmtime)
+    return g[-1] if g else None  # newest run
 
 
 stats = one(f"prof_{tag}_trace/*/*_kernel_stats.csv")
