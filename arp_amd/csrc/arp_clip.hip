@@ -919,6 +919,7 @@ template <typename T> static int op_gemm_bench(int kernel, int act, int resid, i
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
         if (const char* fe = getenv("ARP_GEMM_FLAGS")) g.flags = atoi(fe);
         if (const char* fe = getenv("ARP_GEMM_STAGGER")) sscanf(fe, "%d,%d", &g.stagger_groups, &g.stagger_cycles);
+        if (const char* fe = getenv("ARP_GEMM_GROUP_M")) g.group_m = atoi(fe);
         auto run = [&]() -> int {
             if (resid) return launch_gemm_auto<T, float, ACT_NONE, true, SITE_OP>(g, nullptr, kernel);
             if (out_f32) return launch_gemm_auto<T, float, ACT_NONE, false, SITE_OP>(g, nullptr, kernel);

@@ -31,6 +31,7 @@ struct GemmArgs {
     int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only)
     int ksplit = 1;     // split-K: gridDim.y slices of K; slice s writes to out + s * slice_stride (bias/resid ignored by callers)
     size_t slice_stride = 0;
+    int group_m = 0;          // gemm256: tile-rows per L2 group (0 = default)
     int stagger_groups = 0;   // >1: the first wave of workgroups starts in `stagger_groups` phase groups spread over
     int stagger_cycles = 0;   //     `stagger_cycles` shader cycles, so CUs do not all reach their store epilogue together
 };
@@ -65,6 +66,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 
     const T* __restrict__ A = static_cast<const T*>(g.A);
     const T* __restrict__ W = static_cast<const T*>(g.W);
+
+    // Two workgroups share a CU.  Launched together they stay in lockstep (equal tiles) and reach their store
+    // epilogues together; delaying the second resident wave of workgroups by about half a tile puts one
+    // workgroup's epilogue under the other's K loop.
+    if (g.stagger_groups > 1 && blockIdx.x >= 256 && blockIdx.x < 512 && blockIdx.y == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)g.stagger_cycles) __builtin_amdgcn_s_sleep(64);
+    }
 
     // ---- LDS-DMA staging: each wave-instruction fills 1 KiB = 8 rows x 128 B -----------------
     // lane -> (row-in-group = lane/8, physical chunk = lane%8); it fetches logical chunk

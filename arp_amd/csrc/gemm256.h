@@ -68,10 +68,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     const int n_tiles = (g.N + G2_BN - 1) / G2_BN;
     const int m_tiles = (g.M + G2_BM - 1) / G2_BM;
     int t = xcd_remap(blockIdx.x, m_tiles * n_tiles);
-    const int per_group = G2_GROUP_M * n_tiles;
+    const int group_m = g.group_m > 0 ? g.group_m : G2_GROUP_M;
+    const int per_group = group_m * n_tiles;
     const int grp = t / per_group;
-    const int first_m = grp * G2_GROUP_M;
-    const int gsize = min(m_tiles - first_m, G2_GROUP_M);
+    const int first_m = grp * group_m;
+    const int gsize = min(m_tiles - first_m, group_m);
     t -= grp * per_group;
     const int m0 = (first_m + t % gsize) * G2_BM;
     const int n0 = (t / gsize) * G2_BN;
@@ -309,8 +310,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
             for (int it = 0; it < 16; ++it) {
                 const int r = it * 16 + wave * 2 + (lane >> 5);
                 const int m = m0 + r, n = n0 + (lane & 31) * 8;
-                if (m < g.M && n < g.N)
-                    *reinterpret_cast<uint4*>(out + (size_t)m * g.ldo + n) = *reinterpret_cast<const uint4*>(smem + r * RS + (lane & 31) * 16);
+                if (m < g.M && n < g.N) {
+                    const u32x4_v v = *reinterpret_cast<const u32x4_v*>(smem + r * RS + (lane & 31) * 16);
+                    if (g.flags & 4) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_v*>(out + (size_t)m * g.ldo + n));
+                    else *reinterpret_cast<u32x4_v*>(out + (size_t)m * g.ldo + n) = v;
+                }
             }
         } else {
             constexpr int RSF = 256 * 4 + 16;

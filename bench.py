@@ -69,6 +69,7 @@ def bench_policy(a):
     from arp_amd import _ffi, clip, synth_policy as S
     from arp_amd.train import PolicyConfig, PolicyTrainer
     _ffi.require_gpu()
+    local_rank %= _ffi.device_count()
     _ffi.check(_ffi.lib.arp_set_device(local_rank))
     cfg = PolicyConfig(lambda_ret=0.01)
     tr = PolicyTrainer(cfg, mode=a.mode, device=local_rank)
@@ -186,6 +187,7 @@ def main():
 
     from arp_amd import _ffi, clip, synth
     _ffi.require_gpu()
+    local_rank %= _ffi.device_count()  # one rank per GPU; on a box with fewer GPUs than ranks they share (test rigs only)
     _ffi.check(_ffi.lib.arp_set_device(local_rank))
     cfg = clip.MODELS[a.model]
     weights = synth.clip_weights(cfg, seed=0)
