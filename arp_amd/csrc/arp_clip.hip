@@ -213,6 +213,12 @@ struct arp_clip {
     bool is_sibling = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int gemm_force = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (ARP_GEMM env)
+    // Fold LayerNorm into the consumer GEMMs of the vision tower in bf16 mode (ARP_LN_FOLD=1).  Numerically fine
+    // (cosine error 3.6e-4 vs 4.8e-4 unfused) but MEASURED SLOWER on MI355X (74.2 k vs 79.7 k frames/s): the extra
+    // per-row loads and reductions land in the GEMM epilogues, which are the serialised part of every tile,
+    // while the LayerNorm kernels they replace overlap with the other stream's GEMMs.  Off by default.
+    bool ln_fold = false;
+    DevBuf stats;
 
     int ntok() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
     size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
@@ -277,7 +283,7 @@ static int get_staged(arp_clip* c, const std::string& name, std::vector<int64_t>
     return 0;
 }
 
-static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers, int heads, TowerW& tw) {
+static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers, int heads, TowerW& tw, bool fold) {
     tw.width = d; tw.layers = layers; tw.heads = heads;
     tw.L.resize(layers);
     for (int i = 0; i < layers; ++i) {
@@ -296,7 +302,29 @@ static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers,
         ARP_TRY(get_staged(c, p + "mlp.c_fc.bias", {4 * d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_fc));
         ARP_TRY(get_staged(c, p + "mlp.c_proj.weight", {d, 4 * d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), d, 4 * d, false, &L.w_proj));
         ARP_TRY(get_staged(c, p + "mlp.c_proj.bias", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_proj));
+        if (fold) {  // LayerNorm folded into in_proj (ln_1) and c_fc (ln_2): tower.h fold_layernorm
+            const HostTensor *w, *b, *lw, *lb;
+            std::vector<bf16_t> wf;
+            std::vector<float> cc, dd;
+            auto put = [&](const std::vector<bf16_t>& m, void** out) -> int {
+                void* dp = nullptr;
+                ARP_HIP_OK(hipMalloc(&dp, m.size() * 2));
+                ARP_HIP_OK(hipMemcpy(dp, m.data(), m.size() * 2, hipMemcpyHostToDevice));
+                c->owned.push_back(dp);
+                *out = dp;
+                return 0;
+            };
+            ARP_TRY(get_staged(c, p + "attn.in_proj_weight", {3 * d, d}, &w)); ARP_TRY(get_staged(c, p + "attn.in_proj_bias", {3 * d}, &b));
+            ARP_TRY(get_staged(c, p + "ln_1.weight", {d}, &lw)); ARP_TRY(get_staged(c, p + "ln_1.bias", {d}, &lb));
+            fold_layernorm(w->data.data(), lw->data.data(), lb->data.data(), b->data.data(), 3 * d, d, wf, cc, dd);
+            ARP_TRY(put(wf, &L.w_in_f)); ARP_TRY(upload_f32(c, cc, &L.c_in)); ARP_TRY(upload_f32(c, dd, &L.d_in));
+            ARP_TRY(get_staged(c, p + "mlp.c_fc.weight", {4 * d, d}, &w)); ARP_TRY(get_staged(c, p + "mlp.c_fc.bias", {4 * d}, &b));
+            ARP_TRY(get_staged(c, p + "ln_2.weight", {d}, &lw)); ARP_TRY(get_staged(c, p + "ln_2.bias", {d}, &lb));
+            fold_layernorm(w->data.data(), lw->data.data(), lb->data.data(), b->data.data(), 4 * d, d, wf, cc, dd);
+            ARP_TRY(put(wf, &L.w_fc_f)); ARP_TRY(upload_f32(c, cc, &L.c_fc)); ARP_TRY(upload_f32(c, dd, &L.d_fc));
+        }
     }
+    tw.folded = fold;
     return 0;
 }
 
@@ -315,9 +343,9 @@ static int layernorm(arp_clip* c, const char* site, const float* in, size_t in_s
 }
 template <typename T>
 static int run_blocks(arp_clip* c, const TowerW& tw, const char* tag, float* x, T* h, T* qkv, T* ao, T* fc, int B, int N,
-                      int causal) {
+                      int causal, float* stats = nullptr) {
     TowerCtx t = ctx_of(c);
-    return run_blocks<T, ACT_QGELU, 0>(t, tw, tag, x, h, qkv, ao, fc, B, N, causal, 1e-5f);
+    return run_blocks<T, ACT_QGELU, 0>(t, tw, tag, x, h, qkv, ao, fc, B, N, causal, 1e-5f, stats);
 }
 
 
@@ -336,6 +364,7 @@ static int ensure_workspace(arp_clip* c, int frames) {
     ARP_TRY(c->fc.ensure(M * 4 * D * e));
     ARP_TRY(c->cls_h.ensure(B * D * e));
     ARP_TRY(c->feat.ensure(B * k.embed * 4));
+    ARP_TRY(c->stats.ensure(M * (size_t)std::max(D >> 7, 1) * 8));
     c->ws_frames = frames;
     return 0;
 }
@@ -378,7 +407,7 @@ static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizeP
 #undef ARP_ASM_CALL
         ARP_HIP_OK(hipGetLastError());
     }
-    ARP_TRY(run_blocks<T>(c, c->vis, "vit", c->x.as<float>(), c->h.as<T>(), c->qkv.as<T>(), c->ao.as<T>(), c->fc.as<T>(), nb, N, 0));
+    ARP_TRY(run_blocks<T>(c, c->vis, "vit", c->x.as<float>(), c->h.as<T>(), c->qkv.as<T>(), c->ao.as<T>(), c->fc.as<T>(), nb, N, 0, c->stats.as<float>()));
     // ln_post on the CLS rows only, then proj (arp_dt/models/openai/layers.py:330-332)
     ARP_TRY(layernorm<T>(c, "vit.ln_post", c->x.as<float>(), (size_t)N * D, c->cls_h.as<T>(), D, c->lnpost_w, c->lnpost_b, nb, D, 1e-5f));
     ARP_TRY((gemm<T, float, ACT_NONE, false, SITE_PROJ>(c, "vit.proj", c->cls_h.p, c->proj_t, nullptr, nullptr, c->feat.p, nb, k.embed, D)));
@@ -473,7 +502,7 @@ static int make_sibling(arp_clip* c) {
     s->prof = Profiler();
     s->prof.on = c->prof.on;
     s->ws_frames = 0;
-    DevBuf* bufs[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards};
+    DevBuf* bufs[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards, &s->stats};
     for (auto* b : bufs) *b = DevBuf();
     s->stream = nullptr;
     s->ev_fork = s->ev_join = nullptr;
@@ -568,6 +597,7 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     c->cfg = k;
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 1024;
     if (const char* e = getenv("ARP_GEMM")) c->gemm_force = atoi(e);
+    if (const char* e = getenv("ARP_LN_FOLD")) c->ln_fold = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail("hipStreamCreate failed");
@@ -584,7 +614,7 @@ int arp_clip_destroy(arp_clip* c) {
         arp_clip* s = c->sibling;
         (void)hipStreamSynchronize(s->stream);
         s->prof.destroy();
-        DevBuf* sb[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards};
+        DevBuf* sb[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards, &s->stats};
         for (auto* b : sb) b->release();
         (void)hipStreamDestroy(s->stream);
         s->plans.clear();
@@ -599,7 +629,7 @@ int arp_clip_destroy(arp_clip* c) {
         kv.second->v_tab.release();
         delete kv.second;
     }
-    DevBuf* bufs[] = {&c->txt_feat, &c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->cls_h, &c->feat, &c->frames_in, &c->rewards};
+    DevBuf* bufs[] = {&c->txt_feat, &c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->cls_h, &c->feat, &c->frames_in, &c->rewards, &c->stats};
     for (auto* b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -636,13 +666,13 @@ int arp_clip_finalize_weights(arp_clip* c) {
     ARP_TRY(get_staged(c, "visual.ln_post.weight", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpost_w));
     ARP_TRY(get_staged(c, "visual.ln_post.bias", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpost_b));
     ARP_TRY(get_staged(c, "visual.proj", {D, E}, &t)); ARP_TRY(upload_mat(c, t->data.data(), D, E, true, &c->proj_t));
-    ARP_TRY(load_tower(c, "visual.transformer.", D, k.layers, k.heads, c->vis));
+    ARP_TRY(load_tower(c, "visual.transformer.", D, k.layers, k.heads, c->vis, c->ln_fold && k.mode == ARP_MODE_BF16 && (D & 127) == 0));
     ARP_TRY(get_staged(c, "token_embedding.weight", {k.vocab, Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->tok_emb));
     ARP_TRY(get_staged(c, "positional_embedding", {k.ctx, Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->tpos));
     ARP_TRY(get_staged(c, "ln_final.weight", {Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnf_w));
     ARP_TRY(get_staged(c, "ln_final.bias", {Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnf_b));
     ARP_TRY(get_staged(c, "text_projection", {Tw, E}, &t)); ARP_TRY(upload_mat(c, t->data.data(), Tw, E, true, &c->tproj_t));
-    ARP_TRY(load_tower(c, "transformer.", Tw, k.txt_layers, k.txt_heads, c->txt));
+    ARP_TRY(load_tower(c, "transformer.", Tw, k.txt_layers, k.txt_heads, c->txt, false));
     if (c->staged.count("logit_scale") && c->staged["logit_scale"].shape == std::vector<int64_t>{1}) c->staged["logit_scale"].shape.clear();
     ARP_TRY(get_staged(c, "logit_scale", {}, &t));
     c->logit_scale = t->data[0];

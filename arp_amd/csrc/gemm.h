@@ -31,6 +31,16 @@ struct GemmArgs {
     int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only)
     int ksplit = 1;     // split-K: gridDim.y slices of K; slice s writes to out + s * slice_stride (bias/resid ignored by callers)
     size_t slice_stride = 0;
+    // LayerNorm folding.  Consumer side (a GEMM whose A operand is the UN-normalised row x):
+    //   out = rstd_m * (x.W'^T - mu_m * c) + d,  W' = W diag(gamma), c[n] = sum_k W'[n,k], d = W beta + bias (passed as bias)
+    const float* ln_stats = nullptr;  // [M][ln_parts][2]: (sum, sum of squares) of row m over each 128-column segment
+    const float* ln_c = nullptr;      // [N]
+    int ln_parts = 0;
+    float ln_inv_d = 0.f, ln_eps = 0.f;
+    // Producer side (the f32 residual epilogue): also emit the operand-type copy of the new row and its partial sums
+    void* xb_out = nullptr;           // [M, ldxb] T
+    int ldxb = 0;
+    float* stats_out = nullptr;       // [M][N/128][2]
     int group_m = 0;          // gemm256: tile-rows per L2 group (0 = default)
     int stagger_groups = 0;   // >1: the first wave of workgroups starts in `stagger_groups` phase groups spread over
     int stagger_cycles = 0;   //     `stagger_cycles` shader cycles, so CUs do not all reach their store epilogue together
@@ -47,6 +57,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
+}
+
+// mean / rstd of row m from its 128-column partial sums
+__device__ __forceinline__ void ln_row_stats(const GemmArgs& g, int m, float& mu, float& rs) {
+    const float* st = g.ln_stats + (size_t)m * g.ln_parts * 2;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < g.ln_parts; ++p) {
+        s += st[2 * p];
+        q += st[2 * p + 1];
+    }
+    mu = s * g.ln_inv_d;
+    rs = 1.0f / sqrtf(fmaxf(q * g.ln_inv_d - mu * mu, 0.f) + g.ln_eps);
+}
+// sum over each 32-lane half of the wavefront (all lanes of the half receive it)
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
@@ -179,11 +207,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
         if constexpr (sizeof(OutT) == 2) {
             constexpr int RS = 128 * 2 + 16;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi) {
+                float mu = 0.f, rs = 1.f;
+                if (g.ln_stats) ln_row_stats(g, min(m0 + wr * 64 + mi * 16 + fr, g.M - 1), mu, rs);
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int row = wr * 64 + mi * 16 + fr, col = wc * 64 + ni * 16 + fg * 4;
                     float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+                    if (g.ln_stats && n0 + col < g.N) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n0 + col);
+                        v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
+                        v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
+                    }
                     if (g.bias && n0 + col < g.N) {
                         const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -192,6 +227,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
                     *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 }
+            }
             __syncthreads();
 #pragma unroll 4
             for (int it = 0; it < 8; ++it) {
@@ -225,13 +261,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                 for (int it = 0; it < 8; ++it) {
                     const int lr = it * 8 + wave * 2 + (lane >> 5);
                     const int m = m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), n = n0 + (lane & 31) * 4;
-                    if (m < g.M && n < g.N) {
-                        float4 v = *reinterpret_cast<const float4*>(smem + lr * RSF + (lane & 31) * 16);
+                    const bool ok = m < g.M && n < g.N;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) {
+                        v = *reinterpret_cast<const float4*>(smem + lr * RSF + (lane & 31) * 16);
                         if constexpr (RESID) {
                             const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                         }
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
+                        if (g.xb_out) store4(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, v.x, v.y, v.z, v.w);
+                    }
+                    if (g.stats_out) {  // one 128-column segment per 32-lane half
+                        const float s = half_wave_sum((v.x + v.y) + (v.z + v.w));
+                        const float q = half_wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+                        if ((lane & 31) == 0 && ok) {
+                            float* st = g.stats_out + ((size_t)m * (g.N >> 7) + (n0 >> 7)) * 2;
+                            st[0] = s;
+                            st[1] = q;
+                        }
                     }
                 }
             }

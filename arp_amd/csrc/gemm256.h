@@ -288,15 +288,22 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int mq = 0; mq < 2; ++mq)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int row = wr * 128 + mq * 64 + mi * 16 + fr;
+                    float mu = 0.f, rs = 1.f;
+                    if (g.ln_stats) ln_row_stats(g, min(m0 + row, g.M - 1), mu, rs);  // folded LayerNorm (gemm.h)
 #pragma unroll
                     for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni) {
-                            const int row = wr * 128 + mq * 64 + mi * 16 + fr;
                             const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
                             const f32x4_v a4 = acc[mq][nq][ni][mi];
                             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                            if (g.ln_stats && n0 + col < g.N) {
+                                const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n0 + col);
+                                v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
+                                v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
+                            }
                             if (g.bias && n0 + col < g.N) {
                                 const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
                                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -305,6 +312,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                             for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
                             *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                         }
+                }
             __syncthreads();
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
@@ -344,13 +352,25 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                 for (int it = 0; it < 16; ++it) {
                     const int lr = it * 8 + wave;
                     const int m = m0 + (lr >> 6) * 128 + p * 64 + (lr & 63), n = n0 + lane * 4;
-                    if (m < g.M && n < g.N) {
-                        float4 v = *reinterpret_cast<const float4*>(smem + lr * RSF + lane * 16);
+                    const bool ok = m < g.M && n < g.N;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) {
+                        v = *reinterpret_cast<const float4*>(smem + lr * RSF + lane * 16);
                         if constexpr (RESID) {
                             const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                         }
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
+                        if (g.xb_out) store4(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, v.x, v.y, v.z, v.w);
+                    }
+                    if (g.stats_out) {  // folded-LayerNorm producer: one 128-column segment per 32-lane half
+                        const float s = half_wave_sum((v.x + v.y) + (v.z + v.w));
+                        const float q = half_wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+                        if ((lane & 31) == 0 && ok) {
+                            float* st = g.stats_out + ((size_t)m * (g.N >> 7) + ((n0 >> 7) + (lane >> 5))) * 2;
+                            st[0] = s;
+                            st[1] = q;
+                        }
                     }
                 }
             }

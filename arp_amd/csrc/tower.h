@@ -18,10 +18,81 @@ enum Site { SITE_PATCH = 0, SITE_QKV = 1, SITE_OUT = 2, SITE_FC1 = 3, SITE_FC2 =
 struct LayerW {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
     void *w_in, *w_out, *w_fc, *w_proj;
+    // LayerNorm-folded operands (bf16 mode): W' = W diag(gamma), c = row sums of W', d = W beta + bias
+    void *w_in_f = nullptr, *w_fc_f = nullptr;
+    float *c_in = nullptr, *d_in = nullptr, *c_fc = nullptr, *d_fc = nullptr;
 };
 struct TowerW {
     int width = 0, layers = 0, heads = 0;
+    bool folded = false;  // every layer carries the folded operands
     std::vector<LayerW> L;
+};
+
+// Host-side LayerNorm folding for a Linear that consumes LN(x):
+//   LN(x) W^T + b = rstd * (x W'^T - mu * c) + d,   W' = W diag(gamma),  c[n] = sum_k W'[n,k],  d = W beta + b.
+// W' is rounded to bf16 first and c is summed from the ROUNDED values, so the mean subtraction cancels exactly
+// what the MFMA accumulates.
+inline void fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K,
+                           std::vector<bf16_t>& Wf, std::vector<float>& c, std::vector<float>& d) {
+    Wf.resize((size_t)N * K);
+    c.assign(N, 0.f);
+    d.assign(N, 0.f);
+    for (int n = 0; n < N; ++n) {
+        double cs = 0.0, ds = bias ? (double)bias[n] : 0.0;
+        for (int k = 0; k < K; ++k) {
+            const float w = W[(size_t)n * K + k];
+            const bf16_t wb = host_f2bf(w * gamma[k]);
+            Wf[(size_t)n * K + k] = wb;
+            uint32_t u = (uint32_t)wb << 16;
+            float wf;
+            memcpy(&wf, &u, 4);
+            cs += (double)wf;
+            ds += (double)w * (double)beta[k];
+        }
+        c[n] = (float)cs;
+        d[n] = (float)ds;
+    }
+}
+
+// x f32 [rows, D] -> operand-type copy xb and the per-128-column partial (sum, sumsq) the folded GEMMs consume.
+template <typename T>
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, T* __restrict__ xb, float* __restrict__ stats,
+                                                        int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int parts = D >> 7;
+    for (int c0 = 0; c0 < D; c0 += 256) {  // one 256-column chunk per iteration: two 128-column segments
+        const int c = c0 + lane * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            load4(x + (size_t)row * D + c, v);
+            store4(xb + (size_t)row * D + c, v[0], v[1], v[2], v[3]);
+        }
+        float s = (v[0] + v[1]) + (v[2] + v[3]);
+        float q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        const int seg = (c0 >> 7) + (lane >> 5);
+        if ((lane & 31) == 0 && seg < parts) {
+            stats[((size_t)row * parts + seg) * 2] = s;
+            stats[((size_t)row * parts + seg) * 2 + 1] = q;
+        }
+    }
+}
+
+// optional LayerNorm-fold plumbing of one GEMM launch
+struct GemmFold {
+    const float* stats = nullptr;  // consumer
+    const float* c = nullptr;
+    int parts = 0;
+    float inv_d = 0.f, eps = 0.f;
+    void* xb_out = nullptr;        // producer
+    int ldxb = 0;
+    float* stats_out = nullptr;
 };
 
 // what a tower launch needs from its owner
@@ -34,8 +105,12 @@ struct TowerCtx {
 
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
 static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* W, const float* bias, const float* resid, void* out,
-                int M, int N, int K) {
+                int M, int N, int K, const GemmFold* f = nullptr) {
     GemmArgs g;
+    if (f) {
+        g.ln_stats = f->stats; g.ln_c = f->c; g.ln_parts = f->parts; g.ln_inv_d = f->inv_d; g.ln_eps = f->eps;
+        g.xb_out = f->xb_out; g.ldxb = f->ldxb; g.stats_out = f->stats_out;
+    }
     g.A = A; g.W = W; g.bias = bias; g.resid = resid; g.out = out;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
     ProfScope ps(*c.prof, c.stream, site);
@@ -111,11 +186,37 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
 // SB: site-id base so that every call site is its own kernel instantiation in a rocprof trace.
 template <typename T, int ACT, int SB>
 static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, T* h, T* qkv, T* ao, T* fc, int B, int N, int causal,
-                      float eps) {
+                      float eps, float* stats = nullptr) {
     const int D = tw.width, M = B * N;
     const std::string t(tag);
     const std::string s_ln1 = t + ".ln_1", s_qkv = t + ".qkv", s_attn = t + ".attn", s_out = t + ".out_proj", s_ln2 = t + ".ln_2",
-                      s_fc1 = t + ".c_fc", s_fc2 = t + ".c_proj";
+                      s_fc1 = t + ".c_fc", s_fc2 = t + ".c_proj", s_st = t + ".ln_stats";
+    if (stats && tw.folded && sizeof(T) == 2 && (D & 127) == 0) {
+        // LayerNorm folded into the consumer GEMMs: `h` holds the bf16 copy of the residual stream, `stats` its
+        // per-128-column partial sums; both are re-emitted by the epilogue of every residual GEMM.  No LN kernel runs.
+        GemmFold cons, prod;
+        cons.stats = stats; cons.parts = D >> 7; cons.inv_d = 1.0f / (float)D; cons.eps = eps;
+        prod.xb_out = h; prod.ldxb = D; prod.stats_out = stats;
+        {
+            ProfScope ps(*c.prof, c.stream, s_st.c_str());
+            hipLaunchKernelGGL((row_stats_kernel<T>), dim3((M + 3) / 4), dim3(256), 0, c.stream, x, h, stats, M, D);
+            ARP_HIP_OK(hipGetLastError());
+        }
+        for (int i = 0; i < tw.layers; ++i) {
+            const LayerW& L = tw.L[i];
+            cons.c = L.c_in;
+            ARP_TRY((tower_gemm<T, T, ACT_NONE, false, SB + SITE_QKV>(c, s_qkv.c_str(), h, L.w_in_f, L.d_in, nullptr, qkv, M, 3 * D, D, &cons)));
+            {
+                ProfScope ps(*c.prof, c.stream, s_attn.c_str());
+                ARP_TRY(launch_attention<T>(c.stream, c.attn_impl, qkv, ao, B, N, D, tw.heads, causal));
+            }
+            ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out.c_str(), ao, L.w_out, L.b_out, x, x, M, D, D, &prod)));
+            cons.c = L.c_fc;
+            ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc1.c_str(), h, L.w_fc_f, L.d_fc, nullptr, fc, M, 4 * D, D, &cons)));
+            ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_FC2>(c, s_fc2.c_str(), fc, L.w_proj, L.b_proj, x, x, M, D, 4 * D, &prod)));
+        }
+        return 0;
+    }
     for (int i = 0; i < tw.layers; ++i) {
         const LayerW& L = tw.L[i];
         ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));

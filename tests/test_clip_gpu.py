@@ -139,3 +139,38 @@ def test_two_stream_split_matches_single_stream(gpu_lib):
     ref = C.compute_reward(Wt, ocfg, fr[:6], tok)
     assert np.abs(ra[:6] - ref).max() / float(np.exp(Wt["logit_scale"])) < COS_TOL_BF16
     a.close(); b.close()
+
+
+MID = dict(patch=32, width=128, layers=3, heads=2, embed=64, img_res=224, txt_width=64, txt_layers=2, txt_heads=2, ctx=77, vocab=512)
+
+
+def test_layernorm_fold_matches_unfused(gpu_lib, monkeypatch):
+    """bf16 mode folds LayerNorm into the consumer GEMMs (gamma into W, mean/rstd from the residual GEMM's epilogue
+    partial sums).  Folded and unfused paths must agree with each other and with the oracle; LN scale/bias are far
+    from identity and the rows have a large mean so the mean-subtraction term is exercised."""
+    from arp_amd import clip, synth
+    from oracle import clip_np as C
+    ocfg = C.ClipConfig(**MID)
+    Wt = synth.clip_weights(ocfg, seed=17)
+    rng = np.random.default_rng(3)
+    for k in list(Wt):
+        if k.startswith("visual") and (".ln_1." in k or ".ln_2." in k):
+            Wt[k] = (Wt[k] + (0.5 * rng.standard_normal(Wt[k].shape) if k.endswith("weight") else 0.3 * rng.standard_normal(Wt[k].shape))).astype(np.float32)
+    Wt["visual.class_embedding"] = (Wt["visual.class_embedding"] + 0.5).astype(np.float32)   # rows with a large mean
+    Wt["visual.ln_pre.bias"] = (Wt["visual.ln_pre.bias"] + 0.7).astype(np.float32)
+    tok = synth.prompt_tokens(1, 5, ctx=ocfg.ctx, vocab=ocfg.vocab, seed=4)
+    fr = synth.procgen_like_frames(9, seed=5)
+    ref = C.compute_reward(Wt, ocfg, fr, tok)
+    scale = float(np.exp(Wt["logit_scale"]))
+    out = {}
+    for fold in ("0", "1"):
+        monkeypatch.setenv("ARP_LN_FOLD", fold)
+        m = clip.ClipLabeller(clip.ClipConfig(**MID), Wt, mode="bf16").set_text(tok)
+        m.profile(True)
+        out[fold] = m.label(fr)
+        sites = m.profile_read()
+        assert ("vit.ln_1" in sites) == (fold == "0") and ("vit.ln_stats" in sites) == (fold == "1")
+        m.close()
+    e0, e1 = np.abs(out["0"] - ref).max() / scale, np.abs(out["1"] - ref).max() / scale
+    print(f"cosine err unfused {e0:.2e}, folded {e1:.2e}, folded vs unfused {np.abs(out['0'] - out['1']).max() / scale:.2e}")
+    assert e0 < COS_TOL_BF16 and e1 < COS_TOL_BF16
