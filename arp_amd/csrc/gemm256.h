@@ -438,12 +438,19 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     return 0;
 }
 
-// Picks the 256x256 pipelined kernel when the grid fills the chip, else the 128x128 kernel.
+}  // namespace arp
+#include "gemm_p.h"
+namespace arp {
+
+// force: 0 = auto, 1 = 128x128 (2 WG/CU, two-phase), 2 = 256x256 (1 WG/CU, four-phase pipelined),
+// 3 = 256x128 paired (2 WG/CU, 3-deep ring).  Auto: a big-tile kernel when the grid fills the chip.
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
 inline int launch_gemm_auto(const GemmArgs& g, hipStream_t stream, int force = 0) {
     const long tiles256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
-    const bool big = force == 2 || (force == 0 && tiles256 >= 192);
-    if (big) return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);
+    if (force == 3) return launch_gemm_p<T, OutT, ACT, RESID, SITE>(g, stream);
+    if (force == 2) return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);
+    if (force == 1) return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, stream);
+    if (tiles256 >= 192) return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);
     return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, stream);
 }
 

@@ -33,15 +33,15 @@ GEMM_SHAPES = [  # M, N, K
 ]
 
 
-@pytest.mark.parametrize("kernel", ["128", "256"])
+@pytest.mark.parametrize("kernel", ["128", "256", "paired"])
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 def test_gemm_nt(gpu_lib, mode, shape, kernel, monkeypatch):
     """Both GEMM kernels (ARP_GEMM=1: 128x128 two-phase; ARP_GEMM=2: 256x256 four-phase pipelined)."""
-    monkeypatch.setenv("ARP_GEMM", "1" if kernel == "128" else "2")
+    monkeypatch.setenv("ARP_GEMM", {"128": "1", "256": "2", "paired": "3"}[kernel])
     M, N, K = shape
-    if mode == 1 and K % 64:
-        pytest.skip("bf16 GEMM needs K % 64 == 0")
+    if mode == 1 and K % (32 if kernel == "paired" else 64):
+        pytest.skip("bf16 GEMM needs K % 64 == 0 (K % 32 for the paired kernel)")
     rng = np.random.default_rng(M * 7 + N * 3 + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
@@ -64,11 +64,12 @@ def test_gemm_nt(gpu_lib, mode, shape, kernel, monkeypatch):
         assert err < tol, f"gemm mode={mode} shape={shape} act={act} bias={use_b} resid={use_r}: max err {err} (tol {tol})"
 
 
-def test_gemm256_race_screen(gpu_lib, monkeypatch):
+@pytest.mark.parametrize("kernel", ["2", "3"])
+def test_gemm256_race_screen(gpu_lib, monkeypatch, kernel):
     """The pipelined kernel's LDS hand-offs are ordered by counted vmcnt + barriers: repeated launches on
     a chip-filling shape must be bit-identical to each other and correct (a race shows up as rare
     wrong tiles)."""
-    monkeypatch.setenv("ARP_GEMM", "2")
+    monkeypatch.setenv("ARP_GEMM", kernel)
     rng = np.random.default_rng(5)
     for (M, N, K) in ((8192, 1536, 768), (4100, 768, 3072), (2048, 2304, 64), (2048, 2304, 128)):
         A = rng.standard_normal((M, K)).astype(np.float32)
