@@ -68,43 +68,44 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
 
 // ---- MFMA kernel (bf16, head_dim 64) -------------------------------------------------------------
 // NT = number of 16-key tiles (keys padded to a multiple of 32, i.e. NT even).
-// LDS: K  [NT*16 keys][128 B]             (chunk-swizzled like the GEMM tiles)
-//      Vt [64 d][VT_STRIDE bytes]         (VT_STRIDE = NT*32 + 8: +8 B pad -> conflict-free b64 reads)
+// LDS: K [NT*16 keys][128 B] and V [NT*16 keys][128 B], both row-major with the 16-byte chunk index XOR-swizzled
+// by (key & 7).  K fragments are plain ds_read_b128 row reads; the V^T fragments of O^T = V^T . P^T are fetched
+// with the CDNA4 transposing read ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group, delivered column-major),
+// so V is staged exactly like K -- no 2-byte transposing stores.
+typedef __attribute__((ext_vector_type(4))) short tr_b64_v;
+
 template <int NT>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int D,
                                                         int heads, float scale, int causal) {
     constexpr int NP = NT * 16;
-    constexpr int VT_STRIDE = NP * 2 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
-    char* Vt = smem + NP * 128;
+    char* Vs = smem + NP * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const size_t ld = 3 * (size_t)D;
     const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
 
-    // stage K (row-major, swizzled) and V (transposed); pad keys are zero-filled
-    for (int i = tid; i < NP * 8; i += 256) {
+    for (int i = tid; i < NP * 8; i += 256) {  // pad keys are zero-filled
         const int key = i >> 3, ch = i & 7;
         u32x4_v kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
         if (key < N) {
             kv = *reinterpret_cast<const u32x4_v*>(base + key * ld + D + ch * 8);
             vv = *reinterpret_cast<const u32x4_v*>(base + key * ld + 2 * D + ch * 8);
         }
-        *reinterpret_cast<u32x4_v*>(Ks + key * 128 + ((ch ^ (key & 7)) << 4)) = kv;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int d0 = ch * 8 + 2 * j;
-            *reinterpret_cast<uint16_t*>(Vt + d0 * VT_STRIDE + key * 2) = (uint16_t)(vv[j] & 0xffffu);
-            *reinterpret_cast<uint16_t*>(Vt + (d0 + 1) * VT_STRIDE + key * 2) = (uint16_t)(vv[j] >> 16);
-        }
+        const int off = key * 128 + ((ch ^ (key & 7)) << 4);
+        *reinterpret_cast<u32x4_v*>(Ks + off) = kv;
+        *reinterpret_cast<u32x4_v*>(Vs + off) = vv;
     }
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
     const int nqb = (N + 15) >> 4;
+    const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
+    // transposing-read addressing: lane 4q+p of a 16-lane group points at row (key0 + q), columns 4p..4p+3 of the
+    // 16-column block [16*dt, 16*dt+16); lane i receives column i of the four rows
+    const int trq = fr >> 2, trp = fr & 3;
     for (int qb = wave; qb < nqb; qb += 4) {
-        // Q fragment as the B operand: lane (q = fr, group fg) holds Q[q][32*ks + 8*fg .. +7]
         int qrow = qb * 16 + fr;
         const int qvalid = qrow < N;
         qrow = qvalid ? qrow : N - 1;
@@ -126,7 +127,6 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
             }
         }
-        // softmax over keys for query column fr: local over (kt, r), then across the 4 lane groups
         const int qidx = qb * 16 + fr;
         const int klim = causal ? (qidx < N ? qidx + 1 : N) : N;
         float mx = -INFINITY;
@@ -135,18 +135,19 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + fg * 4 + r;
-                const float v = (key < klim) ? s[kt][r] * scale : -INFINITY;
+                const float v = (key < klim) ? s[kt][r] : -INFINITY;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mc = mx * c2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[kt][r] - mx);  // masked keys: exp(-inf) = 0
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, -mc));  // masked keys: 2^-inf = 0
                 s[kt][r] = p;
                 sum += p;
             }
@@ -154,9 +155,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
 
-        // O^T[d][q] = sum_key Vt[d][key] * P^T[key][q].  k-slot (fg, j) of step st <-> key
-        // 32*st + 16*(j>>2) + 4*fg + (j&3): B operand straight from s[2st], s[2st+1]; the A operand
-        // (Vt) reads the same permuted keys: two 8-byte reads per step.
+        // O^T[d][q] = sum_key V^T[d][key] * P^T[key][q].  k-slot (fg, j) of step st <-> key 32*st + 16*(j>>2) + 4*fg + (j&3):
+        // the B operand comes straight from s[2st], s[2st+1]; the A operand is two transposing reads of V.
         f32x4_v o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
@@ -168,12 +168,16 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
             pb[2] = pack_bf2(s[2 * st + 1][0], s[2 * st + 1][1]);
             pb[3] = pack_bf2(s[2 * st + 1][2], s[2 * st + 1][3]);
             const bf16x8_v pf = __builtin_bit_cast(bf16x8_v, pb);
+            const int k0 = 32 * st + 4 * fg + trq, k1 = k0 + 16;  // the row this lane addresses in each block
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const char* vrow = Vt + (dt * 16 + fr) * VT_STRIDE + (32 * st + 4 * fg) * 2;
-                const u32x2_v lo = *reinterpret_cast<const u32x2_v*>(vrow);
-                const u32x2_v hi = *reinterpret_cast<const u32x2_v*>(vrow + 32);
-                const u32x4_v va = {lo[0], lo[1], hi[0], hi[1]};
+                const int ch = 2 * dt + (trp >> 1);
+                const tr_b64_v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) tr_b64_v*)(Vs + k0 * 128 + ((ch ^ (k0 & 7)) << 4) + (trp & 1) * 8));
+                const tr_b64_v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) tr_b64_v*)(Vs + k1 * 128 + ((ch ^ (k1 & 7)) << 4) + (trp & 1) * 8));
+                const u32x2_v l2 = __builtin_bit_cast(u32x2_v, lo), h2 = __builtin_bit_cast(u32x2_v, hi);
+                const u32x4_v va = {l2[0], l2[1], h2[0], h2[1]};
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, va), pf, o[dt], 0, 0, 0);
             }
         }

@@ -141,7 +141,7 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
 #define ARP_ATTN_CASE(nt)                                                                                                   \
     case nt: {                                                                                                              \
         auto kern = attn_mfma_kernel<nt>;                                                                                   \
-        const int lds = nt * 16 * 128 + 64 * (nt * 32 + 8);                                                                 \
+        const int lds = nt * 16 * 256;                                                                 \
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal);              \
         ARP_HIP_OK(hipGetLastError());                                                                                      \
