@@ -38,6 +38,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
 RcclApi* rccl_api() {
@@ -53,9 +54,12 @@ RcclApi* rccl_api() {
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
     api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(h, "ncclBroadcast"));
-    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Broadcast;
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    api.ok = api.GetErrorString && api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Broadcast;
     return api.ok ? &api : nullptr;
 }
+
+int rccl_fail(const char* what, ncclResult_t r) { return fail(std::string(what) + ": " + rccl_api()->GetErrorString(r)); }
 
 enum { SITE_DT = 16 };
 
@@ -829,7 +833,7 @@ int arp_dt_comm_unique_id(void* id128) {
     if (!id128) return fail("null argument");
     if (!rccl_api()) return fail("librccl.so.1 could not be loaded");
     ncclUniqueId id;
-    if (rccl_api()->GetUniqueId(&id) != ncclSuccess) return fail("ncclGetUniqueId failed");
+    if (ncclResult_t r = rccl_api()->GetUniqueId(&id); r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
     static_assert(sizeof(ncclUniqueId) == 128, "unexpected ncclUniqueId size");
     memcpy(id128, &id, 128);
     return 0;
@@ -841,7 +845,7 @@ int arp_dt_comm_init(arp_dt* c, const void* id128, int world, int rank) {
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     if (!rccl_api()) return fail("librccl.so.1 could not be loaded");
-    if (rccl_api()->CommInitRank(&c->comm, world, id, rank) != ncclSuccess) return fail("ncclCommInitRank failed");
+    if (ncclResult_t r = rccl_api()->CommInitRank(&c->comm, world, id, rank); r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
     c->has_comm = true;
     c->cfg.world = world;
     c->cfg.rank = rank;
@@ -855,7 +859,8 @@ int arp_dt_broadcast_state(arp_dt* c) {
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     DevBuf* fb[] = {&c->params, &c->mu, &c->nu};
     for (auto* b : fb)
-        if (rccl_api()->Broadcast(b->p, b->p, c->P, ncclFloat, 0, c->comm, c->stream) != ncclSuccess) return fail("ncclBroadcast failed");
+        if (ncclResult_t r = rccl_api()->Broadcast(b->p, b->p, c->P, ncclFloat, 0, c->comm, c->stream); r != ncclSuccess)
+            return rccl_fail("ncclBroadcast", r);
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     c->shadows_stale = true;
     return 0;

@@ -10,12 +10,12 @@
 // Two kernels:
 //   attn_valu_kernel<T,HD>  : exact-f32 VALU kernel, one query row per lane, online softmax.
 //                             Parity mode (T=float), and the bit-simple fallback for T=bf16.
-//   attn_mfma_kernel        : bf16, HD = 64, QK^T and PV on v_mfma_f32_16x16x32_bf16; K staged
-//                             row-major (XOR-swizzled 16-B chunks), V staged TRANSPOSED so both
-//                             MFMA operand reads are contiguous; S is computed transposed
-//                             (S^T = K.Q^T) so that the softmax'd accumulator IS the B operand of
-//                             O^T = V^T.P^T with no cross-lane movement (cdna_hip_programming.md
-//                             section 3, "an accumulator tile as the next MFMA's operand").
+//   attn_mfma_kernel        : bf16, HD = 64, QK^T and PV on v_mfma_f32_16x16x32_bf16; K and V staged
+//                             row-major (XOR-swizzled 16-B chunks), V^T fragments fetched with the
+//                             transposing LDS read; S is computed transposed (S^T = K.Q^T) so that the
+//                             softmax'd accumulator IS the B operand of O^T = V^T.P^T with no
+//                             cross-lane movement (cdna_hip_programming.md section 3, "an accumulator
+//                             tile as the next MFMA's operand").
 #pragma once
 #include "common.h"
 
