@@ -22,6 +22,7 @@
 #include "enc_internal.h"
 #include "gemm.h"
 #include "gemm256.h"
+#include "policy_fused.h"
 #include "runtime.h"
 
 using namespace arp;
@@ -98,6 +99,12 @@ struct arp_dt {
     std::vector<DevBuf> xs, ln0, qkv, att, hmid, ln1, u, gl;  // per block
     DevBuf img, hf, a_in, r_in, ha, hr, logits, ret, metrics;
     DevBuf dlogits, dret, dha, dhr, da_in, dr_in, dhf, dh, t1, t2, t3, dws, dbs, dimg, dz, dqkv;
+    // fused policy kernel (policy_fused.h): per-layer saved output gradients + the grouped-launch tables
+    bool fused = false;
+    std::vector<DevBuf> d_x1, d_u, d_mid, d_qkv, dws0, dbs0, dws1, dbs1;
+    DevBuf dwsf, dbsf, dtok, loss_part, gtab, gprefix, ctab, cprefix;
+    int n_gemm = 0, gemm_tiles = 0, n_cs = 0, cs_tiles = 0;
+    PfArgs pf;
     ncclComm_t comm = nullptr;
     bool has_comm = false;
     // forward + backward + L2 term captured once per batch geometry and replayed (about 120 short launches)
@@ -297,6 +304,85 @@ template <typename T> int refresh_shadows(arp_dt* c) {
     return 0;
 }
 
+// The fused kernel covers the shipped geometry family: up to 16 tokens per sample, widths in MFMA-tile multiples.
+bool fused_eligible(const arp_dt_cfg& k) {
+    if (const char* e = getenv("ARP_DT_FUSED"))
+        if (atoi(e) == 0) return false;
+    const int E = k.emb, H = k.mlp_ratio * k.emb;
+    return 3 * k.window <= 16 && E % 16 == 0 && H % 16 == 0 && k.n_actions <= 16 && k.depth <= PF_MAX_DEPTH && E % k.heads == 0 &&
+           pf_lds_bytes(E, H, k.heads) <= 160 * 1024;
+}
+
+// kernel arguments of policy_fused_kernel and the problem tables of the two grouped gradient launches
+int build_fused_plan(arp_dt* c) {
+    const arp_dt_cfg& k = c->cfg;
+    const int E = k.emb, H = k.mlp_ratio * E, T = k.window, L = 3 * T, NA = k.n_actions, depth = k.depth;
+    const int R = c->B * T, BL = c->B * L;
+    PfArgs& a = c->pf;
+    memset(&a, 0, sizeof(a));
+    a.T = T; a.L = L; a.E = E; a.H = H; a.heads = k.heads; a.NA = NA; a.depth = depth; a.do_bwd = 1; a.R = R; a.lambda = k.lambda_ret;
+    a.img = c->img.as<float>(); a.rtg = c->rtg.as<float>(); a.action = c->action.as<int>();
+    a.Wr = c->p("rtg_input/kernel"); a.emb = c->p("action_input/embedding");
+    std::vector<SmallGemm> gj;
+    std::vector<ColSumJob> cj;
+    // dW[Nout, Kin] = dY[rows, Nout]^T . X[rows, Kin]
+    auto add_dw = [&](const float* dY, const float* X, float* dW, int Nout, int Kin, int rows) {
+        gj.push_back(SmallGemm{dY, X, nullptr, nullptr, dW, Nout, Kin, rows, Nout, Kin, Kin, 1, 0, ACT_NONE, 0});
+    };
+    auto add_cs = [&](const float* in, float* out, int rows, int C) { cj.push_back(ColSumJob{in, out, rows, C}); };
+    for (int i = 0; i < depth; ++i) {
+        const std::string p = "policy/Block_" + std::to_string(i) + "/";
+        PfBlk& b = a.blk[i];
+        b.ln0w = c->p(p + "LayerNorm_0/scale"); b.ln0b = c->p(p + "LayerNorm_0/bias");
+        b.wqkv = c->p(p + "Attention_0/Dense_0/kernel"); b.bqkv = c->p(p + "Attention_0/Dense_0/bias");
+        b.wo = c->p(p + "Attention_0/Dense_1/kernel"); b.bo = c->p(p + "Attention_0/Dense_1/bias");
+        b.ln1w = c->p(p + "LayerNorm_1/scale"); b.ln1b = c->p(p + "LayerNorm_1/bias");
+        b.wfc1 = c->p(p + "FeedForward_0/fc1/kernel"); b.wfc2 = c->p(p + "FeedForward_0/fc2/kernel");
+        b.x = c->xs[i].as<float>(); b.ln0 = c->ln0[i].as<float>(); b.qkv = c->qkv[i].as<float>(); b.att = c->att[i].as<float>();
+        b.hmid = c->hmid[i].as<float>(); b.ln1 = c->ln1[i].as<float>(); b.u = c->u[i].as<float>(); b.gl = c->gl[i].as<float>();
+        b.d_x1 = c->d_x1[i].as<float>(); b.d_u = c->d_u[i].as<float>(); b.d_mid = c->d_mid[i].as<float>(); b.d_qkv = c->d_qkv[i].as<float>();
+        b.dws0 = c->dws0[i].as<float>(); b.dbs0 = c->dbs0[i].as<float>(); b.dws1 = c->dws1[i].as<float>(); b.dbs1 = c->dbs1[i].as<float>();
+        add_dw(b.d_qkv, b.ln0, c->g(p + "Attention_0/Dense_0/kernel"), 3 * E, E, BL);
+        add_dw(b.d_mid, b.att, c->g(p + "Attention_0/Dense_1/kernel"), E, E, BL);
+        add_dw(b.d_u, b.ln1, c->g(p + "FeedForward_0/fc1/kernel"), H, E, BL);
+        add_dw(b.d_x1, b.gl, c->g(p + "FeedForward_0/fc2/kernel"), E, H, BL);
+        add_cs(b.d_qkv, c->g(p + "Attention_0/Dense_0/bias"), BL, 3 * E);
+        add_cs(b.d_mid, c->g(p + "Attention_0/Dense_1/bias"), BL, E);
+        add_cs(b.dws0, c->g(p + "LayerNorm_0/scale"), BL, E); add_cs(b.dbs0, c->g(p + "LayerNorm_0/bias"), BL, E);
+        add_cs(b.dws1, c->g(p + "LayerNorm_1/scale"), BL, E); add_cs(b.dbs1, c->g(p + "LayerNorm_1/bias"), BL, E);
+    }
+    a.lnfw = c->p("policy/LayerNorm_0/scale"); a.lnfb = c->p("policy/LayerNorm_0/bias");
+    a.wa0 = c->p("action_outputs_0/layers_0/kernel"); a.ba0 = c->p("action_outputs_0/layers_0/bias"); a.wa2 = c->p("action_outputs_0/layers_2/kernel");
+    a.wr0 = c->p("return_outputs_0/layers_0/kernel"); a.br0 = c->p("return_outputs_0/layers_0/bias"); a.wr2 = c->p("return_outputs_0/layers_2/kernel");
+    a.xf = c->xs[depth].as<float>(); a.a_in = c->a_in.as<float>(); a.r_in = c->r_in.as<float>(); a.ha = c->ha.as<float>(); a.hr = c->hr.as<float>();
+    a.logits = c->logits.as<float>(); a.ret = c->ret.as<float>(); a.dlogits = c->dlogits.as<float>(); a.dret = c->dret.as<float>();
+    a.dha = c->dha.as<float>(); a.dhr = c->dhr.as<float>(); a.dwsf = c->dwsf.as<float>(); a.dbsf = c->dbsf.as<float>();
+    a.dtok = c->dtok.as<float>(); a.dz = c->dz.as<float>(); a.loss_part = c->loss_part.as<float>();
+    add_dw(a.dlogits, a.ha, c->g("action_outputs_0/layers_2/kernel"), NA, E, R);
+    add_dw(a.dha, a.a_in, c->g("action_outputs_0/layers_0/kernel"), E, E, R);
+    add_dw(a.dret, a.hr, c->g("return_outputs_0/layers_2/kernel"), 1, E, R);
+    add_dw(a.dhr, a.r_in, c->g("return_outputs_0/layers_0/kernel"), E, E, R);
+    add_cs(a.dwsf, c->g("policy/LayerNorm_0/scale"), BL, E); add_cs(a.dbsf, c->g("policy/LayerNorm_0/bias"), BL, E);
+    add_cs(a.dha, c->g("action_outputs_0/layers_0/bias"), R, E); add_cs(a.dhr, c->g("return_outputs_0/layers_0/bias"), R, E);
+    add_cs(a.dz, c->g("image_text_input/bias"), R, E);
+    std::vector<int> gp(1, 0), cp(1, 0);
+    for (auto& g : gj) gp.push_back(gp.back() + cdiv(g.M, 32) * cdiv(g.N, 32));
+    for (auto& j : cj) cp.push_back(cp.back() + cdiv(j.C, 64));
+    c->n_gemm = (int)gj.size(); c->gemm_tiles = gp.back(); c->n_cs = (int)cj.size(); c->cs_tiles = cp.back();
+    ARP_TRY(c->gtab.ensure(gj.size() * sizeof(SmallGemm))); ARP_TRY(c->gprefix.ensure(gp.size() * 4));
+    ARP_TRY(c->ctab.ensure(cj.size() * sizeof(ColSumJob))); ARP_TRY(c->cprefix.ensure(cp.size() * 4));
+    ARP_HIP_OK(hipMemcpy(c->gtab.p, gj.data(), gj.size() * sizeof(SmallGemm), hipMemcpyHostToDevice));
+    ARP_HIP_OK(hipMemcpy(c->gprefix.p, gp.data(), gp.size() * 4, hipMemcpyHostToDevice));
+    ARP_HIP_OK(hipMemcpy(c->ctab.p, cj.data(), cj.size() * sizeof(ColSumJob), hipMemcpyHostToDevice));
+    ARP_HIP_OK(hipMemcpy(c->cprefix.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
+    static bool attr_set = false;
+    if (!attr_set) {
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    return 0;
+}
+
 int ensure_buffers(arp_dt* c, int B) {
     if (B == c->B) return 0;
     const arp_dt_cfg& k = c->cfg;
@@ -332,11 +418,32 @@ int ensure_buffers(arp_dt* c, int B) {
     ARP_TRY(f32(c->dws, BL * E)); ARP_TRY(f32(c->dbs, BL * E)); ARP_TRY(f32(c->dimg, R * E)); ARP_TRY(f32(c->dz, R * E));
     ARP_TRY(f32(c->dqkv, BL * 3 * E));
     c->B = B;
+    c->fused = fused_eligible(k);
+    if (c->fused) {
+        for (auto* v : {&c->d_x1, &c->d_u, &c->d_mid, &c->d_qkv, &c->dws0, &c->dbs0, &c->dws1, &c->dbs1}) v->resize(k.depth);
+        for (int i = 0; i < k.depth; ++i) {
+            ARP_TRY(f32(c->d_x1[i], BL * E)); ARP_TRY(f32(c->d_u[i], BL * H)); ARP_TRY(f32(c->d_mid[i], BL * E)); ARP_TRY(f32(c->d_qkv[i], BL * 3 * E));
+            ARP_TRY(f32(c->dws0[i], BL * E)); ARP_TRY(f32(c->dbs0[i], BL * E)); ARP_TRY(f32(c->dws1[i], BL * E)); ARP_TRY(f32(c->dbs1[i], BL * E));
+        }
+        ARP_TRY(f32(c->dwsf, BL * E)); ARP_TRY(f32(c->dbsf, BL * E)); ARP_TRY(f32(c->dtok, BL * E)); ARP_TRY(f32(c->loss_part, (size_t)B * 4));
+        ARP_TRY(build_fused_plan(c));
+    }
+    return 0;
+}
+
+// tokens -> transformer -> heads -> losses (and, with do_bwd, the activation gradients) in one launch
+int policy_fused(arp_dt* c, bool do_bwd) {
+    const arp_dt_cfg& k = c->cfg;
+    c->pf.do_bwd = do_bwd ? 1 : 0;
+    hipLaunchKernelGGL(policy_fused_kernel, dim3(c->B), dim3(PF_THREADS), pf_lds_bytes(k.emb, k.mlp_ratio * k.emb, k.heads), c->stream, c->pf);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c->stream, c->loss_part.as<float>(), c->B, c->R(), k.n_actions, k.lambda_ret,
+                       c->metrics.as<float>());
+    ARP_HIP_OK(hipGetLastError());
     return 0;
 }
 
 // ---- forward: everything up to the losses; leaves every activation the backward needs -----------------
-template <typename T> int forward(arp_dt* c) {
+template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     const arp_dt_cfg& k = c->cfg;
     const int E = k.emb, D = k.enc_dim, H = k.mlp_ratio * E, NA = k.n_actions, depth = k.depth;
     const int R = c->R(), L = c->L(), BL = c->B * L;
@@ -365,7 +472,10 @@ template <typename T> int forward(arp_dt* c) {
     }
     // image_text_input + tanh (arp_dt/ARPDT.py:475-484): [R, tokens*dim] x [tokens*dim, E], split over K
     ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
-    {
+    if (c->fused) {
+        ProfScope ps(c->prof, c->stream, "dt.policy_fwd");
+        ARP_TRY(policy_fused(c, with_bwd));
+    } else {
         ProfScope ps(c->prof, c->stream, "dt.policy_fwd");
         hipLaunchKernelGGL(tokens_fwd_kernel, dim3(cdiv((size_t)R * E, 256)), dim3(256), 0, c->stream, c->img.as<float>(), c->rtg.as<float>(),
                            c->action.as<int>(), c->p("rtg_input/kernel"), c->p("action_input/embedding"), c->xs[0].as<float>(), R, E);
@@ -411,7 +521,16 @@ template <typename T> int backward(arp_dt* c) {
     const int Kin = k.enc_tokens * D;
     const int Mxp = (int)((Mx + 63) / 64 * 64), Rp = (R + 63) / 64 * 64;
     float* dh = c->dh.as<float>();
-    {
+    if (c->fused) {
+        // activation gradients came out of policy_fused_kernel; every parameter gradient of the transformer, the
+        // heads, the LayerNorms and the embeddings is produced by three launches
+        ProfScope ps(c->prof, c->stream, "dt.policy_bwd");
+        hipLaunchKernelGGL(grouped_small_gemm_kernel, dim3(c->gemm_tiles), dim3(256), 0, c->stream, c->gtab.as<SmallGemm>(), c->gprefix.as<int>(), c->n_gemm);
+        hipLaunchKernelGGL(grouped_colsum_kernel, dim3(c->cs_tiles), dim3(256), 0, c->stream, c->ctab.as<ColSumJob>(), c->cprefix.as<int>(), c->n_cs);
+        hipLaunchKernelGGL(tokens_bwd_par_kernel, dim3(NA + 1), dim3(256), 0, c->stream, c->dtok.as<float>(), c->rtg.as<float>(), c->action.as<int>(),
+                           c->g("rtg_input/kernel"), c->g("action_input/embedding"), R, E, NA);
+        ARP_HIP_OK(hipGetLastError());
+    } else {
         ProfScope ps(c->prof, c->stream, "dt.policy_bwd");
         // heads (arp_dt/ARPDT.py:94-99,206-220)
         ARP_TRY(linear_bwd(c, c->ha.as<float>(), c->p("action_outputs_0/layers_2/kernel"), c->dlogits.as<float>(), c->g("action_outputs_0/layers_2/kernel"),
@@ -531,7 +650,7 @@ int apply_update(arp_dt* c, float lr) {
 }
 
 template <typename T> int fwd_bwd(arp_dt* c) {
-    ARP_TRY(forward<T>(c));
+    ARP_TRY(forward<T>(c, true));
     ARP_TRY(backward<T>(c));
     return l2_penalty(c);
 }
@@ -660,9 +779,11 @@ int arp_dt_destroy(arp_dt* c) {
     DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
-                     &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv};
+                     &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,
+                     &c->dwsf, &c->dbsf, &c->dtok, &c->loss_part, &c->gtab, &c->gprefix, &c->ctab, &c->cprefix};
     for (auto* b : all) b->release();
-    for (auto* v : {&c->xs, &c->ln0, &c->qkv, &c->att, &c->hmid, &c->ln1, &c->u, &c->gl})
+    for (auto* v : {&c->xs, &c->ln0, &c->qkv, &c->att, &c->hmid, &c->ln1, &c->u, &c->gl, &c->d_x1, &c->d_u, &c->d_mid, &c->d_qkv, &c->dws0, &c->dbs0,
+                    &c->dws1, &c->dbs1})
         for (auto& b : *v) b.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -796,8 +917,8 @@ int arp_dt_backward(arp_dt* c) {
     if (!c) return fail("null handle");
     if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(forward<bf16_t>(c)); ARP_TRY(backward<bf16_t>(c)); }
-    else { ARP_TRY(forward<float>(c)); ARP_TRY(backward<float>(c)); }
+    if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(forward<bf16_t>(c, true)); ARP_TRY(backward<bf16_t>(c)); }
+    else { ARP_TRY(forward<float>(c, true)); ARP_TRY(backward<float>(c)); }
     ARP_TRY(l2_penalty(c));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     return 0;

@@ -18,14 +18,14 @@ struct SmallGemm {
     int M, N, K, lda, ldb, ldc, ta, tb, act, accumulate;
 };
 
-__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
+__device__ __forceinline__ void small_gemm_tile(const SmallGemm& g, int bx, int by) {
     // K in steps of 64 (a 12-token-transformer GEMM has K = 128..512: 2..8 steps), operands prefetched into
     // registers one step ahead so the global-memory latency of step k+1 hides under the FMAs of step k.
     constexpr int KS = 64;
     __shared__ float As[KS][33];
     __shared__ float Bs[KS][33];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m0 = by * 32, n0 = bx * 32;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     float ra[8], rb[8];
     auto fetch = [&](int k0) {
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
             }
         }
 }
+__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) { small_gemm_tile(g, blockIdx.x, blockIdx.y); }
 
 // ---- split-K partial reduce:  out[m,n] = act(sum_s part[s,m,n] + bias[n]) ---------------------------
 template <typename OutT>
@@ -217,12 +218,12 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, i
     if (threadIdx.x == 0) out[row] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 // column sums of a small [R, C] f32 matrix: out[c] = sum_r in[r, c]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+__device__ __forceinline__ void colsum_tile(const float* __restrict__ in, int R, int C, float* __restrict__ out, int bx) {
     // 64 columns per block (lane = column: coalesced rows), rows split over the 4 waves with 4 independent
     // accumulators each, then a fixed-order combine
     __shared__ float red[4][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + x;
+    const int c = bx * 64 + x;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < C) {
         int r = y;
@@ -237,6 +238,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     red[y][x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (y == 0 && c < C) out[c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+}
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+    colsum_tile(in, R, C, out, blockIdx.x);
 }
 
 // ---- LayerNorm forward (f32 in/out, saves nothing: backward recomputes the statistics) ------------------

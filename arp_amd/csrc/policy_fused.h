@@ -1,0 +1,713 @@
+// The 12-token policy transformer of path (2), forward AND the activation half of backward, as ONE kernel:
+// one 512-thread workgroup per sample keeps the sample's tokens in LDS from token assembly to the loss and
+// back down to d(image embedding).  (Reference: arp_dt/ARPDT.py:159-222,238-261 tokens, heads, losses;
+// arp_dt/layers.py:11-166 Transformer/Block/Attention/FeedForward.)
+//
+// Why: at B = 32 samples per GPU the transformer is 384 token rows x E = 128 -- about 1 GFLOP per step spread over
+// ~85 dependent launches of a few microseconds each (0.9 ms of a 2.1 ms step).  Per sample nothing couples the
+// samples except the parameter gradients, so:
+//   * this kernel does everything per-sample and SAVES, for every linear layer, its input X and its output
+//     gradient dY (and per-row LayerNorm scale/bias contributions);
+//   * the parameter gradients dW = dY^T X, db = colsum(dY) are then produced for all layers at once by two
+//     grouped launches (grouped_small_gemm_kernel / grouped_colsum_kernel): fixed-order, no atomics.
+//
+// Matmuls run on v_mfma_f32_16x16x4_f32 (true fp32) with the 16-row token block as one MFMA operand and the weight
+// rows streamed from L2 as the other: 16 B per lane per load in both the NT (forward, W[out][in] rows along the
+// contraction) and NN (backward, dX = dY . W) forms.  Token rows beyond L are zero padding: rows never mix in a
+// linear layer or LayerNorm, and attention only visits keys j <= i < L.
+#pragma once
+#include "common.h"
+#include "dtops.h"
+
+namespace arp {
+
+constexpr int PF_THREADS = 512, PF_NW = 8, PF_MAX_DEPTH = 4;
+
+struct PfBlk {
+    const float *ln0w, *ln0b, *wqkv, *bqkv, *wo, *bo, *ln1w, *ln1b, *wfc1, *wfc2;  // weights, device layout [out, in]
+    float *x, *ln0, *qkv, *att, *hmid, *ln1, *u, *gl;                              // saved forward activations [B*L, .]
+    float *d_x1, *d_u, *d_mid, *d_qkv, *dws0, *dbs0, *dws1, *dbs1;                 // saved output gradients / LN row terms
+};
+struct PfArgs {
+    int T, L, E, H, heads, NA, depth, do_bwd, R;
+    float lambda;
+    const float *img, *rtg;  // [R, E] tanh'd image embedding, [R]
+    const int* action;       // [R]
+    const float *Wr, *emb;   // rtg_input/kernel [E], action_input/embedding [NA, E]
+    PfBlk blk[PF_MAX_DEPTH];
+    const float *lnfw, *lnfb, *wa0, *ba0, *wa2, *wr0, *br0, *wr2;
+    float *xf, *a_in, *r_in, *ha, *hr, *logits, *ret;           // saved forward (head stage)
+    float *dlogits, *dret, *dha, *dhr, *dwsf, *dbsf, *dtok, *dz;  // saved backward
+    float* loss_part;                                           // [B][4]: sum CE, hits, sum squared error
+};
+
+inline size_t pf_lds_bytes(int E, int H, int heads) {
+    const int WB = H > 3 * E ? H : 3 * E;
+    return ((size_t)4 * 16 * (E + 4) + (size_t)3 * 16 * (WB + 4) + (size_t)2 * heads * 256 + 64) * 4;
+}
+
+// ---- in-kernel building blocks ---------------------------------------------------------------------------
+// out[i][n] = sum_k Xs[i][k] * W[n][k]   (NT).  Each wave owns 16-column tiles n0 = 16*(wave + 8*t); the weight rows are
+// prefetched one chunk (16*CH k-values) ahead.  epi(i, n, acc): lane's token row i and 4 consecutive columns n..n+3.
+template <int CH, class Epi>
+__device__ __forceinline__ void pf_lin_nt_t(const float* Xs, int ldx, const float* __restrict__ W, int N, int K, int wave, int lane, Epi epi) {
+    const int q = lane >> 4, j = lane & 15;
+    const int nchunk = K / (16 * CH);
+    const int ntile = (N + 15) >> 4;
+    const int tiles_w = wave < ntile ? (ntile - 1 - wave) / PF_NW + 1 : 0;
+    const int nf = tiles_w * nchunk;
+    float4 wc[CH], wn[CH];
+    auto loadw = [&](float4(&w)[CH], int f) {
+        const int tile = wave + PF_NW * (f / nchunk), ch = f % nchunk;
+        const int n = tile * 16 + j;
+        const bool ok = n < N;
+        const float* p = W + (size_t)(ok ? n : 0) * K + ch * 16 * CH + 4 * q;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) w[s] = ok ? *reinterpret_cast<const float4*>(p + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (nf > 0) loadw(wc, 0);
+    f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < nf; ++f) {
+        if (f + 1 < nf) loadw(wn, f + 1);
+        const int ch = f % nchunk;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const float4 x = *reinterpret_cast<const float4*>(Xs + j * ldx + ch * 16 * CH + 16 * s + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s].x, x.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s].y, x.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s].z, x.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s].w, x.w, acc, 0, 0, 0);
+        }
+        if (ch == nchunk - 1) {
+            epi(j, (wave + PF_NW * (f / nchunk)) * 16 + 4 * q, acc);
+            acc = f32x4_v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s) wc[s] = wn[s];
+    }
+}
+template <class Epi>
+__device__ __forceinline__ void pf_lin_nt(const float* Xs, int ldx, const float* __restrict__ W, int N, int K, int wave, int lane, Epi epi) {
+    if (K % 128 == 0) pf_lin_nt_t<8>(Xs, ldx, W, N, K, wave, lane, epi);
+    else if (K % 64 == 0) pf_lin_nt_t<4>(Xs, ldx, W, N, K, wave, lane, epi);
+    else pf_lin_nt_t<1>(Xs, ldx, W, N, K, wave, lane, epi);
+}
+
+// out[i][c] = sum_n dYs[i][n] * W[n][c]   (NN; contraction over the N rows of W, output over its K columns, K % 16 == 0).
+// dYs columns beyond N may hold anything finite: their weights are loaded as zeros.
+template <class Epi>
+__device__ __forceinline__ void pf_lin_nn(const float* dYs, int ldy, const float* __restrict__ W, int N, int K, int wave, int lane, Epi epi) {
+    const int q = lane >> 4, j = lane & 15;
+    const int nchunk = (N + 63) >> 6;  // 64 contraction indices per chunk
+    const int ntile = K >> 4;
+    const int tiles_w = wave < ntile ? (ntile - 1 - wave) / PF_NW + 1 : 0;
+    const int nf = tiles_w * nchunk;
+    float wc[16], wn[16];
+    auto loadw = [&](float(&w)[16], int f) {
+        const int tile = wave + PF_NW * (f / nchunk), ch = f % nchunk;
+        const float* p = W + tile * 16 + j;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int n = ch * 64 + s4 * 16 + 4 * q + s;
+                w[s4 * 4 + s] = n < N ? p[(size_t)n * K] : 0.f;
+            }
+    };
+    if (nf > 0) loadw(wc, 0);
+    f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < nf; ++f) {
+        if (f + 1 < nf) loadw(wn, f + 1);
+        const int ch = f % nchunk;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 y = *reinterpret_cast<const float4*>(dYs + j * ldy + ch * 64 + s4 * 16 + 4 * q);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s4 * 4 + 0], y.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s4 * 4 + 1], y.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s4 * 4 + 2], y.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s4 * 4 + 3], y.w, acc, 0, 0, 0);
+        }
+        if (ch == nchunk - 1) {
+            epi(j, (wave + PF_NW * (f / nchunk)) * 16 + 4 * q, acc);
+            acc = f32x4_v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wc[s] = wn[s];
+    }
+}
+
+// LayerNorm of the 16 LDS rows (2 per wave), Flax eps 1e-6; same arithmetic as ln_fwd_f32_kernel
+__device__ __forceinline__ void pf_ln_fwd(const float* src, float* dst, int ld, const float* __restrict__ w, const float* __restrict__ b, int E,
+                                          float* __restrict__ save, int rows_valid, int wave, int lane) {
+    for (int i = wave; i < 16; i += PF_NW) {
+        const float* xr = src + i * ld;
+        float s = 0.f;
+        for (int c = lane; c < E; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / E;
+        float qq = 0.f;
+        for (int c = lane; c < E; c += 64) { const float d = xr[c] - mean; qq += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(qq) / E + 1e-6f);
+        for (int c = lane; c < E; c += 64) {
+            const float v = (xr[c] - mean) * rstd * w[c] + b[c];
+            dst[i * ld + c] = v;
+            if (save && i < rows_valid) save[(size_t)i * E + c] = v;
+        }
+    }
+}
+// LayerNorm backward on LDS rows: dxs[i] (+)= d/dx ; per-row dy*xhat and dy saved for the deferred column sums.
+// Same arithmetic as ln_bwd_f32_kernel.
+__device__ __forceinline__ void pf_ln_bwd(const float* xs, const float* dys, float* dxs, int ld, const float* __restrict__ w, int E, bool accumulate,
+                                          float* __restrict__ dws, float* __restrict__ dbs, int rows_valid, int wave, int lane) {
+    for (int i = wave; i < 16; i += PF_NW) {
+        const float* xr = xs + i * ld;
+        const float* dyr = dys + i * ld;
+        float s = 0.f;
+        for (int c = lane; c < E; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / E;
+        float qq = 0.f;
+        for (int c = lane; c < E; c += 64) { const float d = xr[c] - mean; qq += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(qq) / E + 1e-6f);
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < E; c += 64) {
+            const float xh = (xr[c] - mean) * rstd, gg = dyr[c] * w[c];
+            s1 += gg;
+            s2 += gg * xh;
+            if (i < rows_valid) {
+                dws[(size_t)i * E + c] = dyr[c] * xh;
+                dbs[(size_t)i * E + c] = dyr[c];
+            }
+        }
+        s1 = wave_sum(s1) / E;
+        s2 = wave_sum(s2) / E;
+        for (int c = lane; c < E; c += 64) {
+            const float xh = (xr[c] - mean) * rstd, gg = dyr[c] * w[c];
+            const float v = rstd * (gg - s1 - xh * s2);
+            dxs[i * ld + c] = accumulate ? dxs[i * ld + c] + v : v;
+        }
+    }
+}
+
+
+// ---- causal attention of one sample on MFMA (head_dim a multiple of 16, <= 16 tokens): one wave per head ------------
+// S^T[key][i] = sum_d K[key][d] Q[i][d] lands as lane (q, j) <-> query i = j, keys 4q..4q+3, so the softmax is two
+// cross-group shuffles and P^T is already the B operand of O^T = V^T . P^T.
+__device__ __forceinline__ f32x4_v pf_attn_probs(const float* sQ, int ldW, int E, int hd, int h, int L, float scale, int q, int j) {
+    f32x4_v st = {0.f, 0.f, 0.f, 0.f};
+    for (int d0 = 0; d0 < hd; d0 += 16) {
+        const float4 kk = *reinterpret_cast<const float4*>(sQ + j * ldW + E + h * hd + d0 + 4 * q);
+        const float4 qq = *reinterpret_cast<const float4*>(sQ + j * ldW + h * hd + d0 + 4 * q);
+        st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.x, qq.x, st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.y, qq.y, st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.z, qq.z, st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_16x16x4f32(kk.w, qq.w, st, 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool ok = (4 * q + r) <= j && j < L;
+        st[r] = ok ? st[r] * scale : -INFINITY;
+        mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float e = (st[r] == -INFINITY) ? 0.f : expf(st[r] - mx);
+        st[r] = e;
+        sum += e;
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[r] *= inv;
+    return st;
+}
+__device__ __forceinline__ void pf_attn_fwd_mfma(const float* sQ, float* sA, int ldW, int ldE, int E, int hd, int heads, int L, float scale,
+                                                 float* __restrict__ att_save, int wave, int lane) {
+    const int q = lane >> 4, j = lane & 15;
+    for (int h = wave; h < heads; h += PF_NW) {
+        const f32x4_v p = pf_attn_probs(sQ, ldW, E, hd, h, L, scale, q, j);
+        for (int d0 = 0; d0 < hd; d0 += 16) {
+            f32x4_v o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_16x16x4f32(sQ[(4 * q + s) * ldW + 2 * E + h * hd + d0 + j], p[s], o, 0, 0, 0);
+            const int c = h * hd + d0 + 4 * q;
+            *reinterpret_cast<float4*>(sA + j * ldE + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (j < L) *reinterpret_cast<float4*>(att_save + (size_t)j * E + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+// pass a: P and dS (to LDS as [i][key]) and dQ;  pass b (after a barrier): dK and dV from the LDS copies
+__device__ __forceinline__ void pf_attn_bwd_mfma_a(const float* sQ, const float* sA, float* sU, float* sP, float* sS, int ldW, int ldE, int E, int hd,
+                                                   int heads, int L, float scale, float* __restrict__ dqkv_save, int wave, int lane) {
+    const int q = lane >> 4, j = lane & 15;
+    for (int h = wave; h < heads; h += PF_NW) {
+        const f32x4_v p = pf_attn_probs(sQ, ldW, E, hd, h, L, scale, q, j);
+        f32x4_v dp = {0.f, 0.f, 0.f, 0.f};  // dP^T[key][i] = sum_d V[key][d] dO[i][d]
+        for (int d0 = 0; d0 < hd; d0 += 16) {
+            const float4 vv = *reinterpret_cast<const float4*>(sQ + j * ldW + 2 * E + h * hd + d0 + 4 * q);
+            const float4 gg = *reinterpret_cast<const float4*>(sA + j * ldE + h * hd + d0 + 4 * q);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.x, gg.x, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.y, gg.y, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.z, gg.z, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vv.w, gg.w, dp, 0, 0, 0);
+        }
+        float dot = (p[0] * dp[0] + p[1] * dp[1]) + (p[2] * dp[2] + p[3] * dp[3]);
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        f32x4_v ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = p[r] * (dp[r] - dot) * scale;
+        *reinterpret_cast<float4*>(sP + h * 256 + j * 16 + 4 * q) = make_float4(p[0], p[1], p[2], p[3]);
+        *reinterpret_cast<float4*>(sS + h * 256 + j * 16 + 4 * q) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+        for (int d0 = 0; d0 < hd; d0 += 16) {  // dQ^T[d][i] = sum_key K[key][d] dS^T[key][i]
+            f32x4_v o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) o = __builtin_amdgcn_mfma_f32_16x16x4f32(sQ[(4 * q + s) * ldW + E + h * hd + d0 + j], ds[s], o, 0, 0, 0);
+            const int c = h * hd + d0 + 4 * q;
+            *reinterpret_cast<float4*>(sU + j * ldW + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (j < L) *reinterpret_cast<float4*>(dqkv_save + (size_t)j * 3 * E + c) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+__device__ __forceinline__ void pf_attn_bwd_mfma_b(const float* sQ, const float* sA, float* sU, const float* sP, const float* sS, int ldW, int ldE, int E,
+                                                   int hd, int heads, int L, float* __restrict__ dqkv_save, int wave, int lane) {
+    const int q = lane >> 4, j = lane & 15;
+    for (int h = wave; h < heads; h += PF_NW) {
+        for (int d0 = 0; d0 < hd; d0 += 16) {
+            f32x4_v dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int i = 4 * q + s;  // contraction over queries
+                dk = __builtin_amdgcn_mfma_f32_16x16x4f32(sQ[i * ldW + h * hd + d0 + j], sS[h * 256 + i * 16 + j], dk, 0, 0, 0);
+                dv = __builtin_amdgcn_mfma_f32_16x16x4f32(sA[i * ldE + h * hd + d0 + j], sP[h * 256 + i * 16 + j], dv, 0, 0, 0);
+            }
+            const int c = h * hd + d0 + 4 * q;  // lane: key j, head-dim columns c..c+3
+            *reinterpret_cast<float4*>(sU + j * ldW + E + c) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+            *reinterpret_cast<float4*>(sU + j * ldW + 2 * E + c) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            if (j < L) {
+                *reinterpret_cast<float4*>(dqkv_save + (size_t)j * 3 * E + E + c) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+                *reinterpret_cast<float4*>(dqkv_save + (size_t)j * 3 * E + 2 * E + c) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float pf_gelu_grad(float r) {  // d/du of the tanh-approximate GELU (as ew_bwd_kernel)
+    const float c = 0.7978845608028654f, a = 0.044715f;
+    const float t = tanhf(c * (r + a * r * r * r));
+    return 0.5f * (1.f + t) + 0.5f * r * (1.f - t * t) * c * (1.f + 3.f * a * r * r);
+}
+
+__global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float pf_sm[];
+    const int E = a.E, H = a.H, L = a.L, T = a.T, NA = a.NA, heads = a.heads;
+    const int hd = E / heads;
+    const int WB = H > 3 * E ? H : 3 * E;
+    const int ldE = E + 4, ldW = WB + 4;
+    float* sX = pf_sm;            // residual stream x
+    float* sM = sX + 16 * ldE;    // hmid / scratch
+    float* sY = sM + 16 * ldE;    // LayerNorm output (forward); gradient stream dh (backward)
+    float* sA = sY + 16 * ldE;    // attention output / scratch
+    float* sQ = sA + 16 * ldE;    // qkv
+    float* sU = sQ + 16 * ldW;    // fc1 pre-activation / dqkv
+    float* sG = sU + 16 * ldW;    // gelu output
+    float* sP = sG + 16 * ldW;    // [heads][16][16] probabilities
+    float* sS = sP + heads * 256; // [heads][16][16] dS
+    const int total = 4 * 16 * ldE + 3 * 16 * ldW + 2 * heads * 256 + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const size_t t0 = (size_t)b * L, r0 = (size_t)b * T;
+    const float scale = 1.0f / sqrtf((float)hd);
+
+    for (int i = tid; i < total; i += PF_THREADS) pf_sm[i] = 0.f;
+    __syncthreads();
+    // ---- token assembly: per time step [image, rtg, action] (ARPDT.py:159-172,278-293) ----------------------
+    for (int idx = tid; idx < L * E; idx += PF_THREADS) {
+        const int i = idx / E, e = idx - i * E;
+        const int t = i / 3, m = i - 3 * t;
+        float v;
+        if (m == 0) v = a.img[(r0 + t) * E + e];
+        else if (m == 1) v = a.rtg[r0 + t] * a.Wr[e];
+        else v = a.emb[(size_t)a.action[r0 + t] * E + e];
+        sX[i * ldE + e] = v;
+        a.blk[0].x[(t0 + i) * E + e] = v;
+    }
+    __syncthreads();
+
+    auto store4g = [](float* p, const f32x4_v& v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); };
+
+    // ---- forward blocks ------------------------------------------------------------------------------------
+    for (int bi = 0; bi < a.depth; ++bi) {
+        const PfBlk& k = a.blk[bi];
+        pf_ln_fwd(sX, sY, ldE, k.ln0w, k.ln0b, E, k.ln0 + t0 * E, L, wave, lane);
+        __syncthreads();
+        pf_lin_nt(sY, ldE, k.wqkv, 3 * E, E, wave, lane, [&](int i, int n, f32x4_v v) {
+            const float4 bb = *reinterpret_cast<const float4*>(k.bqkv + n);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            *reinterpret_cast<float4*>(sQ + i * ldW + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (i < L) store4g(k.qkv + (t0 + i) * 3 * E + n, v);
+        });
+        __syncthreads();
+        // causal attention (layers.py:70-90): scores * scale, masked, softmax, P.V
+        if (hd % 16 == 0) {
+            pf_attn_fwd_mfma(sQ, sA, ldW, ldE, E, hd, heads, L, scale, k.att + t0 * E, wave, lane);
+        } else {
+            for (int item = tid; item < heads * 16; item += PF_THREADS) {
+                const int h = item >> 4, i = item & 15;
+                float* pr = sP + h * 256 + i * 16;
+                if (i < L) {
+                    const float* qv = sQ + i * ldW + h * hd;
+                    float mx = -INFINITY;
+                    for (int jj = 0; jj <= i; ++jj) {
+                        const float* kv = sQ + jj * ldW + E + h * hd;
+                        float s = 0.f;
+                        for (int d = 0; d < hd; ++d) s = fmaf(qv[d], kv[d], s);
+                        s *= scale;
+                        pr[jj] = s;
+                        mx = fmaxf(mx, s);
+                    }
+                    float sum = 0.f;
+                    for (int jj = 0; jj <= i; ++jj) { const float e = expf(pr[jj] - mx); pr[jj] = e; sum += e; }
+                    const float inv = 1.0f / sum;
+                    for (int jj = 0; jj < 16; ++jj) pr[jj] = jj <= i ? pr[jj] * inv : 0.f;
+                } else {
+                    for (int jj = 0; jj < 16; ++jj) pr[jj] = 0.f;
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 16 * E; idx += PF_THREADS) {
+                const int i = idx / E, c = idx - i * E, h = c / hd;
+                const float* pr = sP + h * 256 + i * 16;
+                float o = 0.f;
+                for (int jj = 0; jj <= i && jj < L; ++jj) o = fmaf(pr[jj], sQ[jj * ldW + 2 * E + c], o);
+                sA[i * ldE + c] = o;
+                if (i < L) k.att[(t0 + i) * E + c] = o;
+            }
+        }
+        __syncthreads();
+        pf_lin_nt(sA, ldE, k.wo, E, E, wave, lane, [&](int i, int n, f32x4_v v) {
+            const float4 bb = *reinterpret_cast<const float4*>(k.bo + n);
+            const float4 xr = *reinterpret_cast<const float4*>(sX + i * ldE + n);
+            v[0] += bb.x + xr.x; v[1] += bb.y + xr.y; v[2] += bb.z + xr.z; v[3] += bb.w + xr.w;
+            *reinterpret_cast<float4*>(sM + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (i < L) store4g(k.hmid + (t0 + i) * E + n, v);
+        });
+        __syncthreads();
+        pf_ln_fwd(sM, sY, ldE, k.ln1w, k.ln1b, E, k.ln1 + t0 * E, L, wave, lane);
+        __syncthreads();
+        pf_lin_nt(sY, ldE, k.wfc1, H, E, wave, lane, [&](int i, int n, f32x4_v v) {
+            f32x4_v gl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gl[r] = apply_act<ACT_GELU_TANH>(v[r]);
+            *reinterpret_cast<float4*>(sG + i * ldW + n) = make_float4(gl[0], gl[1], gl[2], gl[3]);
+            if (i < L) {
+                store4g(k.u + (t0 + i) * H + n, v);
+                store4g(k.gl + (t0 + i) * H + n, gl);
+            }
+        });
+        __syncthreads();
+        float* xnext = bi + 1 < a.depth ? a.blk[bi + 1].x : a.xf;
+        pf_lin_nt(sG, ldW, k.wfc2, E, H, wave, lane, [&](int i, int n, f32x4_v v) {
+            const float4 mr = *reinterpret_cast<const float4*>(sM + i * ldE + n);
+            v[0] += mr.x; v[1] += mr.y; v[2] += mr.z; v[3] += mr.w;
+            *reinterpret_cast<float4*>(sX + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (i < L) store4g(xnext + (t0 + i) * E + n, v);
+        });
+        __syncthreads();
+    }
+    // ---- final LayerNorm, head inputs (ARPDT.py:203-205: action head <- rtg tokens 1::3, return head <- image tokens 0::3)
+    pf_ln_fwd(sX, sY, ldE, a.lnfw, a.lnfb, E, nullptr, 0, wave, lane);
+    float* hA = sU;               // a_in  [16][ldE]
+    float* hHa = sU + 16 * ldE;   // relu(layers_0(a_in))
+    float* hR = sG;               // r_in
+    float* hHr = sG + 16 * ldE;   // relu(layers_0(r_in))
+    __syncthreads();
+    for (int idx = tid; idx < 16 * E; idx += PF_THREADS) {
+        const int t = idx / E, c = idx - t * E;
+        float va = 0.f, vr = 0.f;
+        if (t < T) {
+            va = sY[(3 * t + 1) * ldE + c];
+            vr = sY[(3 * t) * ldE + c];
+            a.a_in[(r0 + t) * E + c] = va;
+            a.r_in[(r0 + t) * E + c] = vr;
+        }
+        hA[t * ldE + c] = va;
+        hR[t * ldE + c] = vr;
+    }
+    __syncthreads();
+    pf_lin_nt(hA, ldE, a.wa0, E, E, wave, lane, [&](int i, int n, f32x4_v v) {
+        const float4 bb = *reinterpret_cast<const float4*>(a.ba0 + n);
+        v[0] = fmaxf(v[0] + bb.x, 0.f); v[1] = fmaxf(v[1] + bb.y, 0.f); v[2] = fmaxf(v[2] + bb.z, 0.f); v[3] = fmaxf(v[3] + bb.w, 0.f);
+        if (i >= T) v = f32x4_v{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<float4*>(hHa + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (i < T) store4g(a.ha + (r0 + i) * E + n, v);
+    });
+    pf_lin_nt(hR, ldE, a.wr0, E, E, wave, lane, [&](int i, int n, f32x4_v v) {
+        const float4 bb = *reinterpret_cast<const float4*>(a.br0 + n);
+        v[0] = fmaxf(v[0] + bb.x, 0.f); v[1] = fmaxf(v[1] + bb.y, 0.f); v[2] = fmaxf(v[2] + bb.z, 0.f); v[3] = fmaxf(v[3] + bb.w, 0.f);
+        if (i >= T) v = f32x4_v{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<float4*>(hHr + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
+        if (i < T) store4g(a.hr + (r0 + i) * E + n, v);
+    });
+    __syncthreads();
+    // logits -> sQ[i][0..NA), return prediction -> sQ[i][16]
+    pf_lin_nt(hHa, ldE, a.wa2, NA, E, wave, lane, [&](int i, int n, f32x4_v v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < NA) {
+                sQ[i * ldW + n + r] = v[r];
+                if (i < T) a.logits[(r0 + i) * NA + n + r] = v[r];
+            }
+    });
+    pf_lin_nt(hHr, ldE, a.wr2, 1, E, wave, lane, [&](int i, int n, f32x4_v v) {
+        if (n == 0) {
+            sQ[i * ldW + 16] = v[0];
+            if (i < T) a.ret[r0 + i] = v[0];
+        }
+    });
+    // sA <- dlogits, sM <- dret (both zero elsewhere)
+    for (int i = tid; i < 16 * ldE; i += PF_THREADS) { sA[i] = 0.f; sM[i] = 0.f; }
+    __syncthreads();
+    // ---- losses (ARPDT.py:238-261): CE summed over all B*T*NA elements / (B*T*NA); MSE / (B*T) -------------
+    if (tid < T) {
+        const int t = tid;
+        const float* l = sQ + t * ldW;
+        float mx = l[0];
+        int am = 0;
+        for (int c = 1; c < NA; ++c)
+            if (l[c] > mx) { mx = l[c]; am = c; }
+        float sum = 0.f;
+        for (int c = 0; c < NA; ++c) sum += expf(l[c] - mx);
+        const float lse = logf(sum) + mx;
+        const int lab = a.action[r0 + t];
+        for (int c = 0; c < NA; ++c) {
+            const float d = (expf(l[c] - lse) - (c == lab ? 1.f : 0.f)) / ((float)a.R * NA);
+            sA[t * ldE + c] = d;
+            a.dlogits[(r0 + t) * NA + c] = d;
+        }
+        const float dr = l[16] - a.rtg[r0 + t];
+        const float dd = a.lambda * 2.f * dr / (float)a.R;
+        sM[t * ldE] = dd;
+        a.dret[r0 + t] = dd;
+        // per-sample partials, combined over t in a fixed order by lane 0 below
+        sS[t * 4 + 0] = lse - l[lab];
+        sS[t * 4 + 1] = (am == lab) ? 1.f : 0.f;
+        sS[t * 4 + 2] = dr * dr;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ce = 0.f, hit = 0.f, se = 0.f;
+        for (int t = 0; t < T; ++t) { ce += sS[t * 4]; hit += sS[t * 4 + 1]; se += sS[t * 4 + 2]; }
+        a.loss_part[b * 4 + 0] = ce;
+        a.loss_part[b * 4 + 1] = hit;
+        a.loss_part[b * 4 + 2] = se;
+        a.loss_part[b * 4 + 3] = 0.f;
+    }
+    if (!a.do_bwd) return;
+
+    // ======================================= backward (activations) =========================================
+    float* hDha = sQ;              // [16][ldE]
+    float* hDhr = sQ + 16 * ldE;
+    __syncthreads();
+    pf_lin_nn(sA, ldE, a.wa2, NA, E, wave, lane, [&](int i, int c, f32x4_v v) {
+        const float4 hh = *reinterpret_cast<const float4*>(hHa + i * ldE + c);
+        v[0] = hh.x > 0.f ? v[0] : 0.f; v[1] = hh.y > 0.f ? v[1] : 0.f; v[2] = hh.z > 0.f ? v[2] : 0.f; v[3] = hh.w > 0.f ? v[3] : 0.f;
+        *reinterpret_cast<float4*>(hDha + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
+        if (i < T) store4g(a.dha + (r0 + i) * E + c, v);
+    });
+    pf_lin_nn(sM, ldE, a.wr2, 1, E, wave, lane, [&](int i, int c, f32x4_v v) {
+        const float4 hh = *reinterpret_cast<const float4*>(hHr + i * ldE + c);
+        v[0] = hh.x > 0.f ? v[0] : 0.f; v[1] = hh.y > 0.f ? v[1] : 0.f; v[2] = hh.z > 0.f ? v[2] : 0.f; v[3] = hh.w > 0.f ? v[3] : 0.f;
+        *reinterpret_cast<float4*>(hDhr + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
+        if (i < T) store4g(a.dhr + (r0 + i) * E + c, v);
+    });
+    __syncthreads();
+    for (int i = tid; i < 16 * ldE; i += PF_THREADS) sA[i] = 0.f;  // sA <- d(hf): rows 3t+1 <- d a_in, rows 3t <- d r_in
+    __syncthreads();
+    pf_lin_nn(hDha, ldE, a.wa0, E, E, wave, lane, [&](int i, int c, f32x4_v v) {
+        if (i < T) *reinterpret_cast<float4*>(sA + (3 * i + 1) * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
+    });
+    pf_lin_nn(hDhr, ldE, a.wr0, E, E, wave, lane, [&](int i, int c, f32x4_v v) {
+        if (i < T) *reinterpret_cast<float4*>(sA + (3 * i) * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
+    });
+    __syncthreads();
+    pf_ln_bwd(sX, sA, sY, ldE, a.lnfw, E, false, a.dwsf + t0 * E, a.dbsf + t0 * E, L, wave, lane);  // sY = dh
+    __syncthreads();
+
+    for (int bi = a.depth - 1; bi >= 0; --bi) {
+        const PfBlk& k = a.blk[bi];
+        // x_{i+1} = hmid + gelu(ln1 Wfc1) Wfc2 : dY of fc2 is dh itself
+        for (int idx = tid; idx < L * E; idx += PF_THREADS) {
+            const int i = idx / E, c = idx - i * E;
+            k.d_x1[(t0 + i) * E + c] = sY[i * ldE + c];
+            sM[i * ldE + c] = k.hmid[(t0 + i) * E + c];  // for the LayerNorm_1 backward below
+        }
+        pf_lin_nn(sY, ldE, k.wfc2, E, H, wave, lane, [&](int i, int c, f32x4_v v) {
+            if (i < L) {
+                const float4 uu = *reinterpret_cast<const float4*>(k.u + (t0 + i) * H + c);
+                v[0] *= pf_gelu_grad(uu.x); v[1] *= pf_gelu_grad(uu.y); v[2] *= pf_gelu_grad(uu.z); v[3] *= pf_gelu_grad(uu.w);
+                store4g(k.d_u + (t0 + i) * H + c, v);
+            } else {
+                v = f32x4_v{0.f, 0.f, 0.f, 0.f};
+            }
+            *reinterpret_cast<float4*>(sU + i * ldW + c) = make_float4(v[0], v[1], v[2], v[3]);
+        });
+        __syncthreads();
+        pf_lin_nn(sU, ldW, k.wfc1, H, E, wave, lane, [&](int i, int c, f32x4_v v) {
+            *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
+        });
+        __syncthreads();
+        pf_ln_bwd(sM, sA, sY, ldE, k.ln1w, E, true, k.dws1 + t0 * E, k.dbs1 + t0 * E, L, wave, lane);  // sY = d hmid
+        __syncthreads();
+        // hmid = x_i + att Wo + bo
+        for (int idx = tid; idx < L * E; idx += PF_THREADS) {
+            const int i = idx / E, c = idx - i * E;
+            k.d_mid[(t0 + i) * E + c] = sY[i * ldE + c];
+            sM[i * ldE + c] = k.x[(t0 + i) * E + c];  // for the LayerNorm_0 backward below
+        }
+        for (int idx = tid; idx < L * 3 * E; idx += PF_THREADS) {
+            const int i = idx / (3 * E), c = idx - i * 3 * E;
+            sQ[i * ldW + c] = k.qkv[(t0 + i) * 3 * E + c];
+        }
+        pf_lin_nn(sY, ldE, k.wo, E, E, wave, lane, [&](int i, int c, f32x4_v v) {
+            *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);  // d att
+        });
+        __syncthreads();
+        // attention backward: probabilities recomputed; dS = P * (dP - sum_j P dP) * scale
+        if (hd % 16 == 0) {
+            pf_attn_bwd_mfma_a(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, scale, k.d_qkv + t0 * 3 * E, wave, lane);
+            __syncthreads();
+            pf_attn_bwd_mfma_b(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, k.d_qkv + t0 * 3 * E, wave, lane);
+        } else {
+            for (int item = tid; item < heads * 16; item += PF_THREADS) {
+                const int h = item >> 4, i = item & 15;
+                float* pr = sP + h * 256 + i * 16;
+                float* ds = sS + h * 256 + i * 16;
+                if (i < L) {
+                    const float* qv = sQ + i * ldW + h * hd;
+                    const float* dO = sA + i * ldE + h * hd;
+                    float mx = -INFINITY;
+                    for (int jj = 0; jj <= i; ++jj) {
+                        const float* kv = sQ + jj * ldW + E + h * hd;
+                        float s = 0.f;
+                        for (int d = 0; d < hd; ++d) s = fmaf(qv[d], kv[d], s);
+                        s *= scale;
+                        pr[jj] = s;
+                        mx = fmaxf(mx, s);
+                    }
+                    float sum = 0.f;
+                    for (int jj = 0; jj <= i; ++jj) { const float e = expf(pr[jj] - mx); pr[jj] = e; sum += e; }
+                    const float inv = 1.0f / sum;
+                    float dot = 0.f;
+                    for (int jj = 0; jj <= i; ++jj) {
+                        const float p = pr[jj] * inv;
+                        pr[jj] = p;
+                        const float* vv = sQ + jj * ldW + 2 * E + h * hd;
+                        float dp = 0.f;
+                        for (int d = 0; d < hd; ++d) dp = fmaf(dO[d], vv[d], dp);
+                        ds[jj] = dp;
+                        dot += p * dp;
+                    }
+                    for (int jj = 0; jj < 16; ++jj) {
+                        if (jj <= i) ds[jj] = pr[jj] * (ds[jj] - dot) * scale;
+                        else { ds[jj] = 0.f; pr[jj] = 0.f; }
+                    }
+                } else {
+                    for (int jj = 0; jj < 16; ++jj) { pr[jj] = 0.f; ds[jj] = 0.f; }
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 16 * E; idx += PF_THREADS) {
+                const int t = idx / E, c = idx - t * E, h = c / hd;
+                const float* P = sP + h * 256;
+                const float* S = sS + h * 256;
+                float dq = 0.f, dk = 0.f, dv = 0.f;
+                for (int jj = 0; jj < L; ++jj) {
+                    dq = fmaf(S[t * 16 + jj], sQ[jj * ldW + E + c], dq);
+                    dk = fmaf(S[jj * 16 + t], sQ[jj * ldW + c], dk);
+                    dv = fmaf(P[jj * 16 + t], sA[jj * ldE + c], dv);
+                }
+                if (t >= L) { dq = 0.f; dk = 0.f; dv = 0.f; }
+                sU[t * ldW + c] = dq;
+                sU[t * ldW + E + c] = dk;
+                sU[t * ldW + 2 * E + c] = dv;
+                if (t < L) {
+                    float* o = k.d_qkv + (t0 + t) * 3 * E;
+                    o[c] = dq;
+                    o[E + c] = dk;
+                    o[2 * E + c] = dv;
+                }
+            }
+        }
+        __syncthreads();
+        pf_lin_nn(sU, ldW, k.wqkv, 3 * E, E, wave, lane, [&](int i, int c, f32x4_v v) {
+            *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
+        });
+        __syncthreads();
+        pf_ln_bwd(sM, sA, sY, ldE, k.ln0w, E, true, k.dws0 + t0 * E, k.dbs0 + t0 * E, L, wave, lane);  // sY = d x_i
+        __syncthreads();
+    }
+    // d tokens; d(pre-tanh image embedding) = d img * (1 - img^2)   (ARPDT.py:484)
+    for (int idx = tid; idx < L * E; idx += PF_THREADS) {
+        const int i = idx / E, e = idx - i * E;
+        const float g = sY[i * ldE + e];
+        a.dtok[(t0 + i) * E + e] = g;
+        const int t = i / 3;
+        if (i - 3 * t == 0) {
+            const float y = a.img[(r0 + t) * E + e];
+            a.dz[(r0 + t) * E + e] = g * (1.f - y * y);
+        }
+    }
+}
+
+// metrics: [0] loss = trans + lambda*ret, [1] acc (fraction), [2] trans_loss, [3] return_loss  (as loss_kernel)
+__global__ void loss_finish_kernel(const float* __restrict__ part, int B, int R, int NA, float lambda, float* __restrict__ metrics) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ce = 0.f, hit = 0.f, se = 0.f;
+    for (int b = 0; b < B; ++b) { ce += part[b * 4]; hit += part[b * 4 + 1]; se += part[b * 4 + 2]; }
+    const float trans = ce / ((float)R * NA), rl = se / (float)R;
+    metrics[0] = trans + lambda * rl;
+    metrics[1] = hit / (float)R;
+    metrics[2] = trans;
+    metrics[3] = rl;
+}
+
+// ---- grouped launches for the deferred parameter gradients ---------------------------------------------------
+// tile_prefix[p] .. tile_prefix[p+1] are the 32x32 output tiles of problem p
+__global__ __launch_bounds__(256) void grouped_small_gemm_kernel(const SmallGemm* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
+    int p = 0;
+    while (p + 1 < n && (int)blockIdx.x >= tile_prefix[p + 1]) ++p;
+    const SmallGemm g = tab[p];
+    const int local = blockIdx.x - tile_prefix[p];
+    const int nbx = (g.N + 31) / 32;
+    small_gemm_tile(g, local % nbx, local / nbx);
+}
+// embedding / rtg-projection gradients from d tokens: block a < NA sums the action-token rows whose action is a
+// (in row order), block NA the rtg-token rows weighted by rtg  (same sums as tokens_bwd_kernel, no read-modify-write chain)
+__global__ __launch_bounds__(256) void tokens_bwd_par_kernel(const float* __restrict__ dtok, const float* __restrict__ rtg, const int* __restrict__ action,
+                                                             float* __restrict__ dWr, float* __restrict__ demb, int R, int E, int n_actions) {
+    const int a = blockIdx.x;
+    for (int e = threadIdx.x; e < E; e += 256) {
+        float s = 0.f;
+        if (a < n_actions) {
+            for (int r = 0; r < R; ++r)
+                if (action[r] == a) s += dtok[((size_t)r * 3 + 2) * E + e];
+            demb[(size_t)a * E + e] = s;
+        } else {
+            for (int r = 0; r < R; ++r) s += rtg[r] * dtok[((size_t)r * 3 + 1) * E + e];
+            dWr[e] = s;
+        }
+    }
+}
+struct ColSumJob { const float* in; float* out; int R, C; };
+__global__ __launch_bounds__(256) void grouped_colsum_kernel(const ColSumJob* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
+    int p = 0;
+    while (p + 1 < n && (int)blockIdx.x >= tile_prefix[p + 1]) ++p;
+    const ColSumJob j = tab[p];
+    colsum_tile(j.in, j.R, j.C, j.out, blockIdx.x - tile_prefix[p]);
+}
+
+}  // namespace arp

@@ -23,7 +23,7 @@ SHAPES = {  # name: (M, N, K, act, resid, out_f32)
 names = sys.argv[1:] or list(SHAPES)
 for name in names:
     M, N, K, act, resid, f32 = SHAPES[name]
-    for kern in (2, 3):
+    for kern in (1, 2, 3):
         ms = C.c_float()
         _ffi.check(_ffi.lib.arp_op_gemm_bench(1, kern, act, resid, f32, M, N, K, 20, C.byref(ms)))
         print(f"{name:12s} kernel={ {1: '128', 2: '256', 3: 'pair'}[kern] } M={M} N={N} K={K}: {ms.value * 1e3:8.1f} us  {2.0 * M * N * K / ms.value / 1e9:7.1f} TFLOP/s", flush=True)

@@ -158,3 +158,47 @@ def test_greedy_action_and_return(gpu_lib):
     r = ref["return_pred"].numpy()
     assert np.abs(tr.greedy_return(enc, act, rtg) - np.sign(r) * (np.exp(np.abs(r)) - 1)).max() < 1e-5
     tr.close()
+
+
+@pytest.mark.parametrize("kw,B", [(TINY, 4), (SMALL, 6)])
+def test_fused_policy_kernel_matches_unfused_path(gpu_lib, kw, B, monkeypatch):
+    """policy_fused_kernel + the grouped gradient launches against the one-kernel-per-op path (ARP_DT_FUSED=0):
+    same f32 arithmetic up to summation order."""
+    from arp_amd.train import PolicyTrainer
+    cfg, _, P, (enc, act, rtg), _, _ = _setup(kw, B, 11)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ARP_DT_FUSED", fused)
+        tr = PolicyTrainer(cfg, mode="f32")
+        tr.set_params(P)
+        tr.set_batch(enc, act, rtg)
+        out = tr.forward()
+        tr.backward()
+        res[fused] = (out, tr.get_grads())
+        tr.close()
+    (o1, g1), (o0, g0) = res["1"], res["0"]
+    assert np.abs(o1["action_pred"] - o0["action_pred"]).max() < 1e-5
+    assert np.abs(o1["return_pred"] - o0["return_pred"]).max() < 1e-5
+    for k in ("loss", "acc", "trans_loss", "return_loss"):
+        assert abs(o1[k] - o0[k]) < 1e-5, k
+    bad = [(k, float(np.abs(g1[k] - g0[k]).max() / max(np.abs(g0[k]).max(), 1e-6))) for k in P]
+    bad = [b for b in bad if not b[1] < 5e-5]
+    assert not bad, bad
+
+
+def test_long_window_uses_unfused_path(gpu_lib):
+    """window 6 -> 18 tokens per sample: beyond the fused kernel's 16-row tile, served by the per-op kernels."""
+    from arp_amd.train import PolicyTrainer
+    from oracle import arpdt_torch as O
+    kw = dict(TINY, window=6)
+    cfg, ocfg, P, (enc, act, rtg), Pt, tb = _setup(kw, 3, 13)
+    g_ref, _, _ = O.grads(Pt, ocfg, *tb)
+    tr = PolicyTrainer(cfg, mode="f32")
+    tr.set_params(P)
+    tr.set_batch(enc, act, rtg)
+    tr.backward()
+    g = tr.get_grads()
+    bad = [(k, float(np.abs(g[k] - g_ref[k].numpy()).max() / max(np.abs(g_ref[k].numpy()).max(), 1e-6))) for k in P]
+    bad = [b for b in bad if not b[1] < 2e-4]
+    assert not bad, bad
+    tr.close()
