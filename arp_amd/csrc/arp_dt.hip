@@ -309,8 +309,10 @@ bool fused_eligible(const arp_dt_cfg& k) {
     if (const char* e = getenv("ARP_DT_FUSED"))
         if (atoi(e) == 0) return false;
     const int E = k.emb, H = k.mlp_ratio * k.emb;
-    return 3 * k.window <= 16 && E % 16 == 0 && H % 16 == 0 && k.n_actions <= 16 && k.depth <= PF_MAX_DEPTH && E % k.heads == 0 &&
-           pf_lds_bytes(E, H, k.heads) <= 160 * 1024;
+    // instantiated geometries: the shipped one (E = 128, mlp_ratio 4) and the half-width one the tests use
+    const bool shape = (E == 128 && H == 512) || (E == 64 && H == 256);
+    return shape && 3 * k.window <= 16 && k.n_actions <= 16 && k.depth <= PF_MAX_DEPTH && E % k.heads == 0 && (E / k.heads) % 16 == 0 &&
+           pf_lds_bytes(E, H, k.heads, k.depth) <= 160 * 1024;
 }
 
 // kernel arguments of policy_fused_kernel and the problem tables of the two grouped gradient launches
@@ -377,7 +379,8 @@ int build_fused_plan(arp_dt* c) {
     ARP_HIP_OK(hipMemcpy(c->cprefix.p, cp.data(), cp.size() * 4, hipMemcpyHostToDevice));
     static bool attr_set = false;
     if (!attr_set) {
-        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_fused_kernel<128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_fused_kernel<64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     return 0;
@@ -435,7 +438,9 @@ int ensure_buffers(arp_dt* c, int B) {
 int policy_fused(arp_dt* c, bool do_bwd) {
     const arp_dt_cfg& k = c->cfg;
     c->pf.do_bwd = do_bwd ? 1 : 0;
-    hipLaunchKernelGGL(policy_fused_kernel, dim3(c->B), dim3(PF_THREADS), pf_lds_bytes(k.emb, k.mlp_ratio * k.emb, k.heads), c->stream, c->pf);
+    const size_t lds = pf_lds_bytes(k.emb, k.mlp_ratio * k.emb, k.heads, k.depth);
+    if (k.emb == 128) hipLaunchKernelGGL((policy_fused_kernel<128, 512>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
+    else hipLaunchKernelGGL((policy_fused_kernel<64, 256>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c->stream, c->loss_part.as<float>(), c->B, c->R(), k.n_actions, k.lambda_ret,
                        c->metrics.as<float>());
     ARP_HIP_OK(hipGetLastError());

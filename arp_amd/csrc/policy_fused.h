@@ -12,10 +12,18 @@
 //     grouped launches (grouped_small_gemm_kernel / grouped_colsum_kernel): fixed-order, no atomics.
 //
 // Matmuls run on v_mfma_f32_16x16x4_f32 (true fp32) with the 16-row token block as one MFMA operand and the weight
-// rows streamed from L2 as the other: 16 B per lane per load in both the NT (forward, W[out][in] rows along the
-// contraction) and NN (backward, dX = dY . W) forms.  Token rows beyond L are zero padding: rows never mix in a
-// linear layer or LayerNorm, and attention only visits keys j <= i < L.
+// rows streamed from L2 as the other, in both the NT (forward, W[out][in] rows along the contraction) and NN
+// (backward, dX = dY . W) forms; attention (<= 16 tokens, head_dim a multiple of 16) is MFMA too, one wave per head.
+// Token rows beyond L are zero padding: rows never mix in a linear layer or LayerNorm, and attention only visits keys
+// j <= i < L.  The kernel is instantiated per (E, H) so that every address inside a pipelined group is base + immediate
+// (the runtime-shape version spilled to scratch); other geometries run the one-kernel-per-op path in arp_dt.hip.
+//
+// Measured (B = 32, E = 128, depth 2, s_memtime stamps per phase): 378 k cycles ~ 155 us, against ~910 us for the
+// per-op path.  The eight big linears take 245 k of it; with the weight loads removed they take 145 k (the f32-MFMA
+// floor at 32 cycles per 16x16x4 issue), so weight streaming still costs ~70 % on top of the MFMAs.
 #pragma once
+#include <utility>
+
 #include "common.h"
 #include "dtops.h"
 
@@ -41,103 +49,202 @@ struct PfArgs {
     float* loss_part;                                           // [B][4]: sum CE, hits, sum squared error
 };
 
-inline size_t pf_lds_bytes(int E, int H, int heads) {
+inline size_t pf_lds_bytes(int E, int H, int heads, int depth) {
     const int WB = H > 3 * E ? H : 3 * E;
-    return ((size_t)4 * 16 * (E + 4) + (size_t)3 * 16 * (WB + 4) + (size_t)2 * heads * 256 + 64) * 4;
+    return ((size_t)4 * 16 * (E + 4) + (size_t)3 * 16 * (WB + 4) + (size_t)2 * heads * 256 + 64 + (size_t)(8 * depth + 5) * E) * 4;  // (the NN form may read up to 127 finite floats past a row: always inside the allocation)
 }
 
 // ---- in-kernel building blocks ---------------------------------------------------------------------------
-// out[i][n] = sum_k Xs[i][k] * W[n][k]   (NT).  Each wave owns 16-column tiles n0 = 16*(wave + 8*t); the weight rows are
-// prefetched one chunk (16*CH k-values) ahead.  epi(i, n, acc): lane's token row i and 4 consecutive columns n..n+3.
-template <int CH, class Epi>
-__device__ __forceinline__ void pf_lin_nt_t(const float* Xs, int ldx, const float* __restrict__ W, int N, int K, int wave, int lane, Epi epi) {
-    const int q = lane >> 4, j = lane & 15;
-    const int nchunk = K / (16 * CH);
-    const int ntile = (N + 15) >> 4;
-    const int tiles_w = wave < ntile ? (ntile - 1 - wave) / PF_NW + 1 : 0;
-    const int nf = tiles_w * nchunk;
-    float4 wc[CH], wn[CH];
-    auto loadw = [&](float4(&w)[CH], int f) {
-        const int tile = wave + PF_NW * (f / nchunk), ch = f % nchunk;
-        const int n = tile * 16 + j;
-        const bool ok = n < N;
-        const float* p = W + (size_t)(ok ? n : 0) * K + ch * 16 * CH + 4 * q;
-#pragma unroll
-        for (int s = 0; s < CH; ++s) w[s] = ok ? *reinterpret_cast<const float4*>(p + 16 * s) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    if (nf > 0) loadw(wc, 0);
-    f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
-    for (int f = 0; f < nf; ++f) {
-        if (f + 1 < nf) loadw(wn, f + 1);
-        const int ch = f % nchunk;
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {
-            const float4 x = *reinterpret_cast<const float4*>(Xs + j * ldx + ch * 16 * CH + 16 * s + 4 * q);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s].x, x.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s].y, x.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s].z, x.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s].w, x.w, acc, 0, 0, 0);
-        }
-        if (ch == nchunk - 1) {
-            epi(j, (wave + PF_NW * (f / nchunk)) * 16 + 4 * q, acc);
-            acc = f32x4_v{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int s = 0; s < CH; ++s) wc[s] = wn[s];
-    }
+// Both linear forms stream their weights through a ring of R register slots, one slot per 16-wide contraction step:
+// a slot is refilled (with the same step of the NEXT group) right after its 4 MFMAs, so about R loads -- 8 KB per wave,
+// 64 KB per workgroup -- are in flight while the MFMAs run.  The loops are branch-free in their vector-memory traffic:
+// the refill is unconditional (the last group is peeled instead of guarded), epilogues write LDS only and the activations
+// are saved to global memory by separate passes.  Any conditional load or store inside such a loop makes hipcc's
+// s_waitcnt vmcnt counts conservative, which silently serialises load and compute.  Shapes are template parameters so
+// every address inside a group is base + immediate.
+//
+// out[i][n] = sum_k Xs[i][k] * W[n][k]   (NT).  Each wave owns the 16-column tiles n0 = 16*(wave + 8*t).
+// epi(i, n, acc): this lane's token row i and 4 consecutive columns n..n+3.
+// hipcc's own s_waitcnt insertion waits vmcnt(0) at the head of such a loop (every refill of the previous group), which
+// serialises load and compute; so the weight loads are inline asm (invisible to that pass) and the waits are explicit,
+// counted ones -- loads return in issue order, and nothing else touches vector memory inside the loop.
+template <int OFF> __device__ __forceinline__ void pf_gload4(f32x4_v& d, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory");
 }
-template <class Epi>
-__device__ __forceinline__ void pf_lin_nt(const float* Xs, int ldx, const float* __restrict__ W, int N, int K, int wave, int lane, Epi epi) {
-    if (K % 128 == 0) pf_lin_nt_t<8>(Xs, ldx, W, N, K, wave, lane, epi);
-    else if (K % 64 == 0) pf_lin_nt_t<4>(Xs, ldx, W, N, K, wave, lane, epi);
-    else pf_lin_nt_t<1>(Xs, ldx, W, N, K, wave, lane, epi);
+__device__ __forceinline__ void pf_gload1(float& d, const float* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void pf_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-// out[i][c] = sum_n dYs[i][n] * W[n][c]   (NN; contraction over the N rows of W, output over its K columns, K % 16 == 0).
-// dYs columns beyond N may hold anything finite: their weights are loaded as zeros.
-template <class Epi>
-__device__ __forceinline__ void pf_lin_nn(const float* dYs, int ldy, const float* __restrict__ W, int N, int K, int wave, int lane, Epi epi) {
+template <int N, int K, int LDX, class Epi>
+__device__ __forceinline__ void pf_lin_nt(const float* Xs, const float* __restrict__ W, int wave, int lane, Epi epi) {
+    static_assert(N % 16 == 0 && K % 16 == 0, "tile multiples");
+    constexpr int KS = K / 16, R = (KS % 8 == 0) ? 8 : (KS % 4 == 0 ? 4 : (KS % 2 == 0 ? 2 : 1)), GP = KS / R, NTL = N / 16;
     const int q = lane >> 4, j = lane & 15;
-    const int nchunk = (N + 63) >> 6;  // 64 contraction indices per chunk
-    const int ntile = K >> 4;
-    const int tiles_w = wave < ntile ? (ntile - 1 - wave) / PF_NW + 1 : 0;
-    const int nf = tiles_w * nchunk;
-    float wc[16], wn[16];
-    auto loadw = [&](float(&w)[16], int f) {
-        const int tile = wave + PF_NW * (f / nchunk), ch = f % nchunk;
-        const float* p = W + tile * 16 + j;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int n = ch * 64 + s4 * 16 + 4 * q + s;
-                w[s4 * 4 + s] = n < N ? p[(size_t)n * K] : 0.f;
-            }
+    const int tiles_w = wave < NTL ? (NTL - 1 - wave) / PF_NW + 1 : 0;
+    const int NG = tiles_w * GP;
+    if (NG == 0) return;
+    const float* pl = W + (size_t)(wave * 16 + j) * K + 4 * q;  // next group to load
+    const float* xs = Xs + j * LDX + 4 * q;
+    f32x4_v w[R];
+    f32x4_v acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    int tile = wave, lg = 0, cg = 0;
+    auto next_ptr = [&]() {
+        if (GP > 1 && ++lg < GP) pl += R * 16;
+        else { lg = 0; pl += (size_t)PF_NW * 16 * K - (GP - 1) * R * 16; }
     };
-    if (nf > 0) loadw(wc, 0);
-    f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
-    for (int f = 0; f < nf; ++f) {
-        if (f + 1 < nf) loadw(wn, f + 1);
-        const int ch = f % nchunk;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const float4 y = *reinterpret_cast<const float4*>(dYs + j * ldy + ch * 64 + s4 * 16 + 4 * q);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s4 * 4 + 0], y.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s4 * 4 + 1], y.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s4 * 4 + 2], y.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[s4 * 4 + 3], y.w, acc, 0, 0, 0);
-        }
-        if (ch == nchunk - 1) {
-            epi(j, (wave + PF_NW * (f / nchunk)) * 16 + 4 * q, acc);
+    auto mfma4 = [&](const f32x4_v& wv, const float* xp) {
+        const float4 x = *reinterpret_cast<const float4*>(xp);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], x.x, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], x.y, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], x.z, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x.w, acc2, 0, 0, 0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    [&]<int... U>(std::integer_sequence<int, U...>) { (pf_gload4<U * 64>(w[U], pl), ...); }(std::make_integer_sequence<int, R>{});
+    __builtin_amdgcn_sched_barrier(0);
+    next_ptr();
+    for (int gg = 0; gg + 1 < NG; ++gg) {
+        const float* xg = xs + cg * (R * 16);
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ((pf_wait_vm<R - 1>(), mfma4(w[U], xg + U * 16), __builtin_amdgcn_sched_barrier(0), pf_gload4<U * 64>(w[U], pl),
+              __builtin_amdgcn_sched_barrier(0)),
+             ...);
+        }(std::make_integer_sequence<int, R>{});
+        next_ptr();
+        if (++cg == GP) {
+            cg = 0;
+            epi(j, tile * 16 + 4 * q, acc + acc2);
             acc = f32x4_v{0.f, 0.f, 0.f, 0.f};
+            acc2 = f32x4_v{0.f, 0.f, 0.f, 0.f};
+            tile += PF_NW;
         }
+    }
+    {
+        const float* xg = xs + cg * (R * 16);
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ((pf_wait_vm<R - 1 - U>(), mfma4(w[U], xg + U * 16)), ...);
+        }(std::make_integer_sequence<int, R>{});
+        epi(j, tile * 16 + 4 * q, acc + acc2);  // the last group always closes a tile
+    }
+}
+
+// out[i][c] = sum_n dYs[i][n] * W[n][c]   (NN; contraction over the N rows of W, output over its K columns).
+template <int N, int K, int LDY, class Epi>
+__device__ __forceinline__ void pf_lin_nn(const float* dYs, const float* __restrict__ W, int wave, int lane, Epi epi) {
+    static_assert(N % 16 == 0 && K % 16 == 0, "tile multiples");
+    constexpr int NS = N / 16, R = (NS % 8 == 0) ? 8 : (NS % 4 == 0 ? 4 : (NS % 2 == 0 ? 2 : 1)), GP = NS / R, KT = K / 16;
+    const int q = lane >> 4, j = lane & 15;
+    const int tiles_w = wave < KT ? (KT - 1 - wave) / PF_NW + 1 : 0;
+    const int NG = tiles_w * GP;
+    if (NG == 0) return;
+    const float* pl = W + (size_t)(4 * q) * K + wave * 16 + j;
+    const float* ys = dYs + j * LDY + 4 * q;
+    float w[R][4];  // [step][r] = contraction row 4q + r of the step, this lane's output column
+    f32x4_v acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    int tile = wave, lg = 0, cg = 0;
+    auto next_ptr = [&]() {
+        if (GP > 1 && ++lg < GP) pl += (size_t)R * 16 * K;
+        else { lg = 0; pl += PF_NW * 16 - (ptrdiff_t)(GP - 1) * R * 16 * K; }
+    };
+    auto load_step = [&](float(&d)[4], const float* p) {
+        pf_gload1(d[0], p); pf_gload1(d[1], p + K); pf_gload1(d[2], p + 2 * K); pf_gload1(d[3], p + 3 * K);
+    };
+    auto mfma4 = [&](const float(&wv)[4], const float* yp) {
+        const float4 y = *reinterpret_cast<const float4*>(yp);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], y.x, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], y.y, acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], y.z, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], y.w, acc2, 0, 0, 0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) wc[s] = wn[s];
+    for (int u = 0; u < R; ++u) load_step(w[u], pl + (size_t)u * 16 * K);
+    __builtin_amdgcn_sched_barrier(0);
+    next_ptr();
+    for (int gg = 0; gg + 1 < NG; ++gg) {
+        const float* yg = ys + cg * (R * 16);
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            pf_wait_vm<4 * (R - 1)>();
+            mfma4(w[u], yg + u * 16);
+            __builtin_amdgcn_sched_barrier(0);
+            load_step(w[u], pl + (size_t)u * 16 * K);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        next_ptr();
+        if (++cg == GP) {
+            cg = 0;
+            epi(j, tile * 16 + 4 * q, acc + acc2);
+            acc = f32x4_v{0.f, 0.f, 0.f, 0.f};
+            acc2 = f32x4_v{0.f, 0.f, 0.f, 0.f};
+            tile += PF_NW;
+        }
+    }
+    {
+        const float* yg = ys + cg * (R * 16);
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ((pf_wait_vm<4 * (R - 1 - U)>(), mfma4(w[U], yg + U * 16)), ...);
+        }(std::make_integer_sequence<int, R>{});
+        epi(j, tile * 16 + 4 * q, acc + acc2);
+    }
+}
+
+// The head layers with N <= 16 outputs (NT: the logits / the return prediction) or N <= 16 contraction rows (NN: their
+// input gradients): one MFMA tile, every load issued up front.  Rows >= N are clamped (finite): the NT epilogue must
+// skip columns >= N, and the NN operand dYs must hold zeros in columns N..15.
+template <int K, int LDX, class Epi>
+__device__ __forceinline__ void pf_lin_nt_small(const float* Xs, const float* __restrict__ W, int N, int wave, int lane, Epi epi) {
+    if (wave != 0) return;
+    constexpr int KS = K / 16;
+    const int q = lane >> 4, j = lane & 15;
+    const float* p = W + (size_t)(j < N ? j : N - 1) * K + 4 * q;
+    float4 w[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) w[u] = *reinterpret_cast<const float4*>(p + u * 16);
+    f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+        const float4 x = *reinterpret_cast<const float4*>(Xs + j * LDX + u * 16 + 4 * q);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].x, x.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].y, x.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].z, x.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u].w, x.w, acc, 0, 0, 0);
+    }
+    epi(j, 4 * q, acc);
+}
+template <int K, int LDY, class Epi>
+__device__ __forceinline__ void pf_lin_nn_small(const float* dYs, const float* __restrict__ W, int N, int wave, int lane, Epi epi) {
+    const int q = lane >> 4, j = lane & 15;
+    for (int tile = wave; tile < K / 16; tile += PF_NW) {
+        const float* p = W + tile * 16 + j;
+        float wv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wv[r] = p[(size_t)(4 * q + r < N ? 4 * q + r : N - 1) * K];
+        const float4 y = *reinterpret_cast<const float4*>(dYs + j * LDY + 4 * q);
+        f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], y.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], y.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[2], y.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], y.w, acc, 0, 0, 0);
+        epi(j, tile * 16 + 4 * q, acc);
+    }
+}
+
+// rows [0, rows) of an LDS tile -> global rows (float4 runs; width % 4 == 0)
+__device__ __forceinline__ void pf_save_rows(const float* src, int ld, int width, float* __restrict__ dst, int rows, int tid) {
+    const int w4 = width >> 2;
+    for (int idx = tid; idx < rows * w4; idx += PF_THREADS) {
+        const int i = idx / w4, c = (idx - i * w4) * 4;
+        *reinterpret_cast<float4*>(dst + (size_t)i * width + c) = *reinterpret_cast<const float4*>(src + i * ld + c);
     }
 }
 
 // LayerNorm of the 16 LDS rows (2 per wave), Flax eps 1e-6; same arithmetic as ln_fwd_f32_kernel
-__device__ __forceinline__ void pf_ln_fwd(const float* src, float* dst, int ld, const float* __restrict__ w, const float* __restrict__ b, int E,
+__device__ __forceinline__ void pf_ln_fwd(const float* src, float* dst, int ld, const float* w, const float* b, int E,
                                           float* __restrict__ save, int rows_valid, int wave, int lane) {
     for (int i = wave; i < 16; i += PF_NW) {
         const float* xr = src + i * ld;
@@ -156,7 +263,7 @@ __device__ __forceinline__ void pf_ln_fwd(const float* src, float* dst, int ld, 
 }
 // LayerNorm backward on LDS rows: dxs[i] (+)= d/dx ; per-row dy*xhat and dy saved for the deferred column sums.
 // Same arithmetic as ln_bwd_f32_kernel.
-__device__ __forceinline__ void pf_ln_bwd(const float* xs, const float* dys, float* dxs, int ld, const float* __restrict__ w, int E, bool accumulate,
+__device__ __forceinline__ void pf_ln_bwd(const float* xs, const float* dys, float* dxs, int ld, const float* w, int E, bool accumulate,
                                           float* __restrict__ dws, float* __restrict__ dbs, int rows_valid, int wave, int lane) {
     for (int i = wave; i < 16; i += PF_NW) {
         const float* xr = xs + i * ld;
@@ -301,12 +408,13 @@ __device__ __forceinline__ float pf_gelu_grad(float r) {  // d/du of the tanh-ap
     return 0.5f * (1.f + t) + 0.5f * r * (1.f - t * t) * c * (1.f + 3.f * a * r * r);
 }
 
+template <int E, int H>
 __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float pf_sm[];
-    const int E = a.E, H = a.H, L = a.L, T = a.T, NA = a.NA, heads = a.heads;
+    const int L = a.L, T = a.T, NA = a.NA, heads = a.heads;
     const int hd = E / heads;
-    const int WB = H > 3 * E ? H : 3 * E;
-    const int ldE = E + 4, ldW = WB + 4;
+    constexpr int WB = H > 3 * E ? H : 3 * E;
+    constexpr int ldE = E + 4, ldW = WB + 4;
     float* sX = pf_sm;            // residual stream x
     float* sM = sX + 16 * ldE;    // hmid / scratch
     float* sY = sM + 16 * ldE;    // LayerNorm output (forward); gradient stream dh (backward)
@@ -317,12 +425,27 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
     float* sP = sG + 16 * ldW;    // [heads][16][16] probabilities
     float* sS = sP + heads * 256; // [heads][16][16] dS
     const int total = 4 * 16 * ldE + 3 * 16 * ldW + 2 * heads * 256 + 64;
+    // every bias / LayerNorm vector lives in LDS for the whole kernel: an epilogue or a LayerNorm row that loaded them
+    // from global memory would wait a full memory latency per tile (and drain the weight prefetch with it)
+    float* sV = pf_sm + total;  // per block [ln0w ln0b bqkv(3E) bo ln1w ln1b], then [lnfw lnfb ba0 br0 Wr]
+    float* sVt = sV + 8 * a.depth * E;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const size_t t0 = (size_t)b * L, r0 = (size_t)b * T;
     const float scale = 1.0f / sqrtf((float)hd);
 
     for (int i = tid; i < total; i += PF_THREADS) pf_sm[i] = 0.f;
+    for (int bi = 0; bi < a.depth; ++bi) {
+        const PfBlk& k = a.blk[bi];
+        float* v = sV + 8 * bi * E;
+        for (int e = tid; e < E; e += PF_THREADS) {
+            v[e] = k.ln0w[e]; v[E + e] = k.ln0b[e]; v[5 * E + e] = k.bo[e]; v[6 * E + e] = k.ln1w[e]; v[7 * E + e] = k.ln1b[e];
+            v[2 * E + e] = k.bqkv[e]; v[3 * E + e] = k.bqkv[E + e]; v[4 * E + e] = k.bqkv[2 * E + e];
+        }
+    }
+    for (int e = tid; e < E; e += PF_THREADS) {
+        sVt[e] = a.lnfw[e]; sVt[E + e] = a.lnfb[e]; sVt[2 * E + e] = a.ba0[e]; sVt[3 * E + e] = a.br0[e]; sVt[4 * E + e] = a.Wr[e];
+    }
     __syncthreads();
     // ---- token assembly: per time step [image, rtg, action] (ARPDT.py:159-172,278-293) ----------------------
     for (int idx = tid; idx < L * E; idx += PF_THREADS) {
@@ -330,7 +453,7 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
         const int t = i / 3, m = i - 3 * t;
         float v;
         if (m == 0) v = a.img[(r0 + t) * E + e];
-        else if (m == 1) v = a.rtg[r0 + t] * a.Wr[e];
+        else if (m == 1) v = a.rtg[r0 + t] * sVt[4 * E + e];
         else v = a.emb[(size_t)a.action[r0 + t] * E + e];
         sX[i * ldE + e] = v;
         a.blk[0].x[(t0 + i) * E + e] = v;
@@ -342,84 +465,50 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
     // ---- forward blocks ------------------------------------------------------------------------------------
     for (int bi = 0; bi < a.depth; ++bi) {
         const PfBlk& k = a.blk[bi];
-        pf_ln_fwd(sX, sY, ldE, k.ln0w, k.ln0b, E, k.ln0 + t0 * E, L, wave, lane);
+        const float* vb = sV + 8 * bi * E;
+        pf_ln_fwd(sX, sY, ldE, vb, vb + E, E, k.ln0 + t0 * E, L, wave, lane);
         __syncthreads();
-        pf_lin_nt(sY, ldE, k.wqkv, 3 * E, E, wave, lane, [&](int i, int n, f32x4_v v) {
-            const float4 bb = *reinterpret_cast<const float4*>(k.bqkv + n);
+        pf_lin_nt<3 * E, E, ldE>(sY, k.wqkv, wave, lane, [&](int i, int n, f32x4_v v) {
+            const float4 bb = *reinterpret_cast<const float4*>(vb + 2 * E + n);
             v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             *reinterpret_cast<float4*>(sQ + i * ldW + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (i < L) store4g(k.qkv + (t0 + i) * 3 * E + n, v);
         });
         __syncthreads();
+        pf_save_rows(sQ, ldW, 3 * E, k.qkv + t0 * 3 * E, L, tid);
         // causal attention (layers.py:70-90): scores * scale, masked, softmax, P.V
-        if (hd % 16 == 0) {
-            pf_attn_fwd_mfma(sQ, sA, ldW, ldE, E, hd, heads, L, scale, k.att + t0 * E, wave, lane);
-        } else {
-            for (int item = tid; item < heads * 16; item += PF_THREADS) {
-                const int h = item >> 4, i = item & 15;
-                float* pr = sP + h * 256 + i * 16;
-                if (i < L) {
-                    const float* qv = sQ + i * ldW + h * hd;
-                    float mx = -INFINITY;
-                    for (int jj = 0; jj <= i; ++jj) {
-                        const float* kv = sQ + jj * ldW + E + h * hd;
-                        float s = 0.f;
-                        for (int d = 0; d < hd; ++d) s = fmaf(qv[d], kv[d], s);
-                        s *= scale;
-                        pr[jj] = s;
-                        mx = fmaxf(mx, s);
-                    }
-                    float sum = 0.f;
-                    for (int jj = 0; jj <= i; ++jj) { const float e = expf(pr[jj] - mx); pr[jj] = e; sum += e; }
-                    const float inv = 1.0f / sum;
-                    for (int jj = 0; jj < 16; ++jj) pr[jj] = jj <= i ? pr[jj] * inv : 0.f;
-                } else {
-                    for (int jj = 0; jj < 16; ++jj) pr[jj] = 0.f;
-                }
-            }
-            __syncthreads();
-            for (int idx = tid; idx < 16 * E; idx += PF_THREADS) {
-                const int i = idx / E, c = idx - i * E, h = c / hd;
-                const float* pr = sP + h * 256 + i * 16;
-                float o = 0.f;
-                for (int jj = 0; jj <= i && jj < L; ++jj) o = fmaf(pr[jj], sQ[jj * ldW + 2 * E + c], o);
-                sA[i * ldE + c] = o;
-                if (i < L) k.att[(t0 + i) * E + c] = o;
-            }
-        }
+        pf_attn_fwd_mfma(sQ, sA, ldW, ldE, E, hd, heads, L, scale, k.att + t0 * E, wave, lane);
         __syncthreads();
-        pf_lin_nt(sA, ldE, k.wo, E, E, wave, lane, [&](int i, int n, f32x4_v v) {
-            const float4 bb = *reinterpret_cast<const float4*>(k.bo + n);
+        pf_lin_nt<E, E, ldE>(sA, k.wo, wave, lane, [&](int i, int n, f32x4_v v) {
+            const float4 bb = *reinterpret_cast<const float4*>(vb + 5 * E + n);
             const float4 xr = *reinterpret_cast<const float4*>(sX + i * ldE + n);
             v[0] += bb.x + xr.x; v[1] += bb.y + xr.y; v[2] += bb.z + xr.z; v[3] += bb.w + xr.w;
             *reinterpret_cast<float4*>(sM + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (i < L) store4g(k.hmid + (t0 + i) * E + n, v);
         });
         __syncthreads();
-        pf_ln_fwd(sM, sY, ldE, k.ln1w, k.ln1b, E, k.ln1 + t0 * E, L, wave, lane);
+        pf_save_rows(sM, ldE, E, k.hmid + t0 * E, L, tid);
+        pf_ln_fwd(sM, sY, ldE, vb + 6 * E, vb + 7 * E, E, k.ln1 + t0 * E, L, wave, lane);
         __syncthreads();
-        pf_lin_nt(sY, ldE, k.wfc1, H, E, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<H, E, ldE>(sY, k.wfc1, wave, lane, [&](int i, int n, f32x4_v v) {
             f32x4_v gl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) gl[r] = apply_act<ACT_GELU_TANH>(v[r]);
             *reinterpret_cast<float4*>(sG + i * ldW + n) = make_float4(gl[0], gl[1], gl[2], gl[3]);
-            if (i < L) {
-                store4g(k.u + (t0 + i) * H + n, v);
-                store4g(k.gl + (t0 + i) * H + n, gl);
-            }
+            *reinterpret_cast<float4*>(sU + i * ldW + n) = make_float4(v[0], v[1], v[2], v[3]);
         });
         __syncthreads();
+        pf_save_rows(sU, ldW, H, k.u + t0 * H, L, tid);
+        pf_save_rows(sG, ldW, H, k.gl + t0 * H, L, tid);
         float* xnext = bi + 1 < a.depth ? a.blk[bi + 1].x : a.xf;
-        pf_lin_nt(sG, ldW, k.wfc2, E, H, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<E, H, ldW>(sG, k.wfc2, wave, lane, [&](int i, int n, f32x4_v v) {
             const float4 mr = *reinterpret_cast<const float4*>(sM + i * ldE + n);
             v[0] += mr.x; v[1] += mr.y; v[2] += mr.z; v[3] += mr.w;
             *reinterpret_cast<float4*>(sX + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (i < L) store4g(xnext + (t0 + i) * E + n, v);
         });
         __syncthreads();
+        pf_save_rows(sX, ldE, E, xnext + t0 * E, L, tid);
     }
     // ---- final LayerNorm, head inputs (ARPDT.py:203-205: action head <- rtg tokens 1::3, return head <- image tokens 0::3)
-    pf_ln_fwd(sX, sY, ldE, a.lnfw, a.lnfb, E, nullptr, 0, wave, lane);
+    pf_ln_fwd(sX, sY, ldE, sVt, sVt + E, E, nullptr, 0, wave, lane);
     float* hA = sU;               // a_in  [16][ldE]
     float* hHa = sU + 16 * ldE;   // relu(layers_0(a_in))
     float* hR = sG;               // r_in
@@ -438,15 +527,15 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
         hR[t * ldE + c] = vr;
     }
     __syncthreads();
-    pf_lin_nt(hA, ldE, a.wa0, E, E, wave, lane, [&](int i, int n, f32x4_v v) {
-        const float4 bb = *reinterpret_cast<const float4*>(a.ba0 + n);
+    pf_lin_nt<E, E, ldE>(hA, a.wa0, wave, lane, [&](int i, int n, f32x4_v v) {
+        const float4 bb = *reinterpret_cast<const float4*>(sVt + 2 * E + n);
         v[0] = fmaxf(v[0] + bb.x, 0.f); v[1] = fmaxf(v[1] + bb.y, 0.f); v[2] = fmaxf(v[2] + bb.z, 0.f); v[3] = fmaxf(v[3] + bb.w, 0.f);
         if (i >= T) v = f32x4_v{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<float4*>(hHa + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
         if (i < T) store4g(a.ha + (r0 + i) * E + n, v);
     });
-    pf_lin_nt(hR, ldE, a.wr0, E, E, wave, lane, [&](int i, int n, f32x4_v v) {
-        const float4 bb = *reinterpret_cast<const float4*>(a.br0 + n);
+    pf_lin_nt<E, E, ldE>(hR, a.wr0, wave, lane, [&](int i, int n, f32x4_v v) {
+        const float4 bb = *reinterpret_cast<const float4*>(sVt + 3 * E + n);
         v[0] = fmaxf(v[0] + bb.x, 0.f); v[1] = fmaxf(v[1] + bb.y, 0.f); v[2] = fmaxf(v[2] + bb.z, 0.f); v[3] = fmaxf(v[3] + bb.w, 0.f);
         if (i >= T) v = f32x4_v{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<float4*>(hHr + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -454,7 +543,7 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
     });
     __syncthreads();
     // logits -> sQ[i][0..NA), return prediction -> sQ[i][16]
-    pf_lin_nt(hHa, ldE, a.wa2, NA, E, wave, lane, [&](int i, int n, f32x4_v v) {
+    pf_lin_nt_small<E, ldE>(hHa, a.wa2, NA, wave, lane, [&](int i, int n, f32x4_v v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (n + r < NA) {
@@ -462,7 +551,7 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
                 if (i < T) a.logits[(r0 + i) * NA + n + r] = v[r];
             }
     });
-    pf_lin_nt(hHr, ldE, a.wr2, 1, E, wave, lane, [&](int i, int n, f32x4_v v) {
+    pf_lin_nt_small<E, ldE>(hHr, a.wr2, 1, wave, lane, [&](int i, int n, f32x4_v v) {
         if (n == 0) {
             sQ[i * ldW + 16] = v[0];
             if (i < T) a.ret[r0 + i] = v[0];
@@ -512,13 +601,13 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
     float* hDha = sQ;              // [16][ldE]
     float* hDhr = sQ + 16 * ldE;
     __syncthreads();
-    pf_lin_nn(sA, ldE, a.wa2, NA, E, wave, lane, [&](int i, int c, f32x4_v v) {
+    pf_lin_nn_small<E, ldE>(sA, a.wa2, NA, wave, lane, [&](int i, int c, f32x4_v v) {
         const float4 hh = *reinterpret_cast<const float4*>(hHa + i * ldE + c);
         v[0] = hh.x > 0.f ? v[0] : 0.f; v[1] = hh.y > 0.f ? v[1] : 0.f; v[2] = hh.z > 0.f ? v[2] : 0.f; v[3] = hh.w > 0.f ? v[3] : 0.f;
         *reinterpret_cast<float4*>(hDha + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
         if (i < T) store4g(a.dha + (r0 + i) * E + c, v);
     });
-    pf_lin_nn(sM, ldE, a.wr2, 1, E, wave, lane, [&](int i, int c, f32x4_v v) {
+    pf_lin_nn_small<E, ldE>(sM, a.wr2, 1, wave, lane, [&](int i, int c, f32x4_v v) {
         const float4 hh = *reinterpret_cast<const float4*>(hHr + i * ldE + c);
         v[0] = hh.x > 0.f ? v[0] : 0.f; v[1] = hh.y > 0.f ? v[1] : 0.f; v[2] = hh.z > 0.f ? v[2] : 0.f; v[3] = hh.w > 0.f ? v[3] : 0.f;
         *reinterpret_cast<float4*>(hDhr + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
@@ -527,14 +616,14 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
     __syncthreads();
     for (int i = tid; i < 16 * ldE; i += PF_THREADS) sA[i] = 0.f;  // sA <- d(hf): rows 3t+1 <- d a_in, rows 3t <- d r_in
     __syncthreads();
-    pf_lin_nn(hDha, ldE, a.wa0, E, E, wave, lane, [&](int i, int c, f32x4_v v) {
+    pf_lin_nn<E, E, ldE>(hDha, a.wa0, wave, lane, [&](int i, int c, f32x4_v v) {
         if (i < T) *reinterpret_cast<float4*>(sA + (3 * i + 1) * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
     });
-    pf_lin_nn(hDhr, ldE, a.wr0, E, E, wave, lane, [&](int i, int c, f32x4_v v) {
+    pf_lin_nn<E, E, ldE>(hDhr, a.wr0, wave, lane, [&](int i, int c, f32x4_v v) {
         if (i < T) *reinterpret_cast<float4*>(sA + (3 * i) * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
     });
     __syncthreads();
-    pf_ln_bwd(sX, sA, sY, ldE, a.lnfw, E, false, a.dwsf + t0 * E, a.dbsf + t0 * E, L, wave, lane);  // sY = dh
+    pf_ln_bwd(sX, sA, sY, ldE, sVt, E, false, a.dwsf + t0 * E, a.dbsf + t0 * E, L, wave, lane);  // sY = dh
     __syncthreads();
 
     for (int bi = a.depth - 1; bi >= 0; --bi) {
@@ -545,22 +634,27 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
             k.d_x1[(t0 + i) * E + c] = sY[i * ldE + c];
             sM[i * ldE + c] = k.hmid[(t0 + i) * E + c];  // for the LayerNorm_1 backward below
         }
-        pf_lin_nn(sY, ldE, k.wfc2, E, H, wave, lane, [&](int i, int c, f32x4_v v) {
+        for (int idx = tid * 4; idx < L * H; idx += PF_THREADS * 4) {  // fc1 pre-activations for gelu' (H % 4 == 0)
+            const int i = idx / H, c = idx - i * H;
+            *reinterpret_cast<float4*>(sG + i * ldW + c) = *reinterpret_cast<const float4*>(k.u + (t0 + i) * H + c);
+        }
+        __syncthreads();
+        pf_lin_nn<E, H, ldE>(sY, k.wfc2, wave, lane, [&](int i, int c, f32x4_v v) {
             if (i < L) {
-                const float4 uu = *reinterpret_cast<const float4*>(k.u + (t0 + i) * H + c);
+                const float4 uu = *reinterpret_cast<const float4*>(sG + i * ldW + c);
                 v[0] *= pf_gelu_grad(uu.x); v[1] *= pf_gelu_grad(uu.y); v[2] *= pf_gelu_grad(uu.z); v[3] *= pf_gelu_grad(uu.w);
-                store4g(k.d_u + (t0 + i) * H + c, v);
             } else {
                 v = f32x4_v{0.f, 0.f, 0.f, 0.f};
             }
             *reinterpret_cast<float4*>(sU + i * ldW + c) = make_float4(v[0], v[1], v[2], v[3]);
         });
         __syncthreads();
-        pf_lin_nn(sU, ldW, k.wfc1, H, E, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_save_rows(sU, ldW, H, k.d_u + t0 * H, L, tid);
+        pf_lin_nn<H, E, ldW>(sU, k.wfc1, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
         });
         __syncthreads();
-        pf_ln_bwd(sM, sA, sY, ldE, k.ln1w, E, true, k.dws1 + t0 * E, k.dbs1 + t0 * E, L, wave, lane);  // sY = d hmid
+        pf_ln_bwd(sM, sA, sY, ldE, sV + 8 * bi * E + 6 * E, E, true, k.dws1 + t0 * E, k.dbs1 + t0 * E, L, wave, lane);  // sY = d hmid
         __syncthreads();
         // hmid = x_i + att Wo + bo
         for (int idx = tid; idx < L * E; idx += PF_THREADS) {
@@ -572,82 +666,20 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
             const int i = idx / (3 * E), c = idx - i * 3 * E;
             sQ[i * ldW + c] = k.qkv[(t0 + i) * 3 * E + c];
         }
-        pf_lin_nn(sY, ldE, k.wo, E, E, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<E, E, ldE>(sY, k.wo, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);  // d att
         });
         __syncthreads();
         // attention backward: probabilities recomputed; dS = P * (dP - sum_j P dP) * scale
-        if (hd % 16 == 0) {
-            pf_attn_bwd_mfma_a(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, scale, k.d_qkv + t0 * 3 * E, wave, lane);
-            __syncthreads();
-            pf_attn_bwd_mfma_b(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, k.d_qkv + t0 * 3 * E, wave, lane);
-        } else {
-            for (int item = tid; item < heads * 16; item += PF_THREADS) {
-                const int h = item >> 4, i = item & 15;
-                float* pr = sP + h * 256 + i * 16;
-                float* ds = sS + h * 256 + i * 16;
-                if (i < L) {
-                    const float* qv = sQ + i * ldW + h * hd;
-                    const float* dO = sA + i * ldE + h * hd;
-                    float mx = -INFINITY;
-                    for (int jj = 0; jj <= i; ++jj) {
-                        const float* kv = sQ + jj * ldW + E + h * hd;
-                        float s = 0.f;
-                        for (int d = 0; d < hd; ++d) s = fmaf(qv[d], kv[d], s);
-                        s *= scale;
-                        pr[jj] = s;
-                        mx = fmaxf(mx, s);
-                    }
-                    float sum = 0.f;
-                    for (int jj = 0; jj <= i; ++jj) { const float e = expf(pr[jj] - mx); pr[jj] = e; sum += e; }
-                    const float inv = 1.0f / sum;
-                    float dot = 0.f;
-                    for (int jj = 0; jj <= i; ++jj) {
-                        const float p = pr[jj] * inv;
-                        pr[jj] = p;
-                        const float* vv = sQ + jj * ldW + 2 * E + h * hd;
-                        float dp = 0.f;
-                        for (int d = 0; d < hd; ++d) dp = fmaf(dO[d], vv[d], dp);
-                        ds[jj] = dp;
-                        dot += p * dp;
-                    }
-                    for (int jj = 0; jj < 16; ++jj) {
-                        if (jj <= i) ds[jj] = pr[jj] * (ds[jj] - dot) * scale;
-                        else { ds[jj] = 0.f; pr[jj] = 0.f; }
-                    }
-                } else {
-                    for (int jj = 0; jj < 16; ++jj) { pr[jj] = 0.f; ds[jj] = 0.f; }
-                }
-            }
-            __syncthreads();
-            for (int idx = tid; idx < 16 * E; idx += PF_THREADS) {
-                const int t = idx / E, c = idx - t * E, h = c / hd;
-                const float* P = sP + h * 256;
-                const float* S = sS + h * 256;
-                float dq = 0.f, dk = 0.f, dv = 0.f;
-                for (int jj = 0; jj < L; ++jj) {
-                    dq = fmaf(S[t * 16 + jj], sQ[jj * ldW + E + c], dq);
-                    dk = fmaf(S[jj * 16 + t], sQ[jj * ldW + c], dk);
-                    dv = fmaf(P[jj * 16 + t], sA[jj * ldE + c], dv);
-                }
-                if (t >= L) { dq = 0.f; dk = 0.f; dv = 0.f; }
-                sU[t * ldW + c] = dq;
-                sU[t * ldW + E + c] = dk;
-                sU[t * ldW + 2 * E + c] = dv;
-                if (t < L) {
-                    float* o = k.d_qkv + (t0 + t) * 3 * E;
-                    o[c] = dq;
-                    o[E + c] = dk;
-                    o[2 * E + c] = dv;
-                }
-            }
-        }
+        pf_attn_bwd_mfma_a(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, scale, k.d_qkv + t0 * 3 * E, wave, lane);
         __syncthreads();
-        pf_lin_nn(sU, ldW, k.wqkv, 3 * E, E, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_attn_bwd_mfma_b(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, k.d_qkv + t0 * 3 * E, wave, lane);
+        __syncthreads();
+        pf_lin_nn<3 * E, E, ldW>(sU, k.wqkv, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
         });
         __syncthreads();
-        pf_ln_bwd(sM, sA, sY, ldE, k.ln0w, E, true, k.dws0 + t0 * E, k.dbs0 + t0 * E, L, wave, lane);  // sY = d x_i
+        pf_ln_bwd(sM, sA, sY, ldE, sV + 8 * bi * E, E, true, k.dws0 + t0 * E, k.dbs0 + t0 * E, L, wave, lane);  // sY = d x_i
         __syncthreads();
     }
     // d tokens; d(pre-tanh image embedding) = d img * (1 - img^2)   (ARPDT.py:484)
