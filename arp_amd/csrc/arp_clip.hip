@@ -209,9 +209,10 @@ struct arp_clip {
     Profiler prof;
     // second stream: a shallow clone (shared weights, own workspace/stream/profiler) that labels the other half of a
     // batch concurrently, so one half's memory-bound kernels and GEMM tails overlap the other half's GEMMs
-    arp_clip* sibling = nullptr;
+    std::vector<arp_clip*> siblings;  // n_streams - 1 clones
     bool is_sibling = false;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;  // one per sibling
     int gemm_force = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (ARP_GEMM env)
     // Fold LayerNorm into the consumer GEMMs of the vision tower in bf16 mode (ARP_LN_FOLD=1).  Numerically fine
     // (cosine error 3.6e-4 vs 4.8e-4 unfused) but MEASURED SLOWER on MI355X (74.2 k vs 79.7 k frames/s): the extra
@@ -496,7 +497,8 @@ static int label_dev_single(arp_clip* c, const uint8_t* frames_dev, int n, int H
 static int make_sibling(arp_clip* c) {
     arp_clip* s = new arp_clip(*c);  // shares every weight pointer; owns nothing of them
     s->is_sibling = true;
-    s->sibling = nullptr;
+    s->siblings.clear();
+    s->ev_join.clear();
     s->owned.clear();
     s->staged.clear();
     s->prof = Profiler();
@@ -505,37 +507,49 @@ static int make_sibling(arp_clip* c) {
     DevBuf* bufs[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards, &s->stats};
     for (auto* b : bufs) *b = DevBuf();
     s->stream = nullptr;
-    s->ev_fork = s->ev_join = nullptr;
+    s->ev_fork = nullptr;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         delete s;
         return fail("hipStreamCreate failed");
     }
-    ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    c->sibling = s;
+    if (!c->ev_fork) ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    hipEvent_t ej = nullptr;
+    ARP_HIP_OK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    c->ev_join.push_back(ej);
+    c->siblings.push_back(s);
     return 0;
 }
 
 static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev) {
     ARP_TRY(check_ready(c, true));
-    if (c->cfg.n_streams < 2 || n < 256) return label_dev_single(c, frames_dev, n, H, W, use_crop, rewards_dev);
+    int ns = c->cfg.n_streams;
+    while (ns > 1 && n / ns < 128) --ns;  // keep every part big enough to fill the chip's GEMM grid
+    if (ns < 2) return label_dev_single(c, frames_dev, n, H, W, use_crop, rewards_dev);
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    if (!c->sibling) ARP_TRY(make_sibling(c));
-    arp_clip* s = c->sibling;
+    while ((int)c->siblings.size() < ns - 1) ARP_TRY(make_sibling(c));
     ResizePlan* plan;
     ARP_TRY(get_plan(c, H, W, use_crop, &plan));
-    s->plans = c->plans;  // shared, owned by the primary
-    s->txt_feat = c->txt_feat;
-    s->n_prompts = c->n_prompts;
-    s->logit_scale = c->logit_scale;
-    s->prof.on = c->prof.on;
-    const int n0 = n / 2;
     ARP_HIP_OK(hipEventRecord(c->ev_fork, c->stream));
-    ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_fork, 0));
-    ARP_TRY(label_dev_single(c, frames_dev, n0, H, W, use_crop, rewards_dev));
-    ARP_TRY(label_dev_single(s, frames_dev + (size_t)n0 * H * W * 3, n - n0, H, W, use_crop, rewards_dev + n0));
-    ARP_HIP_OK(hipEventRecord(c->ev_join, s->stream));
-    ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    // contiguous parts: part 0 on the primary stream, part i on sibling i-1
+    const int per = (n + ns - 1) / ns;
+    for (int i = 0; i < ns; ++i) {
+        const int b0 = i * per, nb = std::min(per, n - b0);
+        if (nb <= 0) break;
+        arp_clip* s = i == 0 ? c : c->siblings[i - 1];
+        if (i > 0) {
+            s->plans = c->plans;  // shared, owned by the primary
+            s->txt_feat = c->txt_feat;
+            s->n_prompts = c->n_prompts;
+            s->logit_scale = c->logit_scale;
+            s->prof.on = c->prof.on;
+            ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_fork, 0));
+        }
+        ARP_TRY(label_dev_single(s, frames_dev + (size_t)b0 * H * W * 3, nb, H, W, use_crop, rewards_dev + b0));
+        if (i > 0) {
+            ARP_HIP_OK(hipEventRecord(c->ev_join[i - 1], s->stream));
+            ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join[i - 1], 0));
+        }
+    }
     return 0;
 }
 
@@ -610,8 +624,7 @@ int arp_clip_destroy(arp_clip* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->sibling) {
-        arp_clip* s = c->sibling;
+    for (arp_clip* s : c->siblings) {
         (void)hipStreamSynchronize(s->stream);
         s->prof.destroy();
         DevBuf* sb[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards, &s->stats};
@@ -619,9 +632,9 @@ int arp_clip_destroy(arp_clip* c) {
         (void)hipStreamDestroy(s->stream);
         s->plans.clear();
         delete s;
-        (void)hipEventDestroy(c->ev_fork);
-        (void)hipEventDestroy(c->ev_join);
     }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_join) (void)hipEventDestroy(e);
     c->prof.destroy();
     for (void* p : c->owned) (void)hipFree(p);
     for (auto& kv : c->plans) {
@@ -795,9 +808,9 @@ int arp_preprocess(const uint8_t* frames, int n, int H, int W, int use_crop, int
 }
 
 int arp_clip_set_streams(arp_clip* c, int n_streams) {
-    if (!c || n_streams < 0 || n_streams > 2) return fail("n_streams must be 0, 1 or 2");
+    if (!c || n_streams < 0 || n_streams > 4) return fail("n_streams must be 0..4");
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
-    if (c->sibling) ARP_HIP_OK(hipStreamSynchronize(c->sibling->stream));
+    for (arp_clip* s : c->siblings) ARP_HIP_OK(hipStreamSynchronize(s->stream));
     c->cfg.n_streams = n_streams;
     return 0;
 }
@@ -805,19 +818,19 @@ int arp_clip_set_streams(arp_clip* c, int n_streams) {
 int arp_clip_profile_enable(arp_clip* c, int on) {
     if (!c) return fail("null handle");
     c->prof.on = on != 0;
-    if (c->sibling) c->sibling->prof.on = c->prof.on;
+    for (arp_clip* s : c->siblings) s->prof.on = c->prof.on;
     return 0;
 }
 int arp_clip_profile_reset(arp_clip* c) {
     if (!c) return fail("null handle");
     c->prof.reset();
-    if (c->sibling) c->sibling->prof.reset();
+    for (arp_clip* s : c->siblings) s->prof.reset();
     return 0;
 }
 int arp_clip_profile_json(arp_clip* c, char* buf, int buf_len) {
     if (!c || !buf) return fail("null argument");
-    if (c->sibling) {  // fold the second stream's launches into the primary's sites
-        Profiler& q = c->sibling->prof;
+    for (arp_clip* sb : c->siblings) {  // fold the other streams' launches into the primary's sites
+        Profiler& q = sb->prof;
         q.collect();
         c->prof.collect();
         for (size_t i = 0; i < q.names.size(); ++i) {

@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--parity-frames", type=int, default=4, help="frames checked against the oracle before timing (rank 0)")
-    ap.add_argument("--streams", type=int, default=2, help="label path: 2 = the two halves of each batch run on two HIP streams of "
+    ap.add_argument("--streams", type=int, default=2, help="label path: N = each batch is labelled in N contiguous parts on N HIP streams of "
                     "the same GPU (one half's LayerNorm/attention/GEMM tails overlap the other half's GEMMs); 1 = single stream")
     ap.add_argument("--path", default="label", choices=["label", "policy"],
                     help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary)")
@@ -258,7 +258,8 @@ def main():
     prof_ms = clip.elapsed_ms(e2, e3)
     # isolated per-kernel figures: the same steps on ONE stream (no other kernel shares the chip with a launch)
     iso = None
-    if a.streams >= 2 and a.batch >= 256:
+    nsplit = max(1, min(a.streams, a.batch // 128))  # parts a batch is labelled in, one HIP stream each (label_dev in arp_clip.hip)
+    if nsplit > 1:
         model.set_streams(1)
         step()
         model.sync()
@@ -271,8 +272,7 @@ def main():
     model.profile(False)
 
     if rank == 0:
-        nsplit = 2 if (a.streams >= 2 and a.batch >= 256) else 1  # launches per call site per layer (half batches)
-        sites = {k: v / nsplit for k, v in gemm_sites(cfg, a.batch).items()}
+        sites = {k: v * -(-a.batch // nsplit) / a.batch for k, v in gemm_sites(cfg, a.batch).items()}
         dom = max(sites, key=lambda s: prof.get(s, {"ms": 0})["ms"])
         avg_ms = prof[dom]["ms"] / max(prof[dom]["calls"], 1)
         achieved = sites[dom] / (avg_ms * 1e-3) / 1e12
@@ -284,7 +284,7 @@ def main():
                 rec = json.load(open(tpath)).get(dom, {})
                 traffic = rec.get("hbm_bytes_per_launch")
                 # the committed PMC run may have used a different launch size: scale by workgroup count
-                exp_grid = 512 * (-(-(a.batch * cfg.tokens // (2 if (a.streams >= 2 and a.batch >= 256) else 1)) // 256)) * {
+                exp_grid = 512 * (-(-(-(-a.batch // nsplit) * cfg.tokens) // 256)) * {
                     "vit.c_fc": 4 * cfg.width, "vit.qkv": 3 * cfg.width}.get(dom, cfg.width) // 256
                 if traffic and rec.get("grid_threads") and rec["grid_threads"] != exp_grid:
                     traffic = traffic * exp_grid / rec["grid_threads"]
@@ -311,7 +311,7 @@ def main():
                        "parallelism": f"shard{world} (no collective)", "streams_per_gpu": nsplit},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "kernel": f"gemm256_nt_kernel @ {dom}",
-                         "note": (f"each launch covers {a.batch // nsplit} frames; with --streams 2 two such launches (the two half batches) share "
+                         "note": (f"each launch covers {-(-a.batch // nsplit)} frames; with --streams {nsplit} that many such launches (the parts of a batch) share "
                                   "the chip, so a launch's HIP-event duration includes time it ran beside the other stream's kernels; "
                                   "--streams 1 gives the isolated per-kernel figure") if nsplit > 1 else "single stream", "flops_per_launch": sites[dom],
                          "avg_launch_ms": avg_ms, "launches": prof[dom]["calls"]},

@@ -62,8 +62,8 @@ typedef struct arp_clip_cfg {
     int32_t device;     /* HIP device ordinal */
     int32_t max_batch;  /* frames per internal pass (workspace size); <= 0 -> 1024 */
     int32_t attn_impl;  /* 0 = auto (MFMA kernel where available), 1 = force the VALU kernel */
-    int32_t n_streams;  /* 2 = label the two halves of a batch (>= 256 frames) on two HIP streams so one half's
-                           memory-bound kernels and GEMM tails overlap the other half's GEMMs; 0/1 = one stream */
+    int32_t n_streams;  /* N in 2..4 = label a batch in N contiguous parts (each >= 128 frames) on N HIP streams so one
+                           part's memory-bound kernels and GEMM tails overlap another part's GEMMs; 0/1 = one stream */
 } arp_clip_cfg;
 
 int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out);
@@ -86,7 +86,7 @@ int arp_clip_label(arp_clip* h, const uint8_t* frames_host, int n, int H, int W,
 int arp_clip_label_dev_async(arp_clip* h, const uint8_t* frames_dev, int n, int H, int W, int use_crop,
                              float* rewards_dev);
 int arp_clip_sync(arp_clip* h);
-int arp_clip_set_streams(arp_clip* h, int n_streams); /* switch between one and two streams (see arp_clip_cfg.n_streams) */
+int arp_clip_set_streams(arp_clip* h, int n_streams); /* change the stream count, 0..4 (see arp_clip_cfg.n_streams) */
 
 /* model.encode_image (label_reward.py:156, clip_goal_conditioned variant) */
 int arp_clip_encode_image(arp_clip* h, const uint8_t* frames_host, int n, int H, int W, int use_crop, int normalize,
