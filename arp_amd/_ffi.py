@@ -36,6 +36,11 @@ class DtCfg(C.Structure):
         "device", "world", "rank")] + [(n, C.c_float) for n in ("lambda_ret", "weight_decay", "clip_norm", "b1", "b2", "eps")]
 
 
+class FtCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("layers", "width_v", "width_t", "embed", "hidden", "n_actions", "mode", "device", "use_vip", "use_id")] + [
+        (n, C.c_float) for n in ("gamma", "logit_scale", "weight_decay", "b1", "b2", "eps")]
+
+
 class EncCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("patch", "width", "layers", "heads", "mlp_ratio", "img_res", "mode", "device", "max_frames",
                                           "attn_impl")]
@@ -109,6 +114,24 @@ SIGNATURES = {
     "arp_dt_profile_enable": (_i, [_vp, _i]),
     "arp_dt_profile_reset": (_i, [_vp]),
     "arp_dt_profile_json": (_i, [_vp, C.c_char_p, _i]),
+    "arp_ft_create": (_i, [C.POINTER(FtCfg), C.POINTER(_vp)]),
+    "arp_ft_destroy": (_i, [_vp]),
+    "arp_ft_num_params": (_i, [_vp, _i64p, _i32p]),
+    "arp_ft_param_info": (_i, [_vp, _i, C.c_char_p, _i, _i64p, _i32p]),
+    "arp_ft_set_tensor": (_i, [_vp, C.c_char_p, _i, _fp]),
+    "arp_ft_get_tensor": (_i, [_vp, C.c_char_p, _i, _fp]),
+    "arp_ft_set_step": (_i, [_vp, C.c_int64]),
+    "arp_ft_get_step": (_i, [_vp, _i64p]),
+    "arp_ft_set_batch": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i32p, _i]),
+    "arp_ft_forward": (_i, [_vp, _fp, _fp, _fp]),
+    "arp_ft_backward": (_i, [_vp]),
+    "arp_ft_train_step": (_i, [_vp, C.c_float, _fp]),
+    "arp_ft_train_step_async": (_i, [_vp, C.c_float]),
+    "arp_ft_sync": (_i, [_vp]),
+    "arp_ft_event_record": (_i, [_vp, _vp]),
+    "arp_ft_profile_enable": (_i, [_vp, _i]),
+    "arp_ft_profile_reset": (_i, [_vp]),
+    "arp_ft_profile_json": (_i, [_vp, C.c_char_p, _i]),
     "arp_enc_create": (_i, [C.POINTER(EncCfg), C.POINTER(_vp)]),
     "arp_enc_destroy": (_i, [_vp]),
     "arp_enc_load_weight": (_i, [_vp, C.c_char_p, _fp, _i64p, _i]),

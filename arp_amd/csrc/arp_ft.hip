@@ -1,0 +1,545 @@
+// the CLIP multi-scale adapter fine-tune step (BASELINE.json configs[4]) -- the trainable head on top of
+// the frozen CLIP towers, as one HIP train step behind the C ABI (include/arp_hip.h, arp_ft_*).
+//
+// Reference: finetune_module/clip_multiscale_adapter.py (CLIPMultiscaleAdapter.encode_image :134-149, encode_text
+// :151-175, forward :177-250), finetune_module/layers.py:6-60 (AdapterMLP), finetune_module/finetune.py:139-141
+// (CLIP frozen; torch.optim.AdamW over everything else).  The frozen towers' outputs -- per-block CLS / EOT features
+// (detached by the reference's hooks, utils.py:6-18) and the final CLIP features -- are this step's INPUTS, exactly as
+// BASELINE.json configs[3] feeds the policy step with encodings.
+//
+// Per step (B samples, 3 frames each; Mi = 3B image rows, Mt = B text rows; F = layers*width_t + embed):
+//   U  = X Wint^T (bias-free)            f = [U | clip feature]
+//   A  = relu(f W1^T + b1) W2^T + b2     y = res f + (1 - res) A      a = y / ||y||
+//   scores, VIP loss, C = [a1 | t | a2 | t] -> relu(C V1^T + c1) V2^T + c2 -> CE;  loss = vip + lambda_id * id
+// Every contraction with a large weight is an NT MFMA GEMM (gemm.h / gemm256.h).  The row counts are tiny (<= 192), so
+// forward / dX GEMMs are weight-streaming bound and run split-K to fill the chip, and the weight-gradient GEMMs
+// (dW = dY^T X, contraction over <= 192 rows) are output-write bound.  Parameters use torch's own names and [out, in]
+// layout, which is already the NT operand layout.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/arp_hip.h"
+#include "common.h"
+#include "dtops.h"
+#include "ftops.h"
+#include "gemm.h"
+#include "gemm256.h"
+#include "runtime.h"
+
+using namespace arp;
+
+namespace {
+struct FtParam {
+    std::string name;
+    std::vector<int64_t> shape;
+    size_t off = 0, size = 0;
+};
+inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
+enum { SITE_FT = 24 };
+}  // namespace
+
+struct arp_ft {
+    arp_ft_cfg cfg;
+    hipStream_t stream = nullptr;
+    std::vector<FtParam> infos;
+    std::map<std::string, int> index;
+    size_t P = 0;
+    DevBuf params, grads, mu, nu;
+    long long step = 0;
+    bool shadows_stale = true;
+    int B = 0;
+    // operand-type weight shadows: forward layout [out, in] (aliases the f32 parameters in f32 mode) and, where the
+    // backward needs dX, the transposed layout [in, out]
+    DevBuf sWint[2], sW1[2], sW2[2], sW1t[2], sW2t[2], sV1, sV1t;
+    // inputs
+    DevBuf x_in[2], x_fin[2], r, action;
+    // per tower (0 = image rows Mi, 1 = text rows Mt)
+    DevBuf X[2], XT[2], f[2], fT_[2], fTt[2], H[2], HT[2], A[2], a[2], nrm[2], da[2], dA[2], dAT_[2], dAt[2], dfd[2], dH[2], dHp[2], dHpt[2], df[2], dUt[2],
+        dres_part[2];
+    DevBuf scores, ds, C, CT_, Ct, Hinv, logits, dlogits, dHinv, dHinvT_, dHinvt, dC, metrics, scal, part;
+    Profiler prof;
+
+    size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
+    int Dv() const { return cfg.layers * cfg.width_v; }
+    int Dt() const { return cfg.layers * cfg.width_t; }
+    int F() const { return cfg.layers * cfg.width_t + cfg.embed; }
+    int Hd() const { return cfg.hidden * (cfg.layers + 1); }
+    float* p(const std::string& n) { return params.as<float>() + infos[index.at(n)].off; }
+    float* g(const std::string& n) { return grads.as<float>() + infos[index.at(n)].off; }
+    size_t psize(const std::string& n) { return infos[index.at(n)].size; }
+};
+
+namespace {
+
+void build_layout(arp_ft* c) {
+    const int F = c->F(), Hd = c->Hd();
+    std::vector<FtParam> v;
+    auto add = [&](const std::string& name, std::vector<int64_t> shape) {
+        FtParam pi;
+        pi.name = name;
+        pi.shape = shape;
+        pi.size = 1;
+        for (auto d : shape) pi.size *= (size_t)d;
+        v.push_back(pi);
+    };
+    add("image_intermediate_linear.weight", {c->Dt(), c->Dv()});
+    add("text_intermediate_linear.weight", {c->Dt(), c->Dt()});
+    for (const char* a : {"image_adapter", "text_adapter"}) {
+        add(std::string(a) + ".layers.0.weight", {Hd, F});
+        add(std::string(a) + ".layers.0.bias", {Hd});
+        add(std::string(a) + ".layers.3.weight", {F, Hd});
+        add(std::string(a) + ".layers.3.bias", {F});
+    }
+    add("inverse_layer.layers.0.weight", {c->cfg.hidden, 4 * F});
+    add("inverse_layer.layers.0.bias", {c->cfg.hidden});
+    add("inverse_layer.layers.3.weight", {c->cfg.n_actions, c->cfg.hidden});
+    add("inverse_layer.layers.3.bias", {c->cfg.n_actions});
+    add("image_residual_weight", {});
+    add("text_residual_weight", {});
+    add("lambda_id", {});
+    size_t off = 0;
+    for (auto& pi : v) {
+        pi.off = off;
+        off += (pi.size + 3) & ~(size_t)3;
+    }
+    c->P = off;
+    c->infos = v;
+    for (size_t i = 0; i < v.size(); ++i) c->index[v[i].name] = (int)i;
+}
+
+template <typename TI, typename TM, typename TO>
+int ft_transpose(arp_ft* c, const TI* in, int ldi, const TM* mask, TO* outN, int ldn, TO* outT, int ldt, int R, int Cc) {
+    hipLaunchKernelGGL((transpose_mask_kernel<TI, TM, TO>), dim3(cdiv(Cc, 64), cdiv(R, 64)), dim3(256), 0, c->stream, in, ldi, mask, nullptr, 1.f, outN,
+                       ldn, outT, ldt, R, Cc);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// out[M, N] (ldo) = act(A[M, K] . W[N, K]^T + bias) (+ resid, same view as out).  Split over K whenever the 128x128
+// grid alone would leave most of the chip idle (the row counts of this step are <= 192).
+template <typename T, typename OutT>
+int ft_gemm(arp_ft* c, const char* site, const void* A, int lda, const void* W, int ldw, const float* bias, int act, const float* resid, OutT* out,
+            int ldo, int M, int N, int K) {
+    constexpr int EPB = 128 / (int)sizeof(T);
+    const int nk = K / EPB;
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    int S = std::max(1, std::min(nk, 1024 / std::max(tiles, 1)));
+    const int per = (nk + S - 1) / S;
+    S = (nk + per - 1) / per;
+    ProfScope ps(c->prof, c->stream, site);
+    GemmArgs g;
+    g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw;
+    if (S == 1 && act == ACT_NONE && !resid && tiles >= 256) {  // big output, short contraction: the weight-gradient GEMMs
+        g.bias = bias; g.resid = nullptr; g.out = out; g.ldr = ldo; g.ldo = ldo;
+        return launch_gemm_auto<T, OutT, ACT_NONE, false, SITE_FT>(g, c->stream, 0);
+    }
+    ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
+    g.bias = nullptr; g.resid = nullptr; g.out = c->part.p; g.ldr = N; g.ldo = N;
+    g.ksplit = S; g.slice_stride = (size_t)M * N;
+    ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_FT + 1>(g, c->stream)));
+    const size_t MN = (size_t)M * N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out, resid,
+                       ldo == N ? 0 : ldo);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int sgemm(arp_ft* c, const float* A, int ta, const float* Bm, int tb, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int act = ACT_NONE) {
+    SmallGemm g{A, Bm, bias, nullptr, C, M, N, K, lda, ldb, N, ta, tb, act, 0};
+    hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv(N, 32), cdiv(M, 32)), dim3(256), 0, c->stream, g);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+const char* TW[2] = {"image", "text"};
+
+template <typename T> int refresh_shadows(arp_ft* c) {
+    if (!c->shadows_stale) return 0;
+    ProfScope ps(c->prof, c->stream, "ft.refresh_shadows");
+    const int F = c->F(), Hd = c->Hd(), Hi = c->cfg.hidden;
+    constexpr bool f32 = sizeof(T) == 4;
+    for (int w = 0; w < 2; ++w) {
+        const std::string a = std::string(TW[w]) + "_adapter", il = std::string(TW[w]) + "_intermediate_linear.weight";
+        const int Din = w == 0 ? c->Dv() : c->Dt();
+        // forward-layout shadows are the parameters themselves in f32 mode
+        if (!f32) ARP_TRY((ft_transpose<float, float, T>(c, c->p(il), Din, nullptr, c->sWint[w].as<T>(), Din, nullptr, 0, c->Dt(), Din)));
+        ARP_TRY((ft_transpose<float, float, T>(c, c->p(a + ".layers.0.weight"), F, nullptr, f32 ? nullptr : c->sW1[w].as<T>(), F, c->sW1t[w].as<T>(), Hd, Hd, F)));
+        ARP_TRY((ft_transpose<float, float, T>(c, c->p(a + ".layers.3.weight"), Hd, nullptr, f32 ? nullptr : c->sW2[w].as<T>(), Hd, c->sW2t[w].as<T>(), F, F, Hd)));
+    }
+    ARP_TRY((ft_transpose<float, float, T>(c, c->p("inverse_layer.layers.0.weight"), 4 * F, nullptr, f32 ? nullptr : c->sV1.as<T>(), 4 * F, c->sV1t.as<T>(), Hi,
+                                           Hi, 4 * F)));
+    c->shadows_stale = false;
+    return 0;
+}
+template <typename T> const T* fwd_w(arp_ft* c, DevBuf& shadow, const std::string& name) {
+    if constexpr (sizeof(T) == 4) return reinterpret_cast<const T*>(c->p(name));
+    return shadow.as<T>();
+}
+
+int ensure_buffers(arp_ft* c, int B) {
+    if (B == c->B) return 0;
+    const size_t e = c->esz();
+    const int F = c->F(), Hd = c->Hd(), Hi = c->cfg.hidden, NA = c->cfg.n_actions, E = c->cfg.embed;
+    auto f32 = [&](DevBuf& b, size_t n) { return b.ensure(std::max<size_t>(n, 4) * 4); };
+    auto typ = [&](DevBuf& b, size_t n) { return b.ensure(std::max<size_t>(n, 8) * e); };
+    auto typz = [&](DevBuf& b, size_t n) {  // transposed operands: the K padding (rows .. 64-multiple) must read as zeros
+        ARP_TRY(b.ensure(std::max<size_t>(n, 8) * e));
+        ARP_HIP_OK(hipMemsetAsync(b.p, 0, std::max<size_t>(n, 8) * e, c->stream));
+        return 0;
+    };
+    for (int w = 0; w < 2; ++w) {
+        const size_t M = w == 0 ? 3 * (size_t)B : (size_t)B, Mp = (M + 63) / 64 * 64;
+        const size_t Din = w == 0 ? c->Dv() : c->Dt();
+        ARP_TRY(f32(c->x_in[w], M * Din)); ARP_TRY(f32(c->x_fin[w], M * E));
+        ARP_TRY(typ(c->X[w], M * Din)); ARP_TRY(typz(c->XT[w], Din * Mp));
+        ARP_TRY(f32(c->f[w], M * F)); ARP_TRY(typ(c->fT_[w], M * F)); ARP_TRY(typz(c->fTt[w], F * Mp));
+        ARP_TRY(typ(c->H[w], M * Hd)); ARP_TRY(typz(c->HT[w], Hd * Mp));
+        ARP_TRY(f32(c->A[w], M * F)); ARP_TRY(f32(c->a[w], M * F)); ARP_TRY(f32(c->nrm[w], M)); ARP_TRY(f32(c->da[w], M * F));
+        ARP_TRY(f32(c->dA[w], M * F)); ARP_TRY(typ(c->dAT_[w], M * F)); ARP_TRY(typz(c->dAt[w], F * Mp)); ARP_TRY(f32(c->dfd[w], M * F));
+        ARP_TRY(typ(c->dH[w], M * Hd)); ARP_TRY(typ(c->dHp[w], M * Hd)); ARP_TRY(typz(c->dHpt[w], Hd * Mp));
+        ARP_TRY(f32(c->df[w], M * F)); ARP_TRY(typz(c->dUt[w], (size_t)c->Dt() * Mp)); ARP_TRY(f32(c->dres_part[w], M));
+    }
+    const size_t Bp = ((size_t)B + 63) / 64 * 64;
+    ARP_TRY(f32(c->r, B)); ARP_TRY(f32(c->action, B)); ARP_TRY(f32(c->scores, 3 * (size_t)B)); ARP_TRY(f32(c->ds, 3 * (size_t)B));
+    ARP_TRY(f32(c->C, (size_t)B * 4 * F)); ARP_TRY(typ(c->CT_, (size_t)B * 4 * F)); ARP_TRY(typz(c->Ct, (size_t)4 * F * Bp));
+    ARP_TRY(f32(c->Hinv, (size_t)B * Hi)); ARP_TRY(f32(c->logits, (size_t)B * NA)); ARP_TRY(f32(c->dlogits, (size_t)B * NA));
+    ARP_TRY(f32(c->dHinv, (size_t)B * Hi)); ARP_TRY(typ(c->dHinvT_, (size_t)B * Hi)); ARP_TRY(typz(c->dHinvt, (size_t)Hi * Bp));
+    ARP_TRY(f32(c->dC, (size_t)B * 4 * F)); ARP_TRY(f32(c->metrics, 8)); ARP_TRY(f32(c->scal, 64));
+    c->B = B;
+    return 0;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------
+template <typename T> int forward(arp_ft* c) {
+    const arp_ft_cfg& k = c->cfg;
+    const int B = c->B, F = c->F(), Hd = c->Hd(), Hi = k.hidden, NA = k.n_actions, E = k.embed, Dt = c->Dt();
+    ARP_TRY(refresh_shadows<T>(c));
+    for (int w = 0; w < 2; ++w) {
+        const int M = w == 0 ? 3 * B : B, Mp = (M + 63) / 64 * 64, Din = w == 0 ? c->Dv() : Dt;
+        const std::string a = std::string(TW[w]) + "_adapter", pre = std::string("ft.") + TW[w];
+        // frozen-tower features -> operand type, both layouts (the transposed one feeds dWint)
+        ARP_TRY((ft_transpose<float, float, T>(c, c->x_in[w].as<float>(), Din, nullptr, c->X[w].as<T>(), Din, c->XT[w].as<T>(), Mp, M, Din)));
+        // f = [X Wint^T | final]   (:141-143 / :164-166)
+        ARP_TRY((ft_gemm<T, float>(c, (pre + "_inter").c_str(), c->X[w].p, Din, fwd_w<T>(c, c->sWint[w], std::string(TW[w]) + "_intermediate_linear.weight"), Din,
+                                   nullptr, ACT_NONE, nullptr, c->f[w].as<float>(), F, M, Dt, Din)));
+        hipLaunchKernelGGL(ft_copy_cols_kernel, dim3(cdiv((size_t)M * E, 256)), dim3(256), 0, c->stream, c->x_fin[w].as<float>(), E, c->f[w].as<float>(), F,
+                           Dt, M);
+        ARP_TRY((ft_transpose<float, float, T>(c, c->f[w].as<float>(), F, nullptr, c->fT_[w].as<T>(), F, c->fTt[w].as<T>(), Mp, M, F)));
+        // AdapterMLP (layers.py:43-60 with num_layers = 2): Linear -> ReLU -> Linear
+        ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc1").c_str(), c->fT_[w].p, F, fwd_w<T>(c, c->sW1[w], a + ".layers.0.weight"), F, c->p(a + ".layers.0.bias"), ACT_RELU,
+                               nullptr, c->H[w].as<T>(), Hd, M, Hd, F)));
+        ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc2").c_str(), c->H[w].p, Hd, fwd_w<T>(c, c->sW2[w], a + ".layers.3.weight"), Hd, c->p(a + ".layers.3.bias"),
+                                   ACT_NONE, nullptr, c->A[w].as<float>(), F, M, F, Hd)));
+        ProfScope ps(c->prof, c->stream, "ft.rowops");
+        hipLaunchKernelGGL(ft_mix_norm_fwd_kernel, dim3(M), dim3(256), 0, c->stream, c->f[w].as<float>(), c->A[w].as<float>(),
+                           c->p(std::string(TW[w]) + "_residual_weight"), c->a[w].as<float>(), c->nrm[w].as<float>(), F);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    {
+        ProfScope ps(c->prof, c->stream, "ft.rowops");
+        hipLaunchKernelGGL(ft_scores_kernel, dim3(3 * B), dim3(256), 0, c->stream, c->a[0].as<float>(), c->a[1].as<float>(), expf(k.logit_scale),
+                           c->scores.as<float>(), B, F);
+        hipLaunchKernelGGL(ft_build_c_kernel, dim3(cdiv((size_t)B * 4 * F, 256)), dim3(256), 0, c->stream, c->a[0].as<float>(), c->a[1].as<float>(),
+                           c->C.as<float>(), B, F);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    const int Bp = (B + 63) / 64 * 64;
+    ARP_TRY((ft_transpose<float, float, T>(c, c->C.as<float>(), 4 * F, nullptr, c->CT_.as<T>(), 4 * F, c->Ct.as<T>(), Bp, B, 4 * F)));
+    ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1", c->CT_.p, 4 * F, fwd_w<T>(c, c->sV1, "inverse_layer.layers.0.weight"), 4 * F,
+                               c->p("inverse_layer.layers.0.bias"), ACT_RELU, nullptr, c->Hinv.as<float>(), Hi, B, Hi, 4 * F)));
+    ProfScope ps(c->prof, c->stream, "ft.loss");
+    ARP_TRY(sgemm(c, c->Hinv.as<float>(), 0, c->p("inverse_layer.layers.3.weight"), 1, c->p("inverse_layer.layers.3.bias"), c->logits.as<float>(), B, NA, Hi,
+                  Hi, Hi));
+    hipLaunchKernelGGL(ft_loss_kernel, dim3(1), dim3(256), 0, c->stream, c->scores.as<float>(), c->r.as<float>(), c->logits.as<float>(), c->action.as<int>(),
+                       B, NA, k.gamma, c->p("lambda_id"), k.use_vip, k.use_id, c->metrics.as<float>(), c->ds.as<float>(), c->dlogits.as<float>(),
+                       c->g("lambda_id"));
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// ---- backward: every entry of c->grads written exactly once ----------------------------------------------------------
+template <typename T> int backward(arp_ft* c) {
+    const arp_ft_cfg& k = c->cfg;
+    const int B = c->B, F = c->F(), Hd = c->Hd(), Hi = k.hidden, NA = k.n_actions, Dt = c->Dt();
+    const int Bp = (B + 63) / 64 * 64;
+    {
+        // inverse model (:232-237): logits = relu(C V1^T + c1) V2^T + c2
+        ProfScope ps(c->prof, c->stream, "ft.inverse_bwd_small");
+        ARP_TRY(sgemm(c, c->dlogits.as<float>(), 1, c->Hinv.as<float>(), 0, nullptr, c->g("inverse_layer.layers.3.weight"), NA, Hi, B, NA, Hi));
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(NA, 64)), dim3(256), 0, c->stream, c->dlogits.as<float>(), B, NA, c->g("inverse_layer.layers.3.bias"));
+        ARP_TRY(sgemm(c, c->dlogits.as<float>(), 0, c->p("inverse_layer.layers.3.weight"), 0, nullptr, c->dHinv.as<float>(), B, Hi, NA, NA, Hi));
+        // relu mask (Hinv is the post-activation), both layouts
+        ARP_TRY((ft_transpose<float, float, T>(c, c->dHinv.as<float>(), Hi, c->Hinv.as<float>(), c->dHinvT_.as<T>(), Hi, c->dHinvt.as<T>(), Bp, B, Hi)));
+        hipLaunchKernelGGL((rowsum_kernel<T>), dim3(Hi), dim3(256), 0, c->stream, c->dHinvt.as<T>(), Bp, B, c->g("inverse_layer.layers.0.bias"), Hi);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1_dW", c->dHinvt.p, Bp, c->Ct.p, Bp, nullptr, ACT_NONE, nullptr, c->g("inverse_layer.layers.0.weight"), 4 * F, Hi,
+                               4 * F, Bp)));
+    ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1_dX", c->dHinvT_.p, Hi, c->sV1t.p, Hi, nullptr, ACT_NONE, nullptr, c->dC.as<float>(), 4 * F, B, 4 * F, Hi)));
+    {
+        ProfScope ps(c->prof, c->stream, "ft.rowops");
+        hipLaunchKernelGGL(ft_feat_grad_kernel, dim3(cdiv((size_t)B * F, 256)), dim3(256), 0, c->stream, c->ds.as<float>(), c->a[0].as<float>(),
+                           c->a[1].as<float>(), c->dC.as<float>(), expf(k.logit_scale), c->da[0].as<float>(), c->da[1].as<float>(), B, F);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    for (int w = 0; w < 2; ++w) {
+        const int M = w == 0 ? 3 * B : B, Mp = (M + 63) / 64 * 64, Din = w == 0 ? c->Dv() : Dt;
+        const std::string a = std::string(TW[w]) + "_adapter", pre = std::string("ft.") + TW[w], rwn = std::string(TW[w]) + "_residual_weight";
+        {
+            ProfScope ps(c->prof, c->stream, "ft.rowops");
+            hipLaunchKernelGGL(ft_mix_norm_bwd_kernel, dim3(M), dim3(256), 0, c->stream, c->da[w].as<float>(), c->a[w].as<float>(), c->nrm[w].as<float>(),
+                               c->f[w].as<float>(), c->A[w].as<float>(), c->p(rwn), c->dA[w].as<float>(), c->dfd[w].as<float>(),
+                               c->dres_part[w].as<float>(), F);
+            hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->dres_part[w].as<float>(), M, 1.0f, c->scal.as<float>() + 8 + w, 0);
+            hipLaunchKernelGGL(dres_to_drw_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 8 + w, c->p(rwn), c->g(rwn));
+            hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(F, 64)), dim3(256), 0, c->stream, c->dA[w].as<float>(), M, F, c->g(a + ".layers.3.bias"));
+            ARP_HIP_OK(hipGetLastError());
+        }
+        ARP_TRY((ft_transpose<float, float, T>(c, c->dA[w].as<float>(), F, nullptr, c->dAT_[w].as<T>(), F, c->dAt[w].as<T>(), Mp, M, F)));
+        ARP_TRY((ft_transpose<T, T, T>(c, c->H[w].as<T>(), Hd, nullptr, nullptr, 0, c->HT[w].as<T>(), Mp, M, Hd)));
+        // A = H W2^T + b2
+        ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc2_dW").c_str(), c->dAt[w].p, Mp, c->HT[w].p, Mp, nullptr, ACT_NONE, nullptr, c->g(a + ".layers.3.weight"), Hd, F,
+                                   Hd, Mp)));
+        ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc2_dX").c_str(), c->dAT_[w].p, F, c->sW2t[w].p, F, nullptr, ACT_NONE, nullptr, c->dH[w].as<T>(), Hd, M, Hd, F)));
+        // relu mask (H is the post-activation), both layouts; H = relu(f W1^T + b1)
+        ARP_TRY((ft_transpose<T, T, T>(c, c->dH[w].as<T>(), Hd, c->H[w].as<T>(), c->dHp[w].as<T>(), Hd, c->dHpt[w].as<T>(), Mp, M, Hd)));
+        hipLaunchKernelGGL((rowsum_kernel<T>), dim3(Hd), dim3(256), 0, c->stream, c->dHpt[w].as<T>(), Mp, M, c->g(a + ".layers.0.bias"), Hd);
+        ARP_HIP_OK(hipGetLastError());
+        ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc1_dW").c_str(), c->dHpt[w].p, Mp, c->fTt[w].p, Mp, nullptr, ACT_NONE, nullptr, c->g(a + ".layers.0.weight"), F, Hd,
+                                   F, Mp)));
+        // df = res*dy (direct path) + dHpre W1
+        ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc1_dX").c_str(), c->dHp[w].p, Hd, c->sW1t[w].p, Hd, nullptr, ACT_NONE, c->dfd[w].as<float>(),
+                                   c->df[w].as<float>(), F, M, F, Hd)));
+        // U = X Wint^T occupies the first Dt columns of f
+        ARP_TRY((ft_transpose<float, float, T>(c, c->df[w].as<float>(), F, nullptr, nullptr, 0, c->dUt[w].as<T>(), Mp, M, Dt)));
+        ARP_TRY((ft_gemm<T, float>(c, (pre + "_inter_dW").c_str(), c->dUt[w].p, Mp, c->XT[w].p, Mp, nullptr, ACT_NONE, nullptr,
+                                   c->g(std::string(TW[w]) + "_intermediate_linear.weight"), Din, Dt, Din, Mp)));
+    }
+    return 0;
+}
+
+int apply_update(arp_ft* c, float lr) {
+    ProfScope ps(c->prof, c->stream, "ft.adamw");
+    const double t = (double)(c->step + 1);
+    const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
+    hipLaunchKernelGGL(ft_adamw_kernel, dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(), c->mu.as<float>(),
+                       c->nu.as<float>(), 1.0f, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P);
+    ARP_HIP_OK(hipGetLastError());
+    c->step += 1;
+    c->shadows_stale = true;
+    return 0;
+}
+
+template <typename T> int step_impl(arp_ft* c, float lr, float* aux) {
+    ARP_TRY(forward<T>(c));
+    ARP_TRY(backward<T>(c));
+    ARP_TRY(apply_update(c, lr));
+    if (aux) {
+        ARP_HIP_OK(hipMemcpyAsync(aux, c->metrics.p, 16, hipMemcpyDeviceToHost, c->stream));
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =================================== C ABI ===============================================================
+extern "C" {
+
+int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
+    if (!cfg || !out) return fail("null argument");
+    const arp_ft_cfg& k = *cfg;
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16) return fail("bad mode");
+    if (k.layers <= 0 || k.width_v <= 0 || k.width_t <= 0 || k.embed <= 0 || k.hidden <= 0 || k.n_actions <= 0) return fail("bad geometry");
+    const int kq = k.mode == ARP_MODE_BF16 ? 64 : 32;
+    const int F = k.layers * k.width_t + k.embed;
+    // every contraction length of an MFMA GEMM must be a whole number of K-tiles
+    for (int d : {k.layers * k.width_v, k.layers * k.width_t, F, k.hidden * (k.layers + 1), k.hidden})
+        if (d % kq) return fail("feature widths must be multiples of " + std::to_string(kq));
+    int ndev = 0;
+    ARP_HIP_OK(hipGetDeviceCount(&ndev));
+    if (k.device < 0 || k.device >= ndev) return fail("no such HIP device: " + std::to_string(k.device));
+    ARP_HIP_OK(hipSetDevice(k.device));
+    arp_ft* c = new arp_ft();
+    c->cfg = k;
+    build_layout(c);
+    auto body = [&]() -> int {
+        ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
+        for (auto* b : fb) {
+            ARP_TRY(b->ensure(c->P * 4));
+            ARP_HIP_OK(hipMemset(b->p, 0, c->P * 4));
+        }
+        const size_t e = c->esz(), Fd = c->F(), Hd = c->Hd(), Hi = k.hidden;
+        const bool bf = k.mode == ARP_MODE_BF16;
+        for (int w = 0; w < 2; ++w) {
+            const size_t Din = w == 0 ? c->Dv() : c->Dt();
+            if (bf) { ARP_TRY(c->sWint[w].ensure((size_t)c->Dt() * Din * e)); ARP_TRY(c->sW1[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2[w].ensure(Hd * Fd * e)); }
+            ARP_TRY(c->sW1t[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2t[w].ensure(Hd * Fd * e));
+        }
+        if (bf) ARP_TRY(c->sV1.ensure(Hi * 4 * Fd * e));
+        ARP_TRY(c->sV1t.ensure(Hi * 4 * Fd * e));
+        return 0;
+    };
+    if (body() != 0) { arp_ft_destroy(c); return -1; }
+    *out = c;
+    return 0;
+}
+
+int arp_ft_destroy(arp_ft* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->prof.destroy();
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->sV1, &c->sV1t, &c->r, &c->action, &c->scores, &c->ds, &c->C, &c->CT_, &c->Ct, &c->Hinv, &c->logits,
+                     &c->dlogits, &c->dHinv, &c->dHinvT_, &c->dHinvt, &c->dC, &c->metrics, &c->scal, &c->part};
+    for (auto* b : all) b->release();
+    for (int w = 0; w < 2; ++w) {
+        DevBuf* tw[] = {&c->sWint[w], &c->sW1[w], &c->sW2[w], &c->sW1t[w], &c->sW2t[w], &c->x_in[w], &c->x_fin[w], &c->X[w], &c->XT[w], &c->f[w], &c->fT_[w],
+                        &c->fTt[w], &c->H[w], &c->HT[w], &c->A[w], &c->a[w], &c->nrm[w], &c->da[w], &c->dA[w], &c->dAT_[w], &c->dAt[w], &c->dfd[w], &c->dH[w],
+                        &c->dHp[w], &c->dHpt[w], &c->df[w], &c->dUt[w], &c->dres_part[w]};
+        for (auto* b : tw) b->release();
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int arp_ft_num_params(arp_ft* c, int64_t* total, int32_t* n_tensors) {
+    if (!c) return fail("null handle");
+    size_t n = 0;
+    for (auto& pi : c->infos) n += pi.size;
+    if (total) *total = (int64_t)n;
+    if (n_tensors) *n_tensors = (int32_t)c->infos.size();
+    return 0;
+}
+
+int arp_ft_param_info(arp_ft* c, int i, char* name_buf, int name_len, int64_t* shape4, int32_t* ndim) {
+    if (!c || i < 0 || i >= (int)c->infos.size() || !name_buf || !shape4 || !ndim) return fail("bad argument");
+    const FtParam& pi = c->infos[i];
+    if ((int)pi.name.size() + 1 > name_len) return fail("name buffer too small");
+    memcpy(name_buf, pi.name.c_str(), pi.name.size() + 1);
+    *ndim = (int32_t)pi.shape.size();
+    for (size_t d = 0; d < pi.shape.size() && d < 4; ++d) shape4[d] = pi.shape[d];
+    return 0;
+}
+
+// which: 0 = params, 1 = grads, 2 = adam exp_avg, 3 = adam exp_avg_sq.  torch layout ([out, in] weights) on both sides.
+static int ft_tensor_io(arp_ft* c, const char* name, int which, float* host, int write) {
+    if (!c || !name || !host) return fail("null argument");
+    auto it = c->index.find(name);
+    if (it == c->index.end()) return fail(std::string("unknown parameter: ") + name);
+    const FtParam& pi = c->infos[it->second];
+    DevBuf* bufs[] = {&c->params, &c->grads, &c->mu, &c->nu};
+    if (which < 0 || which > 3) return fail("bad tensor selector");
+    float* dev = bufs[which]->as<float>() + pi.off;
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    if (write) {
+        ARP_HIP_OK(hipMemcpy(dev, host, pi.size * 4, hipMemcpyHostToDevice));
+        if (which == 0) c->shadows_stale = true;
+    } else {
+        ARP_HIP_OK(hipMemcpy(host, dev, pi.size * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+int arp_ft_set_tensor(arp_ft* c, const char* name, int which, const float* data) { return ft_tensor_io(c, name, which, const_cast<float*>(data), 1); }
+int arp_ft_get_tensor(arp_ft* c, const char* name, int which, float* out) { return ft_tensor_io(c, name, which, out, 0); }
+int arp_ft_set_step(arp_ft* c, int64_t step) {
+    if (!c || step < 0) return fail("bad argument");
+    c->step = step;
+    return 0;
+}
+int arp_ft_get_step(arp_ft* c, int64_t* step) {
+    if (!c || !step) return fail("bad argument");
+    *step = c->step;
+    return 0;
+}
+
+int arp_ft_set_batch(arp_ft* c, const float* img_inter, const float* img_final, const float* txt_inter, const float* txt_final, const float* r,
+                     const int32_t* action, int B) {
+    if (!c || !img_inter || !img_final || !txt_inter || !txt_final || !r || !action || B <= 0) return fail("bad argument");
+    for (int i = 0; i < B; ++i)
+        if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(ensure_buffers(c, B));
+    const size_t E = c->cfg.embed;
+    ARP_HIP_OK(hipMemcpyAsync(c->x_in[0].p, img_inter, (size_t)3 * B * c->Dv() * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[0].p, img_final, (size_t)3 * B * E * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_in[1].p, txt_inter, (size_t)B * c->Dt() * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[1].p, txt_final, (size_t)B * E * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->r.p, r, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_ft_forward(arp_ft* c, float* metrics4, float* scores, float* logits) {
+    if (!c) return fail("null handle");
+    if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : forward<float>(c));
+    if (metrics4) ARP_HIP_OK(hipMemcpyAsync(metrics4, c->metrics.p, 16, hipMemcpyDeviceToHost, c->stream));
+    if (scores) ARP_HIP_OK(hipMemcpyAsync(scores, c->scores.p, (size_t)3 * c->B * 4, hipMemcpyDeviceToHost, c->stream));
+    if (logits) ARP_HIP_OK(hipMemcpyAsync(logits, c->logits.p, (size_t)c->B * c->cfg.n_actions * 4, hipMemcpyDeviceToHost, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_ft_backward(arp_ft* c) {
+    if (!c) return fail("null handle");
+    if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(forward<bf16_t>(c)); ARP_TRY(backward<bf16_t>(c)); }
+    else { ARP_TRY(forward<float>(c)); ARP_TRY(backward<float>(c)); }
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int arp_ft_train_step_async(arp_ft* c, float lr) {
+    if (!c) return fail("null handle");
+    if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, nullptr) : step_impl<float>(c, lr, nullptr);
+}
+int arp_ft_train_step(arp_ft* c, float lr, float* aux4) {
+    if (!c || !aux4) return fail("null argument");
+    if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, aux4) : step_impl<float>(c, lr, aux4);
+}
+int arp_ft_sync(arp_ft* c) {
+    if (!c) return fail("null handle");
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int arp_ft_event_record(arp_ft* c, arp_event* e) {
+    if (!c || !e) return fail("null argument");
+    ARP_HIP_OK(hipEventRecord(e->e, c->stream));
+    return 0;
+}
+int arp_ft_profile_enable(arp_ft* c, int on) {
+    if (!c) return fail("null handle");
+    c->prof.on = on != 0;
+    return 0;
+}
+int arp_ft_profile_reset(arp_ft* c) {
+    if (!c) return fail("null handle");
+    c->prof.reset();
+    return 0;
+}
+int arp_ft_profile_json(arp_ft* c, char* buf, int buf_len) {
+    if (!c || !buf) return fail("null argument");
+    const std::string s = c->prof.json();
+    if ((int)s.size() + 1 > buf_len) return fail("profile buffer too small");
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+}  // extern "C"

@@ -78,12 +78,13 @@ __device__ __forceinline__ void small_gemm_tile(const SmallGemm& g, int bx, int 
             }
         }
 }
-__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) { small_gemm_tile(g, blockIdx.x, blockIdx.y); }
+static __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) { small_gemm_tile(g, blockIdx.x, blockIdx.y); }
 
 // ---- split-K partial reduce:  out[m,n] = act(sum_s part[s,m,n] + bias[n]) ---------------------------
 template <typename OutT>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t MN, int N,
-                                                            const float* __restrict__ bias, int act, OutT* __restrict__ out) {
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t MN, int N,
+                                                            const float* __restrict__ bias, int act, OutT* __restrict__ out,
+                                                            const float* __restrict__ resid = nullptr, int ldo = 0) {
     // 64 outputs per block, 4 slice groups per output (fixed order: group partials are added 0..3)
     __shared__ float red[4][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (bias) s += bias[i % N];
     if (act == ACT_TANH) s = tanhf(s);
     else if (act == ACT_RELU) s = fmaxf(s, 0.f);
-    Elem<OutT>::st(out + i, s);
+    // ldo > 0: the output (and the residual) are strided [M, ldo] views; otherwise dense [M, N]
+    const size_t o = ldo > 0 ? (i / N) * (size_t)ldo + i % N : i;
+    if (resid) s += resid[o];
+    Elem<OutT>::st(out + o, s);
 }
 
 // ---- f32 -> T conversion ----------------------------------------------------------------------------
@@ -118,7 +122,7 @@ template <typename T> __global__ __launch_bounds__(256) void convert_kernel(cons
 //   outN[r*ldn + c] = v (if outN)        outT[c*ldt + r] = v (if outT)
 // 64x64 tiles through LDS; both the read and the two writes are row-contiguous.
 template <typename TI, typename TM, typename TO>
-__global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restrict__ in, int ldi, const TM* __restrict__ mask,
+static __global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restrict__ in, int ldi, const TM* __restrict__ mask,
                                                              const float* __restrict__ scale_ptr, float scale, TO* __restrict__ outN,
                                                              int ldn, TO* __restrict__ outT, int ldt, int R, int Ccols) {
     __shared__ float tile[64][65];
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restric
 
 // ---- adapter mix (arp_dt/ARPDT.py:466-472):  y = res*a + (1-res)*x,  res = sigmoid(residual_weight) -----
 template <typename T>
-__global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ a, const T* __restrict__ x, const float* __restrict__ rw,
+static __global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ a, const T* __restrict__ x, const float* __restrict__ rw,
                                                           T* __restrict__ y, size_t n) {
     const float res = 1.0f / (1.0f + expf(-rw[0]));
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ 
 
 // partial[b] = sum over the block's slice of dy * (a - x)      (d loss / d res; finished by reduce_sum)
 template <typename T>
-__global__ __launch_bounds__(256) void adapter_dres_kernel(const T* __restrict__ dy, const T* __restrict__ a, const T* __restrict__ x,
+static __global__ __launch_bounds__(256) void adapter_dres_kernel(const T* __restrict__ dy, const T* __restrict__ a, const T* __restrict__ x,
                                                            float* __restrict__ partial, size_t n) {
     __shared__ float red[4];
     float s = 0.f;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void adapter_dres_kernel(const T* __restrict__
 }
 
 // out[0] (+)= scale * sum_i in[i]   -- single block, fixed order
-__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ in, int n, float scale, float* __restrict__ out,
+static __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ in, int n, float scale, float* __restrict__ out,
                                                          int accumulate) {
     __shared__ float red[4];
     float s = 0.f;
@@ -190,17 +194,17 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
     }
 }
 
-__global__ void sigmoid_scalar_kernel(float* x) { x[0] = 1.0f / (1.0f + expf(-x[0])); }
+static __global__ void sigmoid_scalar_kernel(float* x) { x[0] = 1.0f / (1.0f + expf(-x[0])); }
 
 // residual_weight gradient: d/d rw = dres * res * (1 - res)
-__global__ void dres_to_drw_kernel(const float* __restrict__ dres, const float* __restrict__ rw, float* __restrict__ grad) {
+static __global__ void dres_to_drw_kernel(const float* __restrict__ dres, const float* __restrict__ rw, float* __restrict__ grad) {
     const float res = 1.0f / (1.0f + expf(-rw[0]));
     grad[0] = dres[0] * res * (1.f - res);
 }
 
 // ---- row sums of a [R, ld] matrix (bias gradients from the TRANSPOSED gradient: one row per output unit)
 template <typename T>
-__global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, int ld, int cols, float* __restrict__ out, int rows) {
+static __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, int ld, int cols, float* __restrict__ out, int rows) {
     __shared__ float red[4];
     const int row = blockIdx.x;  // one workgroup per row; ld % 4 == 0 (rows are 8/16-byte aligned)
     const T* r = in + (size_t)row * ld;
@@ -239,12 +243,12 @@ __device__ __forceinline__ void colsum_tile(const float* __restrict__ in, int R,
     __syncthreads();
     if (y == 0 && c < C) out[c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
 }
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
     colsum_tile(in, R, C, out, blockIdx.x);
 }
 
 // ---- LayerNorm forward (f32 in/out, saves nothing: backward recomputes the statistics) ------------------
-__global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+static __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                          float* __restrict__ y, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void ln_fwd_f32_kernel(const float* __restrict
 }
 // LayerNorm backward: dx (written or accumulated), and per-row contributions to dscale / dbias
 // (dws[row, c] = dy*xhat, dbs[row, c] = dy; summed over rows by colsum_kernel).
-__global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
+static __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
                                                          float* __restrict__ dx, int accumulate, float* __restrict__ dws,
                                                          float* __restrict__ dbs, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __restrict
 // ---- causal multi-head attention backward for the policy (L <= 64 tokens, head_dim <= 64), f32 ---------
 // qkv [B*L, 3E], dout [B*L, E] -> dqkv [B*L, 3E].  One workgroup per (sample, head); probabilities are
 // recomputed (arp_dt/layers.py:70-90: scale, masked fill, softmax).
-__global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+static __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                             float* __restrict__ dqkv, int L, int E, int heads, float scale) {
     extern __shared__ float sm[];
     const int hd = E / heads;
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restr
 
 // ---- token assembly (arp_dt/ARPDT.py:159-172,278-293): per time step [image, rtg, action] -------------
 // tok[(b*T + t)*3 + 0] = img[b*T+t];  +1 = rtg[b*T+t] * Wr;  +2 = Emb[action[b*T+t]]
-__global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict__ img, const float* __restrict__ rtg,
+static __global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict__ img, const float* __restrict__ rtg,
                                                          const int* __restrict__ action, const float* __restrict__ Wr,
                                                          const float* __restrict__ emb, float* __restrict__ tok, int R, int E) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256) void tokens_fwd_kernel(const float* __restrict
     tok[((size_t)r * 3 + 2) * E + e] = emb[(size_t)action[r] * E + e];
 }
 // backward: dimg = dtok[.,0];  dWr[e] = sum_r rtg[r]*dtok[r,1,e];  dEmb[a,e] = sum_{r: action=a} dtok[r,2,e]
-__global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ rtg,
+static __global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ rtg,
                                                          const int* __restrict__ action, float* __restrict__ dimg,
                                                          float* __restrict__ dWr, float* __restrict__ demb, int R, int E, int n_actions) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void tokens_bwd_kernel(const float* __restrict
 
 // gather / scatter of the head inputs (arp_dt/ARPDT.py:203-205): action head <- rtg-token rows (1::3),
 // return head <- image-token rows (0::3)
-__global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restrict__ hf, float* __restrict__ a_in, float* __restrict__ r_in,
+static __global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restrict__ hf, float* __restrict__ a_in, float* __restrict__ r_in,
                                                            int R, int E) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R * E) return;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void heads_gather_kernel(const float* __restri
     r_in[i] = hf[((size_t)r * 3 + 0) * E + e];
     a_in[i] = hf[((size_t)r * 3 + 1) * E + e];
 }
-__global__ __launch_bounds__(256) void heads_scatter_kernel(const float* __restrict__ da_in, const float* __restrict__ dr_in,
+static __global__ __launch_bounds__(256) void heads_scatter_kernel(const float* __restrict__ da_in, const float* __restrict__ dr_in,
                                                             float* __restrict__ dhf, int R, int E) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= R * E) return;
@@ -414,7 +418,7 @@ enum { EW_RELU_BWD = 0, EW_TANH_BWD = 1, EW_GELU_BWD = 2 };
 // RELU_BWD: out = g * (y > 0)   (ref = activation output)
 // TANH_BWD: out = g * (1 - y^2) (ref = activation output)
 // GELU_BWD: out = g * gelu_tanh'(u) (ref = PRE-activation)
-__global__ __launch_bounds__(256) void ew_bwd_kernel(const float* __restrict__ g, const float* __restrict__ ref, float* __restrict__ out,
+static __global__ __launch_bounds__(256) void ew_bwd_kernel(const float* __restrict__ g, const float* __restrict__ ref, float* __restrict__ out,
                                                      size_t n, int op) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -429,14 +433,14 @@ __global__ __launch_bounds__(256) void ew_bwd_kernel(const float* __restrict__ g
     }
     out[i] = g[i] * d;
 }
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ y, size_t n) {
+static __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = apply_act<ACT_GELU_TANH>(u[i]);
 }
 
 // ---- losses (arp_dt/ARPDT.py:238-261,498-507), single block; also the gradients w.r.t. logits / return ---
 // metrics: [0] loss = trans + lambda*ret, [1] acc (fraction), [2] trans_loss, [3] return_loss
-__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ logits, const float* __restrict__ ret,
+static __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ logits, const float* __restrict__ ret,
                                                    const int* __restrict__ action, const float* __restrict__ rtg, int R, int NA,
                                                    float lambda, float* __restrict__ metrics, float* __restrict__ dlogits,
                                                    float* __restrict__ dret) {
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
 
 // ---- optimizer ---------------------------------------------------------------------------------------------
 // partial[b] = sum of x^2 over the block's grid-stride slice of [begin, end)
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+static __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
     __shared__ float red[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += x[i] * x[i];
@@ -486,14 +490,14 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 // g += wd * p on a range (the explicit L2 term of main_procgen.py:114-117 differentiates to wd * p)
-__global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ g, const float* __restrict__ p, float wd, size_t n) {
+static __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ g, const float* __restrict__ p, float wd, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) g[i] += wd * p[i];
 }
 // scal: [0] = sum of squares of the (already averaged-over-ranks) gradient.
 // optax.clip_by_global_norm(c) then adam (b1, b2, eps outside the sqrt, bias correction with t = step+1);
 // the adamw decay mask of the reference is all-False, so no decoupled decay.
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
+static __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
                                                    float* __restrict__ nu, const float* __restrict__ scal, float gscale, float clip,
                                                    float lr, float b1, float b2, float eps, float bc1, float bc2, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -1,0 +1,176 @@
+// Glue kernels of the CLIP multi-scale adapter fine-tune step (reference:
+// finetune_module/clip_multiscale_adapter.py:134-250, finetune_module/finetune.py:139-141).  The contractions run on the
+// MFMA GEMMs of gemm.h / gemm256.h; these are the row-wise pieces around them.  Fixed-order reductions only.
+#pragma once
+#include "common.h"
+
+namespace arp {
+
+// dst[m, col0 + c] = src[m, c]   (the CLIP feature behind the projected per-block features: torch.cat, :143 / :166)
+static __global__ __launch_bounds__(256) void ft_copy_cols_kernel(const float* __restrict__ src, int w, float* __restrict__ dst, int ldd, int col0,
+                                                                  int M) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * w) return;
+    const int m = (int)(i / w), c = (int)(i - (size_t)m * w);
+    dst[(size_t)m * ldd + col0 + c] = src[i];
+}
+
+__device__ __forceinline__ float ft_block_sum(float v, float* red) {  // 256 threads, result to every thread
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// y = res*f + (1-res)*A ; a = y / max(||y||, 1e-12)   (res weights the ORIGINAL feature here, :145-148 / :168-170)
+static __global__ __launch_bounds__(256) void ft_mix_norm_fwd_kernel(const float* __restrict__ f, const float* __restrict__ A,
+                                                                     const float* __restrict__ rw, float* __restrict__ a_out,
+                                                                     float* __restrict__ nrm, int F) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const float res = 1.0f / (1.0f + expf(-rw[0]));
+    const float* fr = f + (size_t)m * F;
+    const float* ar = A + (size_t)m * F;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < F; c += 256) {
+        const float y = res * fr[c] + (1.f - res) * ar[c];
+        ss += y * y;
+    }
+    ss = ft_block_sum(ss, red);
+    const float n = fmaxf(sqrtf(ss), 1e-12f);
+    if (threadIdx.x == 0) nrm[m] = n;
+    for (int c = threadIdx.x; c < F; c += 256) a_out[(size_t)m * F + c] = (res * fr[c] + (1.f - res) * ar[c]) / n;
+}
+
+// s[k*B + b] = scale * <a[k*B + b], t[b]>   (the diagonal of logit_scale * a_k t^T, :203-207)
+static __global__ __launch_bounds__(256) void ft_scores_kernel(const float* __restrict__ a, const float* __restrict__ t, float scale,
+                                                               float* __restrict__ s, int B, int F) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, b = row % B;
+    float d = 0.f;
+    for (int c = threadIdx.x; c < F; c += 256) d += a[(size_t)row * F + c] * t[(size_t)b * F + c];
+    d = ft_block_sum(d, red);
+    if (threadIdx.x == 0) s[row] = scale * d;
+}
+
+// VIP loss + inverse-dynamics cross entropy and their gradients w.r.t. the scores / logits (:214-246), single block.
+// The exponent of the VIP term broadcasts r [B,1] against the scores [B] to a [B,B] matrix in the reference; its mean
+// factorises as mean_i exp(-(r_i - 1)) * mean_j exp(-(gamma s2_j - s1_j)).
+// metrics: [0] loss, [1] vip_loss, [2] id_loss, [3] lambda_id.   dlambda = d loss / d lambda_id.
+static __global__ __launch_bounds__(256) void ft_loss_kernel(const float* __restrict__ s, const float* __restrict__ r, const float* __restrict__ logits,
+                                                             const int* __restrict__ action, int B, int NA, float gamma,
+                                                             const float* __restrict__ lambda_id, int use_vip, int use_id,
+                                                             float* __restrict__ metrics, float* __restrict__ ds, float* __restrict__ dlogits,
+                                                             float* __restrict__ dlambda) {
+    __shared__ float red[4];
+    const float lam = lambda_id[0];
+    float s0 = 0.f, er = 0.f, ee = 0.f, ce = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        s0 += s[b];
+        er += expf(-(r[b] - 1.0f));
+        ee += expf(-(gamma * s[2 * B + b] - s[B + b]));
+        const float* l = logits + (size_t)b * NA;
+        float mx = l[0];
+        for (int c = 1; c < NA; ++c) mx = fmaxf(mx, l[c]);
+        float sum = 0.f;
+        for (int c = 0; c < NA; ++c) sum += expf(l[c] - mx);
+        const float lse = logf(sum) + mx;
+        ce += lse - l[action[b]];
+        for (int c = 0; c < NA; ++c)
+            dlogits[(size_t)b * NA + c] = use_id ? lam * (expf(l[c] - lse) - (c == action[b] ? 1.f : 0.f)) / (float)B : 0.f;
+    }
+    s0 = ft_block_sum(s0, red);
+    er = ft_block_sum(er, red);
+    ee = ft_block_sum(ee, red);
+    ce = ft_block_sum(ce, red);
+    const float Rm = er / (float)B, Z = Rm * ee / (float)B;
+    const float vip = (1.f - gamma) * -(s0 / (float)B) + logf(1e-8f + Z);
+    const float idl = ce / (float)B;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float e = expf(-(gamma * s[2 * B + b] - s[B + b]));
+        const float w = use_vip ? Rm * e / ((float)B * (1e-8f + Z)) : 0.f;
+        ds[b] = use_vip ? -(1.f - gamma) / (float)B : 0.f;
+        ds[B + b] = w;
+        ds[2 * B + b] = -gamma * w;
+    }
+    if (threadIdx.x == 0) {
+        metrics[0] = (use_vip ? vip : 0.f) + (use_id ? lam * idl : 0.f);
+        metrics[1] = vip;
+        metrics[2] = idl;
+        metrics[3] = lam;
+        dlambda[0] = use_id ? idl : 0.f;
+    }
+}
+
+// C[b] = [a1, t, a2, t]   (:232-235)
+static __global__ __launch_bounds__(256) void ft_build_c_kernel(const float* __restrict__ a, const float* __restrict__ t, float* __restrict__ C,
+                                                                int B, int F) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * 4 * F) return;
+    const int b = (int)(i / (4 * F)), c = (int)(i - (size_t)b * 4 * F);
+    const int seg = c / F, cc = c - seg * F;
+    C[i] = seg == 0 ? a[((size_t)B + b) * F + cc] : seg == 2 ? a[((size_t)2 * B + b) * F + cc] : t[(size_t)b * F + cc];
+}
+
+// da[k*B+b] = ds[k*B+b]*scale*t[b] + (dC part of a_k);   dt[b] = scale * sum_k ds[k*B+b]*a[k*B+b] + dC[b, F:2F] + dC[b, 3F:4F]
+static __global__ __launch_bounds__(256) void ft_feat_grad_kernel(const float* __restrict__ ds, const float* __restrict__ a,
+                                                                  const float* __restrict__ t, const float* __restrict__ dC, float scale,
+                                                                  float* __restrict__ da, float* __restrict__ dt, int B, int F) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * F) return;
+    const int b = (int)(i / F), c = (int)(i - (size_t)b * F);
+    const float tv = t[i];
+    const float* dc = dC + (size_t)b * 4 * F;
+    float acc = 0.f;
+    for (int k = 0; k < 3; ++k) {
+        const size_t row = (size_t)k * B + b;
+        const float d = ds[row] * scale;
+        acc += d * a[row * F + c];
+        da[row * F + c] = d * tv + (k == 1 ? dc[c] : k == 2 ? dc[2 * F + c] : 0.f);
+    }
+    dt[i] = acc + dc[F + c] + dc[3 * F + c];
+}
+
+// backward of normalise + mix for one row:  dy = (da - a <a, da>) / n ;  dA = (1-res) dy ;  dfd = res dy ;
+// dres_part[m] = <dy, f - A>
+static __global__ __launch_bounds__(256) void ft_mix_norm_bwd_kernel(const float* __restrict__ da, const float* __restrict__ a,
+                                                                     const float* __restrict__ nrm, const float* __restrict__ f,
+                                                                     const float* __restrict__ A, const float* __restrict__ rw,
+                                                                     float* __restrict__ dA, float* __restrict__ dfd, float* __restrict__ dres_part,
+                                                                     int F) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const float res = 1.0f / (1.0f + expf(-rw[0]));
+    const size_t o = (size_t)m * F;
+    float dot = 0.f;
+    for (int c = threadIdx.x; c < F; c += 256) dot += a[o + c] * da[o + c];
+    dot = ft_block_sum(dot, red);
+    const float inv = 1.0f / nrm[m];
+    float dr = 0.f;
+    for (int c = threadIdx.x; c < F; c += 256) {
+        const float dy = (da[o + c] - a[o + c] * dot) * inv;
+        dA[o + c] = (1.f - res) * dy;
+        dfd[o + c] = res * dy;
+        dr += dy * (f[o + c] - A[o + c]);
+    }
+    dr = ft_block_sum(dr, red);
+    if (threadIdx.x == 0) dres_part[m] = dr;
+}
+
+// torch.optim.AdamW: decoupled decay on EVERY parameter (finetune.py:141 passes model.parameters()), bias correction
+static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
+                                                              float* __restrict__ nu, float gscale, float lr, float wd, float b1, float b2,
+                                                              float eps, float bc1, float bc2, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float m = b1 * mu[i] + (1.f - b1) * gi;
+    const float v = b2 * nu[i] + (1.f - b2) * gi * gi;
+    mu[i] = m;
+    nu[i] = v;
+    const float pd = p[i] * (1.f - lr * wd);
+    p[i] = pd - (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + eps);
+}
+
+}  // namespace arp

@@ -409,7 +409,7 @@ __device__ __forceinline__ float pf_gelu_grad(float r) {  // d/du of the tanh-ap
 }
 
 template <int E, int H>
-__global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
+static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float pf_sm[];
     const int L = a.L, T = a.T, NA = a.NA, heads = a.heads;
     const int hd = E / heads;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
 }
 
 // metrics: [0] loss = trans + lambda*ret, [1] acc (fraction), [2] trans_loss, [3] return_loss  (as loss_kernel)
-__global__ void loss_finish_kernel(const float* __restrict__ part, int B, int R, int NA, float lambda, float* __restrict__ metrics) {
+static __global__ void loss_finish_kernel(const float* __restrict__ part, int B, int R, int NA, float lambda, float* __restrict__ metrics) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float ce = 0.f, hit = 0.f, se = 0.f;
     for (int b = 0; b < B; ++b) { ce += part[b * 4]; hit += part[b * 4 + 1]; se += part[b * 4 + 2]; }
@@ -709,7 +709,7 @@ __global__ void loss_finish_kernel(const float* __restrict__ part, int B, int R,
 
 // ---- grouped launches for the deferred parameter gradients ---------------------------------------------------
 // tile_prefix[p] .. tile_prefix[p+1] are the 32x32 output tiles of problem p
-__global__ __launch_bounds__(256) void grouped_small_gemm_kernel(const SmallGemm* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
+static __global__ __launch_bounds__(256) void grouped_small_gemm_kernel(const SmallGemm* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
     int p = 0;
     while (p + 1 < n && (int)blockIdx.x >= tile_prefix[p + 1]) ++p;
     const SmallGemm g = tab[p];
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void grouped_small_gemm_kernel(const SmallGemm
 }
 // embedding / rtg-projection gradients from d tokens: block a < NA sums the action-token rows whose action is a
 // (in row order), block NA the rtg-token rows weighted by rtg  (same sums as tokens_bwd_kernel, no read-modify-write chain)
-__global__ __launch_bounds__(256) void tokens_bwd_par_kernel(const float* __restrict__ dtok, const float* __restrict__ rtg, const int* __restrict__ action,
+static __global__ __launch_bounds__(256) void tokens_bwd_par_kernel(const float* __restrict__ dtok, const float* __restrict__ rtg, const int* __restrict__ action,
                                                              float* __restrict__ dWr, float* __restrict__ demb, int R, int E, int n_actions) {
     const int a = blockIdx.x;
     for (int e = threadIdx.x; e < E; e += 256) {
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void tokens_bwd_par_kernel(const float* __rest
     }
 }
 struct ColSumJob { const float* in; float* out; int R, C; };
-__global__ __launch_bounds__(256) void grouped_colsum_kernel(const ColSumJob* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
+static __global__ __launch_bounds__(256) void grouped_colsum_kernel(const ColSumJob* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
     int p = 0;
     while (p + 1 < n && (int)blockIdx.x >= tile_prefix[p + 1]) ++p;
     const ColSumJob j = tab[p];

@@ -1,0 +1,223 @@
+"""SURVEY row N2 -- the CLIP multi-scale adapter fine-tune step on the MI355X (BASELINE.json configs[4]).
+
+Host-side mirror of ``finetune_module/clip_multiscale_adapter.py::CLIPMultiscaleAdapter`` (its trainable head) and of the
+optimiser step in ``finetune_module/finetune.py:69-93,139-141``, over the C ABI ``arp_ft_*`` (include/arp_hip.h).  The
+frozen CLIP towers stay outside this step, as the reference freezes them (``finetune.py:139-140``): their per-block CLS /
+EOT features (what the reference's forward hooks collect, ``utils.py:6-18``) and final features are the batch.  Parameter
+names and layouts are torch's own ``state_dict`` entries, so a reference checkpoint's non-``clip_model.*`` tensors load
+as they are.
+"""
+import ctypes as C
+import json
+from dataclasses import asdict, dataclass
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib
+
+MODES = {"f32": _ffi.MODE_F32, "bf16": _ffi.MODE_BF16}
+AUX_KEYS = ("loss", "vip_loss", "id_loss", "lambda_id")
+
+
+@dataclass
+class FinetuneConfig:
+    layers: int = 12
+    width_v: int = 768
+    width_t: int = 512
+    embed: int = 512
+    hidden: int = 1024
+    n_actions: int = 15
+    gamma: float = 0.98                       # clip_multiscale_adapter.py:107
+    logit_scale: float = float(np.log(1 / 0.07))  # clip_model.logit_scale (:95)
+    use_vip: bool = True                      # finetune.py:41-42
+    use_id: bool = True
+    weight_decay: float = 0.001               # finetune.py:31
+    b1: float = 0.9
+    b2: float = 0.999
+    eps: float = 1e-8
+
+    @property
+    def d_img(self):
+        return self.layers * self.width_v
+
+    @property
+    def d_txt(self):
+        return self.layers * self.width_t
+
+    @property
+    def feat(self):
+        return self.layers * self.width_t + self.embed
+
+
+class FinetuneTrainer:
+    """Parameters, AdamW state and the staged batch live on the GPU; one host thread per handle."""
+
+    def __init__(self, cfg, mode="bf16", device=0):
+        self.cfg = cfg
+        c = _ffi.FtCfg(cfg.layers, cfg.width_v, cfg.width_t, cfg.embed, cfg.hidden, cfg.n_actions, MODES[mode], device, int(cfg.use_vip), int(cfg.use_id),
+                       cfg.gamma, cfg.logit_scale, cfg.weight_decay, cfg.b1, cfg.b2, cfg.eps)
+        h = C.c_void_p()
+        check(lib.arp_ft_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._B = 0
+        total, n = C.c_int64(), C.c_int32()
+        check(lib.arp_ft_num_params(self._h, C.byref(total), C.byref(n)))
+        self.n_params = total.value
+        self.shapes = {}
+        for i in range(n.value):
+            name = C.create_string_buffer(256)
+            shape = (C.c_int64 * 4)()
+            nd = C.c_int32()
+            check(lib.arp_ft_param_info(self._h, i, name, 256, shape, C.byref(nd)))
+            self.shapes[name.value.decode()] = tuple(int(shape[d]) for d in range(nd.value))
+
+    def close(self):
+        if self._h:
+            check(lib.arp_ft_destroy(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ----------------------------------------------------------------------------------------
+    def set_tensors(self, tensors, which=0):
+        missing = set(self.shapes) - set(tensors)
+        if missing and which == 0:
+            raise KeyError(f"missing parameters: {sorted(missing)}")
+        for name, v in tensors.items():
+            if name.startswith("clip_model."):
+                continue  # frozen towers: not part of this step
+            a = np.require(np.asarray(v, dtype=np.float32), requirements="C")
+            if tuple(a.shape) != self.shapes[name]:
+                raise ValueError(f"{name}: shape {a.shape}, expected {self.shapes[name]}")
+            check(lib.arp_ft_set_tensor(self._h, name.encode(), which, _ffi.as_ptr(a, C.c_float)))
+
+    def get_tensors(self, which=0):
+        out = {}
+        for name, shp in self.shapes.items():
+            a = np.empty(shp, np.float32)
+            check(lib.arp_ft_get_tensor(self._h, name.encode(), which, _ffi.as_ptr(a, C.c_float)))
+            out[name] = a
+        return out
+
+    set_params = set_tensors
+    load_state_dict = set_tensors
+
+    def get_params(self):
+        return self.get_tensors(0)
+
+    state_dict = get_params
+
+    def get_grads(self):
+        return self.get_tensors(1)
+
+    @property
+    def step(self):
+        s = C.c_int64()
+        check(lib.arp_ft_get_step(self._h, C.byref(s)))
+        return s.value
+
+    @step.setter
+    def step(self, v):
+        check(lib.arp_ft_set_step(self._h, int(v)))
+
+    # -- compute --------------------------------------------------------------------------------------
+    def set_batch(self, img_inter, img_final, txt_inter, txt_final, r, action):
+        """img_inter [3,B,layers*width_v], img_final [3,B,embed] (image0..2), txt_inter [B,layers*width_t], txt_final [B,embed],
+        r [B] or [B,1] as stored in the batch, action [B] class ids."""
+        c = self.cfg
+        f32 = lambda x: np.require(np.asarray(x, dtype=np.float32), requirements="C")
+        img_inter, img_final, txt_inter, txt_final = f32(img_inter), f32(img_final), f32(txt_inter), f32(txt_final)
+        r = f32(np.asarray(r).reshape(-1))
+        action = np.require(np.asarray(action, dtype=np.int32).reshape(-1), requirements="C")
+        B = action.shape[0]
+        if img_inter.shape != (3, B, c.d_img) or img_final.shape != (3, B, c.embed) or txt_inter.shape != (B, c.d_txt) or \
+                txt_final.shape != (B, c.embed) or r.shape != (B,):
+            raise ValueError(f"batch shapes: {img_inter.shape} {img_final.shape} {txt_inter.shape} {txt_final.shape} {r.shape} {action.shape}")
+        p = _ffi.as_ptr
+        check(lib.arp_ft_set_batch(self._h, p(img_inter, C.c_float), p(img_final, C.c_float), p(txt_inter, C.c_float), p(txt_final, C.c_float),
+                                   p(r, C.c_float), p(action, C.c_int32), B))
+        self._B = B
+
+    def forward(self):
+        """CLIPMultiscaleAdapter.forward (clip_multiscale_adapter.py:177-250) on the staged batch."""
+        B = self._B
+        m = np.empty(4, np.float32)
+        s = np.empty((3, B), np.float32)
+        lg = np.empty((B, self.cfg.n_actions), np.float32)
+        check(lib.arp_ft_forward(self._h, _ffi.as_ptr(m, C.c_float), _ffi.as_ptr(s, C.c_float), _ffi.as_ptr(lg, C.c_float)))
+        return {"loss": float(m[0]), "vip_loss": float(m[1]), "id_loss": float(m[2]), "lambda_id": float(m[3]), "scores": s, "logits": lg}
+
+    def backward(self):
+        check(lib.arp_ft_backward(self._h))
+
+    def train_step(self, lr):
+        """loss.backward(); optimizer.step() of finetune.py:81-84; returns the pre-update losses."""
+        aux = np.empty(4, np.float32)
+        check(lib.arp_ft_train_step(self._h, float(lr), _ffi.as_ptr(aux, C.c_float)))
+        return {k: float(aux[i]) for i, k in enumerate(AUX_KEYS)}
+
+    def train_step_async(self, lr):
+        check(lib.arp_ft_train_step_async(self._h, float(lr)))
+
+    def sync(self):
+        check(lib.arp_ft_sync(self._h))
+
+    def record(self, event):
+        check(lib.arp_ft_event_record(self._h, event.ptr))
+
+    def profile(self, on=True):
+        check(lib.arp_ft_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        check(lib.arp_ft_profile_reset(self._h))
+
+    def profile_read(self):
+        buf = C.create_string_buffer(1 << 16)
+        check(lib.arp_ft_profile_json(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+
+def flops_per_sample(cfg):
+    """Algorithmic FLOPs of one sample's forward + backward through the head (2 per MAC; weight gradients included)."""
+    F, Hd = cfg.feat, cfg.hidden * (cfg.layers + 1)
+    img = cfg.d_txt * cfg.d_img + 2 * F * Hd      # per image row, forward MACs
+    txt = cfg.d_txt * cfg.d_txt + 2 * F * Hd
+    inv = 4 * F * cfg.hidden + cfg.hidden * cfg.n_actions
+    # backward: dW for every layer, dX for every layer but the two bias-free input projections
+    fwd = 3 * img + txt + inv
+    bwd = 3 * (img + 2 * F * Hd) + (txt + 2 * F * Hd) + 2 * inv
+    return 2.0 * (fwd + bwd)
+
+
+def synth_params(cfg, seed=0):
+    """Seeded stand-in for a checkpoint (numpy PCG64): fan-in scaled weights, small biases, the reference's scalar inits."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    F, Hd = cfg.feat, cfg.hidden * (cfg.layers + 1)
+    shapes = {"image_intermediate_linear.weight": (cfg.d_txt, cfg.d_img), "text_intermediate_linear.weight": (cfg.d_txt, cfg.d_txt)}
+    for a in ("image_adapter", "text_adapter"):
+        shapes.update({f"{a}.layers.0.weight": (Hd, F), f"{a}.layers.0.bias": (Hd,), f"{a}.layers.3.weight": (F, Hd), f"{a}.layers.3.bias": (F,)})
+    shapes.update({"inverse_layer.layers.0.weight": (cfg.hidden, 4 * F), "inverse_layer.layers.0.bias": (cfg.hidden,),
+                   "inverse_layer.layers.3.weight": (cfg.n_actions, cfg.hidden), "inverse_layer.layers.3.bias": (cfg.n_actions,)})
+    P = {}
+    for k, shp in shapes.items():
+        if k.endswith(".bias"):
+            P[k] = (0.02 * rng.standard_normal(shp, dtype=np.float32)).astype(np.float32)
+        else:
+            P[k] = (rng.standard_normal(shp, dtype=np.float32) / np.float32(np.sqrt(shp[1]))).astype(np.float32)
+    P["image_residual_weight"] = np.float32(4.0) * np.ones((), np.float32)   # clip_multiscale_adapter.py:91-92
+    P["text_residual_weight"] = np.float32(4.0) * np.ones((), np.float32)
+    P["lambda_id"] = np.float32(np.log(1 / 0.07)) * np.ones((), np.float32)   # :103
+    return P
+
+
+def synth_batch(cfg, B, seed=0):
+    """Random stand-ins for the frozen towers' outputs (O(1) features, as LayerNormed residual streams are)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (rng.standard_normal((3, B, cfg.d_img), dtype=np.float32), rng.standard_normal((3, B, cfg.embed), dtype=np.float32),
+            rng.standard_normal((B, cfg.d_txt), dtype=np.float32), rng.standard_normal((B, cfg.embed), dtype=np.float32),
+            rng.integers(0, 2, (B,)).astype(np.float32), rng.integers(0, cfg.n_actions, (B,)).astype(np.int32))

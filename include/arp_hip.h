@@ -174,6 +174,57 @@ int arp_dt_profile_enable(arp_dt* h, int on);
 int arp_dt_profile_reset(arp_dt* h);
 int arp_dt_profile_json(arp_dt* h, char* buf, int buf_len);
 
+/* ---- row N2: CLIP multi-scale adapter fine-tune step (BASELINE.json configs[4]) --------------------------------
+ * The trainable head of finetune_module/clip_multiscale_adapter.py::CLIPMultiscaleAdapter on top of the FROZEN CLIP
+ * towers (finetune_module/finetune.py:139-140): encode_image :134-149, encode_text :151-175, forward :177-250
+ * (VIP loss + lambda_id * inverse-dynamics CE), optimiser torch.optim.AdamW over every non-CLIP parameter (:141).
+ * The towers' outputs are the step's inputs: the per-block CLS (image) / EOT (text) features the reference collects with
+ * forward hooks (finetune_module/utils.py:6-18), concatenated block 0..layers-1, and the final CLIP features.
+ * Parameters cross under torch's state_dict names with torch's [out, in] Linear layout:
+ *   "image_intermediate_linear.weight", "text_intermediate_linear.weight", "{image,text}_adapter.layers.{0,3}.{weight,bias}",
+ *   "inverse_layer.layers.{0,3}.{weight,bias}", "image_residual_weight", "text_residual_weight", "lambda_id". */
+typedef struct arp_ft arp_ft;
+typedef struct arp_ft_cfg {
+    int32_t layers;     /* clip_model.transformer.layers (12): blocks whose features are concatenated, both towers */
+    int32_t width_v;    /* 768 */
+    int32_t width_t;    /* 512 (= input_dim = output_dim of the reference constructor) */
+    int32_t embed;      /* 512 */
+    int32_t hidden;     /* hidden_dim 1024: adapters use hidden*(layers+1), the inverse model uses hidden */
+    int32_t n_actions;  /* 15 */
+    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_BF16 */
+    int32_t device;
+    int32_t use_vip;    /* use_vip_loss */
+    int32_t use_id;     /* use_id_loss */
+    float gamma;        /* 0.98 (:107) */
+    float logit_scale;  /* ln of the similarity scale, clip_model.logit_scale (:95) */
+    float weight_decay; /* AdamW decoupled decay, finetune.py:31 (0.001) */
+    float b1, b2, eps;  /* 0.9, 0.999, 1e-8 */
+} arp_ft_cfg;
+int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out);
+int arp_ft_destroy(arp_ft* h);
+int arp_ft_num_params(arp_ft* h, int64_t* total, int32_t* n_tensors);
+int arp_ft_param_info(arp_ft* h, int i, char* name_buf, int name_len, int64_t* shape4, int32_t* ndim);
+/* which: 0 = parameter, 1 = gradient, 2 = AdamW exp_avg, 3 = AdamW exp_avg_sq */
+int arp_ft_set_tensor(arp_ft* h, const char* name, int which, const float* data);
+int arp_ft_get_tensor(arp_ft* h, const char* name, int which, float* out);
+int arp_ft_set_step(arp_ft* h, int64_t step);
+int arp_ft_get_step(arp_ft* h, int64_t* step);
+/* img_inter [3, B, layers*width_v] and img_final [3, B, embed]: frames image0, image1, image2 of each sample
+ * (clip_multiscale_adapter.py:185-202; image3 is only read when goal_conditioned); txt_inter [B, layers*width_t],
+ * txt_final [B, embed]; r [B] as stored in the batch (the loss uses r - 1, :215); action [B] class ids. */
+int arp_ft_set_batch(arp_ft* h, const float* img_inter, const float* img_final, const float* txt_inter, const float* txt_final,
+                     const float* r, const int32_t* action, int B);
+/* metrics4: loss, vip_loss, id_loss, lambda_id.  scores [3, B] and logits [B, n_actions] may be NULL. */
+int arp_ft_forward(arp_ft* h, float* metrics4, float* scores, float* logits);
+int arp_ft_backward(arp_ft* h);                        /* forward + backward: fills every gradient */
+int arp_ft_train_step(arp_ft* h, float lr, float* aux4); /* forward + backward + AdamW; aux4 as metrics4 (pre-update) */
+int arp_ft_train_step_async(arp_ft* h, float lr);
+int arp_ft_sync(arp_ft* h);
+int arp_ft_event_record(arp_ft* h, arp_event* e);
+int arp_ft_profile_enable(arp_ft* h, int on);
+int arp_ft_profile_reset(arp_ft* h);
+int arp_ft_profile_json(arp_ft* h, char* buf, int buf_len);
+
 /* ---- row N1: frozen M3AE image encoder (forward_representation) -----------------------------------
  * arp_dt/models/m3ae/model.py:471-496 as called under stop_gradient by arp_dt/ARPDT.py:413-462.
  * Weights cross under their Flax tree path ('/'-flattened, [in,out] kernels): "cls_token",
