@@ -39,12 +39,14 @@ def gemm_sites(cfg, batch):
     }
 
 
-def cpu_baseline(model, seconds, policy_batch=0):
+def cpu_baseline(model, seconds, policy_batch=0, finetune_batch=0):
     """Runs the oracle's torch-CPU port in a child process (before this process touches the GPU)."""
     try:
         cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--model", model, "--target-seconds", str(seconds)]
         if policy_batch:
             cmd = [sys.executable, "-m", "oracle.cpu_baseline_policy", "--batch", str(policy_batch), "--target-seconds", str(seconds)]
+        if finetune_batch:
+            cmd = [sys.executable, "-m", "oracle.cpu_baseline_finetune", "--batch", str(finetune_batch), "--target-seconds", str(seconds)]
         out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
@@ -144,6 +146,56 @@ def bench_policy(a):
         dist.destroy_process_group()
 
 
+def bench_finetune(a):
+    """Secondary benchmark: the CLIP multi-scale adapter fine-tune head step (BASELINE.json configs[4]):
+    B = 64 samples x 3 frames, frozen-tower features resident in HBM, forward + backward + AdamW over 476 M parameters.
+    Single GPU, as the reference (finetune_module/finetune.py)."""
+    cpu = cpu_baseline(a.model, a.cpu_seconds, finetune_batch=a.finetune_batch) if a.cpu_seconds > 0 else None
+    from arp_amd import _ffi, finetune as FT
+    _ffi.require_gpu()
+    cfg = FT.FinetuneConfig()
+    tr = FT.FinetuneTrainer(cfg, mode=a.mode, device=0)
+    tr.set_params(FT.synth_params(cfg, seed=0))
+    tr.set_batch(*FT.synth_batch(cfg, a.finetune_batch, seed=100))
+    lr = 1e-4
+    for _ in range(a.warmup):
+        tr.train_step_async(lr)
+    tr.sync()
+    _ffi.check(_ffi.lib.arp_dev_synchronize())
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.train_step_async(lr)
+    tr.sync()
+    _ffi.check(_ffi.lib.arp_dev_synchronize())
+    elapsed = time.perf_counter() - t0
+    tr.profile(True)
+    tr.profile_reset()
+    for _ in range(a.steps):
+        tr.train_step_async(lr)
+    tr.sync()
+    prof = tr.profile_read()
+    aux = tr.train_step(lr)
+    # dominant kernel: AdamW, HBM-bound -- reads p, g, m, v and writes p, m, v: 7 x 4 B per parameter
+    site = "ft.adamw"
+    nbytes = 28.0 * tr.n_params
+    avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
+    flops = FT.flops_per_sample(cfg) * a.finetune_batch
+    print(json.dumps({
+        "metric": "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": a.finetune_batch * a.steps / elapsed,
+        "unit": "samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
+        "config": {"workload": f"CLIPMultiscaleAdapter head train step, {a.finetune_batch} samples x 3 frames, ViT-B/16-shaped tower features "
+                               f"[3,B,9216]+[3,B,512] / [B,6144]+[B,512] resident in HBM, {tr.n_params / 1e6:.0f} M trainable params "
+                               f"(BASELINE.json configs[4])", "parallelism": "single GPU (as the reference)"},
+        "roofline": {"bound": "hbm", "achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": f"ft_adamw_kernel @ {site}",
+                     "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms},
+        "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12},
+        "cpu_baseline": cpu, "final_aux": aux,
+        "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
+    tr.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,14 +208,18 @@ def main():
     ap.add_argument("--parity-frames", type=int, default=4, help="frames checked against the oracle before timing (rank 0)")
     ap.add_argument("--streams", type=int, default=2, help="label path: N = each batch is labelled in N contiguous parts on N HIP streams of "
                     "the same GPU (one half's LayerNorm/attention/GEMM tails overlap the other half's GEMMs); 1 = single stream")
-    ap.add_argument("--path", default="label", choices=["label", "policy"],
-                    help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary)")
+    ap.add_argument("--path", default="label", choices=["label", "policy", "finetune"],
+                    help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary); "
+                         "finetune = CLIP multi-scale adapter head step (configs[4], secondary)")
+    ap.add_argument("--finetune-batch", type=int, default=64, help="samples per step (finetune.py:25)")
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
     a = ap.parse_args()
     if a.path == "policy":
         return bench_policy(a)
+    if a.path == "finetune":
+        return bench_finetune(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
