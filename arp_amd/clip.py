@@ -179,6 +179,25 @@ class ClipLabeller:
                                         int(bool(use_crop)), int(bool(normalize)), _ffi.as_ptr(out, C.c_float)))
         return out
 
+    def encode_image_multiscale(self, frames):
+        """Frozen-tower side of the fine-tune step (finetune_module/clip_multiscale_adapter.py:120-149): per-block
+        CLS features [n, layers*width] and the un-normalised CLIP feature [n, embed], through the fine-tune transform."""
+        f = self._frames(frames)
+        inter = np.empty((f.shape[0], self.cfg.layers * self.cfg.width), np.float32)
+        fin = np.empty((f.shape[0], self.cfg.embed), np.float32)
+        check(lib.arp_clip_encode_image_multiscale(self._h, _ffi.as_ptr(f, C.c_uint8), f.shape[0], f.shape[1], f.shape[2],
+                                                   _ffi.as_ptr(inter, C.c_float), _ffi.as_ptr(fin, C.c_float)))
+        return inter, fin
+
+    def encode_text_multiscale(self, tokens):
+        """Per-block EOT-token features [n, txt_layers*txt_width] and the un-normalised text feature (:151-166)."""
+        t = np.require(np.asarray(tokens, dtype=np.int32).reshape(-1, self.cfg.ctx), requirements="C")
+        inter = np.empty((t.shape[0], self.cfg.txt_layers * self.cfg.txt_width), np.float32)
+        fin = np.empty((t.shape[0], self.cfg.embed), np.float32)
+        check(lib.arp_clip_encode_text_multiscale(self._h, _ffi.as_ptr(t, C.c_int32), t.shape[0], _ffi.as_ptr(inter, C.c_float),
+                                                  _ffi.as_ptr(fin, C.c_float)))
+        return inter, fin
+
     def label_device_async(self, frames_dev, n, h, w, rewards_dev, use_crop=False):
         check(lib.arp_clip_label_dev_async(self._h, frames_dev.ptr, n, h, w, int(bool(use_crop)), rewards_dev.ptr))
 

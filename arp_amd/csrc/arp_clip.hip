@@ -209,6 +209,11 @@ struct arp_clip {
     Profiler prof;
     // second stream: a shallow clone (shared weights, own workspace/stream/profiler) that labels the other half of a
     // batch concurrently, so one half's memory-bound kernels and GEMM tails overlap the other half's GEMMs
+    // multi-scale export target of the NEXT tower run (row N2); cleared after use
+    float* ms_out = nullptr;
+    int ms_ld = 0;
+    const int* ms_rows = nullptr;
+    int pre_bilinear = 0;  // next forward_chunk uses the fine-tune transform (bilinear) instead of the PIL-bicubic one
     std::vector<arp_clip*> siblings;  // n_streams - 1 clones
     bool is_sibling = false;
     hipEvent_t ev_fork = nullptr;
@@ -233,6 +238,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.prof = &c->prof;
     t.attn_impl = c->cfg.attn_impl;
     t.gemm_force = c->gemm_force;
+    t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
     return t;
 }
 
@@ -393,7 +399,14 @@ template <typename T>
 static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizePlan* plan) {
     const arp_clip_cfg& k = c->cfg;
     const int G = k.img_res / k.patch, N = c->ntok(), D = k.width, KP = 3 * k.patch * k.patch;
-    {
+    if (c->pre_bilinear) {
+        ProfScope ps(c->prof, c->stream, "preprocess_bilinear");
+        const int H = c->pre_bilinear >> 16, W = c->pre_bilinear & 0xffff, R = k.img_res;
+        const size_t total = (size_t)nb * 3 * R * (R / 4);
+        hipLaunchKernelGGL((preprocess_bilinear_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, frames_dev, c->patches.as<T>(), nb,
+                           H, W, R, k.patch, (H != R && W != R) ? 1 : 0);
+        ARP_HIP_OK(hipGetLastError());
+    } else {
         ProfScope ps(c->prof, c->stream, "preprocess");
         ARP_TRY((launch_preprocess<T, PRE_PATCH>(*plan, frames_dev, nb, k.patch, c->lut, c->patches.p, c->stream)));
     }
@@ -420,11 +433,15 @@ static int forward_chunk_dispatch(arp_clip* c, const uint8_t* frames_dev, int nb
     return forward_chunk<float>(c, frames_dev, nb, plan);
 }
 
-template <typename T> static int run_text(arp_clip* c, const int32_t* tokens, int np) {
+// ms_host != null: multi-scale export of the EOT rows [np, layers*txt_width]; out_host != null: return the (optionally
+// normalised) features instead of caching them as the prompt set
+template <typename T> static int run_text(arp_clip* c, const int32_t* tokens, int np, float* out_host = nullptr, bool normalize = true,
+                                          float* ms_host = nullptr) {
     const arp_clip_cfg& k = c->cfg;
     const int Tw = k.txt_width, ctx = k.ctx, M = np * ctx;
     const size_t e = sizeof(T);
-    DevBuf tok, eot, x, h, qkv, ao, fc, hs;
+    DevBuf tok, eot, x, h, qkv, ao, fc, hs, ms, feat_tmp;
+    DevBuf& feat = out_host ? feat_tmp : c->txt_feat;
     int rc = 0;
     std::vector<int> eot_rows(np);
     for (int p = 0; p < np; ++p) {
@@ -439,13 +456,17 @@ template <typename T> static int run_text(arp_clip* c, const int32_t* tokens, in
         ARP_TRY(tok.ensure((size_t)M * 4)); ARP_TRY(eot.ensure((size_t)np * 4));
         ARP_TRY(x.ensure((size_t)M * Tw * 4)); ARP_TRY(h.ensure((size_t)M * Tw * e)); ARP_TRY(qkv.ensure((size_t)M * 3 * Tw * e));
         ARP_TRY(ao.ensure((size_t)M * Tw * e)); ARP_TRY(fc.ensure((size_t)M * 4 * Tw * e)); ARP_TRY(hs.ensure((size_t)np * Tw * e));
-        ARP_TRY(c->txt_feat.ensure((size_t)np * k.embed * 4));
+        ARP_TRY(feat.ensure((size_t)np * k.embed * 4));
+        if (ms_host) ARP_TRY(ms.ensure((size_t)np * c->txt.layers * Tw * 4));
         ARP_HIP_OK(hipMemcpyAsync(tok.p, tokens, (size_t)M * 4, hipMemcpyHostToDevice, c->stream));
         ARP_HIP_OK(hipMemcpyAsync(eot.p, eot_rows.data(), (size_t)np * 4, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(text_embed_kernel, dim3((M + 3) / 4), dim3(256), 0, c->stream, tok.as<int>(), c->tok_emb, c->tpos,
                            x.as<float>(), M, ctx, Tw);
         ARP_HIP_OK(hipGetLastError());
-        ARP_TRY(run_blocks<T>(c, c->txt, "text", x.as<float>(), h.as<T>(), qkv.as<T>(), ao.as<T>(), fc.as<T>(), np, ctx, 1));
+        if (ms_host) { c->ms_out = ms.as<float>(); c->ms_ld = c->txt.layers * Tw; c->ms_rows = eot.as<int>(); }
+        const int rb = run_blocks<T>(c, c->txt, "text", x.as<float>(), h.as<T>(), qkv.as<T>(), ao.as<T>(), fc.as<T>(), np, ctx, 1);
+        c->ms_out = nullptr; c->ms_rows = nullptr;
+        ARP_TRY(rb);
         // ln_final, EOT row, text_projection (arp_dt/models/openai/layers.py:367-369)
 #define ARP_LNG_CALL(NV)                                                                                                     \
     hipLaunchKernelGGL((layernorm_gather_kernel<T, NV>), dim3((np + 3) / 4), dim3(256), 0, c->stream, x.as<float>(), (size_t)Tw, \
@@ -453,16 +474,20 @@ template <typename T> static int run_text(arp_clip* c, const int32_t* tokens, in
         ARP_NV_DISPATCH(Tw, ARP_LNG_CALL);
 #undef ARP_LNG_CALL
         ARP_HIP_OK(hipGetLastError());
-        ARP_TRY((gemm<T, float, ACT_NONE, false, SITE_PROJ>(c, "text.proj", hs.p, c->tproj_t, nullptr, nullptr, c->txt_feat.p, np,
+        ARP_TRY((gemm<T, float, ACT_NONE, false, SITE_PROJ>(c, "text.proj", hs.p, c->tproj_t, nullptr, nullptr, feat.p, np,
                                                             k.embed, Tw)));
-        hipLaunchKernelGGL(l2_normalize_kernel, dim3((np + 3) / 4), dim3(256), 0, c->stream, c->txt_feat.as<float>(), np, k.embed);
-        ARP_HIP_OK(hipGetLastError());
+        if (normalize) {
+            hipLaunchKernelGGL(l2_normalize_kernel, dim3((np + 3) / 4), dim3(256), 0, c->stream, feat.as<float>(), np, k.embed);
+            ARP_HIP_OK(hipGetLastError());
+        }
+        if (out_host) ARP_HIP_OK(hipMemcpyAsync(out_host, feat.p, (size_t)np * k.embed * 4, hipMemcpyDeviceToHost, c->stream));
+        if (ms_host) ARP_HIP_OK(hipMemcpyAsync(ms_host, ms.p, (size_t)np * c->txt.layers * Tw * 4, hipMemcpyDeviceToHost, c->stream));
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
         return 0;
     };
     rc = body();
-    tok.release(); eot.release(); x.release(); h.release(); qkv.release(); ao.release(); fc.release(); hs.release();
-    if (rc == 0) c->n_prompts = np;
+    tok.release(); eot.release(); x.release(); h.release(); qkv.release(); ao.release(); fc.release(); hs.release(); ms.release(); feat_tmp.release();
+    if (rc == 0 && !out_host) c->n_prompts = np;
     return rc;
 }
 
@@ -767,6 +792,55 @@ int arp_clip_encode_image(arp_clip* c, const uint8_t* frames, int n, int H, int 
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
     }
     return 0;
+}
+
+// Frozen-tower outputs for the fine-tune head (row N2): per-block CLS features [n, layers*width] and the un-normalised
+// CLIP image feature [n, embed], through the fine-tune transform (bilinear; clip_multiscale_adapter.py:120-149).
+int arp_clip_encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter, float* final_feat) {
+    ARP_TRY(check_ready(c, false));
+    if (n < 0) return fail("negative frame count");
+    if (n == 0) return 0;
+    if (!frames || !inter || !final_feat) return fail("null buffer");
+    const int R = c->cfg.img_res;
+    if (H <= 0 || W <= 0 || H > 0xffff || W > 0xffff) return fail("bad frame geometry");
+    if ((H != R) != (W != R)) return fail("the reference resizes only when BOTH sides differ from 224 (clip_multiscale_adapter.py:127): "
+                                          "a frame with exactly one side at 224 cannot enter the tower");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    const size_t fb = (size_t)H * W * 3;
+    const int mb = c->cfg.max_batch, E = c->cfg.embed, LD = c->vis.layers * c->cfg.width;
+    ARP_TRY(c->frames_in.ensure((size_t)std::min(n, mb) * fb));
+    ARP_TRY(ensure_workspace(c, std::min(n, mb)));
+    DevBuf ms;
+    int rc = 0;
+    auto body = [&]() -> int {
+        ARP_TRY(ms.ensure((size_t)std::min(n, mb) * LD * 4));
+        for (int off = 0; off < n; off += mb) {
+            const int nb = std::min(mb, n - off);
+            ARP_HIP_OK(hipMemcpyAsync(c->frames_in.p, frames + (size_t)off * fb, (size_t)nb * fb, hipMemcpyHostToDevice, c->stream));
+            c->ms_out = ms.as<float>(); c->ms_ld = LD; c->ms_rows = nullptr; c->pre_bilinear = (H << 16) | W;
+            const int r = forward_chunk_dispatch(c, c->frames_in.as<uint8_t>(), nb, nullptr);
+            c->ms_out = nullptr; c->pre_bilinear = 0;
+            ARP_TRY(r);
+            ARP_HIP_OK(hipMemcpyAsync(final_feat + (size_t)off * E, c->feat.p, (size_t)nb * E * 4, hipMemcpyDeviceToHost, c->stream));
+            ARP_HIP_OK(hipMemcpyAsync(inter + (size_t)off * LD, ms.p, (size_t)nb * LD * 4, hipMemcpyDeviceToHost, c->stream));
+            ARP_HIP_OK(hipStreamSynchronize(c->stream));
+        }
+        return 0;
+    };
+    rc = body();
+    c->ms_out = nullptr; c->pre_bilinear = 0;
+    ms.release();
+    return rc;
+}
+
+// Text side of the same: per-block EOT-token features [n, layers*txt_width] and the un-normalised text feature [n, embed]
+// (clip_multiscale_adapter.py:151-166).  Does not touch the cached prompt set of arp_clip_set_text.
+int arp_clip_encode_text_multiscale(arp_clip* c, const int32_t* tokens, int n, float* inter, float* final_feat) {
+    ARP_TRY(check_ready(c, false));
+    if (!tokens || n <= 0 || !inter || !final_feat) return fail("bad argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_BF16) return run_text<bf16_t>(c, tokens, n, final_feat, false, inter);
+    return run_text<float>(c, tokens, n, final_feat, false, inter);
 }
 
 int arp_bicubic_coeffs(int in_size, int out_size, int32_t* xmin, int32_t* cnt, int32_t* weights, int ksize_cap) {

@@ -133,4 +133,45 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
     }
 }
 
+// ---- the fine-tune path's transform (finetune_module/clip_multiscale_adapter.py:120-132) --------------------------------
+// x.float() -> torchvision resize on a tensor = bilinear, align_corners = False, no antialias (only when BOTH sides
+// differ from 224, :127) -> x / 255 -> (x - mean) / std.  Same arithmetic order as torch's upsample_bilinear2d:
+// src = (dst + 0.5) * in/out - 0.5 clamped at 0;  v = h0 (w0 v00 + w1 v01) + h1 (w0 v10 + w1 v11).
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_bilinear_kernel(const uint8_t* __restrict__ frames, T* __restrict__ out, int n, int H, int W, int R,
+                                                                  int P, int resize) {
+    const int G = R / P;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // one thread = 4 consecutive ox
+    const size_t total = (size_t)n * 3 * R * (R / 4);
+    if (i >= total) return;
+    const int ox4 = (int)(i % (R / 4));
+    const int oy = (int)((i / (R / 4)) % R);
+    const int c = (int)((i / ((size_t)(R / 4) * R)) % 3);
+    const int frame = (int)(i / ((size_t)(R / 4) * R * 3));
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f}, stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    const uint8_t* f = frames + (size_t)frame * H * W * 3;
+    float v[4];
+    const float sy = (float)H / (float)R, sx = (float)W / (float)R;
+    float fy = resize ? ((float)oy + 0.5f) * sy - 0.5f : (float)oy;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = (int)fy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    const float h1 = fy - (float)y0, h0 = 1.f - h1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ox = ox4 * 4 + k;
+        float fx = resize ? ((float)ox + 0.5f) * sx - 0.5f : (float)ox;
+        fx = fx < 0.f ? 0.f : fx;
+        const int x0 = (int)fx, x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float w1 = fx - (float)x0, w0 = 1.f - w1;
+        const float v00 = f[((size_t)y0 * W + x0) * 3 + c], v01 = f[((size_t)y0 * W + x1) * 3 + c];
+        const float v10 = f[((size_t)y1 * W + x0) * 3 + c], v11 = f[((size_t)y1 * W + x1) * 3 + c];
+        const float px = resize ? h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11) : v00;
+        v[k] = (px / 255.0f - mean[c]) / stdv[c];
+    }
+    const int ox = ox4 * 4;
+    const size_t prow = ((size_t)frame * G + oy / P) * G + ox / P;
+    const int kidx = c * P * P + (oy % P) * P + (ox % P);
+    store4(out + prow * (size_t)(3 * P * P) + kidx, v[0], v[1], v[2], v[3]);
+}
+
 }  // namespace arp

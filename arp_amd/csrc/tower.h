@@ -101,7 +101,29 @@ struct TowerCtx {
     Profiler* prof = nullptr;
     int attn_impl = 0;   // 0 = MFMA attention where available, 1 = VALU kernel
     int gemm_force = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel
+    // multi-scale export: after every block, one row per sample of the residual stream -- what the forward
+    // hooks of finetune_module/utils.py:6-18 capture on each resblock output -- is copied to ms_out[b, layer*D ..]
+    float* ms_out = nullptr;
+    int ms_ld = 0;
+    const int* ms_rows = nullptr;  // absolute row per sample (text: the EOT token); null = row b*N (the CLS token)
 };
+
+// out[b, col0 + d] = x[row(b), d]
+static __global__ __launch_bounds__(256) void rows_gather_kernel(const float* __restrict__ x, int D, const int* __restrict__ rows, int row_stride,
+                                                                 float* __restrict__ out, int ld, int col0, int B) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * D) return;
+    const int b = (int)(i / D), d = (int)(i - (size_t)b * D);
+    const size_t row = rows ? (size_t)rows[b] : (size_t)b * row_stride;
+    out[(size_t)b * ld + col0 + d] = x[row * D + d];
+}
+static int tower_export_rows(TowerCtx& c, const float* x, int D, int layer, int B, int N) {
+    if (!c.ms_out) return 0;
+    hipLaunchKernelGGL(rows_gather_kernel, dim3((unsigned)(((size_t)B * D + 255) / 256)), dim3(256), 0, c.stream, x, D, c.ms_rows, N, c.ms_out, c.ms_ld,
+                       layer * D, B);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
 
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
 static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* W, const float* bias, const float* resid, void* out,
@@ -214,6 +236,7 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
             cons.c = L.c_fc;
             ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc1.c_str(), h, L.w_fc_f, L.d_fc, nullptr, fc, M, 4 * D, D, &cons)));
             ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_FC2>(c, s_fc2.c_str(), fc, L.w_proj, L.b_proj, x, x, M, D, 4 * D, &prod)));
+            ARP_TRY(tower_export_rows(c, x, D, i, B, N));
         }
         return 0;
     }
@@ -229,6 +252,7 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
         ARP_TRY(tower_layernorm<T>(c, s_ln2.c_str(), x, D, h, D, L.ln2_w, L.ln2_b, M, D, eps));
         ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc1.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, M, 4 * D, D)));
         ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_FC2>(c, s_fc2.c_str(), fc, L.w_proj, L.b_proj, x, x, M, D, 4 * D)));
+        ARP_TRY(tower_export_rows(c, x, D, i, B, N));
     }
     return 0;
 }

@@ -200,6 +200,14 @@ typedef struct arp_ft_cfg {
     float weight_decay; /* AdamW decoupled decay, finetune.py:31 (0.001) */
     float b1, b2, eps;  /* 0.9, 0.999, 1e-8 */
 } arp_ft_cfg;
+/* The frozen towers' side of the step, on an arp_clip handle (ViT-B/16 in the reference, :118): per-block CLS / EOT
+ * features and the un-normalised CLIP features.  Image frames go through the fine-tune transform of :120-132 (float,
+ * bilinear resize to 224 when both sides differ, /255, normalise) -- NOT the PIL-bicubic one of label_reward.py; the
+ * random ColorJitter of training (:24-36) belongs to the data pipeline and is not applied. */
+int arp_clip_encode_image_multiscale(arp_clip* h, const uint8_t* frames_nhwc, int n, int H, int W,
+                                     float* inter /* [n, layers*width] */, float* final_feat /* [n, embed] */);
+int arp_clip_encode_text_multiscale(arp_clip* h, const int32_t* tokens /* [n, ctx] */, int n,
+                                    float* inter /* [n, txt_layers*txt_width] */, float* final_feat /* [n, embed] */);
 int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out);
 int arp_ft_destroy(arp_ft* h);
 int arp_ft_num_params(arp_ft* h, int64_t* total, int32_t* n_tensors);

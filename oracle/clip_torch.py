@@ -57,6 +57,49 @@ def to_torch(W):
     return {k: torch.from_numpy(np.asarray(v, dtype=np.float32)) for k, v in W.items()}
 
 
+def finetune_transform(frames_u8, n_px=224):
+    """finetune_module/clip_multiscale_adapter.py:120-132 without the random ColorJitter: float, torchvision tensor resize
+    (= bilinear, align_corners False, no antialias; only when BOTH sides differ from 224), / 255, normalise."""
+    x = torch.from_numpy(np.asarray(frames_u8)).permute(0, 3, 1, 2).float()
+    if x.shape[2] != n_px and x.shape[3] != n_px:
+        x = F.interpolate(x, size=(n_px, n_px), mode="bilinear", align_corners=False)
+    x = x / 255.0
+    return (x - MEAN.view(1, 3, 1, 1)) / STD.view(1, 3, 1, 1)
+
+
+@torch.no_grad()
+def encode_image_multiscale(W, cfg, x):
+    """CLIP image feature plus the CLS token after every resblock, concatenated block 0..L-1 -- what the reference's forward
+    hooks collect (finetune_module/utils.py:6-18, clip_multiscale_adapter.py:137-142)."""
+    d = cfg.width
+    x = F.conv2d(x, W["visual.conv1.weight"], stride=cfg.patch)
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([W["visual.class_embedding"].expand(x.shape[0], 1, d), x], 1) + W["visual.positional_embedding"]
+    x = F.layer_norm(x, (d,), W["visual.ln_pre.weight"], W["visual.ln_pre.bias"], 1e-5)
+    inter = []
+    for i in range(cfg.layers):
+        x = _block(x, W, f"visual.transformer.resblocks.{i}.", cfg.heads, None)
+        inter.append(x[:, 0])
+    c = F.layer_norm(x[:, 0], (d,), W["visual.ln_post.weight"], W["visual.ln_post.bias"], 1e-5)
+    return torch.cat(inter, -1), c @ W["visual.proj"]
+
+
+@torch.no_grad()
+def encode_text_multiscale(W, cfg, tokens):
+    """Text feature plus the EOT-token row after every resblock (clip_multiscale_adapter.py:160-165)."""
+    tokens = torch.as_tensor(np.asarray(tokens), dtype=torch.long)
+    x = W["token_embedding.weight"][tokens] + W["positional_embedding"]
+    t = x.shape[1]
+    mask = torch.full((t, t), float("-inf")).triu_(1)
+    rows, eot = torch.arange(x.shape[0]), tokens.argmax(-1)
+    inter = []
+    for i in range(cfg.txt_layers):
+        x = _block(x, W, f"transformer.resblocks.{i}.", cfg.txt_heads, mask)
+        inter.append(x[rows, eot])
+    x = F.layer_norm(x, (cfg.txt_width,), W["ln_final.weight"], W["ln_final.bias"], 1e-5)
+    return torch.cat(inter, -1), x[rows, eot] @ W["text_projection"]
+
+
 @torch.no_grad()
 def encode_image(W, cfg, x):
     d = cfg.width

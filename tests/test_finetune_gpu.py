@@ -119,3 +119,82 @@ def test_error_paths(gpu_lib):
     with pytest.raises(ArpError, match="multiples of"):
         FT.FinetuneTrainer(FT.FinetuneConfig(layers=2, width_v=48, width_t=64, embed=64, hidden=64), mode="bf16")
     tr.close()
+
+
+# ---- the frozen towers' side: per-block CLS / EOT features through the C ABI -----------------------------------------
+TOWER = dict(patch=32, width=64, layers=2, heads=2, embed=64, img_res=224, txt_width=64, txt_layers=2, txt_heads=2, ctx=77, vocab=512)
+
+
+@pytest.mark.parametrize("hw", [(256, 256), (224, 224), (64, 96)])
+def test_multiscale_tower_features_match_oracle(gpu_lib, hw):
+    import torch
+    from arp_amd import clip, synth
+    from oracle import clip_np as C, clip_torch as CT
+    ocfg = C.ClipConfig(**TOWER)
+    W = synth.clip_weights(ocfg, seed=41)
+    fr = synth.procgen_like_frames(3, hw[0], hw[1], seed=42)
+    tok = synth.prompt_tokens(3, [7, 3, 5], ctx=ocfg.ctx, vocab=ocfg.vocab, seed=43)
+    Wt = CT.to_torch(W)
+    ref_ii, ref_if = CT.encode_image_multiscale(Wt, ocfg, CT.finetune_transform(fr))
+    ref_ti, ref_tf = CT.encode_text_multiscale(Wt, ocfg, tok)
+    m = clip.ClipLabeller(clip.ClipConfig(**TOWER), W, mode="f32")
+    ii, fi = m.encode_image_multiscale(fr)
+    ti, tf = m.encode_text_multiscale(tok)
+    for got, ref, name in ((ii, ref_ii, "image inter"), (fi, ref_if, "image final"), (ti, ref_ti, "text inter"), (tf, ref_tf, "text final")):
+        err = np.abs(got - ref.numpy()).max() / max(np.abs(ref.numpy()).max(), 1e-6)
+        assert err < 2e-4, (name, err)
+    # the multi-scale text call must leave the cached prompt set of set_text alone
+    m.set_text(tok[:1])
+    before = m.text_features().copy()
+    m.encode_text_multiscale(tok)
+    assert np.array_equal(before, m.text_features())
+    m.close()
+
+
+def test_one_side_at_224_is_rejected(gpu_lib):
+    from arp_amd import clip, synth
+    from arp_amd._ffi import ArpError
+    from oracle import clip_np as C
+    m = clip.ClipLabeller(clip.ClipConfig(**TOWER), synth.clip_weights(C.ClipConfig(**TOWER), seed=1), mode="f32")
+    with pytest.raises(ArpError, match="BOTH sides"):
+        m.encode_image_multiscale(synth.procgen_like_frames(1, 224, 256, seed=2))
+    m.close()
+
+
+def test_frames_to_loss_end_to_end(gpu_lib):
+    """uint8 frames + tokens -> towers (multi-scale export) -> head loss and gradients, against the oracle run on the oracle's
+    own tower features: the composition CLIPMultiscaleAdapter.forward performs (clip_multiscale_adapter.py:177-250)."""
+    import torch
+    from arp_amd import clip, synth
+    from arp_amd import finetune as FT
+    from oracle import clip_np as C, clip_torch as CT, finetune_torch as O
+    ocfg = C.ClipConfig(**TOWER)
+    W = synth.clip_weights(ocfg, seed=51)
+    B = 4
+    frames = [synth.procgen_like_frames(B, 256, 256, seed=52 + k) for k in range(3)]
+    tok = synth.prompt_tokens(B, [7, 3, 5, 4], ctx=ocfg.ctx, vocab=ocfg.vocab, seed=60)
+    hcfg = O.HeadConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64)
+    P = O.init_params(hcfg, seed=61)
+    rng = np.random.Generator(np.random.PCG64(62))
+    r, action = rng.integers(0, 2, B).astype(np.float32), rng.integers(0, 15, B).astype(np.int32)
+    Wt = CT.to_torch(W)
+    oi = [CT.encode_image_multiscale(Wt, ocfg, CT.finetune_transform(f)) for f in frames]
+    ot = CT.encode_text_multiscale(Wt, ocfg, tok)
+    obatch = (np.stack([x[0].numpy() for x in oi]), np.stack([x[1].numpy() for x in oi]), ot[0].numpy(), ot[1].numpy(), r, action)
+    g_ref, aux = O.grads(P, hcfg, obatch)
+
+    m = clip.ClipLabeller(clip.ClipConfig(**TOWER), W, mode="f32")
+    gi = [m.encode_image_multiscale(f) for f in frames]
+    gt = m.encode_text_multiscale(tok)
+    tr = FT.FinetuneTrainer(FT.FinetuneConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64, logit_scale=hcfg.logit_scale), mode="f32")
+    tr.set_params(P)
+    tr.set_batch(np.stack([x[0] for x in gi]), np.stack([x[1] for x in gi]), gt[0], gt[1], r, action)
+    out = tr.forward()
+    assert abs(out["loss"] - aux["loss"]) < 2e-3, (out["loss"], aux["loss"])
+    tr.backward()
+    g = tr.get_grads()
+    bad = {k: float(np.abs(g[k] - g_ref[k]).max() / max(np.abs(g_ref[k]).max(), 1e-6)) for k in g_ref}
+    bad = {k: v for k, v in bad.items() if not v < 5e-3}
+    assert not bad, bad
+    tr.close()
+    m.close()
