@@ -156,15 +156,36 @@ def bench_finetune(a):
     cfg = FT.FinetuneConfig()
     tr = FT.FinetuneTrainer(cfg, mode=a.mode, device=0)
     tr.set_params(FT.synth_params(cfg, seed=0))
-    tr.set_batch(*FT.synth_batch(cfg, a.finetune_batch, seed=100))
+    B = a.finetune_batch
     lr = 1e-4
+    towers = None
+    if a.with_towers:
+        # frames in: the frozen CLIP ViT-B/16 towers (random init) produce the per-block CLS / EOT features every step;
+        # the features cross to the head through host memory (9.5 MB per step)
+        from arp_amd import clip, synth
+        ccfg = clip.MODELS["ViT-B/16"]
+        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=0, max_batch=B)
+        frames = [synth.procgen_like_frames(B, seed=200 + k) for k in range(3)]
+        tokens = synth.prompt_tokens(B, [8] * B, seed=203)
+        rb = FT.synth_batch(cfg, B, seed=100)
+
+        def step():
+            fi = [towers.encode_image_multiscale(f) for f in frames]
+            ti = towers.encode_text_multiscale(tokens)
+            tr.set_batch(np.stack([x[0] for x in fi]), np.stack([x[1] for x in fi]), ti[0], ti[1], rb[4], rb[5])
+            tr.train_step_async(lr)
+    else:
+        tr.set_batch(*FT.synth_batch(cfg, B, seed=100))
+
+        def step():
+            tr.train_step_async(lr)
     for _ in range(a.warmup):
-        tr.train_step_async(lr)
+        step()
     tr.sync()
     _ffi.check(_ffi.lib.arp_dev_synchronize())
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tr.train_step_async(lr)
+        step()
     tr.sync()
     _ffi.check(_ffi.lib.arp_dev_synchronize())
     elapsed = time.perf_counter() - t0
@@ -181,7 +202,8 @@ def bench_finetune(a):
     avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
     flops = FT.flops_per_sample(cfg) * a.finetune_batch
     print(json.dumps({
-        "metric": "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": a.finetune_batch * a.steps / elapsed,
+        "metric": "samples/sec CLIP multi-scale adapter fine-tune step (frames in: frozen ViT-B/16 towers + head)" if towers is not None else
+                  "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": a.finetune_batch * a.steps / elapsed,
         "unit": "samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
         "config": {"workload": f"CLIPMultiscaleAdapter head train step, {a.finetune_batch} samples x 3 frames, ViT-B/16-shaped tower features "
@@ -212,6 +234,8 @@ def main():
                     help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary); "
                          "finetune = CLIP multi-scale adapter head step (configs[4], secondary)")
     ap.add_argument("--finetune-batch", type=int, default=64, help="samples per step (finetune.py:25)")
+    ap.add_argument("--with-towers", action="store_true", help="finetune path: run the frozen CLIP ViT-B/16 towers inside the timed step "
+                    "(uint8 frames + tokens in) instead of feeding pre-computed tower features")
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
