@@ -126,6 +126,7 @@ SIGNATURES = {
     "arp_ft_get_step": (_i, [_vp, _i64p]),
     "arp_ft_set_batch": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i32p, _i]),
     "arp_ft_forward": (_i, [_vp, _fp, _fp, _fp]),
+    "arp_ft_encode": (_i, [_vp, _i, _fp, _fp, _i, _fp]),
     "arp_ft_backward": (_i, [_vp]),
     "arp_ft_train_step": (_i, [_vp, C.c_float, _fp]),
     "arp_ft_train_step_async": (_i, [_vp, C.c_float]),

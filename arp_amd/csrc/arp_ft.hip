@@ -216,31 +216,39 @@ int ensure_buffers(arp_ft* c, int B) {
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------
+// One tower's head: tower features (c->x_in[w], c->x_fin[w], M rows) -> adapted, normalised features c->a[w]
+// (clip_multiscale_adapter.py:134-149 / :151-175), leaving every activation the backward needs.
+template <typename T> int encode_tower(arp_ft* c, int w, int M) {
+    const arp_ft_cfg& k = c->cfg;
+    const int F = c->F(), Hd = c->Hd(), E = k.embed, Dt = c->Dt();
+    const int Mp = (M + 63) / 64 * 64, Din = w == 0 ? c->Dv() : Dt;
+    const std::string a = std::string(TW[w]) + "_adapter", pre = std::string("ft.") + TW[w];
+    // frozen-tower features -> operand type, both layouts (the transposed one feeds dWint)
+    ARP_TRY((ft_transpose<float, float, T>(c, c->x_in[w].as<float>(), Din, nullptr, c->X[w].as<T>(), Din, c->XT[w].as<T>(), Mp, M, Din)));
+    // f = [X Wint^T | final]   (:141-143 / :164-166)
+    ARP_TRY((ft_gemm<T, float>(c, (pre + "_inter").c_str(), c->X[w].p, Din, fwd_w<T>(c, c->sWint[w], std::string(TW[w]) + "_intermediate_linear.weight"), Din,
+                               nullptr, ACT_NONE, nullptr, c->f[w].as<float>(), F, M, Dt, Din)));
+    hipLaunchKernelGGL(ft_copy_cols_kernel, dim3(cdiv((size_t)M * E, 256)), dim3(256), 0, c->stream, c->x_fin[w].as<float>(), E, c->f[w].as<float>(), F,
+                       Dt, M);
+    ARP_TRY((ft_transpose<float, float, T>(c, c->f[w].as<float>(), F, nullptr, c->fT_[w].as<T>(), F, c->fTt[w].as<T>(), Mp, M, F)));
+    // AdapterMLP (layers.py:43-60 with num_layers = 2): Linear -> ReLU -> Linear
+    ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc1").c_str(), c->fT_[w].p, F, fwd_w<T>(c, c->sW1[w], a + ".layers.0.weight"), F, c->p(a + ".layers.0.bias"), ACT_RELU,
+                           nullptr, c->H[w].as<T>(), Hd, M, Hd, F)));
+    ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc2").c_str(), c->H[w].p, Hd, fwd_w<T>(c, c->sW2[w], a + ".layers.3.weight"), Hd, c->p(a + ".layers.3.bias"),
+                               ACT_NONE, nullptr, c->A[w].as<float>(), F, M, F, Hd)));
+    ProfScope ps(c->prof, c->stream, "ft.rowops");
+    hipLaunchKernelGGL(ft_mix_norm_fwd_kernel, dim3(M), dim3(256), 0, c->stream, c->f[w].as<float>(), c->A[w].as<float>(),
+                       c->p(std::string(TW[w]) + "_residual_weight"), c->a[w].as<float>(), c->nrm[w].as<float>(), F);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
 template <typename T> int forward(arp_ft* c) {
     const arp_ft_cfg& k = c->cfg;
-    const int B = c->B, F = c->F(), Hd = c->Hd(), Hi = k.hidden, NA = k.n_actions, E = k.embed, Dt = c->Dt();
+    const int B = c->B, F = c->F(), Hi = k.hidden, NA = k.n_actions;
     ARP_TRY(refresh_shadows<T>(c));
-    for (int w = 0; w < 2; ++w) {
-        const int M = w == 0 ? 3 * B : B, Mp = (M + 63) / 64 * 64, Din = w == 0 ? c->Dv() : Dt;
-        const std::string a = std::string(TW[w]) + "_adapter", pre = std::string("ft.") + TW[w];
-        // frozen-tower features -> operand type, both layouts (the transposed one feeds dWint)
-        ARP_TRY((ft_transpose<float, float, T>(c, c->x_in[w].as<float>(), Din, nullptr, c->X[w].as<T>(), Din, c->XT[w].as<T>(), Mp, M, Din)));
-        // f = [X Wint^T | final]   (:141-143 / :164-166)
-        ARP_TRY((ft_gemm<T, float>(c, (pre + "_inter").c_str(), c->X[w].p, Din, fwd_w<T>(c, c->sWint[w], std::string(TW[w]) + "_intermediate_linear.weight"), Din,
-                                   nullptr, ACT_NONE, nullptr, c->f[w].as<float>(), F, M, Dt, Din)));
-        hipLaunchKernelGGL(ft_copy_cols_kernel, dim3(cdiv((size_t)M * E, 256)), dim3(256), 0, c->stream, c->x_fin[w].as<float>(), E, c->f[w].as<float>(), F,
-                           Dt, M);
-        ARP_TRY((ft_transpose<float, float, T>(c, c->f[w].as<float>(), F, nullptr, c->fT_[w].as<T>(), F, c->fTt[w].as<T>(), Mp, M, F)));
-        // AdapterMLP (layers.py:43-60 with num_layers = 2): Linear -> ReLU -> Linear
-        ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc1").c_str(), c->fT_[w].p, F, fwd_w<T>(c, c->sW1[w], a + ".layers.0.weight"), F, c->p(a + ".layers.0.bias"), ACT_RELU,
-                               nullptr, c->H[w].as<T>(), Hd, M, Hd, F)));
-        ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc2").c_str(), c->H[w].p, Hd, fwd_w<T>(c, c->sW2[w], a + ".layers.3.weight"), Hd, c->p(a + ".layers.3.bias"),
-                                   ACT_NONE, nullptr, c->A[w].as<float>(), F, M, F, Hd)));
-        ProfScope ps(c->prof, c->stream, "ft.rowops");
-        hipLaunchKernelGGL(ft_mix_norm_fwd_kernel, dim3(M), dim3(256), 0, c->stream, c->f[w].as<float>(), c->A[w].as<float>(),
-                           c->p(std::string(TW[w]) + "_residual_weight"), c->a[w].as<float>(), c->nrm[w].as<float>(), F);
-        ARP_HIP_OK(hipGetLastError());
-    }
+    ARP_TRY(encode_tower<T>(c, 0, 3 * B));
+    ARP_TRY(encode_tower<T>(c, 1, B));
     {
         ProfScope ps(c->prof, c->stream, "ft.rowops");
         hipLaunchKernelGGL(ft_scores_kernel, dim3(3 * B), dim3(256), 0, c->stream, c->a[0].as<float>(), c->a[1].as<float>(), expf(k.logit_scale),
@@ -488,6 +496,24 @@ int arp_ft_forward(arp_ft* c, float* metrics4, float* scores, float* logits) {
     if (metrics4) ARP_HIP_OK(hipMemcpyAsync(metrics4, c->metrics.p, 16, hipMemcpyDeviceToHost, c->stream));
     if (scores) ARP_HIP_OK(hipMemcpyAsync(scores, c->scores.p, (size_t)3 * c->B * 4, hipMemcpyDeviceToHost, c->stream));
     if (logits) ARP_HIP_OK(hipMemcpyAsync(logits, c->logits.p, (size_t)c->B * c->cfg.n_actions * 4, hipMemcpyDeviceToHost, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Inference half of one tower's head (model.encode_image / model.encode_text of the clip_ft labelling branch,
+// arp_dt/label_reward.py:165-230): tower features [n, .] -> adapted, L2-normalised features [n, F].  Reuses the step's
+// workspaces, so a batch staged with arp_ft_set_batch must be staged again afterwards.
+int arp_ft_encode(arp_ft* c, int which, const float* inter, const float* final_feat, int n, float* out) {
+    if (!c || !inter || !final_feat || !out || n <= 0 || which < 0 || which > 1) return fail("bad argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(ensure_buffers(c, which == 0 ? (n + 2) / 3 : n));
+    c->B = 0;  // the staged batch (if any) is gone
+    const size_t Din = which == 0 ? c->Dv() : c->Dt();
+    ARP_HIP_OK(hipMemcpyAsync(c->x_in[which].p, inter, (size_t)n * Din * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[which].p, final_feat, (size_t)n * c->cfg.embed * 4, hipMemcpyHostToDevice, c->stream));
+    if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(refresh_shadows<bf16_t>(c)); ARP_TRY(encode_tower<bf16_t>(c, which, n)); }
+    else { ARP_TRY(refresh_shadows<float>(c)); ARP_TRY(encode_tower<float>(c, which, n)); }
+    ARP_HIP_OK(hipMemcpyAsync(out, c->a[which].p, (size_t)n * c->F() * 4, hipMemcpyDeviceToHost, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
 }

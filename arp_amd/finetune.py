@@ -152,6 +152,26 @@ class FinetuneTrainer:
         check(lib.arp_ft_forward(self._h, _ffi.as_ptr(m, C.c_float), _ffi.as_ptr(s, C.c_float), _ffi.as_ptr(lg, C.c_float)))
         return {"loss": float(m[0]), "vip_loss": float(m[1]), "id_loss": float(m[2]), "lambda_id": float(m[3]), "scores": s, "logits": lg}
 
+    def _encode(self, which, inter, final):
+        f32 = lambda x: np.require(np.asarray(x, dtype=np.float32), requirements="C")
+        inter, final = f32(inter), f32(final)
+        n = inter.shape[0]
+        din = self.cfg.d_img if which == 0 else self.cfg.d_txt
+        if inter.shape != (n, din) or final.shape != (n, self.cfg.embed):
+            raise ValueError(f"feature shapes: {inter.shape} {final.shape}")
+        out = np.empty((n, self.cfg.feat), np.float32)
+        check(lib.arp_ft_encode(self._h, which, _ffi.as_ptr(inter, C.c_float), _ffi.as_ptr(final, C.c_float), n, _ffi.as_ptr(out, C.c_float)))
+        self._B = 0
+        return out
+
+    def encode_image(self, inter, final):
+        """CLIPMultiscaleAdapter.encode_image after the towers (clip_multiscale_adapter.py:141-149): adapted, normalised."""
+        return self._encode(0, inter, final)
+
+    def encode_text(self, inter, final):
+        """CLIPMultiscaleAdapter.encode_text after the towers (:164-171) for [n, ctx] prompts."""
+        return self._encode(1, inter, final)
+
     def backward(self):
         check(lib.arp_ft_backward(self._h))
 
@@ -180,6 +200,49 @@ class FinetuneTrainer:
         buf = C.create_string_buffer(1 << 16)
         check(lib.arp_ft_profile_json(self._h, buf, len(buf)))
         return json.loads(buf.value.decode())
+
+
+class FinetunedClip:
+    """``model = CLIPMultiscaleAdapter(...); model.load_state_dict(ckpt)`` of the ``clip_ft`` labelling branch
+    (arp_dt/label_reward.py:166-177): frozen towers (``arp_amd.clip.ClipLabeller``) + trained head on one GPU."""
+
+    def __init__(self, towers, head):
+        self.towers, self.head = towers, head
+        self._text = None
+
+    @classmethod
+    def from_state_dict(cls, state_dict, mode="bf16", device=0, model="ViT-B/16", logit_scale=None):
+        """state_dict: the reference checkpoint's tensors as numpy (``clip_model.*`` = the CLIP weights, the rest = the head)."""
+        from . import clip as aclip
+        sd = {k: np.asarray(v) for k, v in state_dict.items()}
+        cw = {k[len("clip_model."):]: v for k, v in sd.items() if k.startswith("clip_model.")}
+        ccfg = aclip.MODELS[model] if isinstance(model, str) else model
+        towers = aclip.ClipLabeller(ccfg, cw, mode=mode, device=device)
+        ls = float(cw["logit_scale"]) if logit_scale is None else float(logit_scale)  # model.logit_scale = clip's, detached (:95)
+        hidden = sd["inverse_layer.layers.0.weight"].shape[0]
+        head = FinetuneTrainer(FinetuneConfig(layers=ccfg.layers, width_v=ccfg.width, width_t=ccfg.txt_width, embed=ccfg.embed, hidden=hidden,
+                                              n_actions=sd["inverse_layer.layers.3.weight"].shape[0], logit_scale=ls), mode=mode, device=device)
+        head.load_state_dict({k: v for k, v in sd.items() if not k.startswith("clip_model.")})
+        return cls(towers, head)
+
+    def set_text(self, tokens):
+        self._text = self.head.encode_text(*self.towers.encode_text_multiscale(tokens))
+        return self
+
+    def label(self, images, use_crop=False):
+        """compute_reward of the clip_ft branch (label_reward.py:197-228): exp(logit_scale) * <adapted image, adapted prompt 0>."""
+        images = np.asarray(images)
+        if use_crop:  # center_crop(images, (image_size // 2,) * 2), image_size = the frame WIDTH (label_reward.py:15-36,104,203)
+            h, w = images.shape[1:3]
+            cs = w // 2
+            sh, sw = int((h - cs) / 2), int((w - cs) / 2)
+            images = images[:, sh: sh + cs, sw: sw + cs]
+        a = self.head.encode_image(*self.towers.encode_image_multiscale(np.ascontiguousarray(images)))
+        return (np.exp(self.head.cfg.logit_scale) * (a @ self._text[0])).astype(np.float32)
+
+    def close(self):
+        self.head.close()
+        self.towers.close()
 
 
 def flops_per_sample(cfg):

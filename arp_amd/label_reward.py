@@ -98,6 +98,13 @@ def make_compute_reward(model_type="clip"):
             f = clip_model.encode_image(images, use_crop=use_crop, normalize=False)
             return -1 * np.linalg.norm(f - f[-1], ord=2, axis=1).astype(np.float64)
 
+    elif model_type == "clip_ft":
+
+        def compute_reward(clip_model, images, text=None, use_crop=False):
+            # clip_model: arp_amd.finetune.FinetunedClip (towers + fine-tuned head, prompt cached by set_text);
+            # label_reward.py:197-228 with a tokenised (tensor) prompt -> logit[0]
+            return clip_model.label(images, use_crop=use_crop)
+
     else:
         raise NotImplementedError(f"model_type {model_type!r} is outside the MI355X hot path (SURVEY.md section 8a, L12)")
     return compute_reward
@@ -217,8 +224,12 @@ def label_reward(
         if weights is None:
             raise ValueError("no pretrained CLIP checkpoint is reachable offline: pass weights=<openai/CLIP state dict> "
                              "or clip_model=<ClipLabeller>")
-        clip_model = ClipLabeller(MODELS[model_name], weights, mode=mode, device=device)
-    if model_type == "clip":
+        if model_type == "clip_ft":  # weights = the fine-tune checkpoint (clip_model.* + head), label_reward.py:166-177
+            from .finetune import FinetunedClip
+            clip_model = FinetunedClip.from_state_dict(weights, mode=mode, device=device, model=model_name)
+        else:
+            clip_model = ClipLabeller(MODELS[model_name], weights, mode=mode, device=device)
+    if model_type in ("clip", "clip_ft"):
         if tokens is None:
             if tokenizer is None:
                 raise ValueError("no BPE vocabulary offline: pass tokens=<int32 [1,77]> or tokenizer=<callable>")

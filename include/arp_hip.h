@@ -224,6 +224,10 @@ int arp_ft_set_batch(arp_ft* h, const float* img_inter, const float* img_final, 
                      const float* r, const int32_t* action, int B);
 /* metrics4: loss, vip_loss, id_loss, lambda_id.  scores [3, B] and logits [B, n_actions] may be NULL. */
 int arp_ft_forward(arp_ft* h, float* metrics4, float* scores, float* logits);
+/* Inference half of one tower's head -- model.encode_image (which = 0) / model.encode_text (which = 1) as the clip_ft
+ * labelling branch calls them (arp_dt/label_reward.py:165-230): tower features [n, layers*width] + [n, embed] -> adapted,
+ * L2-normalised features [n, layers*width_t + embed].  Drops a batch staged with arp_ft_set_batch. */
+int arp_ft_encode(arp_ft* h, int which, const float* inter, const float* final_feat, int n, float* out);
 int arp_ft_backward(arp_ft* h);                        /* forward + backward: fills every gradient */
 int arp_ft_train_step(arp_ft* h, float lr, float* aux4); /* forward + backward + AdamW; aux4 as metrics4 (pre-update) */
 int arp_ft_train_step_async(arp_ft* h, float lr);

@@ -198,3 +198,47 @@ def test_frames_to_loss_end_to_end(gpu_lib):
     assert not bad, bad
     tr.close()
     m.close()
+
+
+@pytest.mark.parametrize("use_crop", [False, True])
+def test_clip_ft_labelling_branch(gpu_lib, use_crop):
+    """label_reward(model_type="clip_ft") (arp_dt/label_reward.py:165-230): towers + fine-tuned head -> reward, rtg datasets."""
+    import torch
+    from arp_amd import label_reward as LR, synth
+    from arp_amd import finetune as FT
+    from oracle import clip_np as C, clip_torch as CT, finetune_torch as O, rtg as R
+    ocfg = C.ClipConfig(**TOWER)
+    W = synth.clip_weights(ocfg, seed=71)
+    hcfg = O.HeadConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64, logit_scale=float(W["logit_scale"]))
+    P = O.init_params(hcfg, seed=72)
+    P["image_residual_weight"] = np.float32(0.5) * np.ones((), np.float32)
+    P["text_residual_weight"] = np.float32(-0.2) * np.ones((), np.float32)
+    lens = [5, 3]
+    frames = synth.procgen_like_frames(sum(lens), 256, 256, seed=73)
+    tok = synth.prompt_tokens(1, 6, ctx=ocfg.ctx, vocab=ocfg.vocab, seed=74)
+    # oracle reward per frame
+    Wt = CT.to_torch(W)
+    fr = frames[:, 64:192, 64:192] if use_crop else frames
+    ii, fi = CT.encode_image_multiscale(Wt, ocfg, CT.finetune_transform(fr))
+    ti, tf = CT.encode_text_multiscale(Wt, ocfg, tok)
+    Pt = O.to_torch(P)
+    a = O._encode(Pt, "image", ii.double(), fi.double())
+    t = O._encode(Pt, "text", ti.double(), tf.double())
+    ref = (np.exp(hcfg.logit_scale) * (a @ t[0])).numpy()
+
+    nf = 4
+    done = np.zeros((sum(lens), nf), bool)
+    done[lens[0] - 1, -1] = done[-1, -1] = True
+    store = {"ob": np.repeat(frames[:, None], nf, axis=1), "done": done}
+    ckpt = {**{"clip_model." + k: v for k, v in W.items()}, **P}
+    LR.label_reward("coinrun", "hard", 500, 0, "collect the coin", "/nonexistent", image_keys="ob", num_frames=nf, env_type="none",
+                    model_type="clip_ft", use_crop=use_crop, store=store, weights=ckpt, tokens=tok, model_name=FT_TOWER_CFG(), mode="f32")
+    got = store["ob_clip_ft_reward"][:, -1]
+    assert np.abs(got - ref).max() < 2e-3 * max(1.0, np.abs(ref).max()), (got, ref)
+    exp_rtg = np.concatenate([R.discount_cumsum(ref[:5]), R.discount_cumsum(ref[5:])])
+    assert np.abs(store["ob_clip_ft_pos_rtg"][:, -1] - exp_rtg).max() < 1e-2
+
+
+def FT_TOWER_CFG():
+    from arp_amd import clip
+    return clip.ClipConfig(**TOWER)
