@@ -164,15 +164,15 @@ def bench_finetune(a):
         # the features cross to the head through host memory (9.5 MB per step)
         from arp_amd import clip, synth
         ccfg = clip.MODELS["ViT-B/16"]
-        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=0, max_batch=B)
-        frames = [synth.procgen_like_frames(B, seed=200 + k) for k in range(3)]
+        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=0, max_batch=3 * B)
+        frames = np.concatenate([synth.procgen_like_frames(B, seed=200 + k) for k in range(3)])  # image0 | image1 | image2
         tokens = synth.prompt_tokens(B, [8] * B, seed=203)
         rb = FT.synth_batch(cfg, B, seed=100)
 
         def step():
-            fi = [towers.encode_image_multiscale(f) for f in frames]
+            ii, fi = towers.encode_image_multiscale(frames)  # one 3B-frame pass through the image tower
             ti = towers.encode_text_multiscale(tokens)
-            tr.set_batch(np.stack([x[0] for x in fi]), np.stack([x[1] for x in fi]), ti[0], ti[1], rb[4], rb[5])
+            tr.set_batch(ii.reshape(3, B, -1), fi.reshape(3, B, -1), ti[0], ti[1], rb[4], rb[5])
             tr.train_step_async(lr)
     else:
         tr.set_batch(*FT.synth_batch(cfg, B, seed=100))
