@@ -52,11 +52,13 @@ struct arp_ft {
     size_t P = 0;
     DevBuf params, grads, mu, nu;
     long long step = 0;
-    bool shadows_stale = true;
+    bool shadows_stale = true;   // the host wrote parameters: rebuild the bf16 mirror from f32
+    bool transposed_stale = true; // parameters moved (host write or AdamW): rebuild the transposed shadows
     int B = 0;
     // operand-type weight shadows: forward layout [out, in] (aliases the f32 parameters in f32 mode) and, where the
     // backward needs dX, the transposed layout [in, out]
-    DevBuf sWint[2], sW1[2], sW2[2], sW1t[2], sW2t[2], sV1, sV1t;
+    DevBuf mirror;  // bf16 mode: bf16 copy of the flat parameter vector (same offsets) = every forward-layout operand
+    DevBuf sW1t[2], sW2t[2], sV1t;
     // inputs
     DevBuf x_in[2], x_fin[2], r, action;
     // per tower (0 = image rows Mi, 1 = text rows Mt)
@@ -159,27 +161,31 @@ int sgemm(arp_ft* c, const float* A, int ta, const float* Bm, int tb, const floa
 
 const char* TW[2] = {"image", "text"};
 
+template <typename T> const T* fwd_w(arp_ft* c, const std::string& name) {
+    if constexpr (sizeof(T) == 4) return reinterpret_cast<const T*>(c->p(name));
+    return c->mirror.as<T>() + c->infos[c->index.at(name)].off;
+}
+
+// Forward-layout operands: the f32 parameters themselves (f32 mode) or their bf16 mirror, which AdamW keeps current; only a
+// host-side parameter write forces a conversion pass.  Transposed operands ([in, out], for dX) are rebuilt every step
+// from the operand-type copy.
 template <typename T> int refresh_shadows(arp_ft* c) {
-    if (!c->shadows_stale) return 0;
+    if (!c->shadows_stale && !c->transposed_stale) return 0;
     ProfScope ps(c->prof, c->stream, "ft.refresh_shadows");
     const int F = c->F(), Hd = c->Hd(), Hi = c->cfg.hidden;
-    constexpr bool f32 = sizeof(T) == 4;
-    for (int w = 0; w < 2; ++w) {
-        const std::string a = std::string(TW[w]) + "_adapter", il = std::string(TW[w]) + "_intermediate_linear.weight";
-        const int Din = w == 0 ? c->Dv() : c->Dt();
-        // forward-layout shadows are the parameters themselves in f32 mode
-        if (!f32) ARP_TRY((ft_transpose<float, float, T>(c, c->p(il), Din, nullptr, c->sWint[w].as<T>(), Din, nullptr, 0, c->Dt(), Din)));
-        ARP_TRY((ft_transpose<float, float, T>(c, c->p(a + ".layers.0.weight"), F, nullptr, f32 ? nullptr : c->sW1[w].as<T>(), F, c->sW1t[w].as<T>(), Hd, Hd, F)));
-        ARP_TRY((ft_transpose<float, float, T>(c, c->p(a + ".layers.3.weight"), Hd, nullptr, f32 ? nullptr : c->sW2[w].as<T>(), Hd, c->sW2t[w].as<T>(), F, F, Hd)));
+    if (sizeof(T) == 2 && c->shadows_stale) {
+        hipLaunchKernelGGL((convert_kernel<T>), dim3(cdiv(c->P, 1024)), dim3(256), 0, c->stream, c->params.as<float>(), c->mirror.as<T>(), c->P);
+        ARP_HIP_OK(hipGetLastError());
     }
-    ARP_TRY((ft_transpose<float, float, T>(c, c->p("inverse_layer.layers.0.weight"), 4 * F, nullptr, f32 ? nullptr : c->sV1.as<T>(), 4 * F, c->sV1t.as<T>(), Hi,
-                                           Hi, 4 * F)));
+    for (int w = 0; w < 2; ++w) {
+        const std::string a = std::string(TW[w]) + "_adapter";
+        ARP_TRY((ft_transpose<T, T, T>(c, fwd_w<T>(c, a + ".layers.0.weight"), F, nullptr, nullptr, 0, c->sW1t[w].as<T>(), Hd, Hd, F)));
+        ARP_TRY((ft_transpose<T, T, T>(c, fwd_w<T>(c, a + ".layers.3.weight"), Hd, nullptr, nullptr, 0, c->sW2t[w].as<T>(), F, F, Hd)));
+    }
+    ARP_TRY((ft_transpose<T, T, T>(c, fwd_w<T>(c, "inverse_layer.layers.0.weight"), 4 * F, nullptr, nullptr, 0, c->sV1t.as<T>(), Hi, Hi, 4 * F)));
     c->shadows_stale = false;
+    c->transposed_stale = false;
     return 0;
-}
-template <typename T> const T* fwd_w(arp_ft* c, DevBuf& shadow, const std::string& name) {
-    if constexpr (sizeof(T) == 4) return reinterpret_cast<const T*>(c->p(name));
-    return shadow.as<T>();
 }
 
 int ensure_buffers(arp_ft* c, int B) {
@@ -226,15 +232,15 @@ template <typename T> int encode_tower(arp_ft* c, int w, int M) {
     // frozen-tower features -> operand type, both layouts (the transposed one feeds dWint)
     ARP_TRY((ft_transpose<float, float, T>(c, c->x_in[w].as<float>(), Din, nullptr, c->X[w].as<T>(), Din, c->XT[w].as<T>(), Mp, M, Din)));
     // f = [X Wint^T | final]   (:141-143 / :164-166)
-    ARP_TRY((ft_gemm<T, float>(c, (pre + "_inter").c_str(), c->X[w].p, Din, fwd_w<T>(c, c->sWint[w], std::string(TW[w]) + "_intermediate_linear.weight"), Din,
+    ARP_TRY((ft_gemm<T, float>(c, (pre + "_inter").c_str(), c->X[w].p, Din, fwd_w<T>(c, std::string(TW[w]) + "_intermediate_linear.weight"), Din,
                                nullptr, ACT_NONE, nullptr, c->f[w].as<float>(), F, M, Dt, Din)));
     hipLaunchKernelGGL(ft_copy_cols_kernel, dim3(cdiv((size_t)M * E, 256)), dim3(256), 0, c->stream, c->x_fin[w].as<float>(), E, c->f[w].as<float>(), F,
                        Dt, M);
     ARP_TRY((ft_transpose<float, float, T>(c, c->f[w].as<float>(), F, nullptr, c->fT_[w].as<T>(), F, c->fTt[w].as<T>(), Mp, M, F)));
     // AdapterMLP (layers.py:43-60 with num_layers = 2): Linear -> ReLU -> Linear
-    ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc1").c_str(), c->fT_[w].p, F, fwd_w<T>(c, c->sW1[w], a + ".layers.0.weight"), F, c->p(a + ".layers.0.bias"), ACT_RELU,
+    ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc1").c_str(), c->fT_[w].p, F, fwd_w<T>(c, a + ".layers.0.weight"), F, c->p(a + ".layers.0.bias"), ACT_RELU,
                            nullptr, c->H[w].as<T>(), Hd, M, Hd, F)));
-    ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc2").c_str(), c->H[w].p, Hd, fwd_w<T>(c, c->sW2[w], a + ".layers.3.weight"), Hd, c->p(a + ".layers.3.bias"),
+    ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc2").c_str(), c->H[w].p, Hd, fwd_w<T>(c, a + ".layers.3.weight"), Hd, c->p(a + ".layers.3.bias"),
                                ACT_NONE, nullptr, c->A[w].as<float>(), F, M, F, Hd)));
     ProfScope ps(c->prof, c->stream, "ft.rowops");
     hipLaunchKernelGGL(ft_mix_norm_fwd_kernel, dim3(M), dim3(256), 0, c->stream, c->f[w].as<float>(), c->A[w].as<float>(),
@@ -259,7 +265,7 @@ template <typename T> int forward(arp_ft* c) {
     }
     const int Bp = (B + 63) / 64 * 64;
     ARP_TRY((ft_transpose<float, float, T>(c, c->C.as<float>(), 4 * F, nullptr, c->CT_.as<T>(), 4 * F, c->Ct.as<T>(), Bp, B, 4 * F)));
-    ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1", c->CT_.p, 4 * F, fwd_w<T>(c, c->sV1, "inverse_layer.layers.0.weight"), 4 * F,
+    ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1", c->CT_.p, 4 * F, fwd_w<T>(c, "inverse_layer.layers.0.weight"), 4 * F,
                                c->p("inverse_layer.layers.0.bias"), ACT_RELU, nullptr, c->Hinv.as<float>(), Hi, B, Hi, 4 * F)));
     ProfScope ps(c->prof, c->stream, "ft.loss");
     ARP_TRY(sgemm(c, c->Hinv.as<float>(), 0, c->p("inverse_layer.layers.3.weight"), 1, c->p("inverse_layer.layers.3.bias"), c->logits.as<float>(), B, NA, Hi,
@@ -337,10 +343,11 @@ int apply_update(arp_ft* c, float lr) {
     const double t = (double)(c->step + 1);
     const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
     hipLaunchKernelGGL(ft_adamw_kernel, dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(), c->mu.as<float>(),
-                       c->nu.as<float>(), 1.0f, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P);
+                       c->nu.as<float>(), 1.0f, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P,
+                       c->cfg.mode == ARP_MODE_BF16 ? c->mirror.as<bf16_t>() : nullptr);
     ARP_HIP_OK(hipGetLastError());
     c->step += 1;
-    c->shadows_stale = true;
+    c->transposed_stale = true;
     return 0;
 }
 
@@ -385,13 +392,8 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
             ARP_HIP_OK(hipMemset(b->p, 0, c->P * 4));
         }
         const size_t e = c->esz(), Fd = c->F(), Hd = c->Hd(), Hi = k.hidden;
-        const bool bf = k.mode == ARP_MODE_BF16;
-        for (int w = 0; w < 2; ++w) {
-            const size_t Din = w == 0 ? c->Dv() : c->Dt();
-            if (bf) { ARP_TRY(c->sWint[w].ensure((size_t)c->Dt() * Din * e)); ARP_TRY(c->sW1[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2[w].ensure(Hd * Fd * e)); }
-            ARP_TRY(c->sW1t[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2t[w].ensure(Hd * Fd * e));
-        }
-        if (bf) ARP_TRY(c->sV1.ensure(Hi * 4 * Fd * e));
+        if (k.mode == ARP_MODE_BF16) ARP_TRY(c->mirror.ensure(c->P * e));
+        for (int w = 0; w < 2; ++w) { ARP_TRY(c->sW1t[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2t[w].ensure(Hd * Fd * e)); }
         ARP_TRY(c->sV1t.ensure(Hi * 4 * Fd * e));
         return 0;
     };
@@ -405,11 +407,11 @@ int arp_ft_destroy(arp_ft* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->sV1, &c->sV1t, &c->r, &c->action, &c->scores, &c->ds, &c->C, &c->CT_, &c->Ct, &c->Hinv, &c->logits,
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->sV1t, &c->r, &c->action, &c->scores, &c->ds, &c->C, &c->CT_, &c->Ct, &c->Hinv, &c->logits,
                      &c->dlogits, &c->dHinv, &c->dHinvT_, &c->dHinvt, &c->dC, &c->metrics, &c->scal, &c->part};
     for (auto* b : all) b->release();
     for (int w = 0; w < 2; ++w) {
-        DevBuf* tw[] = {&c->sWint[w], &c->sW1[w], &c->sW2[w], &c->sW1t[w], &c->sW2t[w], &c->x_in[w], &c->x_fin[w], &c->X[w], &c->XT[w], &c->f[w], &c->fT_[w],
+        DevBuf* tw[] = {&c->sW1t[w], &c->sW2t[w], &c->x_in[w], &c->x_fin[w], &c->X[w], &c->XT[w], &c->f[w], &c->fT_[w],
                         &c->fTt[w], &c->H[w], &c->HT[w], &c->A[w], &c->a[w], &c->nrm[w], &c->da[w], &c->dA[w], &c->dAT_[w], &c->dAt[w], &c->dfd[w], &c->dH[w],
                         &c->dHp[w], &c->dHpt[w], &c->df[w], &c->dUt[w], &c->dres_part[w]};
         for (auto* b : tw) b->release();

@@ -159,9 +159,11 @@ static __global__ __launch_bounds__(256) void ft_mix_norm_bwd_kernel(const float
 }
 
 // torch.optim.AdamW: decoupled decay on EVERY parameter (finetune.py:141 passes model.parameters()), bias correction
+// mirror (bf16 mode): the operand-type copy of the whole flat parameter vector, refreshed here so that the next step's
+// forward GEMMs need no separate conversion pass over the f32 parameters.
 static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
                                                               float* __restrict__ nu, float gscale, float lr, float wd, float b1, float b2,
-                                                              float eps, float bc1, float bc2, size_t n) {
+                                                              float eps, float bc1, float bc2, size_t n, bf16_t* __restrict__ mirror) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i] * gscale;
@@ -170,7 +172,9 @@ static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict_
     mu[i] = m;
     nu[i] = v;
     const float pd = p[i] * (1.f - lr * wd);
-    p[i] = pd - (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + eps);
+    const float pn = pd - (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + eps);
+    p[i] = pn;
+    if (mirror) mirror[i] = f2bf(pn);
 }
 
 }  // namespace arp
