@@ -638,16 +638,23 @@ int l2_penalty(arp_dt* c) {
     return 0;
 }
 
+// L2 term + optax.clip_by_global_norm + adam in two passes over the flat state: (1) both norms, (2) the update with the
+// L2 gradient wd*p folded in.  (main_procgen.py:114-117,490-507; the gradient buffer keeps the raw loss gradient.)
 int apply_update(arp_dt* c, float lr) {
     ProfScope ps(c->prof, c->stream, "dt.clip_adam");
     const int nb = 1024;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, c->stream, c->grads.as<float>(), c->P, c->scal.as<float>() + 16);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, nb, 1.0f, c->scal.as<float>() + 0, 0);
+    const float gscale = 1.0f / (float)std::max(c->cfg.world, 1);
+    float* pg = c->scal.as<float>() + 16;
+    float* pp = pg + nb;
+    hipLaunchKernelGGL(norms_partial_kernel, dim3(nb), dim3(256), 0, c->stream, c->grads.as<float>(), c->params.as<float>(), c->P, c->n_decay, gscale,
+                       c->cfg.weight_decay, pg, pp);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, pg, nb, 1.0f, c->scal.as<float>() + 0, 0);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, pp, nb, 1.0f, c->scal.as<float>() + 1, 0);
     const double t = (double)(c->step + 1);
     const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
-    const float gscale = 1.0f / (float)std::max(c->cfg.world, 1);
     hipLaunchKernelGGL(adam_kernel, dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(), c->mu.as<float>(),
-                       c->nu.as<float>(), c->scal.as<float>(), gscale, c->cfg.clip_norm, lr, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P);
+                       c->nu.as<float>(), c->scal.as<float>(), gscale, c->cfg.weight_decay, c->n_decay, c->cfg.clip_norm, lr, c->cfg.b1, c->cfg.b2,
+                       c->cfg.eps, bc1, bc2, c->P);
     ARP_HIP_OK(hipGetLastError());
     c->step += 1;
     c->shadows_stale = true;
@@ -656,11 +663,10 @@ int apply_update(arp_dt* c, float lr) {
 
 template <typename T> int fwd_bwd(arp_dt* c) {
     ARP_TRY(forward<T>(c, true));
-    ARP_TRY(backward<T>(c));
-    return l2_penalty(c);
+    return backward<T>(c);
 }
 
-// Replays forward + backward + L2 as one hipGraph (the chain is launch-bound: ~120 kernels of a few
+// Replays forward + backward as one hipGraph (a chain of short dependent kernels of a few
 // microseconds).  The first steps of a geometry run eagerly (lazy workspace allocations must not happen under
 // capture); profiling and any capture failure fall back to eager launches.
 template <typename T> int fwd_bwd_graphed(arp_dt* c) {
@@ -727,7 +733,7 @@ template <typename T> int step_impl(arp_dt* c, float lr, float* aux) {
         aux[5] = l2;                 // weight_l2
         aux[6] = (float)step_before; // train_state_step
         aux[7] = lr;                 // learning_rate
-        aux[8] = sqrtf(s[0]) * inv;  // (extra) global gradient norm before clipping
+        aux[8] = sqrtf(s[0]);        // (extra) global norm of the rank-averaged gradient incl. the L2 term, before clipping
     }
     return 0;
 }

@@ -516,6 +516,30 @@ static __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* 
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// One pass for both norms of the update: pg[b] = sum (g*gscale + wd*p [i < n_decay])^2 (the gradient of loss + L2 term,
+// averaged over ranks), pp[b] = sum p^2 over i < n_decay (weight_l2 of main_procgen.py:114-117).
+static __global__ __launch_bounds__(256) void norms_partial_kernel(const float* __restrict__ g, const float* __restrict__ p, size_t n, size_t n_decay,
+                                                                   float gscale, float wd, float* __restrict__ pg, float* __restrict__ pp) {
+    __shared__ float red[2][4];
+    float sg = 0.f, sp = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i] * gscale;
+        if (i < n_decay) {
+            const float pi = p[i];
+            gi += wd * pi;
+            sp += pi * pi;
+        }
+        sg += gi * gi;
+    }
+    sg = wave_sum(sg);
+    sp = wave_sum(sp);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pg[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        pp[blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
 // g += wd * p on a range (the explicit L2 term of main_procgen.py:114-117 differentiates to wd * p)
 static __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ g, const float* __restrict__ p, float wd, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -524,14 +548,16 @@ static __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restric
 // scal: [0] = sum of squares of the (already averaged-over-ranks) gradient.
 // optax.clip_by_global_norm(c) then adam (b1, b2, eps outside the sqrt, bias correction with t = step+1);
 // the adamw decay mask of the reference is all-False, so no decoupled decay.
+// The L2 term's gradient wd*p (first n_decay entries) is added here, not materialised: g holds the raw (rank-summed) loss
+// gradient, scal[0] the squared norm of g*gscale + wd*p from norms_partial_kernel.
 static __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
-                                                   float* __restrict__ nu, const float* __restrict__ scal, float gscale, float clip,
-                                                   float lr, float b1, float b2, float eps, float bc1, float bc2, size_t n) {
+                                                   float* __restrict__ nu, const float* __restrict__ scal, float gscale, float wd, size_t n_decay,
+                                                   float clip, float lr, float b1, float b2, float eps, float bc1, float bc2, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float gnorm = sqrtf(scal[0]) * gscale;
-    const float s = (gnorm < clip) ? gscale : gscale / gnorm * clip;
-    const float gi = g[i] * s;
+    const float gnorm = sqrtf(scal[0]);
+    const float s = (gnorm < clip) ? 1.0f : clip / gnorm;
+    const float gi = (g[i] * gscale + (i < n_decay ? wd * p[i] : 0.f)) * s;
     const float m = b1 * mu[i] + (1.f - b1) * gi;
     const float v = b2 * nu[i] + (1.f - b2) * gi * gi;
     mu[i] = m;
