@@ -122,7 +122,7 @@ static int build_plan(int H, int W, int use_crop, int R, ResizePlan& p) {
     pack_table(th, left, R, hp);
     pack_table(tv, top, R, vp);
     p.kmax_h = th.kmax; p.kmax_v = tv.kmax;
-    // rows of input needed by a tile of TR output rows; shrink TR until the LDS carve fits 64 KiB
+    // rows of input needed by a tile of TR output rows; shrink TR until the LDS carve fits the budget
     const int row_bytes = p.cw * 3;
     for (p.TR = 32; p.TR >= 1; p.TR >>= 1) {
         int need = 0;
@@ -133,9 +133,10 @@ static int build_plan(int H, int W, int use_crop, int R, ResizePlan& p) {
             need = std::max(need, (e & 0xffff) + (e >> 16) - lo);
         }
         p.max_rows = need;
-        p.lds_bytes = (size_t)((R * (1 + th.kmax) * 4 + 15) & ~15) + 768 * 4 + (size_t)((need * row_bytes + 15) & ~15) +
-                      (size_t)need * R * 3 + 16;
-        if (p.lds_bytes <= 64 * 1024) break;
+        // (the fast instance also stages the tile's vertical taps and over-reads up to 27 bytes past a window)
+        p.lds_bytes = (size_t)((R * (1 + th.kmax) * 4 + 15) & ~15) + 768 * 4 + (size_t)((p.TR * (1 + tv.kmax) * 4 + 15) & ~15) +
+                      (size_t)((need * row_bytes + 15) & ~15) + (size_t)need * R * 3 + 64;
+        if (p.lds_bytes <= (size_t)(getenv("ARP_PRE_LDS_KB") ? atoi(getenv("ARP_PRE_LDS_KB")) : 52) * 1024) break;  // three workgroups per CU (measured: 52 KiB 0.30 ms, 78 KiB 0.38 ms per 1024 frames)
     }
     if (p.TR < 1) return fail("preprocess: frame too wide for the LDS tile");
     ARP_TRY(p.h_tab.ensure(hp.size() * 4));
@@ -164,7 +165,9 @@ static int launch_preprocess(const ResizePlan& p, const uint8_t* frames, int n, 
     a.h_tab = p.h_tab.as<int>(); a.v_tab = p.v_tab.as<int>(); a.lut = lut;
     a.n = n; a.H = p.H; a.W = p.W; a.cy = p.cy; a.cx = p.cx; a.ch = p.ch; a.cw = p.cw;
     a.R = p.R; a.P = P; a.kmax_h = p.kmax_h; a.kmax_v = p.kmax_v; a.TR = p.TR; a.max_rows = p.max_rows;
-    auto kern = preprocess_kernel<T, LAYOUT>;
+    // short filters + dword-aligned rows: the register-unpacking instance; anything else: the generic one
+    const bool fast = p.kmax_h <= 8 && p.kmax_v <= 8 && ((p.cw * 3) & 3) == 0 && !getenv("ARP_PREPROCESS_GENERIC");
+    auto kern = fast ? preprocess_fast_kernel<T, LAYOUT> : preprocess_kernel<T, LAYOUT>;
     ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)p.lds_bytes));
     const int tiles = (p.R + p.TR - 1) / p.TR;

@@ -133,6 +133,137 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
     }
 }
 
+// ---- fast instance for short filters (<= 8 taps per axis: every resize of this path, e.g. 256 -> 224 has 5) ---------------
+// Same arithmetic as preprocess_kernel, bit for bit; what changes is how LDS is read.  The generic kernel reads one byte
+// and one weight per tap per output (~19 LDS instructions per output byte over the two passes).  Here
+//   * horizontal: one thread = one output pixel x 4 input rows; the pixel's window (taps x RGB <= 24 contiguous bytes) is
+//     read as 7 aligned dwords per row, realigned with v_alignbyte and unpacked in registers; weights are read once per pixel;
+//   * vertical: one thread = 4 output pixels x RGB = 12 contiguous bytes of the intermediate rows, 3 dword reads per tap,
+//     tap weights staged in LDS; the three channels leave as three 4-wide stores.
+// ~5 LDS instructions per output byte; the kernel becomes HBM-bound.
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void preprocess_fast_kernel(PreprocArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT = 8;
+    const int tid = threadIdx.x;
+    const int tiles = (a.R + a.TR - 1) / a.TR;
+    const int frame = blockIdx.x / tiles;
+    const int oy0 = (blockIdx.x - frame * tiles) * a.TR;
+    const int oy1 = min(oy0 + a.TR, a.R);
+    const int hs = 1 + a.kmax_h, vs = 1 + a.kmax_v;
+    const int in_row_bytes = a.cw * 3;
+    const int mid_row_bytes = a.R * 3;
+
+    int* hT = reinterpret_cast<int*>(smem);
+    float* lut = reinterpret_cast<float*>(smem + ((a.R * hs * 4 + 15) & ~15));
+    int* vT = reinterpret_cast<int*>(lut + 768);
+    uint8_t* in_s = reinterpret_cast<uint8_t*>(vT) + ((a.TR * vs * 4 + 15) & ~15);
+    uint8_t* mid_s = in_s + ((a.max_rows * in_row_bytes + 15) & ~15);
+
+    for (int i = tid; i < a.R * hs; i += 256) hT[i] = a.h_tab[i];
+    for (int i = tid; i < 768; i += 256) lut[i] = a.lut[i];
+    for (int i = tid; i < (oy1 - oy0) * vs; i += 256) vT[i] = a.v_tab[oy0 * vs + i];
+
+    const int v_first = a.v_tab[oy0 * vs];
+    const int v_last = a.v_tab[(oy1 - 1) * vs];
+    const int y_lo = v_first & 0xffff;
+    const int y_hi = (v_last & 0xffff) + (v_last >> 16);
+    const int rows = y_hi - y_lo;
+
+    const uint8_t* fbase = a.frames + (size_t)frame * a.H * a.W * 3;
+    if (a.cx == 0 && a.cw == a.W && (in_row_bytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(fbase) & 15) == 0)) {
+        const uint4* src = reinterpret_cast<const uint4*>(fbase + (size_t)(a.cy + y_lo) * in_row_bytes);
+        uint4* dst = reinterpret_cast<uint4*>(in_s);
+        const int nvec = rows * in_row_bytes / 16;
+        for (int i = tid; i < nvec; i += 256) dst[i] = src[i];
+    } else {
+        for (int i = tid; i < rows * in_row_bytes; i += 256) {
+            const int r = i / in_row_bytes, cb = i - r * in_row_bytes;
+            in_s[i] = fbase[((size_t)(a.cy + y_lo + r) * a.W + a.cx) * 3 + cb];
+        }
+    }
+    __syncthreads();
+
+    // ---- horizontal pass ------------------------------------------------------------------------------------------
+    const int ngroups = (rows + 3) >> 2;
+    for (int i = tid; i < ngroups * a.R; i += 256) {
+        const int rg = i / a.R, ox = i - rg * a.R;
+        const int* t = hT + ox * hs;
+        const int start = (t[0] & 0xffff) * 3, a0 = start & ~3, sh = start & 3;
+        int w[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) w[k] = k < a.kmax_h ? t[1 + k] : 0;  // zero beyond the filter's own length
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = min(rg * 4 + rr, rows - 1);
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(in_s + r * in_row_bytes + a0);
+            uint32_t d[7], e[6];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) d[q] = p[q];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+            int acc[3] = {1 << 21, 1 << 21, 1 << 21};
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int b = 3 * k + c;
+                    // taps are 22-bit fixed point (|w| < 2^23) and samples 8-bit: the full-rate 24-bit multiply is exact
+                    acc[c] += __mul24(w[k], (int)((e[b >> 2] >> (8 * (b & 3))) & 0xffu));
+                }
+            if (rg * 4 + rr < rows) {
+                uint8_t* m = mid_s + r * mid_row_bytes + ox * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    int q = acc[c] >> 22;
+                    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                    m[c] = (uint8_t)q;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical pass + normalise + layout --------------------------------------------------------------------------
+    const int g12n = a.R / 4;  // groups of 4 pixels = 12 bytes
+    const int G = a.R / a.P;
+    for (int i = tid; i < (oy1 - oy0) * g12n; i += 256) {
+        const int oyl = i / g12n, g12 = i - oyl * g12n;
+        const int oy = oy0 + oyl;
+        const int* t = vT + oyl * vs;
+        const int ymin = (t[0] & 0xffff) - y_lo;
+        int acc[12];
+#pragma unroll
+        for (int b = 0; b < 12; ++b) acc[b] = 1 << 21;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int wk = k < a.kmax_v ? t[1 + k] : 0;
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(mid_s + min(ymin + k, rows - 1) * mid_row_bytes + g12 * 12);
+            const uint32_t d[3] = {p[0], p[1], p[2]};
+#pragma unroll
+            for (int b = 0; b < 12; ++b) acc[b] += __mul24(wk, (int)((d[b >> 2] >> (8 * (b & 3))) & 0xffu));
+        }
+        const int ox = g12 * 4;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int q = acc[e * 3 + c] >> 22;
+                q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                v[e] = lut[c * 256 + q];
+            }
+            if constexpr (LAYOUT == PRE_PATCH) {
+                const size_t prow = ((size_t)frame * G + oy / a.P) * G + ox / a.P;
+                const int kidx = c * a.P * a.P + (oy % a.P) * a.P + (ox % a.P);
+                store4(static_cast<T*>(a.out) + prow * (size_t)(3 * a.P * a.P) + kidx, v[0], v[1], v[2], v[3]);
+            } else {
+                store4(static_cast<T*>(a.out) + (((size_t)frame * 3 + c) * a.R + oy) * a.R + ox, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 // ---- the fine-tune path's transform (finetune_module/clip_multiscale_adapter.py:120-132) --------------------------------
 // x.float() -> torchvision resize on a tensor = bilinear, align_corners = False, no antialias (only when BOTH sides
 // differ from 224, :127) -> x / 255 -> (x - mean) / std.  Same arithmetic order as torch's upsample_bilinear2d:
