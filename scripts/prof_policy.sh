@@ -1,8 +1,11 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the policy train step (bench.py --path policy); run on the GPU box via gpurun.
+# rocprofv3 kernel traces of the two training benches (bench.py --path policy / --path finetune); run on the GPU box via gpurun.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r1_policy}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace -- python3 $R/bench.py --path policy --steps 10 --warmup 3 > $R/gpurun_out/prof_${TAG}_trace.log 2>&1
-cd $R/gpurun_out && find prof_${TAG}_trace -name "*kernel_stats.csv" | head; find prof_${TAG}_trace -name "*kernel_trace.csv" -size +20M -delete
+for P in policy finetune; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r1_${P}_trace -- python3 $R/bench.py --path $P --steps 10 --warmup 3 --cpu-seconds 0 > $R/gpurun_out/prof_r1_${P}_trace.log 2>&1
+  find $R/gpurun_out/prof_r1_${P}_trace -name "*kernel_trace.csv" -delete
+  cp $(find $R/gpurun_out/prof_r1_${P}_trace -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r1_${P}_kernel_stats.csv
+done
+ls -la $R/gpurun_out/*.csv
