@@ -41,6 +41,11 @@ def test_no_cpu_fallback():
         clip.preprocess(np.zeros((1, 256, 256, 3), np.uint8))
     with pytest.raises(_ffi.ArpError):
         clip.ClipLabeller(clip.VIT_B32, {}, mode="bf16")
+    from arp_amd import finetune, train
+    with pytest.raises(_ffi.ArpError):
+        finetune.FinetuneTrainer(finetune.FinetuneConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64), mode="f32")
+    with pytest.raises(_ffi.ArpError):
+        train.PolicyTrainer(train.PolicyConfig(), mode="f32")
     out = np.zeros((4, 4), np.float32)
     import ctypes as C
     p = out.ctypes.data_as(C.POINTER(C.c_float))
@@ -151,7 +156,10 @@ def test_label_reward_variants_and_errors():
         L.label_reward("coinrun", "hard", 500, 0, "x", ".", store={"ob": st["ob"]}, clip_model=_FakeClip(),
                        tokens=np.zeros((1, 77), np.int32))  # no done / rewards / is_terminal key (label_reward.py:71-78)
     with pytest.raises(NotImplementedError):
-        L.label_reward("coinrun", "hard", 500, 0, "x", ".", store=st, clip_model=_FakeClip(), model_type="clip_ft")
+        L.label_reward("coinrun", "hard", 500, 0, "x", ".", store=st, clip_model=_FakeClip(), model_type="r3m")
+    # the fine-tuned-model branch (label_reward.py:165-230) writes its own dataset names
+    L.label_reward("coinrun", "hard", 500, 0, "x", ".", store=st, clip_model=_FakeClip(), model_type="clip_ft", tokens=np.zeros((1, 77), np.int32))
+    assert "ob_clip_ft_reward" in st and "ob_clip_ft_pos_rtg" in st
     with pytest.raises(ValueError):
         L.label_reward("coinrun", "hard", 500, 0, "x", ".", store=st, clip_model=_FakeClip())  # neither tokens nor tokenizer
     from arp_amd import data
