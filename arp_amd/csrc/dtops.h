@@ -198,8 +198,18 @@ static __global__ __launch_bounds__(256) void adapter_dres_kernel(const T* __res
                                                            float* __restrict__ partial, size_t n) {
     __shared__ float red[4];
     float s = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    const size_t n4 = n >> 2;  // 4 elements per access; the tail (n % 4) goes to block 0
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float d[4], av[4], xv[4];
+        load4(dy + 4 * i, d);
+        load4(a + 4 * i, av);
+        load4(x + 4 * i, xv);
+        s += (d[0] * (av[0] - xv[0]) + d[1] * (av[1] - xv[1])) + (d[2] * (av[2] - xv[2]) + d[3] * (av[3] - xv[3]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
         s += Elem<T>::ld(dy + i) * (Elem<T>::ld(a + i) - Elem<T>::ld(x + i));
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
