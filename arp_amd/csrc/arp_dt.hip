@@ -261,7 +261,8 @@ int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void*
     constexpr int EPB = 128 / (int)sizeof(T);
     const int nk = K / EPB;
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
-    int S = std::max(1, std::min(nk, 1024 / std::max(tiles, 1)));
+    static const int wg_target = getenv("ARP_SPLITK_WGS") ? atoi(getenv("ARP_SPLITK_WGS")) : 512;  // one resident round (2 WG/CU x 256 CUs); measured best of 256..2048
+    int S = std::max(1, std::min(nk, wg_target / std::max(tiles, 1)));
     const int per = (nk + S - 1) / S;
     S = (nk + per - 1) / per;  // every slice non-empty
     ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
