@@ -116,6 +116,9 @@ SIGNATURES = {
     "arp_dt_profile_json": (_i, [_vp, C.c_char_p, _i]),
     "arp_clip_encode_image_multiscale": (_i, [_vp, _u8p, _i, _i, _i, _fp, _fp]),
     "arp_clip_encode_text_multiscale": (_i, [_vp, _i32p, _i, _fp, _fp]),
+    "arp_clip_encode_image_multiscale_dev": (_i, [_vp, _u8p, _i, _i, _i, _vp, _vp]),
+    "arp_clip_encode_text_multiscale_dev": (_i, [_vp, _i32p, _i, _vp, _vp]),
+    "arp_ft_set_batch_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _fp, _i32p, _i]),
     "arp_ft_create": (_i, [C.POINTER(FtCfg), C.POINTER(_vp)]),
     "arp_ft_destroy": (_i, [_vp]),
     "arp_ft_num_params": (_i, [_vp, _i64p, _i32p]),

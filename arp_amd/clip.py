@@ -189,6 +189,14 @@ class ClipLabeller:
                                                    _ffi.as_ptr(inter, C.c_float), _ffi.as_ptr(fin, C.c_float)))
         return inter, fin
 
+    def encode_multiscale_to(self, frames, tokens, bufs):
+        """Device-resident variant for the fine-tune step: ``bufs`` = (img_inter, img_final, txt_inter, txt_final) DeviceBuffers
+        sized for these frames / prompts; the features stay in HBM for ``FinetuneTrainer.set_batch_device``."""
+        f = self._frames(frames)
+        t = np.require(np.asarray(tokens, dtype=np.int32).reshape(-1, self.cfg.ctx), requirements="C")
+        check(lib.arp_clip_encode_image_multiscale_dev(self._h, _ffi.as_ptr(f, C.c_uint8), f.shape[0], f.shape[1], f.shape[2], bufs[0].ptr, bufs[1].ptr))
+        check(lib.arp_clip_encode_text_multiscale_dev(self._h, _ffi.as_ptr(t, C.c_int32), t.shape[0], bufs[2].ptr, bufs[3].ptr))
+
     def encode_text_multiscale(self, tokens):
         """Per-block EOT-token features [n, txt_layers*txt_width] and the un-normalised text feature (:151-166)."""
         t = np.require(np.asarray(tokens, dtype=np.int32).reshape(-1, self.cfg.ctx), requirements="C")

@@ -439,7 +439,7 @@ static int forward_chunk_dispatch(arp_clip* c, const uint8_t* frames_dev, int nb
 // ms_host != null: multi-scale export of the EOT rows [np, layers*txt_width]; out_host != null: return the (optionally
 // normalised) features instead of caching them as the prompt set
 template <typename T> static int run_text(arp_clip* c, const int32_t* tokens, int np, float* out_host = nullptr, bool normalize = true,
-                                          float* ms_host = nullptr) {
+                                          float* ms_host = nullptr, bool dev_out = false) {
     const arp_clip_cfg& k = c->cfg;
     const int Tw = k.txt_width, ctx = k.ctx, M = np * ctx;
     const size_t e = sizeof(T);
@@ -483,8 +483,9 @@ template <typename T> static int run_text(arp_clip* c, const int32_t* tokens, in
             hipLaunchKernelGGL(l2_normalize_kernel, dim3((np + 3) / 4), dim3(256), 0, c->stream, feat.as<float>(), np, k.embed);
             ARP_HIP_OK(hipGetLastError());
         }
-        if (out_host) ARP_HIP_OK(hipMemcpyAsync(out_host, feat.p, (size_t)np * k.embed * 4, hipMemcpyDeviceToHost, c->stream));
-        if (ms_host) ARP_HIP_OK(hipMemcpyAsync(ms_host, ms.p, (size_t)np * c->txt.layers * Tw * 4, hipMemcpyDeviceToHost, c->stream));
+        const hipMemcpyKind okind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        if (out_host) ARP_HIP_OK(hipMemcpyAsync(out_host, feat.p, (size_t)np * k.embed * 4, okind, c->stream));
+        if (ms_host) ARP_HIP_OK(hipMemcpyAsync(ms_host, ms.p, (size_t)np * c->txt.layers * Tw * 4, okind, c->stream));
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
         return 0;
     };
@@ -799,7 +800,7 @@ int arp_clip_encode_image(arp_clip* c, const uint8_t* frames, int n, int H, int 
 
 // Frozen-tower outputs for the fine-tune head (row N2): per-block CLS features [n, layers*width] and the un-normalised
 // CLIP image feature [n, embed], through the fine-tune transform (bilinear; clip_multiscale_adapter.py:120-149).
-int arp_clip_encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter, float* final_feat) {
+static int encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter, float* final_feat, bool dev_out) {
     ARP_TRY(check_ready(c, false));
     if (n < 0) return fail("negative frame count");
     if (n == 0) return 0;
@@ -824,8 +825,9 @@ int arp_clip_encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, 
             const int r = forward_chunk_dispatch(c, c->frames_in.as<uint8_t>(), nb, nullptr);
             c->ms_out = nullptr; c->pre_bilinear = 0;
             ARP_TRY(r);
-            ARP_HIP_OK(hipMemcpyAsync(final_feat + (size_t)off * E, c->feat.p, (size_t)nb * E * 4, hipMemcpyDeviceToHost, c->stream));
-            ARP_HIP_OK(hipMemcpyAsync(inter + (size_t)off * LD, ms.p, (size_t)nb * LD * 4, hipMemcpyDeviceToHost, c->stream));
+            const hipMemcpyKind kind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+            ARP_HIP_OK(hipMemcpyAsync(final_feat + (size_t)off * E, c->feat.p, (size_t)nb * E * 4, kind, c->stream));
+            ARP_HIP_OK(hipMemcpyAsync(inter + (size_t)off * LD, ms.p, (size_t)nb * LD * 4, kind, c->stream));
             ARP_HIP_OK(hipStreamSynchronize(c->stream));
         }
         return 0;
@@ -836,6 +838,14 @@ int arp_clip_encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, 
     return rc;
 }
 
+int arp_clip_encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter, float* final_feat) {
+    return encode_image_multiscale(c, frames, n, H, W, inter, final_feat, false);
+}
+// Same, with the two outputs in DEVICE memory (arp_dev_malloc): the features go to arp_ft_set_batch_dev without touching the host.
+int arp_clip_encode_image_multiscale_dev(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter_dev, float* final_dev) {
+    return encode_image_multiscale(c, frames, n, H, W, inter_dev, final_dev, true);
+}
+
 // Text side of the same: per-block EOT-token features [n, layers*txt_width] and the un-normalised text feature [n, embed]
 // (clip_multiscale_adapter.py:151-166).  Does not touch the cached prompt set of arp_clip_set_text.
 int arp_clip_encode_text_multiscale(arp_clip* c, const int32_t* tokens, int n, float* inter, float* final_feat) {
@@ -844,6 +854,13 @@ int arp_clip_encode_text_multiscale(arp_clip* c, const int32_t* tokens, int n, f
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     if (c->cfg.mode == ARP_MODE_BF16) return run_text<bf16_t>(c, tokens, n, final_feat, false, inter);
     return run_text<float>(c, tokens, n, final_feat, false, inter);
+}
+int arp_clip_encode_text_multiscale_dev(arp_clip* c, const int32_t* tokens, int n, float* inter_dev, float* final_dev) {
+    ARP_TRY(check_ready(c, false));
+    if (!tokens || n <= 0 || !inter_dev || !final_dev) return fail("bad argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_BF16) return run_text<bf16_t>(c, tokens, n, final_dev, false, inter_dev, true);
+    return run_text<float>(c, tokens, n, final_dev, false, inter_dev, true);
 }
 
 int arp_bicubic_coeffs(int in_size, int out_size, int32_t* xmin, int32_t* cnt, int32_t* weights, int ksize_cap) {

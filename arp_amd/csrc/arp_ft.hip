@@ -491,6 +491,25 @@ int arp_ft_set_batch(arp_ft* c, const float* img_inter, const float* img_final, 
     return 0;
 }
 
+// Same batch with the four feature arrays already in device memory (outputs of arp_clip_encode_*_multiscale_dev).
+int arp_ft_set_batch_dev(arp_ft* c, const float* img_inter_dev, const float* img_final_dev, const float* txt_inter_dev, const float* txt_final_dev,
+                         const float* r, const int32_t* action, int B) {
+    if (!c || !img_inter_dev || !img_final_dev || !txt_inter_dev || !txt_final_dev || !r || !action || B <= 0) return fail("bad argument");
+    for (int i = 0; i < B; ++i)
+        if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(ensure_buffers(c, B));
+    const size_t E = c->cfg.embed;
+    ARP_HIP_OK(hipMemcpyAsync(c->x_in[0].p, img_inter_dev, (size_t)3 * B * c->Dv() * 4, hipMemcpyDeviceToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[0].p, img_final_dev, (size_t)3 * B * E * 4, hipMemcpyDeviceToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_in[1].p, txt_inter_dev, (size_t)B * c->Dt() * 4, hipMemcpyDeviceToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[1].p, txt_final_dev, (size_t)B * E * 4, hipMemcpyDeviceToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->r.p, r, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int arp_ft_forward(arp_ft* c, float* metrics4, float* scores, float* logits) {
     if (!c) return fail("null handle");
     if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");

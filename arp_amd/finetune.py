@@ -143,6 +143,21 @@ class FinetuneTrainer:
                                    p(r, C.c_float), p(action, C.c_int32), B))
         self._B = B
 
+    def feature_buffers(self, B):
+        """Device buffers (img_inter, img_final, txt_inter, txt_final) for ``ClipLabeller.encode_multiscale_to``."""
+        from .clip import DeviceBuffer
+        c = self.cfg
+        return (DeviceBuffer(3 * B * c.d_img * 4), DeviceBuffer(3 * B * c.embed * 4), DeviceBuffer(B * c.d_txt * 4), DeviceBuffer(B * c.embed * 4))
+
+    def set_batch_device(self, bufs, r, action):
+        """As set_batch, with the tower features already in HBM (image rows ordered image0 | image1 | image2)."""
+        r = np.require(np.asarray(r, dtype=np.float32).reshape(-1), requirements="C")
+        action = np.require(np.asarray(action, dtype=np.int32).reshape(-1), requirements="C")
+        B = action.shape[0]
+        check(lib.arp_ft_set_batch_dev(self._h, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, _ffi.as_ptr(r, C.c_float),
+                                       _ffi.as_ptr(action, C.c_int32), B))
+        self._B = B
+
     def forward(self):
         """CLIPMultiscaleAdapter.forward (clip_multiscale_adapter.py:177-250) on the staged batch."""
         B = self._B

@@ -161,18 +161,17 @@ def bench_finetune(a):
     towers = None
     if a.with_towers:
         # frames in: the frozen CLIP ViT-B/16 towers (random init) produce the per-block CLS / EOT features every step;
-        # the features cross to the head through host memory (9.5 MB per step)
         from arp_amd import clip, synth
         ccfg = clip.MODELS["ViT-B/16"]
         towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=0, max_batch=3 * B)
         frames = np.concatenate([synth.procgen_like_frames(B, seed=200 + k) for k in range(3)])  # image0 | image1 | image2
         tokens = synth.prompt_tokens(B, [8] * B, seed=203)
         rb = FT.synth_batch(cfg, B, seed=100)
+        fbufs = tr.feature_buffers(B)
 
         def step():
-            ii, fi = towers.encode_image_multiscale(frames)  # one 3B-frame pass through the image tower
-            ti = towers.encode_text_multiscale(tokens)
-            tr.set_batch(ii.reshape(3, B, -1), fi.reshape(3, B, -1), ti[0], ti[1], rb[4], rb[5])
+            towers.encode_multiscale_to(frames, tokens, fbufs)  # one 3B-frame image pass + B prompts; features stay in HBM
+            tr.set_batch_device(fbufs, rb[4], rb[5])
             tr.train_step_async(lr)
     else:
         tr.set_batch(*FT.synth_batch(cfg, B, seed=100))

@@ -208,6 +208,10 @@ int arp_clip_encode_image_multiscale(arp_clip* h, const uint8_t* frames_nhwc, in
                                      float* inter /* [n, layers*width] */, float* final_feat /* [n, embed] */);
 int arp_clip_encode_text_multiscale(arp_clip* h, const int32_t* tokens /* [n, ctx] */, int n,
                                     float* inter /* [n, txt_layers*txt_width] */, float* final_feat /* [n, embed] */);
+/* The same two calls with their OUTPUTS in device memory (arp_dev_malloc), for arp_ft_set_batch_dev: the tower features
+ * then never cross PCIe. */
+int arp_clip_encode_image_multiscale_dev(arp_clip* h, const uint8_t* frames_nhwc, int n, int H, int W, float* inter_dev, float* final_dev);
+int arp_clip_encode_text_multiscale_dev(arp_clip* h, const int32_t* tokens, int n, float* inter_dev, float* final_dev);
 int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out);
 int arp_ft_destroy(arp_ft* h);
 int arp_ft_num_params(arp_ft* h, int64_t* total, int32_t* n_tensors);
@@ -222,6 +226,8 @@ int arp_ft_get_step(arp_ft* h, int64_t* step);
  * txt_final [B, embed]; r [B] as stored in the batch (the loss uses r - 1, :215); action [B] class ids. */
 int arp_ft_set_batch(arp_ft* h, const float* img_inter, const float* img_final, const float* txt_inter, const float* txt_final,
                      const float* r, const int32_t* action, int B);
+int arp_ft_set_batch_dev(arp_ft* h, const float* img_inter_dev, const float* img_final_dev, const float* txt_inter_dev,
+                         const float* txt_final_dev, const float* r /* host */, const int32_t* action /* host */, int B);
 /* metrics4: loss, vip_loss, id_loss, lambda_id.  scores [3, B] and logits [B, n_actions] may be NULL. */
 int arp_ft_forward(arp_ft* h, float* metrics4, float* scores, float* logits);
 /* Inference half of one tower's head -- model.encode_image (which = 0) / model.encode_text (which = 1) as the clip_ft

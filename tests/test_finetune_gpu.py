@@ -242,3 +242,38 @@ def test_clip_ft_labelling_branch(gpu_lib, use_crop):
 def FT_TOWER_CFG():
     from arp_amd import clip
     return clip.ClipConfig(**TOWER)
+
+
+def test_device_resident_handoff_equals_host_path(gpu_lib):
+    """arp_clip_encode_*_multiscale_dev -> arp_ft_set_batch_dev gives the same loss and gradients as the host-staged batch."""
+    from arp_amd import clip, synth
+    from arp_amd import finetune as FT
+    from oracle import clip_np as C, finetune_torch as O
+    ocfg = C.ClipConfig(**TOWER)
+    W = synth.clip_weights(ocfg, seed=81)
+    B = 3
+    frames = np.concatenate([synth.procgen_like_frames(B, 256, 256, seed=82 + k) for k in range(3)])
+    tok = synth.prompt_tokens(B, [7, 3, 5], ctx=ocfg.ctx, vocab=ocfg.vocab, seed=90)
+    P = O.init_params(O.HeadConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64), seed=91)
+    r, action = np.array([0, 1, 1], np.float32), np.array([3, 0, 14], np.int32)
+    m = clip.ClipLabeller(clip.ClipConfig(**TOWER), W, mode="f32")
+    tr = FT.FinetuneTrainer(FT.FinetuneConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64), mode="f32")
+    tr.set_params(P)
+    ii, fi = m.encode_image_multiscale(frames)
+    ti, tf = m.encode_text_multiscale(tok)
+    tr.set_batch(ii.reshape(3, B, -1), fi.reshape(3, B, -1), ti, tf, r, action)
+    out_h = tr.forward()
+    tr.backward()
+    g_h = tr.get_grads()
+    bufs = tr.feature_buffers(B)
+    m.encode_multiscale_to(frames, tok, bufs)
+    tr.set_batch_device(bufs, r, action)
+    out_d = tr.forward()
+    tr.backward()
+    g_d = tr.get_grads()
+    assert out_h["loss"] == out_d["loss"]
+    assert all(np.array_equal(g_h[k], g_d[k]) for k in g_h)
+    for b in bufs:
+        b.free()
+    tr.close()
+    m.close()
