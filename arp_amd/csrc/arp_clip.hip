@@ -549,11 +549,17 @@ static int make_sibling(arp_clip* c) {
     return 0;
 }
 
-static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev) {
+// host_src != null: the frames still live in host memory; every part uploads its own slice on its own stream right before its
+// compute, so the upload of part i+1 overlaps the kernels of part i (the S2 seam hands over host buffers).
+static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev, const uint8_t* host_src = nullptr) {
     ARP_TRY(check_ready(c, true));
     int ns = c->cfg.n_streams;
     while (ns > 1 && n / ns < 128) --ns;  // keep every part big enough to fill the chip's GEMM grid
-    if (ns < 2) return label_dev_single(c, frames_dev, n, H, W, use_crop, rewards_dev);
+    const size_t fbytes = (size_t)H * W * 3;
+    if (ns < 2) {
+        if (host_src) ARP_HIP_OK(hipMemcpyAsync(const_cast<uint8_t*>(frames_dev), host_src, (size_t)n * fbytes, hipMemcpyHostToDevice, c->stream));
+        return label_dev_single(c, frames_dev, n, H, W, use_crop, rewards_dev);
+    }
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     while ((int)c->siblings.size() < ns - 1) ARP_TRY(make_sibling(c));
     ResizePlan* plan;
@@ -573,6 +579,9 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
             s->prof.on = c->prof.on;
             ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_fork, 0));
         }
+        if (host_src)
+            ARP_HIP_OK(hipMemcpyAsync(const_cast<uint8_t*>(frames_dev) + (size_t)b0 * fbytes, host_src + (size_t)b0 * fbytes, (size_t)nb * fbytes,
+                                      hipMemcpyHostToDevice, s->stream));
         ARP_TRY(label_dev_single(s, frames_dev + (size_t)b0 * H * W * 3, nb, H, W, use_crop, rewards_dev + b0));
         if (i > 0) {
             ARP_HIP_OK(hipEventRecord(c->ev_join[i - 1], s->stream));
@@ -764,8 +773,7 @@ int arp_clip_label(arp_clip* c, const uint8_t* frames, int n, int H, int W, int 
     ARP_TRY(c->rewards.ensure((size_t)std::min(n, mb) * 4));
     for (int off = 0; off < n; off += mb) {
         const int nb = std::min(mb, n - off);
-        ARP_HIP_OK(hipMemcpyAsync(c->frames_in.p, frames + (size_t)off * fb, (size_t)nb * fb, hipMemcpyHostToDevice, c->stream));
-        ARP_TRY(label_dev(c, c->frames_in.as<uint8_t>(), nb, H, W, use_crop, c->rewards.as<float>()));
+        ARP_TRY(label_dev(c, c->frames_in.as<uint8_t>(), nb, H, W, use_crop, c->rewards.as<float>(), frames + (size_t)off * fb));
         ARP_HIP_OK(hipMemcpyAsync(rewards + off, c->rewards.p, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
     }
