@@ -110,7 +110,7 @@ class ClipLabeller:
     operands, f32 accumulate / residual / LayerNorm / softmax) or "f32" (parity; f32-input MFMA).
     """
 
-    def __init__(self, cfg, state_dict, mode="bf16", device=0, max_batch=1024, attn_impl=0, n_streams=1):
+    def __init__(self, cfg, state_dict, mode="bf16", device=0, max_batch=1024, attn_impl=0, n_streams=3):
         _ffi.require_gpu()
         self.cfg = cfg
         self.mode = {"bf16": MODE_BF16, "f32": MODE_F32}[mode]
