@@ -179,3 +179,28 @@ def test_shard_trajectories_balanced_and_complete():
             if ntraj >= 4 * world:
                 per = [bounds[b] - bounds[a] for a, b in sh]
                 assert max(per) <= sum(lens) / world + 50
+
+
+def test_trajectory_batching_changes_nothing():
+    """label_store labels several short trajectories per compute_reward call; values, stacking and rtg are per trajectory."""
+    from arp_amd import label_reward as L
+    st = _store([3, 5, 1, 4, 2])
+    calls = []
+
+    class Counting(_FakeClip):
+        def label(self, frames, use_crop=False):
+            calls.append(len(frames))
+            return super().label(frames, use_crop)
+
+    cr = L.make_compute_reward("clip")
+    one = L.label_store(st, Counting(), cr, batch_frames=0)
+    n_one = len(calls)
+    calls.clear()
+    many = L.label_store(st, Counting(), cr, batch_frames=8)
+    assert n_one == 5 and calls == [8, 7]  # [3+5], [1+4+2]
+    assert one.keys() == many.keys()
+    for k in one:
+        assert one[k][0] == many[k][0] and np.array_equal(one[k][1], many[k][1])
+    calls.clear()
+    L.label_store(st, Counting(), L.make_compute_reward("clip_goal_conditioned"), model_type="clip_goal_conditioned", batch_frames=8)
+    assert calls == []  # goal-conditioned goes through encode_image, one trajectory at a time
