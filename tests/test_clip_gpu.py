@@ -174,3 +174,31 @@ def test_layernorm_fold_matches_unfused(gpu_lib, monkeypatch):
     e0, e1 = np.abs(out["0"] - ref).max() / scale, np.abs(out["1"] - ref).max() / scale
     print(f"cosine err unfused {e0:.2e}, folded {e1:.2e}, folded vs unfused {np.abs(out['0'] - out['1']).max() / scale:.2e}")
     assert e0 < COS_TOL_BF16 and e1 < COS_TOL_BF16
+
+
+def test_full_batch_properties(gpu_lib):
+    """BASELINE configs[1] at full size (1024 frames, ViT-B/32, bf16), through properties that need no oracle at that size:
+    a frame's reward does not depend on what else is in the batch or where it sits (permutation / duplication), on the number
+    of streams, or on the run (bit-identical repeats), and a 16-frame sample agrees with the oracle."""
+    from arp_amd import clip, synth
+    from oracle import clip_np as C
+    cfg = clip.MODELS["ViT-B/32"]
+    W = synth.clip_weights(C.ClipConfig(patch=cfg.patch), seed=0)
+    tok = synth.prompt_tokens(1, 8, seed=2)
+    fr = synth.procgen_like_frames(1024, seed=5)
+    fr[777] = fr[3]  # a duplicate far away in the batch
+    m = clip.ClipLabeller(cfg, W, mode="bf16", max_batch=1024, n_streams=2).set_text(tok)
+    r = m.label(fr)
+    assert r.shape == (1024,) and np.isfinite(r).all()
+    assert np.array_equal(r, m.label(fr))                      # deterministic
+    assert r[777] == r[3]                                       # position-independent
+    perm = np.random.default_rng(0).permutation(1024)
+    assert np.array_equal(m.label(fr[perm]), r[perm])           # batch-composition independent
+    for ns in (1, 3):
+        m.set_streams(ns)
+        assert np.array_equal(m.label(fr), r)                   # stream-count independent
+    assert np.array_equal(m.label(fr[:100]), r[:100])           # sub-batch (different GEMM grid, same per-row arithmetic)
+    idx = np.arange(0, 1024, 64)
+    ref = C.compute_reward(W, C.ClipConfig(patch=cfg.patch), fr[idx], tok)
+    assert np.abs(r[idx] - ref).max() / 100.0 < COS_TOL_BF16
+    m.close()

@@ -277,3 +277,32 @@ def test_device_resident_handoff_equals_host_path(gpu_lib):
         b.free()
     tr.close()
     m.close()
+
+
+def test_full_size_head_step_is_bitwise_reproducible(gpu_lib):
+    """BASELINE configs[4] geometry (B = 64, 476 M trainable parameters, bf16): two runs of two AdamW steps from the same state
+    are bit-identical (fixed-order split-K reductions, no float atomics) and the loss on the fixed batch goes down."""
+    from arp_amd import finetune as FT
+    cfg = FT.FinetuneConfig()
+    P = FT.synth_params(cfg, seed=0)
+    batch = FT.synth_batch(cfg, 64, seed=1)
+    probe = ("image_intermediate_linear.weight", "text_adapter.layers.3.weight", "inverse_layer.layers.0.weight", "lambda_id", "image_residual_weight")
+    runs = []
+    for _ in range(2):
+        tr = FT.FinetuneTrainer(cfg, mode="bf16")
+        tr.set_params(P)
+        tr.set_batch(*batch)
+        aux = [tr.train_step(1e-4) for _ in range(2)]
+        got = {}
+        import ctypes as C
+        from arp_amd import _ffi
+        for k in probe:
+            a = np.empty(tr.shapes[k], np.float32)
+            _ffi.check(_ffi.lib.arp_ft_get_tensor(tr._h, k.encode(), 0, _ffi.as_ptr(a, C.c_float)))
+            got[k] = a
+        runs.append((aux, got))
+        tr.close()
+    (a0, p0), (a1, p1) = runs
+    assert [a["loss"] for a in a0] == [a["loss"] for a in a1]
+    assert all(np.array_equal(p0[k], p1[k]) for k in probe)
+    assert a0[1]["loss"] < a0[0]["loss"]
