@@ -46,7 +46,7 @@ def test_forward_parity(gpu_lib, kw, B, mode, tol):
     tr.close()
 
 
-@pytest.mark.parametrize("kw,B", [(TINY, 4), (SMALL, 6)])
+@pytest.mark.parametrize("kw,B", [(TINY, 4), (SMALL, 6), (TINY, 3)])  # B = 3: 45 adapter rows, ragged for every 4-wide access
 @pytest.mark.parametrize("mode,rtol", [("f32", 2e-4), ("bf16", None)])
 def test_gradient_parity(gpu_lib, kw, B, mode, rtol):
     from arp_amd.train import PolicyTrainer
