@@ -347,6 +347,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 if (p) __syncthreads();
+                // the pass's 16 residual rows per thread are requested BEFORE the tile is staged: all in flight at once
+                // instead of four dependent rounds of load -> add -> store (the operand registers are dead by now)
+                float4 rres[16];
+                if constexpr (RESID) {
+#pragma unroll
+                    for (int it = 0; it < 16; ++it) {
+                        const int lr = it * 8 + wave;
+                        const int m = m0 + (lr >> 6) * 128 + p * 64 + (lr & 63), n = n0 + lane * 4;
+                        rres[it] = (m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                             *reinterpret_cast<float4*>(smem + lrow * RSF + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                 __syncthreads();
-#pragma unroll 4
+#pragma unroll
                 for (int it = 0; it < 16; ++it) {
                     const int lr = it * 8 + wave;
                     const int m = m0 + (lr >> 6) * 128 + p * 64 + (lr & 63), n = n0 + lane * 4;
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                     if (ok) {
                         v = *reinterpret_cast<const float4*>(smem + lr * RSF + lane * 16);
                         if constexpr (RESID) {
-                            const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+                            const float4 r = rres[it];
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                         }
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
