@@ -36,7 +36,8 @@ namespace arp {
 constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
 constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * 128;  // one K-tile: 64 KiB
 static_assert(256 * (256 * 2 + 16) >= 2 * G2_BUF_BYTES && 256 * (256 * 2 + 16) >= 128 * (256 * 4 + 16), "epilogue tile must cover the K-tile ring");
-constexpr int G2_LDS_BYTES = 256 * (256 * 2 + 16);   // 132 KiB: 2 K-tile buffers (128 KiB) or the padded epilogue tile
+constexpr int G2_TILE_BYTES = 256 * (256 * 2 + 16);  // 132 KiB: 2 K-tile buffers (128 KiB) or the padded epilogue tile
+constexpr int G2_LDS_BYTES = G2_TILE_BYTES + 1024;   // + this tile's 256 bias values, fetched while the K loop runs
 constexpr int G2_B_REGION = G2_BM * 128;             // W rows start here inside a buffer
 constexpr int G2_GROUP_M = 8;
 
@@ -217,9 +218,19 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
     bool pre_issued = false;
+    bool pre_issued_bias = false;
     for (int tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
     tile_coords(tix);
     setup_src();
+    // the tile's bias slice (256 floats) goes to LDS by one LDS-DMA of wave 0, issued ahead of the operand units (so every
+    // counted wait covers it): read from global memory in the epilogue it would cost a memory latency with nothing to hide it
+    float* bias_s = reinterpret_cast<float*>(smem + G2_TILE_BYTES);
+    if (g.bias && wave == 0 && !pre_issued_bias) {
+        int n = n0 + lane * 4;
+        n = n + 4 <= g.N ? n : (g.N >= 4 ? g.N - 4 : 0);  // clamped at the ragged edge: those columns are never stored
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + n),
+                                         (__attribute__((address_space(3))) void*)bias_s, 16, 0, 0);
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                                 v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
                             }
                             if (g.bias && n0 + col < g.N) {
-                                const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
+                                const float4 b = *reinterpret_cast<const float4*>(bias_s + col);
                                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                             }
 #pragma unroll
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                             const f32x4_v a4 = acc[p][nq][ni][mi];
                             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
                             if (g.bias && n0 + col < g.N) {
-                                const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
+                                const float4 b = *reinterpret_cast<const float4*>(bias_s + col);
                                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                             }
 #pragma unroll
@@ -447,10 +458,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     };
     epilogue();
     pre_issued = false;
+    pre_issued_bias = false;
     if (tix + (int)gridDim.x < total_tiles) {
         __syncthreads();  // every wave has finished reading the epilogue tile out of LDS
         tile_coords(tix + gridDim.x);
         setup_src();
+        if (g.bias && wave == 0) {
+            int n = n0 + lane * 4;
+            n = n + 4 <= g.N ? n : (g.N >= 4 ? g.N - 4 : 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + n),
+                                             (__attribute__((address_space(3))) void*)(smem + G2_TILE_BYTES), 16, 0, 0);
+        }
+        pre_issued_bias = true;
         issue(0, U0{});
         issue(1, U1{});
         issue(2, U2{});
