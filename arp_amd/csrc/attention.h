@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
 typedef __attribute__((ext_vector_type(4))) short tr_b64_v;
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int D,
+__global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int D,
                                                         int heads, float scale, int causal) {
     constexpr int NP = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
