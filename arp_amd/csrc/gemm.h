@@ -241,6 +241,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 if (p) __syncthreads();
+                // the pass's 8 residual rows per thread are requested before the tile is staged (see gemm256.h)
+                float4 rres[8];
+                if constexpr (RESID) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int lr = it * 8 + wave * 2 + (lane >> 5);
+                        const int m = m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), n = n0 + (lane & 31) * 4;
+                        rres[it] = (m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                         *reinterpret_cast<float4*>(smem + lrow * RSF + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 __syncthreads();
-#pragma unroll 4
+#pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int lr = it * 8 + wave * 2 + (lane >> 5);
                     const int m = m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), n = n0 + (lane & 31) * 4;
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     if (ok) {
                         v = *reinterpret_cast<const float4*>(smem + lr * RSF + (lane & 31) * 16);
                         if constexpr (RESID) {
-                            const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+                            const float4 r = rres[it];
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                         }
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
