@@ -90,8 +90,19 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* 
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + x;
     float s = 0.f;
-    if (i < MN)
-        for (int k = y; k < S; k += 4) s += part[(size_t)k * MN + i];
+    if (i < MN) {
+        // four independent partial sums: four slab loads in flight per thread instead of one dependent load-add chain
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = y;
+        for (; k + 12 < S; k += 16) {
+            s0 += part[(size_t)k * MN + i];
+            s1 += part[(size_t)(k + 4) * MN + i];
+            s2 += part[(size_t)(k + 8) * MN + i];
+            s3 += part[(size_t)(k + 12) * MN + i];
+        }
+        for (; k < S; k += 4) s0 += part[(size_t)k * MN + i];
+        s = (s0 + s1) + (s2 + s3);
+    }
     red[y][x] = s;
     __syncthreads();
     if (y != 0 || i >= MN) return;
