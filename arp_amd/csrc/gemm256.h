@@ -3,22 +3,18 @@
 // Structure (written for CDNA4, one 512-thread workgroup per CU, 128 KiB LDS):
 //   * 8 waves as 2 (M) x 4 (N); each wave owns a 128x64 output block = 2x2 "quadrants" of 64x32
 //     (4x2 MFMA fragments of 16x16), 128 accumulator VGPRs.
-//   * K is consumed in tiles of 128 bytes per row (64 bf16 / 32 f32).  A K-tile is processed in
-//     FOUR PHASES, one quadrant each, in the order (0,0) (0,1) (1,1) (1,0), so consecutive phases
-//     share either the A or the B register sub-tile.
-//   * Every phase is [load segment | s_barrier | MFMA segment | s_barrier].  The two wave groups
-//     (wr = 0 / 1; they sit pairwise on the same SIMDs) run ONE BARRIER OUT OF STEP, so while one
-//     group issues its 16 MFMAs the other issues its LDS reads and LDS-DMA: the SIMD's matrix pipe
-//     always has a wave to serve.
-//   * Operands reach LDS by global_load_lds_dwordx4 (LDS-DMA), 2 instructions per thread per phase
-//     ("unit" = 128 rows x 128 B = 16 KiB).  Units are ordered by FIRST USE, not by position:
-//       U0 = A rows of quadrant-row 0 (needed in phase 1)     U1 = W rows of quadrant-col 0 (phase 1)
-//       U2 = W rows of quadrant-col 1 (phase 2)               U3 = A rows of quadrant-row 1 (phase 3)
-//     and issued 5 units ahead of their first use into a 2-deep ring of K-tile buffers; the only
-//     waits are COUNTED s_waitcnt vmcnt(6) (three units stay in flight across every barrier).
-//     Hazards (unit g = 4*tile + u is issued in phase g-5, waited for in phase g-2 before that
-//     phase's first barrier, first read in phase g-1 or later; its LDS region was last read three
-//     phases before it is overwritten) are argued in DESIGN.md section 5.
+//   * K is consumed in tiles of 128 bytes per row (64 bf16 / 32 f32).  A K-tile is processed in TWO PHASES: A = quadrants
+//     (0,0) (0,1), B = quadrants (1,1) (1,0); the two W register sub-tiles are loaded once per K-tile.
+//   * Every phase is [load segment | s_barrier | MFMA segment (32 MFMAs) | s_barrier].  The two wave groups (wr = 0 / 1; they
+//     sit pairwise on the same SIMDs) run ONE BARRIER OUT OF STEP, so while one group issues its MFMAs the other issues
+//     its LDS reads and LDS-DMA: the SIMD's matrix pipe always has a wave to serve.  (The first version had four phases
+//     per K-tile; 30 % of the wave cycles were parked in barriers / waits, ARP_G2_TWO_PHASE=0 rebuilds it.)
+//   * Operands reach LDS by global_load_lds_dwordx4 (LDS-DMA), 2 instructions per thread per "unit" (128 rows x 128 B =
+//     16 KiB):  U0 = A rows of quadrant-row 0, U1 / U2 = W rows of quadrant-col 0 / 1, U3 = A rows of quadrant-row 1.
+//     Units are issued in STEPS -- even step 2t = {U0,U1,U2} of K-tile t, odd step 2t+1 = {U3} of K-tile t -- three steps
+//     ahead of their first use into a 2-deep ring of K-tile buffers; the only waits are COUNTED s_waitcnt vmcnt(8) (two
+//     steps = 64 KiB stay in flight across every barrier).  Hazards (phase p reads step p, issues step p+3 over the region
+//     of step p-1, waits for step p+1 before its first barrier) are argued in DESIGN.md section 5.
 //   * 16-byte-chunk XOR swizzle applied on the LDS-DMA SOURCE address and on the ds_read_b128
 //     address (the LDS-DMA destination is lane-linear), as in gemm.h.
 //   * block -> tile map: XCD-contiguous ranges, then groups of GROUP_M tile-rows walked column by
@@ -33,6 +29,9 @@
 
 namespace arp {
 
+#ifndef ARP_G2_TWO_PHASE
+#define ARP_G2_TWO_PHASE 1
+#endif
 constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
 constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * 128;  // one K-tile: 64 KiB
 static_assert(256 * (256 * 2 + 16) >= 2 * G2_BUF_BYTES && 256 * (256 * 2 + 16) >= 128 * (256 * 4 + 16), "epilogue tile must cover the K-tile ring");
@@ -46,6 +45,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 // units allowed to stay in flight -> counted wait (2 LDS-DMA instructions per unit per thread)
 __device__ __forceinline__ void wait_units(int allow) {
@@ -217,6 +217,47 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
+#if ARP_G2_TWO_PHASE
+    // ---- two phases per K-tile (halves the barrier count: 30 % of the wave cycles sat in s_barrier / s_waitcnt with four) ----
+    // Issue STEPS: even step 2t = units U0,U1,U2 of K-tile t (first read in phase A(t)), odd step 2t+1 = unit U3 of K-tile t
+    // (first read in phase B(t)).  Phase p reads step p and issues step p+3 -- the buffer region of step p-1, read one phase
+    // earlier by both wave groups -- then waits until step p+1 has landed (steps p+2, p+3 stay in flight: 8 LDS-DMA
+    // instructions per thread) so that it is visible, after the barrier, to the reads of phase p+1.
+    const int S2 = 2 * nk;
+    auto issue_step = [&](int st) {
+        const int t4 = (st >> 1) * 4;
+        if (st & 1) {
+            issue(t4 + 3, U3{});
+        } else {
+            issue(t4 + 0, U0{});
+            issue(t4 + 1, U1{});
+            issue(t4 + 2, U2{});
+        }
+    };
+    auto step_cnt = [&](int st) { return st < S2 ? ((st & 1) ? 2 : 6) : 0; };
+    auto wait_instr = [&](int n) {
+        if (n >= 8) wait_vmcnt<8>();
+        else if (n >= 6) wait_vmcnt<6>();
+        else if (n >= 2) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+    auto phase_tail2 = [&](int p) {
+        wait_instr(step_cnt(p + 2) + step_cnt(p + 3));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this phase's fragment reads are done before any wave may overwrite them
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute2 = [&](auto MQ, auto NQA, auto NQB) {
+        __builtin_amdgcn_s_setprio(1);
+        mfma_quadrant(MQ, NQA);
+        mfma_quadrant(MQ, NQB);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#endif
     bool pre_issued = false;
     bool pre_issued_bias = false;
     for (int tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
@@ -239,6 +280,39 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+#if ARP_G2_TWO_PHASE
+    // ---- prologue: steps 0..2 in flight, step 0 landed and visible ---------------------------------------
+    if (!pre_issued) {
+        issue_step(0);
+        issue_step(1);
+        issue_step(2);
+    }
+    wait_instr(step_cnt(1) + step_cnt(2));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 1) {  // stagger: group 1 runs one barrier behind group 0
+        __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* buf = smem + (kt & 1) * G2_BUF_BYTES;
+        const int p = 2 * kt;
+        // phase A: quadrants (0,0) and (0,1)
+        load_a(buf, 0);
+        load_b(buf, I0{});
+        load_b(buf, I1{});
+        issue_step(p + 3);
+        phase_tail2(p);
+        compute2(I0{}, I0{}, I1{});
+        // phase B: quadrants (1,1) and (1,0) -- the W sub-tiles are still in registers
+        load_a(buf, 1);
+        issue_step(p + 4);
+        phase_tail2(p + 1);
+        compute2(I1{}, I1{}, I0{});
+    }
+#else
     // ---- prologue: units 0..4 in flight, units 0 and 1 landed and visible ---------------------------
     if (!pre_issued) {
         issue(0, U0{});
@@ -283,6 +357,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
         phase_tail(ph + 3);
         compute(I1{}, I0{});
     }
+#endif
     if (wr == 0) {  // re-align the two groups
         __builtin_amdgcn_s_barrier();
     }
@@ -470,11 +545,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                                              (__attribute__((address_space(3))) void*)(smem + G2_TILE_BYTES), 16, 0, 0);
         }
         pre_issued_bias = true;
+#if ARP_G2_TWO_PHASE
+        issue_step(0);
+        issue_step(1);
+        issue_step(2);
+#else
         issue(0, U0{});
         issue(1, U1{});
         issue(2, U2{});
         issue(3, U3{});
         issue(4, U0{});
+#endif
         pre_issued = true;
     }
     }  // tile loop
