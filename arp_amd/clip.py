@@ -11,7 +11,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _ffi
-from ._ffi import MODE_BF16, MODE_F32, check, lib
+from ._ffi import MODE_BF16, MODE_F16, MODE_F32, check, lib
 
 
 @dataclass(frozen=True)
@@ -106,14 +106,15 @@ class ClipLabeller:
     """``ClipLabeller(cfg, state_dict).set_text(tokens).label(frames) -> float32 rewards``.
 
     ``state_dict`` maps openai/CLIP names to arrays (numpy or torch tensors; a real
-    ``clip.load(...)[0].state_dict()`` works as is).  ``mode``: "bf16" (throughput; bf16 MFMA
-    operands, f32 accumulate / residual / LayerNorm / softmax) or "f32" (parity; f32-input MFMA).
+    ``clip.load(...)[0].state_dict()`` works as is).  ``mode``: "f16" (default: IEEE-half MFMA operands --
+    what openai/CLIP itself runs on a GPU -- f32 accumulate / residual / LayerNorm / softmax; rewards within 1e-4 cosine of
+    the fp32 reference at the bf16 rate), "bf16" (same rate, 8-bit significands: 3-8e-4) or "f32" (f32-input MFMA, 1e-7).
     """
 
-    def __init__(self, cfg, state_dict, mode="bf16", device=0, max_batch=1024, attn_impl=0, n_streams=3):
+    def __init__(self, cfg, state_dict, mode="f16", device=0, max_batch=1024, attn_impl=0, n_streams=3):
         _ffi.require_gpu()
         self.cfg = cfg
-        self.mode = {"bf16": MODE_BF16, "f32": MODE_F32}[mode]
+        self.mode = {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32}[mode]
         c = _ffi.ClipCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.embed, cfg.img_res, cfg.txt_width,
                          cfg.txt_layers, cfg.txt_heads, cfg.ctx, cfg.vocab, self.mode, device, max_batch, attn_impl, n_streams)
         h = C.c_void_p()

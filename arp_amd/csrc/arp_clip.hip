@@ -230,7 +230,7 @@ struct arp_clip {
     DevBuf stats;
 
     int ntok() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
-    size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
+    size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
 };
 
 namespace arp {
@@ -270,6 +270,10 @@ static int upload_mat(arp_clip* c, const float* src, int rows, int cols, bool tr
     if (c->cfg.mode == ARP_MODE_BF16) {
         std::vector<bf16_t> hb(n);
         for (size_t i = 0; i < n; ++i) hb[i] = host_f2bf(s[i]);
+        ARP_HIP_OK(hipMemcpy(p, hb.data(), n * 2, hipMemcpyHostToDevice));
+    } else if (c->cfg.mode == ARP_MODE_F16) {
+        std::vector<f16_t> hb(n);
+        for (size_t i = 0; i < n; ++i) hb[i] = host_f2h(s[i]);
         ARP_HIP_OK(hipMemcpy(p, hb.data(), n * 2, hipMemcpyHostToDevice));
     } else {
         ARP_HIP_OK(hipMemcpy(p, s, n * 4, hipMemcpyHostToDevice));
@@ -433,6 +437,7 @@ static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizeP
 
 static int forward_chunk_dispatch(arp_clip* c, const uint8_t* frames_dev, int nb, ResizePlan* plan) {
     if (c->cfg.mode == ARP_MODE_BF16) return forward_chunk<bf16_t>(c, frames_dev, nb, plan);
+    if (c->cfg.mode == ARP_MODE_F16) return forward_chunk<f16_t>(c, frames_dev, nb, plan);
     return forward_chunk<float>(c, frames_dev, nb, plan);
 }
 
@@ -634,10 +639,10 @@ int arp_dev_synchronize(void) {
 int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     if (!cfg || !out) return fail("null argument");
     const arp_clip_cfg& k = *cfg;
-    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16) return fail("bad mode");
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16 && k.mode != ARP_MODE_F16) return fail("bad mode");
     if (k.patch <= 0 || k.img_res % k.patch || k.patch % 4 || k.img_res % 4) return fail("bad patch / img_res");
     if (k.width % k.heads || k.txt_width % k.txt_heads) return fail("width not divisible by heads");
-    const int kq = (k.mode == ARP_MODE_BF16) ? 64 : 32;
+    const int kq = (k.mode == ARP_MODE_F32) ? 32 : 64;
     if (k.width % kq || k.txt_width % kq || (3 * k.patch * k.patch) % kq)
         return fail("width / txt_width / 3*patch^2 must be multiples of " + std::to_string(kq));
     if (k.embed % 4) return fail("embed must be a multiple of 4");
@@ -740,6 +745,7 @@ int arp_clip_set_text(arp_clip* c, const int32_t* tokens, int n_prompts) {
     if (!tokens || n_prompts <= 0) return fail("set_text: need at least one prompt");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     if (c->cfg.mode == ARP_MODE_BF16) return run_text<bf16_t>(c, tokens, n_prompts);
+    if (c->cfg.mode == ARP_MODE_F16) return run_text<f16_t>(c, tokens, n_prompts);
     return run_text<float>(c, tokens, n_prompts);
 }
 
@@ -861,6 +867,7 @@ int arp_clip_encode_text_multiscale(arp_clip* c, const int32_t* tokens, int n, f
     if (!tokens || n <= 0 || !inter || !final_feat) return fail("bad argument");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     if (c->cfg.mode == ARP_MODE_BF16) return run_text<bf16_t>(c, tokens, n, final_feat, false, inter);
+    if (c->cfg.mode == ARP_MODE_F16) return run_text<f16_t>(c, tokens, n, final_feat, false, inter);
     return run_text<float>(c, tokens, n, final_feat, false, inter);
 }
 int arp_clip_encode_text_multiscale_dev(arp_clip* c, const int32_t* tokens, int n, float* inter_dev, float* final_dev) {
@@ -868,6 +875,7 @@ int arp_clip_encode_text_multiscale_dev(arp_clip* c, const int32_t* tokens, int 
     if (!tokens || n <= 0 || !inter_dev || !final_dev) return fail("bad argument");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     if (c->cfg.mode == ARP_MODE_BF16) return run_text<bf16_t>(c, tokens, n, final_dev, false, inter_dev, true);
+    if (c->cfg.mode == ARP_MODE_F16) return run_text<f16_t>(c, tokens, n, final_dev, false, inter_dev, true);
     return run_text<float>(c, tokens, n, final_dev, false, inter_dev, true);
 }
 
@@ -983,7 +991,11 @@ int arp_event_elapsed_ms(arp_event* a, arp_event* b, float* ms) {
 // ---- single-operator entry points ------------------------------------------------------------------
 template <typename T> static int to_dev(const float* src, size_t n, DevBuf& d) {
     ARP_TRY(d.ensure(std::max<size_t>(n * sizeof(T), 16)));
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same_v<T, f16_t>) {
+        std::vector<f16_t> hb(n);
+        for (size_t i = 0; i < n; ++i) hb[i] = host_f2h(src[i]);
+        ARP_HIP_OK(hipMemcpy(d.p, hb.data(), n * 2, hipMemcpyHostToDevice));
+    } else if constexpr (sizeof(T) == 2) {
         std::vector<bf16_t> hb(n);
         for (size_t i = 0; i < n; ++i) hb[i] = host_f2bf(src[i]);
         ARP_HIP_OK(hipMemcpy(d.p, hb.data(), n * 2, hipMemcpyHostToDevice));
@@ -993,7 +1005,11 @@ template <typename T> static int to_dev(const float* src, size_t n, DevBuf& d) {
     return 0;
 }
 template <typename T> static int from_dev(float* dst, size_t n, const DevBuf& d) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same_v<T, f16_t>) {
+        std::vector<uint16_t> hb(n);
+        ARP_HIP_OK(hipMemcpy(hb.data(), d.p, n * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) dst[i] = (float)__builtin_bit_cast(_Float16, hb[i]);
+    } else if constexpr (sizeof(T) == 2) {
         std::vector<bf16_t> hb(n);
         ARP_HIP_OK(hipMemcpy(hb.data(), d.p, n * 2, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) {
@@ -1041,6 +1057,7 @@ extern "C" {
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N,
                    int K) {
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0) return fail("bad argument");
+    if (mode == ARP_MODE_F16) return op_gemm<f16_t>(act, A, W, bias, resid, out, M, N, K);
     return mode == ARP_MODE_BF16 ? op_gemm<bf16_t>(act, A, W, bias, resid, out, M, N, K) : op_gemm<float>(act, A, W, bias, resid, out, M, N, K);
 }
 
@@ -1138,6 +1155,7 @@ extern "C" {
 
 int arp_op_attention(int mode, int impl, const float* qkv, float* out, int B, int N, int D, int heads, int causal) {
     if (!qkv || !out || B <= 0 || N <= 0 || D <= 0 || heads <= 0 || D % heads) return fail("bad argument");
+    if (mode == ARP_MODE_F16) return op_attn<f16_t>(impl, qkv, out, B, N, D, heads, causal);
     return mode == ARP_MODE_BF16 ? op_attn<bf16_t>(impl, qkv, out, B, N, D, heads, causal)
                                  : op_attn<float>(impl, qkv, out, B, N, D, heads, causal);
 }

@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
 // so V is staged exactly like K -- no 2-byte transposing stores.
 typedef __attribute__((ext_vector_type(4))) short tr_b64_v;
 
-template <int NT>
-__global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int D,
+template <typename T, int NT>
+__global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int D,
                                                         int heads, float scale, int causal) {
     constexpr int NP = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const size_t ld = 3 * (size_t)D;
-    const bf16_t* base = qkv + (size_t)b * N * ld + h * 64;
+    const T* base = qkv + (size_t)b * N * ld + h * 64;
 
     for (int i = tid; i < NP * 8; i += 256) {  // pad keys are zero-filled
         const int key = i >> 3, ch = i & 7;
@@ -109,10 +109,9 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
         int qrow = qb * 16 + fr;
         const int qvalid = qrow < N;
         qrow = qvalid ? qrow : N - 1;
-        bf16x8_v qf[2];
+        u32x4_v qf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[ks] = __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const u32x4_v*>(base + qrow * ld + ks * 32 + fg * 8));
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const u32x4_v*>(base + qrow * ld + ks * 32 + fg * 8);
 
         // S^T tile kt: rows = keys 16*kt + 4*fg + r, col = query fr
         f32x4_v s[NT];
@@ -122,9 +121,8 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
             const int krow = kt * 16 + fr;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_v kf = __builtin_bit_cast(
-                    bf16x8_v, *reinterpret_cast<const u32x4_v*>(Ks + krow * 128 + (((ks * 4 + fg) ^ (krow & 7)) << 4)));
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+                const u32x4_v kf = *reinterpret_cast<const u32x4_v*>(Ks + krow * 128 + (((ks * 4 + fg) ^ (krow & 7)) << 4));
+                s[kt] = mfma16<T>(kf, qf[ks], s[kt]);
             }
         }
         const int qidx = qb * 16 + fr;
@@ -163,11 +161,10 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
 #pragma unroll
         for (int st = 0; st < NT / 2; ++st) {
             u32x4_v pb;
-            pb[0] = pack_bf2(s[2 * st][0], s[2 * st][1]);
-            pb[1] = pack_bf2(s[2 * st][2], s[2 * st][3]);
-            pb[2] = pack_bf2(s[2 * st + 1][0], s[2 * st + 1][1]);
-            pb[3] = pack_bf2(s[2 * st + 1][2], s[2 * st + 1][3]);
-            const bf16x8_v pf = __builtin_bit_cast(bf16x8_v, pb);
+            pb[0] = pack2<T>(s[2 * st][0], s[2 * st][1]);
+            pb[1] = pack2<T>(s[2 * st][2], s[2 * st][3]);
+            pb[2] = pack2<T>(s[2 * st + 1][0], s[2 * st + 1][1]);
+            pb[3] = pack2<T>(s[2 * st + 1][2], s[2 * st + 1][3]);
             const int k0 = 32 * st + 4 * fg + trq, k1 = k0 + 16;  // the row this lane addresses in each block
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -178,11 +175,11 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
                     (__attribute__((address_space(3))) tr_b64_v*)(Vs + k1 * 128 + ((ch ^ (k1 & 7)) << 4) + (trp & 1) * 8));
                 const u32x2_v l2 = __builtin_bit_cast(u32x2_v, lo), h2 = __builtin_bit_cast(u32x2_v, hi);
                 const u32x4_v va = {l2[0], l2[1], h2[0], h2[1]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, va), pf, o[dt], 0, 0, 0);
+                o[dt] = mfma16<T>(va, pb, o[dt]);
             }
         }
         if (qvalid) {
-            bf16_t* orow = out + ((size_t)b * N + qidx) * D + h * 64;
+            T* orow = out + ((size_t)b * N + qidx) * D + h * 64;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 store4(orow + dt * 16 + fg * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);

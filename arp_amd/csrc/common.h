@@ -7,7 +7,11 @@
 namespace arp {
 
 typedef uint16_t bf16_t;  // raw bf16 bits; arithmetic always happens in f32
+// raw IEEE binary16 bits as a distinct type (ARP_MODE_F16: same MFMA rate as bf16, 11 significand bits instead of 8)
+struct f16_t { uint16_t b; };
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_v;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_v;
 typedef __attribute__((ext_vector_type(4))) float f32x4_v;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_v;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_v;
@@ -38,6 +42,26 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// f32 -> binary16, round-to-nearest-even (v_cvt_f16_f32); overflow goes to inf as IEEE says
+__device__ __forceinline__ float h2f(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.b); }
+__device__ __forceinline__ f16_t f2h(float f) { return f16_t{__builtin_bit_cast(uint16_t, (_Float16)f)}; }
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+    const f16x2_v v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+// two f32 -> one 32-bit word of the 16-bit operand type T
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) return pack_h2(lo, hi);
+    else return pack_bf2(lo, hi);
+}
+// one 16x16x32 MFMA on 16-bit operands of type T (8 elements per lane in a 128-bit register group)
+template <typename T> __device__ __forceinline__ f32x4_v mfma16(u32x4_v a, u32x4_v b, f32x4_v c) {
+    if constexpr (__is_same(T, f16_t))
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_v, a), __builtin_bit_cast(f16x8_v, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -48,12 +72,25 @@ template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+template <> struct Elem<f16_t> {
+    static __device__ __forceinline__ float ld(const f16_t* p) { return h2f(*p); }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = f2h(v); }
+};
+
 // store 4 consecutive values (16-B aligned for float, 8-B aligned for bf16)
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
     *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(a, b), pack_bf2(c, d));
+}
+__device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_h2(a, b), pack_h2(c, d));
+}
+__device__ __forceinline__ void load4(const f16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    const f16x2_v a = __builtin_bit_cast(f16x2_v, t.x), b = __builtin_bit_cast(f16x2_v, t.y);
+    v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)b[0]; v[3] = (float)b[1];
 }
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
     float4 t = *reinterpret_cast<const float4*>(p);
@@ -108,6 +145,25 @@ static inline bf16_t host_f2bf(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+}
+
+// host-side f32 -> binary16 (RNE, overflow to inf, subnormals kept)
+static inline f16_t host_f2h(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return f16_t{(uint16_t)(sign | 0x7e00u)};        // NaN
+    if (a >= 0x47800000u) return f16_t{(uint16_t)(sign | 0x7c00u)};       // >= 65536 (and inf) -> inf; 65520..65536 handled by rounding below
+    if (a < 0x33000000u) return f16_t{sign};                               // < 2^-25 -> 0
+    int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;                              // 24-bit significand
+    int shift = e >= -14 ? 13 : (13 + (-14 - e));                          // bits dropped
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    uint32_t h = e >= -14 ? (((uint32_t)(e + 15) << 10) + (q - 0x400u)) : q;  // carries propagate into the exponent
+    return f16_t{(uint16_t)(sign | h)};
 }
 
 }  // namespace arp

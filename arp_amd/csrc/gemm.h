@@ -181,8 +181,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     if constexpr (sizeof(T) == 2) {
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_v, wf[ni]), __builtin_bit_cast(bf16x8_v, af[mi]), acc[ni][mi], 0, 0, 0);
+                        acc[ni][mi] = mfma16<T>(wf[ni], af[mi], acc[ni][mi]);
                     } else {
                         // 16 floats of K per (ks): lane group fg holds k = 16*ks + 4*fg + j in element j
                         // of BOTH operands, so the four 16x16x4 MFMAs (j = 0..3) cover them all.
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
-                    *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
                 }
             }
             __syncthreads();

@@ -189,9 +189,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     if constexpr (sizeof(T) == 2) {
-                        acc[mq][nq][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_v, breg[nq][ni][ks]), __builtin_bit_cast(bf16x8_v, areg[mi][ks]),
-                            acc[mq][nq][ni][mi], 0, 0, 0);
+                        acc[mq][nq][ni][mi] = mfma16<T>(breg[nq][ni][ks], areg[mi][ks], acc[mq][nq][ni][mi]);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -414,7 +412,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                             }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
-                            *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                            *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
                         }
                 }
             __syncthreads();

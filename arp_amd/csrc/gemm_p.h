@@ -127,9 +127,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void gemm_p_kernel(GemmArgs g) {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {
                         if constexpr (sizeof(T) == 2) {
-                            acc[mq][nq][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8_v, wf[nq * 2 + ni]), __builtin_bit_cast(bf16x8_v, af[mq * 4 + mi]),
-                                acc[mq][nq][ni][mi], 0, 0, 0);
+                            acc[mq][nq][ni][mi] = mfma16<T>(wf[nq * 2 + ni], af[mq * 4 + mi], acc[mq][nq][ni][mi]);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
@@ -201,7 +199,7 @@ __global__ __launch_bounds__(GP_THREADS, 2) void gemm_p_kernel(GemmArgs g) {
                             }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
-                            *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                            *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
                         }
             __syncthreads();
 #pragma unroll 4

@@ -162,7 +162,7 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
             const int NT = ((N + 31) / 32) * 2;
 #define ARP_ATTN_CASE(nt)                                                                                                   \
     case nt: {                                                                                                              \
-        auto kern = attn_mfma_kernel<nt>;                                                                                   \
+        auto kern = attn_mfma_kernel<T, nt>;                                                                                  \
         const int lds = nt * 16 * 256;                                                                 \
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal);              \

@@ -232,7 +232,8 @@ class FinetunedClip:
         sd = {k: np.asarray(v) for k, v in state_dict.items()}
         cw = {k[len("clip_model."):]: v for k, v in sd.items() if k.startswith("clip_model.")}
         ccfg = aclip.MODELS[model] if isinstance(model, str) else model
-        towers = aclip.ClipLabeller(ccfg, cw, mode=mode, device=device)
+        towers = aclip.ClipLabeller(ccfg, cw, mode=mode, device=device)  # "f16" applies to the towers only
+        mode = "bf16" if mode == "f16" else mode                         # the head kernels know bf16 / f32
         ls = float(cw["logit_scale"]) if logit_scale is None else float(logit_scale)  # model.logit_scale = clip's, detached (:95)
         hidden = sd["inverse_layer.layers.0.weight"].shape[0]
         head = FinetuneTrainer(FinetuneConfig(layers=ccfg.layers, width_v=ccfg.width, width_t=ccfg.txt_width, embed=ccfg.embed, hidden=hidden,

@@ -227,7 +227,7 @@ def label_reward(
     tokens=None,
     tokenizer=None,
     model_name="ViT-B/16",
-    mode="bf16",
+    mode="f16",
     device=0,
     rank=0,
     world=1,

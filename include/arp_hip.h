@@ -22,6 +22,8 @@ extern "C" {
 
 #define ARP_MODE_F32 0  /* parity mode: f32 storage, f32-input MFMA (exact f32 FMA chains)        */
 #define ARP_MODE_BF16 1 /* throughput mode: bf16 GEMM operands, f32 accumulate/residual/LN/softmax */
+#define ARP_MODE_F16 2  /* path (1) only: IEEE binary16 GEMM operands (same MFMA rate as bf16, 11 significand bits --
+                           what openai/CLIP itself runs on a GPU), everything else as BF16 */
 
 #define ARP_ACT_NONE 0
 #define ARP_ACT_QGELU 1
@@ -58,7 +60,7 @@ typedef struct arp_clip_cfg {
     int32_t txt_heads;  /* 8   */
     int32_t ctx;        /* 77  */
     int32_t vocab;      /* 49408 */
-    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_BF16 */
+    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_BF16 | ARP_MODE_F16 */
     int32_t device;     /* HIP device ordinal */
     int32_t max_batch;  /* frames per internal pass (workspace size); <= 0 -> 1024 */
     int32_t attn_impl;  /* 0 = auto (MFMA kernel where available), 1 = force the VALU kernel */

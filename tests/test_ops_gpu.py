@@ -34,14 +34,14 @@ GEMM_SHAPES = [  # M, N, K
 
 
 @pytest.mark.parametrize("kernel", ["128", "256", "paired"])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])  # f32, bf16, f16 operands
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 def test_gemm_nt(gpu_lib, mode, shape, kernel, monkeypatch):
     """Both GEMM kernels (ARP_GEMM=1: 128x128 two-phase; ARP_GEMM=2: 256x256 four-phase pipelined)."""
     monkeypatch.setenv("ARP_GEMM", {"128": "1", "256": "2", "paired": "3"}[kernel])
     M, N, K = shape
-    if mode == 1 and K % (32 if kernel == "paired" else 64):
-        pytest.skip("bf16 GEMM needs K % 64 == 0 (K % 32 for the paired kernel)")
+    if mode != 0 and K % (32 if kernel == "paired" else 64):
+        pytest.skip("16-bit GEMM needs K % 64 == 0 (K % 32 for the paired kernel)")
     rng = np.random.default_rng(M * 7 + N * 3 + K)
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
@@ -51,8 +51,8 @@ def test_gemm_nt(gpu_lib, mode, shape, kernel, monkeypatch):
         out = np.empty((M, N), np.float32)
         gpu_lib.check(gpu_lib.lib.arp_op_gemm_nt(mode, act, _fp(A), _fp(W), _fp(bias) if use_b else None,
                                                  _fp(resid) if use_r else None, _fp(out), M, N, K))
-        a64 = (bf16_round(A) if mode == 1 else A).astype(np.float64)
-        w64 = (bf16_round(W) if mode == 1 else W).astype(np.float64)
+        rnd = {0: lambda x: x, 1: bf16_round, 2: lambda x: x.astype(np.float16).astype(np.float32)}[mode]
+        a64, w64 = rnd(A).astype(np.float64), rnd(W).astype(np.float64)
         ref = a64 @ w64.T
         if use_b:
             ref = ref + bias
@@ -124,16 +124,17 @@ ATTN_CASES = [  # B, N, D, heads, causal
 
 
 @pytest.mark.parametrize("case", ATTN_CASES)
-@pytest.mark.parametrize("mode,impl", [(0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("mode,impl", [(0, 1), (1, 1), (1, 0), (2, 1), (2, 0)])
 def test_attention(gpu_lib, case, mode, impl):
     B, N, D, heads, causal = case
     rng = np.random.default_rng(N * 13 + D)
     qkv = (rng.standard_normal((B * N, 3 * D)) * 1.5).astype(np.float32)
     out = np.empty((B * N, D), np.float32)
     gpu_lib.check(gpu_lib.lib.arp_op_attention(mode, impl, _fp(qkv), _fp(out), B, N, D, heads, causal))
-    ref = _attn_ref(bf16_round(qkv) if mode == 1 else qkv, B, N, D, heads, causal)
+    rnd = {0: lambda x: x, 1: bf16_round, 2: lambda x: x.astype(np.float16).astype(np.float32)}[mode]
+    ref = _attn_ref(rnd(qkv), B, N, D, heads, causal)
     err = np.abs(out - ref).max()
-    tol = 1e-5 if mode == 0 else 2.5e-2  # bf16: P and the output are rounded to 8 mantissa bits
+    tol = {0: 1e-5, 1: 2.5e-2, 2: 3.5e-3}[mode]  # bf16 / f16: P and the output are rounded to 8 / 11 significand bits
     assert err < tol, f"attention case={case} mode={mode} impl={impl}: max err {err}"
     if mode == 1:
         assert np.abs(out - ref).mean() < 2e-3
