@@ -227,6 +227,7 @@ struct arp_clip {
     // per-row loads and reductions land in the GEMM epilogues, which are the serialised part of every tile,
     // while the LayerNorm kernels they replace overlap with the other stream's GEMMs.  Off by default.
     bool ln_fold = false;
+    bool cls_only_last = true;  // vision tower: the last block computes only what ln_post reads (tower.h); ARP_CLS_ONLY=0 disables
     DevBuf stats;
 
     int ntok() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
@@ -359,6 +360,7 @@ template <typename T>
 static int run_blocks(arp_clip* c, const TowerW& tw, const char* tag, float* x, T* h, T* qkv, T* ao, T* fc, int B, int N,
                       int causal, float* stats = nullptr) {
     TowerCtx t = ctx_of(c);
+    t.cls_only_last = (&tw == &c->vis) && c->cls_only_last && !(t.ms_out && t.ms_rows);
     return run_blocks<T, ACT_QGELU, 0>(t, tw, tag, x, h, qkv, ao, fc, B, N, causal, 1e-5f, stats);
 }
 
@@ -655,6 +657,7 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 1024;
     if (const char* e = getenv("ARP_GEMM")) c->gemm_force = atoi(e);
     if (const char* e = getenv("ARP_LN_FOLD")) c->ln_fold = atoi(e) != 0;
+    if (const char* e = getenv("ARP_CLS_ONLY")) c->cls_only_last = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail("hipStreamCreate failed");

@@ -194,7 +194,7 @@ template <typename T> int small_attention_fwd(arp_dt* c, const float* qkv, float
     const size_t lds = (size_t)2 * L * hd * 4;
     const int threads = 64;
 #define ARP_DT_ATT(HD)                                                                                                   \
-    hipLaunchKernelGGL((attn_valu_kernel<float, HD>), dim3(B * heads), dim3(threads), lds, c->stream, qkv, out, L, E, heads, scale, 1)
+    hipLaunchKernelGGL((attn_valu_kernel<float, HD>), dim3(B * heads), dim3(threads), lds, c->stream, qkv, out, L, E, heads, scale, 1, L)
     if (hd == 16) ARP_DT_ATT(16);
     else if (hd == 32) ARP_DT_ATT(32);
     else if (hd == 64) ARP_DT_ATT(64);

@@ -23,7 +23,7 @@ namespace arp {
 
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int D,
-                                                        int heads, float scale, int causal) {
+                                                        int heads, float scale, int causal, int nq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ks = reinterpret_cast<float*>(smem);
     float* Vs = Ks + (size_t)N * HD;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
         Vs[i] = Elem<T>::ld(base + t * ld + 2 * D + d);
     }
     __syncthreads();
-    for (int qi = threadIdx.x; qi < N; qi += blockDim.x) {
+    for (int qi = threadIdx.x; qi < nq; qi += blockDim.x) {  // nq = N, or fewer when only the first rows are consumed
         float q[HD], acc[HD];
 #pragma unroll
         for (int d = 0; d < HD; ++d) {
@@ -76,7 +76,7 @@ typedef __attribute__((ext_vector_type(4))) short tr_b64_v;
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int D,
-                                                        int heads, float scale, int causal) {
+                                                        int heads, float scale, int causal, int nq) {
     constexpr int NP = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
-    const int nqb = (N + 15) >> 4;
+    const int nqb = (nq + 15) >> 4;  // query rows >= nq are not produced (last ViT block: only the class token is read)
     const float c2 = scale * 1.4426950408889634f;  // exp(x*scale) = exp2(x*c2)
     // transposing-read addressing: lane 4q+p of a 16-lane group points at row (key0 + q), columns 4p..4p+3 of the
     // 16-column block [16*dt, 16*dt+16); lane i receives column i of the four rows
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
                 o[dt] = mfma16<T>(va, pb, o[dt]);
             }
         }
-        if (qvalid) {
+        if (qvalid && qidx < nq) {
             T* orow = out + ((size_t)b * N + qidx) * D + h * 64;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)

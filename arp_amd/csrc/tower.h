@@ -99,6 +99,11 @@ struct GemmFold {
 struct TowerCtx {
     hipStream_t stream = nullptr;
     Profiler* prof = nullptr;
+    // Only row 0 of every sample (the class token) is read after the last block (ln_post(x[:,0]), arp_dt/models/openai/
+    // layers.py:330): the last block then runs out_proj / ln_2 / c_fc / c_proj -- and the attention's query side -- on those
+    // B rows instead of all B*N.  Every value that IS consumed is the same dot product as before; 49/50 of the last block's
+    // out_proj + MLP work (6.1 % of the tower's FLOPs at N = 50) is never computed.
+    bool cls_only_last = false;
     int attn_impl = 0;   // 0 = MFMA attention where available, 1 = VALU kernel
     int gemm_force = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel
     // multi-scale export: after every block, one row per sample of the residual stream -- what the forward
@@ -127,14 +132,14 @@ static int tower_export_rows(TowerCtx& c, const float* x, int D, int layer, int 
 
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
 static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* W, const float* bias, const float* resid, void* out,
-                int M, int N, int K, const GemmFold* f = nullptr) {
+                int M, int N, int K, const GemmFold* f = nullptr, int lda = 0, int ldr = 0, int ldo = 0) {
     GemmArgs g;
     if (f) {
         g.ln_stats = f->stats; g.ln_c = f->c; g.ln_parts = f->parts; g.ln_inv_d = f->inv_d; g.ln_eps = f->eps;
         g.xb_out = f->xb_out; g.ldxb = f->ldxb; g.stats_out = f->stats_out;
     }
     g.A = A; g.W = W; g.bias = bias; g.resid = resid; g.out = out;
-    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
+    g.M = M; g.N = N; g.K = K; g.lda = lda ? lda : K; g.ldw = K; g.ldr = ldr ? ldr : N; g.ldo = ldo ? ldo : N;
     ProfScope ps(*c.prof, c.stream, site);
     return launch_gemm_auto<T, OutT, ACT, RESID, SITE>(g, c.stream, c.gemm_force);
 }
@@ -154,8 +159,9 @@ static int tower_layernorm(TowerCtx& c, const char* site, const float* in, size_
 }
 
 template <typename T>
-static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, int B, int N, int D, int heads, int causal) {
+static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, int B, int N, int D, int heads, int causal, int nq = 0) {
     const int hd = D / heads;
+    if (nq <= 0 || nq > N) nq = N;  // query rows produced per sample
     const float scale = 1.0f / sqrtf((float)hd);
     if constexpr (sizeof(T) == 2) {
         if (impl == 0 && hd == 64) {
@@ -165,7 +171,7 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
         auto kern = attn_mfma_kernel<T, nt>;                                                                                  \
         const int lds = nt * 16 * 256;                                                                 \
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal);              \
+        hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal, nq);          \
         ARP_HIP_OK(hipGetLastError());                                                                                      \
         return 0;                                                                                                           \
     }
@@ -187,15 +193,15 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
     if (hd == 64) {
         auto kern = attn_valu_kernel<T, 64>;
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal);
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq);
     } else if (hd == 32) {
         auto kern = attn_valu_kernel<T, 32>;
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal);
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq);
     } else if (hd == 16) {
         auto kern = attn_valu_kernel<T, 16>;
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal);
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq);
     } else {
         return fail("attention: unsupported head_dim " + std::to_string(hd));
     }
@@ -242,6 +248,23 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
     }
     for (int i = 0; i < tw.layers; ++i) {
         const LayerW& L = tw.L[i];
+        if (c.cls_only_last && i == tw.layers - 1 && N > 1) {
+            const std::string s_attn1 = t + ".attn_cls", s_out1 = t + ".out_proj_cls", s_ln21 = t + ".ln_2_cls", s_fc11 = t + ".c_fc_cls",
+                              s_fc21 = t + ".c_proj_cls";
+            const int ND = N * D;  // row stride of the class-token rows inside the [B*N, D] buffers
+            ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));  // K and V need every token
+            ARP_TRY((tower_gemm<T, T, ACT_NONE, false, SB + SITE_QKV>(c, s_qkv.c_str(), h, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, D)));
+            {
+                ProfScope ps(*c.prof, c.stream, s_attn1.c_str());
+                ARP_TRY(launch_attention<T>(c.stream, c.attn_impl, qkv, ao, B, N, D, tw.heads, causal, 1));
+            }
+            ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out1.c_str(), ao, L.w_out, L.b_out, x, x, B, D, D, nullptr, ND, ND, ND)));
+            ARP_TRY(tower_layernorm<T>(c, s_ln21.c_str(), x, ND, h, D, L.ln2_w, L.ln2_b, B, D, eps));
+            ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc11.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, B, 4 * D, D)));
+            ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_FC2>(c, s_fc21.c_str(), fc, L.w_proj, L.b_proj, x, x, B, D, 4 * D, nullptr, 0, ND, ND)));
+            ARP_TRY(tower_export_rows(c, x, D, i, B, N));
+            break;
+        }
         ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));
         ARP_TRY((tower_gemm<T, T, ACT_NONE, false, SB + SITE_QKV>(c, s_qkv.c_str(), h, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, D)));
         {
