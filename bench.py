@@ -407,6 +407,9 @@ def main():
                 "note": f"same kernel @ {dom}, whole {a.batch}-frame batch per launch on a single stream (nothing else resident)"}),
             "cpu_baseline": cpu,
             "whole_pass": {"gflop_per_frame": flops_frame / 1e9, "mfma_frac_of_peak": fps / world * flops_frame / (peak * 1e12),
+                           # the last block runs out_proj + MLP on the class-token row only (tower.h): FLOPs actually issued
+                           "executed_gflop_per_frame": (flops_frame - (0 if os.environ.get("ARP_CLS_ONLY") == "0" else
+                                                        2.0 * (cfg.tokens - 1) * 9 * cfg.width * cfg.width)) / 1e9,
                            "hip_event_ms_per_step": ev_ms / a.steps, "profiled_ms_per_step": prof_ms / a.steps},
             "parity": {"max_cosine_err_vs_oracle": parity, "frames": a.parity_frames, "tolerance": 1e-4,
                        "within_tolerance": None if parity is None else bool(parity < 1e-4)},

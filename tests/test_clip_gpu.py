@@ -177,8 +177,9 @@ def test_layernorm_fold_matches_unfused(gpu_lib, monkeypatch):
     assert e0 < COS_TOL_BF16 and e1 < COS_TOL_BF16
 
 
-def test_full_batch_properties(gpu_lib):
-    """BASELINE configs[1] at full size (1024 frames, ViT-B/32, bf16), through properties that need no oracle at that size:
+@pytest.mark.parametrize("mode,tol", [("f16", COS_TOL_F16), ("bf16", COS_TOL_BF16)])
+def test_full_batch_properties(gpu_lib, mode, tol):
+    """BASELINE configs[1] at full size (1024 frames, ViT-B/32, the default f16 mode and bf16), through properties that need no oracle at that size:
     a frame's reward does not depend on what else is in the batch or where it sits (permutation / duplication), on the number
     of streams, or on the run (bit-identical repeats), and a 16-frame sample agrees with the oracle."""
     from arp_amd import clip, synth
@@ -188,7 +189,7 @@ def test_full_batch_properties(gpu_lib):
     tok = synth.prompt_tokens(1, 8, seed=2)
     fr = synth.procgen_like_frames(1024, seed=5)
     fr[777] = fr[3]  # a duplicate far away in the batch
-    m = clip.ClipLabeller(cfg, W, mode="bf16", max_batch=1024, n_streams=2).set_text(tok)
+    m = clip.ClipLabeller(cfg, W, mode=mode, max_batch=1024, n_streams=2).set_text(tok)
     r = m.label(fr)
     assert r.shape == (1024,) and np.isfinite(r).all()
     assert np.array_equal(r, m.label(fr))                      # deterministic
@@ -201,5 +202,30 @@ def test_full_batch_properties(gpu_lib):
     assert np.array_equal(m.label(fr[:100]), r[:100])           # sub-batch (different GEMM grid, same per-row arithmetic)
     idx = np.arange(0, 1024, 64)
     ref = C.compute_reward(W, C.ClipConfig(patch=cfg.patch), fr[idx], tok)
-    assert np.abs(r[idx] - ref).max() / 100.0 < COS_TOL_BF16
+    assert np.abs(r[idx] - ref).max() / 100.0 < tol
     m.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
+def test_last_block_class_token_only_is_exact(gpu_lib, monkeypatch, mode):
+    """The vision tower's last block computes out_proj / ln_2 / MLP (and the attention's query side) for the class-token
+    rows only -- the rows ln_post reads (arp_dt/models/openai/layers.py:330).  Rewards, features and the multi-scale
+    class-token export must be bit-identical to running the block on every row (ARP_CLS_ONLY=0)."""
+    from arp_amd import clip, synth
+    from oracle import clip_np as C
+    ocfg = C.ClipConfig(**MID)
+    Wt = synth.clip_weights(ocfg, seed=23)
+    tok = synth.prompt_tokens(1, 5, ctx=ocfg.ctx, vocab=ocfg.vocab, seed=4)
+    fr = synth.procgen_like_frames(37, seed=6)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("ARP_CLS_ONLY", flag)
+        m = clip.ClipLabeller(clip.ClipConfig(**MID), Wt, mode=mode, n_streams=1).set_text(tok)
+        m.profile(True)
+        out[flag] = (m.label(fr), m.encode_image(fr)) + tuple(m.encode_image_multiscale(fr))
+        sites = m.profile_read()
+        assert ("vit.c_fc_cls" in sites) == (flag == "1")
+        assert sites["vit.c_fc"]["calls"] == 3 * (MID["layers"] - (flag == "1"))  # label + encode_image + multiscale
+        m.close()
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
