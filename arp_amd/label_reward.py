@@ -122,11 +122,8 @@ def get_torch_clip_reward(clip_model, obs, pos_text=None, use_crop=False):
 
 def _open_store(data_path):
     if data_path.endswith((".hdf5", ".h5")):
-        try:
-            import h5py
-        except ImportError as e:
-            raise ImportError("h5py is required to open HDF5 demonstration files (absent in this image)") from e
-        return h5py.File(data_path, "a"), True
+        from .h5store import H5Store  # ctypes over libhdf5 -- the library h5py wraps; ImportError if absent
+        return H5Store(data_path, "a"), True
     raise ValueError(f"unsupported data file {data_path!r}: pass store=<mapping of arrays> instead")
 
 
@@ -169,7 +166,11 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
             traj = list(range(bounds[idx], min(bounds[idx + 1], len_data)))
             if not traj:
                 continue
-            images = np.asarray(store[img_key][traj[0] : traj[-1] + 1, -1])
+            ds = store[img_key]
+            if hasattr(ds, "read_last_frames"):  # HDF5: one chunk inflated per num_frames rows, in a thread pool (h5store.py)
+                images = ds.read_last_frames(traj[0], traj[-1] + 1)
+            else:
+                images = np.asarray(ds[traj[0] : traj[-1] + 1, -1])
             if per_frame:
                 if pending and pending_frames + len(images) > batch_frames:
                     flush()

@@ -229,3 +229,41 @@ def test_last_block_class_token_only_is_exact(gpu_lib, monkeypatch, mode):
         m.close()
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)
+
+
+def test_label_reward_from_hdf5_file(gpu_lib, tmp_path):
+    """SURVEY row N3 end to end on the GPU: recorder-style HDF5 file in, reward / rtg datasets out (gzip, chunks (1, num_frames)),
+    equal to labelling the same frames from memory."""
+    h5store = pytest.importorskip("arp_amd.h5store")
+    try:
+        h5store.lib()
+    except ImportError as e:
+        pytest.skip(str(e))
+    from arp_amd import clip, label_reward as L, synth
+    from oracle import clip_np as C, rtg
+    ocfg = C.ClipConfig(**TINY)
+    Wt = synth.clip_weights(ocfg, seed=3)
+    tok = synth.prompt_tokens(1, 5, ctx=ocfg.ctx, vocab=ocfg.vocab, seed=4)
+    lens, F = [3, 11, 8, 1], 8
+    frames = synth.procgen_like_frames(sum(lens), 64, 64, seed=9)
+    ob, done, s = [], [], 0
+    for n in lens:
+        idx = np.clip(np.arange(n)[:, None] + np.arange(-F + 1, 1)[None, :], 0, None)
+        d = np.zeros((n, F), np.float32); d[-1, -1] = 1
+        ob.append(frames[s : s + n][idx]); done.append(d); s += n
+    ob, done = np.concatenate(ob), np.concatenate(done)
+    p = str(tmp_path / "data.hdf5")
+    with h5store.H5Store(p, "w") as f:
+        f.create_dataset("ob", data=ob, compression="gzip", chunks=(1, F, 64, 64, 3), maxshape=(None, F, 64, 64, 3))
+        f.create_dataset("done", data=done, compression="gzip", chunks=(1, F), maxshape=(None, F))
+    m = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode="f32").set_text(tok)
+    L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=p, clip_model=m, tokens=tok)
+    ref = rtg.label_file({"ob": ob, "done": done}, lambda im: m.label(im))
+    with h5store.H5Store(p, "r") as f:
+        for k, v in ref.items():
+            assert f[k].chunks == (1, F) and f[k].compression == "gzip" and np.array_equal(f[k][...], v), k
+    orc = C.compute_reward(Wt, ocfg, frames[:4], tok)
+    with h5store.H5Store(p, "r") as f:
+        got = np.concatenate([f["ob_clip_reward"][0:3, -1], f["ob_clip_reward"][3:4, -1]])
+    assert np.abs(got - orc).max() / float(np.exp(Wt["logit_scale"])) < COS_TOL_F32
+    m.close()

@@ -1,0 +1,156 @@
+"""HDF5 demonstration files through libhdf5 (ctypes), the schema of data/PPG/trajectory_recorder.py:148-176, the
+access pattern of arp_dt/label_reward.py:69-87,268,273-289.  Skipped where no libhdf5 can be found."""
+import os
+
+import numpy as np
+import pytest
+
+try:
+    from arp_amd import h5store
+    h5store.lib()
+except ImportError as e:  # pragma: no cover
+    pytest.skip(f"libhdf5 not available: {e}", allow_module_level=True)
+
+from test_host import _FakeClip
+
+F = 8
+
+
+def _recorder_file(path, lens, hw=16, seed=0, trailing=0, bool_done=False):
+    """A file as the recorder writes it: per trajectory, stack_frames (deque of the last F items, first one left-padded,
+    trajectory_recorder.py:103-115), datasets grown by resize (:175), gzip chunks of one row."""
+    rng = np.random.default_rng(seed)
+    frames, ob, done = [], [], []
+    for L in lens:
+        fr = rng.integers(0, 256, (L, hw, hw, 3), dtype=np.uint8)
+        idx = np.clip(np.arange(L)[:, None] + np.arange(-F + 1, 1)[None, :], 0, None)
+        d = np.zeros(L, np.float32)
+        d[-1] = 1
+        frames.append(fr); ob.append(fr[idx]); done.append(d[idx])
+    if trailing:  # rows after the last done flag (an unfinished trajectory)
+        fr = rng.integers(0, 256, (trailing, hw, hw, 3), dtype=np.uint8)
+        idx = np.clip(np.arange(trailing)[:, None] + np.arange(-F + 1, 1)[None, :], 0, None)
+        frames.append(fr); ob.append(fr[idx]); done.append(np.zeros((trailing, F), np.float32))
+    with h5store.H5Store(path, "w") as f:
+        f.attrs["env_name"] = "coinrun"
+        for i, (o, d) in enumerate(zip(ob, done)):
+            d = d.astype(bool) if bool_done else d
+            if i == 0:
+                f.create_dataset("ob", data=o, compression="gzip", chunks=(1, F, hw, hw, 3), maxshape=(None, F, hw, hw, 3))
+                f.create_dataset("done", data=d, compression="gzip", chunks=(1, F), maxshape=(None, F))
+            else:
+                for k, v in (("ob", o), ("done", d)):
+                    ds = f[k]
+                    n0 = ds.shape[0]
+                    ds.resize(n0 + len(v), axis=0)
+                    ds[n0:] = v
+    return np.concatenate(frames), np.concatenate(ob), np.concatenate(done)
+
+
+def test_file_is_hdf5_and_schema_roundtrips(tmp_path):
+    p = str(tmp_path / "data.hdf5")
+    frames, ob, done = _recorder_file(p, [5, 17, 9, 1])
+    assert open(p, "rb").read(8) == b"\x89HDF\r\n\x1a\n"  # the format signature: written by libhdf5 itself
+    assert h5store.lib_version() >= (1, 10, 3)
+    with h5store.H5Store(p, "r") as f:
+        assert sorted(f.keys()) == ["done", "ob"] and "ob" in f and "nope" not in f and f.get("nope") is None
+        assert f.attrs["env_name"] == "coinrun" and f.attrs.get("missing", 3) == 3
+        d = f["ob"]
+        assert d.shape == ob.shape and d.dtype == np.uint8 and d.chunks == (1, F, 16, 16, 3) and d.maxshape == (None, F, 16, 16, 3)
+        assert d.compression == "gzip" and d.compression_opts == 4 and d.fast_path_ok()
+        assert f["done"].shape == (32, F) and f["done"].dtype == np.float32 and f["done"].chunks == (1, F)
+        assert np.array_equal(d[...], ob) and np.array_equal(np.asarray(d), ob)
+        assert np.array_equal(d[3:9, -1], ob[3:9, -1]) and np.array_equal(d[7], ob[7]) and np.array_equal(d[-1, 0], ob[-1, 0])
+        assert np.array_equal(d[[3, 4, 5], -1], ob[[3, 4, 5], -1])      # g[img_key][traj, -1] with a list (label_reward.py:268)
+        assert np.array_equal(d[[9, 2, 30], -1], ob[[9, 2, 30], -1])    # non-consecutive rows
+        assert np.array_equal(f["done"][:, -1], done[:, -1])
+        with pytest.raises(IndexError):
+            d[40]
+        with pytest.raises(KeyError):
+            f["nope"]
+        with pytest.raises(h5store.H5Error):
+            f.create_dataset("x", data=np.zeros(3, np.float32))          # read-only file
+    with pytest.raises(h5store.H5Error):
+        h5store.H5Store(str(tmp_path / "absent.hdf5"), "r")
+
+
+def test_read_last_frames_equals_per_row_reads(tmp_path):
+    p = str(tmp_path / "data.hdf5")
+    lens = [5, 17, 9, 1, 8, 16]
+    frames, ob, _ = _recorder_file(p, lens, seed=1)
+    with h5store.H5Store(p, "r") as f:
+        d = f["ob"]
+        s = 0
+        for L in lens:
+            for threads in (1, 4):
+                got = d.read_last_frames(s, s + L, threads=threads)
+                assert got.dtype == np.uint8 and np.array_equal(got, frames[s : s + L]) and np.array_equal(got, ob[s : s + L, -1])
+            assert np.array_equal(d.read_last_frames(s, s + L, stacked=False), frames[s : s + L])
+            s += L
+        assert d._stack_ok is True
+        assert d.read_last_frames(4, 4).shape == (0, 16, 16, 3)
+        # a partial range inside a trajectory (a rank's shard never splits one, but the reader does not care)
+        assert np.array_equal(d.read_last_frames(7, 19), frames[7:19])
+
+
+def test_unstacked_file_falls_back_to_per_row_reads(tmp_path):
+    """A file whose rows are NOT the recorder's sliding window must still give g[key][rows, -1]."""
+    p = str(tmp_path / "odd.hdf5")
+    rng = np.random.default_rng(2)
+    ob = rng.integers(0, 256, (20, F, 8, 8, 3), dtype=np.uint8)  # independent frames in every slot
+    with h5store.H5Store(p, "w") as f:
+        f.create_dataset("ob", data=ob, compression="gzip", chunks=(1, F, 8, 8, 3), maxshape=(None, F, 8, 8, 3))
+    with h5store.H5Store(p, "r") as f:
+        d = f["ob"]
+        assert np.array_equal(d.read_last_frames(0, 20), ob[:, -1]) and d._stack_ok is False
+        assert np.array_equal(d.read_last_frames(3, 11), ob[3:11, -1])
+    # uncompressed / differently chunked datasets take the plain path
+    with h5store.H5Store(p, "a") as f:
+        f.create_dataset("raw", data=ob)
+        assert not f["raw"].fast_path_ok() and np.array_equal(f["raw"].read_last_frames(2, 9), ob[2:9, -1])
+
+
+@pytest.mark.parametrize("bool_done", [False, True])
+def test_label_reward_on_an_hdf5_file_matches_the_mapping_path(tmp_path, bool_done):
+    """label_reward(data_path=...) end to end (fake model): same datasets as the store= path and as the oracle loop; created as
+    gzip chunks (1, num_frames) float32 with an unlimited first axis (label_reward.py:277-283); a second run overwrites in place."""
+    from arp_amd import label_reward as L
+    from oracle import rtg
+    p = str(tmp_path / "data.hdf5")
+    lens = [1, 3, 9, 17]
+    frames, ob, done = _recorder_file(p, lens, hw=8, seed=3, trailing=3, bool_done=bool_done)
+    fake = _FakeClip()
+    ref = rtg.label_file({"ob": ob, "done": done}, lambda im: fake.label(im))
+    tok = np.zeros((1, 77), np.int32)
+    L.label_reward("coinrun", "hard", 500, 0, "the goal is to collect the coin.", ".", data_path=p, clip_model=fake, tokens=tok)
+    with h5store.H5Store(p, "r") as f:
+        assert set(ref) <= set(f.keys())
+        for k, v in ref.items():
+            d = f[k]
+            assert d.dtype == np.float32 and d.chunks == (1, F) and d.compression == "gzip" and d.maxshape == (None, F)
+            assert np.array_equal(d[...], v), k
+    mtime_keys = None
+    with h5store.H5Store(p, "r") as f:
+        mtime_keys = sorted(f.keys())
+
+    class Shifted(_FakeClip):
+        def label(self, frames, use_crop=False):
+            return super().label(frames) + 1.0
+
+    L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=p, clip_model=Shifted(), tokens=tok)
+    ref2 = rtg.label_file({"ob": ob, "done": done}, lambda im: Shifted().label(im))
+    with h5store.H5Store(p, "r") as f:
+        assert sorted(f.keys()) == mtime_keys
+        for k, v in ref2.items():
+            assert np.array_equal(f[k][...], v), k
+
+
+def test_default_path_layout(tmp_path):
+    """data_path=None builds <base>/<env>_<mode>_level<start>to<num>_num<demos>_frame<frames>[_<env_type>]/data.hdf5 (label_reward.py:62-68)."""
+    from arp_amd import label_reward as L
+    d = tmp_path / "coinrun_hard_level0to500_num500_frame8_et"
+    os.makedirs(d)
+    _recorder_file(str(d / "data.hdf5"), [4, 6], hw=8)
+    L.label_reward("coinrun", "hard", 500, 0, "x", str(tmp_path), env_type="et", clip_model=_FakeClip(), tokens=np.zeros((1, 77), np.int32))
+    with h5store.H5Store(str(d / "data.hdf5"), "r") as f:
+        assert f["ob_clip_reward"].shape == (10, F)
