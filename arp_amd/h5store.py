@@ -146,6 +146,12 @@ def lib():
             except AttributeError as e:
                 raise ImportError(f"{h._name}: missing {name} (HDF5 >= 1.10.3 is required)") from e
             fn.restype, fn.argtypes = res, args
+        try:  # 1.10.5+: where a chunk lives in the file, so that worker threads can pread() it without the library lock
+            h.H5Dget_chunk_info_by_coord.restype = herr_t
+            h.H5Dget_chunk_info_by_coord.argtypes = [hid_t, C.POINTER(hsize_t), C.POINTER(C.c_uint), C.POINTER(C.c_uint64), C.POINTER(hsize_t)]
+            h._arp_has_chunk_info = True
+        except AttributeError:
+            h._arp_has_chunk_info = False
         if h.H5open() < 0:
             raise ImportError("H5open failed")
         h.H5Eset_auto2(0, None, None)  # errors become Python exceptions, not stderr dumps
@@ -467,6 +473,19 @@ class H5Dataset:
             _ck(L.H5Dread_chunk(self._id, H5P_DEFAULT, off, C.byref(mask), buf), "H5Dread_chunk")
         return mask.value, buf
 
+    def _chunk_loc(self, row):
+        """(filter_mask, file address, stored size) of the chunk starting at ``row``; None where the library cannot tell."""
+        L = lib()
+        if not L._arp_has_chunk_info:
+            return None
+        mask, addr, size = C.c_uint(), C.c_uint64(), hsize_t()
+        with _lock:
+            if L.H5Dget_chunk_info_by_coord(self._id, _dims([row] + [0] * (self.ndim - 1)), C.byref(mask), C.byref(addr), C.byref(size)) < 0:
+                return None
+        if addr.value == 0xFFFFFFFFFFFFFFFF:
+            return (0, None, 0)  # never written
+        return (mask.value, addr.value, size.value)
+
     def fast_path_ok(self):
         """Row-chunked (1, F, ...) with deflate as the only filter that changes bytes (a shuffle of 1-byte elements is the identity)."""
         if self.chunks is None or self.ndim < 2 or self.chunks != (1,) + self.shape[1:]:
@@ -492,15 +511,33 @@ class H5Dataset:
         threads = threads or min(32, os.cpu_count() or 4)
         deflate_idx = [f for f, _ in self.filters].index(H5Z_FILTER_DEFLATE)
 
+        fd = getattr(self._store, "_pread_fd", None)
+        if fd is not None and self._store.mode != "r":
+            self._store.flush()  # chunks written through this handle must be in the file before another descriptor reads them
+
         def inflate(job):
             row, raw, lo, cnt = job  # this chunk supplies out[lo : lo + cnt] = its LAST cnt frames
             mask, buf = raw
             if buf is None:
                 return lo, cnt, None
-            data = buf.raw if (mask >> deflate_idx) & 1 else zlib.decompress(buf.raw)  # mask bit i set = filter i skipped for this chunk
+            if isinstance(buf, tuple):  # (address, size): read here, outside the library lock
+                stored = os.pread(fd, buf[1], buf[0])
+                if len(stored) != buf[1]:
+                    raise H5Error(f"{self.name}: short read of the chunk at row {row}")
+            else:
+                stored = memoryview(buf)
+            data = stored if (mask >> deflate_idx) & 1 else zlib.decompress(stored)  # mask bit i set = filter i skipped for this chunk
             if len(data) != F * fbytes:
                 raise H5Error(f"{self.name}: chunk at row {row} inflated to {len(data)} bytes, expected {F * fbytes}")
             return lo, cnt, np.frombuffer(data, self.dtype, count=cnt * (fbytes // self.dtype.itemsize), offset=(F - cnt) * fbytes)
+
+        def raw_of(row):
+            nonlocal fd
+            if fd is not None:
+                loc = self._chunk_loc(row)
+                if loc is not None:
+                    return (loc[0], None if loc[1] is None else (loc[1], loc[2]))
+            return self._raw_chunk(row)  # serial (library lock); inflation still runs in the pool
 
         if stacked:
             # chunk of row i holds the last frames of rows i-F+1 .. i of the same trajectory: walk back from the last row
@@ -514,7 +551,12 @@ class H5Dataset:
             if not getattr(self, "_stack_checked", False):
                 row, lo, cnt = jobs_rows[0]
                 direct = self[r0 + lo : r0 + lo + cnt, -1]
-                got = inflate((row, self._raw_chunk(row), lo, cnt))[2]
+                try:
+                    got = inflate((row, raw_of(row), lo, cnt))[2]
+                except (zlib.error, OSError):  # the pread path mis-addressed the chunk (e.g. a user block): library reads only
+                    os.close(fd)
+                    self._store._pread_fd = fd = None
+                    got = inflate((row, self._raw_chunk(row), lo, cnt))[2]
                 if got is None or not np.array_equal(direct.reshape(-1), got):
                     self._stack_ok = False
                 else:
@@ -527,7 +569,7 @@ class H5Dataset:
 
         def gen():
             for row, lo, cnt in jobs_rows:
-                yield row, self._raw_chunk(row), lo, cnt  # raw reads are serial (library lock); inflation runs in the pool
+                yield row, raw_of(row), lo, cnt
 
         with ThreadPoolExecutor(max_workers=threads) as pool:
             for lo, cnt, flat in pool.map(inflate, gen()):
@@ -570,6 +612,11 @@ class H5Store:
         self._id = fid
         self.mode = mode
         self.attrs = _Attrs(self)
+        # a second, read-only descriptor for pread() of stored chunks from worker threads (read_last_frames)
+        try:
+            self._pread_fd = os.open(path, os.O_RDONLY)
+        except OSError:
+            self._pread_fd = None
 
     def __enter__(self):
         return self
@@ -668,3 +715,6 @@ class H5Store:
         with _lock:
             lib().H5Fclose(self._id)
         self._id = 0
+        if self._pread_fd is not None:
+            os.close(self._pread_fd)
+            self._pread_fd = None

@@ -19,7 +19,11 @@ with h5store.H5Store(path, "w") as f:
     done_all = []
     for s in range(0, rows, tlen):
         n = min(tlen, rows - s)
-        fr = synth.procgen_like_frames(n, seed=s)
+        # Procgen renders 64x64 natively; a 256x256 observation is that picture enlarged: 4x4 blocks of equal pixels, a handful of
+        # colours per region (what gzip sees in a real file; synth.procgen_like_frames adds per-pixel noise and does not compress)
+        rng = np.random.default_rng(s)
+        base = rng.integers(0, 6, (n, 16, 16, 1)).repeat(4, 1).repeat(4, 2) * 40 + rng.integers(0, 3, (n, 64, 64, 3)) * 5
+        fr = base.astype(np.uint8).repeat(4, 1).repeat(4, 2)
         idx = np.clip(np.arange(n)[:, None] + np.arange(-F + 1, 1)[None, :], 0, None)
         d = np.zeros((n, F), np.float32); d[-1, -1] = 1
         if s == 0:
