@@ -120,6 +120,31 @@ def get_torch_clip_reward(clip_model, obs, pos_text=None, use_crop=False):
     return clip_model.label(obs, use_crop=use_crop)
 
 
+def _prefetch(it, depth=4):
+    """Runs the iterator in a background thread, ``depth`` items ahead; exceptions surface at the consumer."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    end = object()
+
+    def work():
+        try:
+            for x in it:
+                q.put((x, None))
+            q.put((end, None))
+        except BaseException as e:  # noqa: BLE001 -- re-raised by the consumer
+            q.put((end, e))
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        x, err = q.get()
+        if x is end:
+            if err is not None:
+                raise err
+            return
+        yield x
+
+
 def _open_store(data_path):
     if data_path.endswith((".hdf5", ".h5")):
         from .h5store import H5Store  # ctypes over libhdf5 -- the library h5py wraps (SURVEY row N3); ImportError if absent
@@ -162,15 +187,15 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                 parts[target_keys[1]].append(stack_outputs(discount_cumsum(r), num_frames))
             pending, pending_frames = [], 0
 
-        for idx in range(t0, t1):
-            traj = list(range(bounds[idx], min(bounds[idx + 1], len_data)))
-            if not traj:
-                continue
-            ds = store[img_key]
-            if hasattr(ds, "read_last_frames"):  # HDF5: one chunk inflated per num_frames rows, in a thread pool (h5store.py)
-                images = ds.read_last_frames(traj[0], traj[-1] + 1)
-            else:
-                images = np.asarray(ds[traj[0] : traj[-1] + 1, -1])
+        ds = store[img_key]
+        spans = [(bounds[idx], min(bounds[idx + 1], len_data)) for idx in range(t0, t1) if bounds[idx] < min(bounds[idx + 1], len_data)]
+        if hasattr(ds, "read_last_frames"):
+            # HDF5: one chunk inflated per num_frames rows, in a thread pool (h5store.py); the next trajectories are read while
+            # the GPU labels the current batch
+            source = _prefetch((ds.read_last_frames(a, b) for a, b in spans), depth=4)
+        else:
+            source = (np.asarray(ds[a:b, -1]) for a, b in spans)
+        for images in source:
             if per_frame:
                 if pending and pending_frames + len(images) > batch_frames:
                     flush()
