@@ -216,6 +216,27 @@ def _np_dtype_of(tid):
     raise TypeError(f"unsupported HDF5 datatype class {cls}")
 
 
+_native = None
+
+
+def _native_inflate():
+    """``arp_h5_inflate_last_frames`` of libarp_hip.so as a numpy-taking callable, or None when the library is not built."""
+    global _native
+    if _native is None:
+        try:
+            from . import _ffi
+        except Exception:  # noqa: BLE001 -- the HDF5 reader stays usable on its Python pool
+            _native = False
+        else:
+            def call(fd, n, addr, size, rawf, chunk_bytes, frame_bytes, offs, cnts, out, threads):
+                u64, u8 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+                _ffi.check(_ffi.lib.arp_h5_inflate_last_frames(
+                    fd, n, addr.ctypes.data_as(u64), size.ctypes.data_as(u64), rawf.ctypes.data_as(u8), chunk_bytes, frame_bytes,
+                    offs.ctypes.data_as(u64), cnts.ctypes.data_as(C.POINTER(C.c_uint32)), out.ctypes.data_as(u8), threads))
+            _native = call
+    return _native or None
+
+
 class _Attrs:
     """``file.attrs`` -- string and numeric scalars (the recorder writes ``env_name``, trajectory_recorder.py:66)."""
 
@@ -493,10 +514,12 @@ class H5Dataset:
         ids = [f for f, _ in self.filters]
         return ids == [H5Z_FILTER_DEFLATE] or (self.dtype.itemsize == 1 and ids == [H5Z_FILTER_SHUFFLE, H5Z_FILTER_DEFLATE])
 
-    def read_last_frames(self, r0, r1, threads=None, stacked=True):
+    def read_last_frames(self, r0, r1, threads=None, stacked=True, native=None, native_threads=None):
         """``self[r0:r1, -1]`` for the rows of ONE trajectory, inflating one chunk per ``num_frames`` rows (module docstring).
         ``stacked=False`` (or a dataset the fast path does not cover) reads every row's chunk -- the reference's access pattern,
-        still inflated in parallel."""
+        still inflated in parallel.  Inflation runs on the C++ threads of ``arp_h5_inflate_last_frames`` (libarp_hip.so) when
+        that library is importable and HDF5 can report chunk addresses; ``native=False`` keeps the Python thread pool
+        (``threads`` workers; zlib releases the GIL)."""
         r0, r1 = int(r0), int(r1)
         n = r1 - r0
         F = self.shape[1]
@@ -563,9 +586,22 @@ class H5Dataset:
                     self._stack_ok = True
                 self._stack_checked = True
             if not self._stack_ok:
-                return self.read_last_frames(r0, r1, threads=threads, stacked=False)
+                return self.read_last_frames(r0, r1, threads=threads, stacked=False, native=native, native_threads=native_threads)
         else:
             jobs_rows = [(r, r - r0, 1) for r in range(r0, r1)]
+
+        if fd is not None and native is not False and _native_inflate() is not None:
+            # native path: chunk locations from the library, pread + inflate + tail copy on C++ threads (csrc/arp_io.cpp)
+            locs = [self._chunk_loc(row) for row, _, _ in jobs_rows]
+            if all(l is not None for l in locs):
+                k = len(jobs_rows)
+                addr = np.array([l[1] or 0 for l in locs], np.uint64)
+                size = np.array([l[2] if l[1] is not None else 0 for l in locs], np.uint64)
+                rawf = np.array([(l[0] >> deflate_idx) & 1 for l in locs], np.uint8)
+                offs = np.array([lo * fbytes for _, lo, _ in jobs_rows], np.uint64)
+                cnts = np.array([cnt for _, _, cnt in jobs_rows], np.uint32)
+                _native_inflate()(fd, k, addr, size, rawf, F * fbytes, fbytes, offs, cnts, out, 0 if native_threads is None else native_threads)
+                return out
 
         def gen():
             for row, lo, cnt in jobs_rows:

@@ -275,6 +275,16 @@ int arp_enc_profile_json(arp_enc* h, char* buf, int buf_len);
 int arp_dt_attach_encoder(arp_dt* h, arp_enc* enc);
 int arp_dt_set_batch_images(arp_dt* h, const float* images, const int32_t* action, const float* rtg, int B);
 
+/* ---- host I/O of path (1) (no GPU involved) -------------------------------
+ * Reads n stored chunks of a gzip-chunked dataset (`ob` of data/PPG/trajectory_recorder.py:148-176: one chunk = one row =
+ * num_frames frames) from file descriptor fd at addr[i] (size[i] bytes as stored; 0 = never written), inflates them on
+ * `threads` native threads (<= 0: one per hardware thread) and copies the LAST cnt[i] frames of chunk i to out + dst_off[i].
+ * stored_raw[i] != 0 (may be NULL): the deflate filter was skipped for that chunk.  Replaces the inflate half of
+ * g[img_key][traj, -1] (arp_dt/label_reward.py:268); chunk addresses come from libhdf5 (arp_amd/h5store.py). */
+int arp_h5_inflate_last_frames(int fd, int n, const uint64_t* addr, const uint64_t* size, const uint8_t* stored_raw,
+                               uint64_t chunk_bytes, uint64_t frame_bytes, const uint64_t* dst_off, const uint32_t* cnt,
+                               uint8_t* out, int threads);
+
 /* ---- single-operator entry points (host buffers; used by the per-kernel parity tests) ---------- */
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid), operands rounded to bf16 in ARP_MODE_BF16. */
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,

@@ -40,10 +40,13 @@ with h5store.H5Store(path, "r") as f:
     t = time.perf_counter(); a = d[0:n, -1]; t_ref = time.perf_counter() - t
     print(f"reference pattern g['ob'][traj, -1] (every row's chunk inflated by the library, one thread): {n / t_ref:.0f} frames/s")
     for th in (1, 8, 32, 64):
-        t = time.perf_counter(); b = d.read_last_frames(0, n, threads=th, stacked=False); t1 = time.perf_counter() - t
-        t = time.perf_counter(); c = d.read_last_frames(0, min(n, tlen), threads=th); t2 = time.perf_counter() - t
+        t = time.perf_counter(); b = d.read_last_frames(0, n, threads=th, stacked=False, native=False); t1 = time.perf_counter() - t
+        t = time.perf_counter(); c = d.read_last_frames(0, min(n, tlen), threads=th, native=False); t2 = time.perf_counter() - t
         assert np.array_equal(a, b) and np.array_equal(a[: len(c)], c)
-        print(f"threads {th:2d}: per-row chunks {n / t1:.0f} frames/s; one chunk per {F} rows {len(c) / t2:.0f} frames/s")
+        t = time.perf_counter(); e = d.read_last_frames(0, min(n, tlen), native_threads=th); t3 = time.perf_counter() - t
+        assert np.array_equal(a[: len(e)], e)
+        print(f"threads {th:2d}: Python pool, per-row chunks {n / t1:.0f} frames/s; one chunk per {F} rows {len(c) / t2:.0f} frames/s; "
+              f"C++ threads (arp_h5_inflate_last_frames), one chunk per {F} rows {len(e) / t3:.0f} frames/s")
 
 cfg = clip.MODELS["ViT-B/32"]
 m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), device=0)

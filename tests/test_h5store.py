@@ -86,6 +86,9 @@ def test_read_last_frames_equals_per_row_reads(tmp_path):
                 got = d.read_last_frames(s, s + L, threads=threads)
                 assert got.dtype == np.uint8 and np.array_equal(got, frames[s : s + L]) and np.array_equal(got, ob[s : s + L, -1])
             assert np.array_equal(d.read_last_frames(s, s + L, stacked=False), frames[s : s + L])
+            for native in (False, True):  # Python pool vs the C++ threads of arp_h5_inflate_last_frames: same bytes
+                assert np.array_equal(d.read_last_frames(s, s + L, native=native, native_threads=3), frames[s : s + L])
+                assert np.array_equal(d.read_last_frames(s, s + L, native=native, stacked=False), frames[s : s + L])
             s += L
         assert d._stack_ok is True
         assert d.read_last_frames(4, 4).shape == (0, 16, 16, 3)
@@ -154,3 +157,39 @@ def test_default_path_layout(tmp_path):
     L.label_reward("coinrun", "hard", 500, 0, "x", str(tmp_path), env_type="et", clip_model=_FakeClip(), tokens=np.zeros((1, 77), np.int32))
     with h5store.H5Store(str(d / "data.hdf5"), "r") as f:
         assert f["ob_clip_reward"].shape == (10, F)
+
+
+def test_native_inflater_reports_corrupt_chunks(tmp_path):
+    """arp_h5_inflate_last_frames (csrc/arp_io.cpp) fails loudly -- error text through arp_last_error -- on a truncated stream, a
+    wrong size and bad arguments; an unwritten chunk reads as zeros."""
+    import ctypes as C
+    import zlib
+    from arp_amd import _ffi
+    raw = np.arange(8 * 48, dtype=np.uint8).reshape(8, 48)
+    z = zlib.compress(raw.tobytes(), 4)
+    p = tmp_path / "blob.bin"
+    p.write_bytes(b"\0" * 7 + z + z[: len(z) // 2])
+    fd = os.open(str(p), os.O_RDONLY)
+    u64, u8 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)
+
+    def run(addr, size, cnt, chunk_bytes=8 * 48, rawf=None):
+        addr, size = np.asarray(addr, np.uint64), np.asarray(size, np.uint64)
+        cnt = np.asarray(cnt, np.uint32)
+        offs = (np.concatenate([[0], np.cumsum(cnt)[:-1]]) * 48).astype(np.uint64)
+        out = np.full((int(cnt.sum()), 48), 255, np.uint8)
+        rf = None if rawf is None else np.asarray(rawf, np.uint8).ctypes.data_as(u8)
+        rc = _ffi.lib.arp_h5_inflate_last_frames(fd, len(addr), addr.ctypes.data_as(u64), size.ctypes.data_as(u64), rf, chunk_bytes, 48,
+                                                 offs.ctypes.data_as(u64), cnt.ctypes.data_as(C.POINTER(C.c_uint32)), out.ctypes.data_as(u8), 2)
+        return rc, out
+
+    rc, out = run([7, 7, 0], [len(z), len(z), 0], [8, 3, 2])
+    assert rc == 0 and np.array_equal(out[:8], raw) and np.array_equal(out[8:11], raw[5:]) and (out[11:] == 0).all()
+    rc, _ = run([7 + len(z)], [len(z) // 2], [1])                       # truncated deflate stream
+    assert rc < 0 and "inflate" in _ffi.last_error()
+    rc, _ = run([7], [len(z)], [1], chunk_bytes=16 * 48)                # inflates to fewer bytes than the chunk should hold
+    assert rc < 0
+    rc, _ = run([7], [len(z)], [9])                                     # more frames than a chunk has
+    assert rc < 0 and "cnt" in _ffi.last_error()
+    rc, _ = run([0], [10_000], [1])                                     # reads past the end of the file
+    assert rc < 0 and "pread" in _ffi.last_error()
+    os.close(fd)
