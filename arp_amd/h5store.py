@@ -515,13 +515,18 @@ class H5Dataset:
         return ids == [H5Z_FILTER_DEFLATE] or (self.dtype.itemsize == 1 and ids == [H5Z_FILTER_SHUFFLE, H5Z_FILTER_DEFLATE])
 
     def read_last_frames(self, r0, r1, threads=None, stacked=True, native=None, native_threads=None):
-        """``self[r0:r1, -1]`` for the rows of ONE trajectory, inflating one chunk per ``num_frames`` rows (module docstring).
+        """``self[r0:r1, -1]`` for the rows of ONE trajectory (see ``read_last_frames_spans``)."""
+        return self.read_last_frames_spans([(r0, r1)], threads=threads, stacked=stacked, native=native, native_threads=native_threads)
+
+    def read_last_frames_spans(self, spans, threads=None, stacked=True, native=None, native_threads=None):
+        """``concatenate([self[a:b, -1] for a, b in spans])`` where every span is the rows of ONE trajectory (or part of one),
+        inflating one chunk per ``num_frames`` rows (module docstring); all spans' chunks go to the workers in one batch.
         ``stacked=False`` (or a dataset the fast path does not cover) reads every row's chunk -- the reference's access pattern,
         still inflated in parallel.  Inflation runs on the C++ threads of ``arp_h5_inflate_last_frames`` (libarp_hip.so) when
         that library is importable and HDF5 can report chunk addresses; ``native=False`` keeps the Python thread pool
         (``threads`` workers; zlib releases the GIL)."""
-        r0, r1 = int(r0), int(r1)
-        n = r1 - r0
+        spans = [(int(a), int(b)) for a, b in spans if int(b) > int(a)]
+        n = sum(b - a for a, b in spans)
         F = self.shape[1]
         frame_shape = self.shape[2:]
         fbytes = int(np.prod(frame_shape)) * self.dtype.itemsize
@@ -529,7 +534,10 @@ class H5Dataset:
         if n <= 0:
             return out
         if not self.fast_path_ok():
-            out[...] = self[r0:r1, -1]
+            o = 0
+            for a, b in spans:
+                out[o : o + b - a] = self[a:b, -1]
+                o += b - a
             return out
         threads = threads or min(8, os.cpu_count() or 4)  # measured on a 256-cpu host: 8 threads 27.8 k frames/s, 32 threads 16 k (GIL hand-offs)
         deflate_idx = [f for f, _ in self.filters].index(H5Z_FILTER_DEFLATE)
@@ -564,16 +572,18 @@ class H5Dataset:
 
         if stacked:
             # chunk of row i holds the last frames of rows i-F+1 .. i of the same trajectory: walk back from the last row
-            jobs_rows = []
-            hi = r1
-            while hi > r0:
-                lo = max(hi - F, r0)
-                jobs_rows.append((hi - 1, lo - r0, hi - lo))
-                hi = lo
+            jobs_rows, base = [], 0
+            for r0, r1 in spans:
+                hi = r1
+                while hi > r0:
+                    lo = max(hi - F, r0)
+                    jobs_rows.append((hi - 1, base + lo - r0, hi - lo))
+                    hi = lo
+                base += r1 - r0
             # cross-check the group that ends the trajectory against plain per-row reads of the same rows (first call per dataset)
             if not getattr(self, "_stack_checked", False):
                 row, lo, cnt = jobs_rows[0]
-                direct = self[r0 + lo : r0 + lo + cnt, -1]
+                direct = self[row - cnt + 1 : row + 1, -1]
                 try:
                     got = inflate((row, raw_of(row), lo, cnt))[2]
                 except (zlib.error, OSError):  # the pread path mis-addressed the chunk (e.g. a user block): library reads only
@@ -586,9 +596,12 @@ class H5Dataset:
                     self._stack_ok = True
                 self._stack_checked = True
             if not self._stack_ok:
-                return self.read_last_frames(r0, r1, threads=threads, stacked=False, native=native, native_threads=native_threads)
+                return self.read_last_frames_spans(spans, threads=threads, stacked=False, native=native, native_threads=native_threads)
         else:
-            jobs_rows = [(r, r - r0, 1) for r in range(r0, r1)]
+            jobs_rows, base = [], 0
+            for r0, r1 in spans:
+                jobs_rows += [(r, base + r - r0, 1) for r in range(r0, r1)]
+                base += r1 - r0
 
         if fd is not None and native is not False and _native_inflate() is not None:
             # native path: chunk locations from the library, pread + inflate + tail copy on C++ threads (csrc/arp_io.cpp)

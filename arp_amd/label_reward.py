@@ -189,9 +189,29 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
 
         ds = store[img_key]
         spans = [(bounds[idx], min(bounds[idx + 1], len_data)) for idx in range(t0, t1) if bounds[idx] < min(bounds[idx + 1], len_data)]
-        if hasattr(ds, "read_last_frames"):
-            # HDF5: one chunk inflated per num_frames rows, in a thread pool (h5store.py); the next trajectories are read while
-            # the GPU labels the current batch
+        if hasattr(ds, "read_last_frames_spans") and per_frame:
+            # HDF5: one chunk inflated per num_frames rows on native threads (h5store.py); whole trajectories are grouped into
+            # batches of up to batch_frames frames that are inflated straight into one buffer (no concatenate), and the next
+            # batch is read while the GPU labels the current one
+            groups, cur, cur_n = [], [], 0
+            for a, b in spans:
+                if cur and cur_n + (b - a) > batch_frames:
+                    groups.append(cur)
+                    cur, cur_n = [], 0
+                cur.append((a, b))
+                cur_n += b - a
+            if cur:
+                groups.append(cur)
+            for grp, frames_all in _prefetch(((g, ds.read_last_frames_spans(g)) for g in groups), depth=2):
+                r_all = np.asarray(compute_reward(clip_model, frames_all, text=text, use_crop=use_crop))
+                o = 0
+                for a, b in grp:
+                    r = r_all[o : o + b - a]
+                    o += b - a
+                    parts[target_keys[0]].append(stack_outputs(r, num_frames))
+                    parts[target_keys[1]].append(stack_outputs(discount_cumsum(r), num_frames))
+            source = ()
+        elif hasattr(ds, "read_last_frames"):
             source = _prefetch((ds.read_last_frames(a, b) for a, b in spans), depth=4)
         else:
             source = (np.asarray(ds[a:b, -1]) for a, b in spans)

@@ -92,6 +92,12 @@ def test_read_last_frames_equals_per_row_reads(tmp_path):
             s += L
         assert d._stack_ok is True
         assert d.read_last_frames(4, 4).shape == (0, 16, 16, 3)
+        bounds = np.concatenate([[0], np.cumsum(lens)])
+        spans = [(int(bounds[i]), int(bounds[i + 1])) for i in (1, 2, 4)] + [(3, 3)]
+        want = np.concatenate([frames[a:b] for a, b in spans])
+        for native in (False, True):
+            assert np.array_equal(d.read_last_frames_spans(spans, native=native), want)
+            assert np.array_equal(d.read_last_frames_spans(spans, native=native, stacked=False), want)
         # a partial range inside a trajectory (a rank's shard never splits one, but the reader does not care)
         assert np.array_equal(d.read_last_frames(7, 19), frames[7:19])
 
