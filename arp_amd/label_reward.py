@@ -20,6 +20,7 @@ Multi-GPU: labelling shards by contiguous trajectory ranges balanced by frame co
 GPU, no collective on the data path; rank 0 is the only writer.
 """
 import os
+import time
 
 import numpy as np
 
@@ -202,14 +203,46 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                 cur_n += b - a
             if cur:
                 groups.append(cur)
-            for grp, frames_all in _prefetch(((g, ds.read_last_frames_spans(g)) for g in groups), depth=2):
-                r_all = np.asarray(compute_reward(clip_model, frames_all, text=text, use_crop=use_crop))
+        if hasattr(ds, "read_last_frames_spans") and per_frame and groups:
+            timing = os.environ.get("ARP_LABEL_TIMING") == "1"
+            t_read = t_wait = t_label = 0.0
+
+            import queue
+            frame_elems = int(np.prod(ds.shape[2:]))
+            free = queue.Queue()  # frame buffers go round: reader fills one, the labeller hands it back (no malloc / munmap per batch)
+            for _ in range(4):
+                free.put(np.empty(max(sum(b - a for a, b in g) for g in groups) * frame_elems, ds.dtype))
+
+            def read(g):
+                nonlocal t_read
+                buf = free.get()
+                t = time.perf_counter()
+                fr = ds.read_last_frames_spans(g, out=buf)
+                t_read += time.perf_counter() - t
+                return g, (fr, buf)
+
+            it = _prefetch((read(g) for g in groups), depth=2)
+            while True:
+                t = time.perf_counter()
+                nxt = next(it, None)
+                t_wait += time.perf_counter() - t
+                if nxt is None:
+                    break
+                grp, (frames_all, buf) = nxt
+                t = time.perf_counter()
+                r_all = np.array(compute_reward(clip_model, frames_all, text=text, use_crop=use_crop))
+                t_label += time.perf_counter() - t
+                del frames_all
+                free.put(buf)
                 o = 0
                 for a, b in grp:
                     r = r_all[o : o + b - a]
                     o += b - a
                     parts[target_keys[0]].append(stack_outputs(r, num_frames))
                     parts[target_keys[1]].append(stack_outputs(discount_cumsum(r), num_frames))
+            if timing:
+                print(f"[label_store] {len(groups)} batches: reader thread busy {t_read:.3f} s, labeller waited for frames {t_wait:.3f} s, "
+                      f"labelling {t_label:.3f} s", flush=True)
             source = ()
         elif hasattr(ds, "read_last_frames"):
             source = _prefetch((ds.read_last_frames(a, b) for a, b in spans), depth=4)
