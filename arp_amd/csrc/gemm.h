@@ -44,6 +44,7 @@ struct GemmArgs {
     int group_m = 0;          // gemm256: tile-rows per L2 group (0 = default)
     int stagger_groups = 0;   // >1: the first wave of workgroups starts in `stagger_groups` phase groups spread over
     int stagger_cycles = 0;   //     `stagger_cycles` shader cycles, so CUs do not all reach their store epilogue together
+    int ovl = 0;              // gemm256, 16-bit output: a workgroup with another tile to do drains this tile's stores under that tile's first phases
 };
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;

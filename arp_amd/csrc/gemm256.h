@@ -32,6 +32,16 @@ namespace arp {
 #ifndef ARP_G2_TWO_PHASE
 #define ARP_G2_TWO_PHASE 1
 #endif
+// Overlapped drain of the 16-bit-output epilogue (see the kernel): MEASURED, NOT ENABLED.  With two tiles per workgroup
+// (ARP_GEMM_TPW=2) the isolated c_fc launch went 286 -> 272 us (-5 %), one persistent workgroup per CU 286 -> 281 us, but the
+// two-stream labelling pass went 91.7 k -> 90.0 k frames/s on the same box (workgroups twice as long interleave the two streams
+// more coarsely), and the extra live state costs the one-tile path two scratch reloads per tile.  The window it opens (start-up +
+// two phases, 2-3 us) is short of the ~8 us a round's 31 MB take to reach HBM when every CU drains at once: hiding that needs
+// the stores on waves that issue no loads for the next tile's first K-tiles.  Build with
+// -DARP_G2_OVERLAP_DRAIN=1 to get it back.
+#ifndef ARP_G2_OVERLAP_DRAIN
+#define ARP_G2_OVERLAP_DRAIN 0
+#endif
 constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
 constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * 128;  // one K-tile: 64 KiB
 static_assert(256 * (256 * 2 + 16) >= 2 * G2_BUF_BYTES && 256 * (256 * 2 + 16) >= 128 * (256 * 4 + 16), "epilogue tile must cover the K-tile ring");
@@ -46,6 +56,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
 // units allowed to stay in flight -> counted wait (2 LDS-DMA instructions per unit per thread)
 __device__ __forceinline__ void wait_units(int allow) {
@@ -234,13 +245,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     };
     auto step_cnt = [&](int st) { return st < S2 ? ((st & 1) ? 2 : 6) : 0; };
     auto wait_instr = [&](int n) {
-        if (n >= 8) wait_vmcnt<8>();
+        if (n >= 24) wait_vmcnt<24>();
+        else if (n >= 8) wait_vmcnt<8>();
         else if (n >= 6) wait_vmcnt<6>();
         else if (n >= 2) wait_vmcnt<2>();
         else wait_vmcnt<0>();
     };
+    // `young` = the previous tile's epilogue stores, issued AFTER this tile's steps 0..2 (overlapped epilogue, below): they are
+    // younger than every step <= 2, so a wait for such a step may leave them in flight too (vmcnt counts in issue order)
+    int young = 0;
     auto phase_tail2 = [&](int p) {
-        wait_instr(step_cnt(p + 2) + step_cnt(p + 3));
+        wait_instr(step_cnt(p + 2) + step_cnt(p + 3) + (p + 1 <= 2 ? young : 0));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this phase's fragment reads are done before any wave may overwrite them
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
 #endif
     bool pre_issued = false;
     bool pre_issued_bias = false;
+    bool pre4 = false;  // this tile's steps 0..2 were issued by the previous tile's overlapped epilogue, AHEAD of that tile's 16 stores
     for (int tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
     tile_coords(tix);
     setup_src();
@@ -285,7 +301,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
         issue_step(1);
         issue_step(2);
     }
-    wait_instr(step_cnt(1) + step_cnt(2));
+    young = pre4 ? 16 : 0;
+    wait_instr(step_cnt(1) + step_cnt(2) + young);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -415,6 +432,47 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                             *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
                         }
                 }
+#if ARP_G2_TWO_PHASE && ARP_G2_OVERLAP_DRAIN
+            // ---- overlapped drain (a workgroup that has another tile to do; interior tiles only) --------------------------
+            // The tile's bytes move LDS -> registers (64 VGPRs: the accumulators are dead), the barrier releases LDS, the NEXT
+            // tile's steps 0..2 are put in flight, and only then are the 16 stores per thread issued.  vmcnt counts in issue
+            // order, so the stores are YOUNGER than those steps: the next tile's first waits (prologue, phases 0 and 1) leave them
+            // in flight (`young`), and the HBM-write-bound drain of this tile overlaps the next tile's start-up and first two phases
+            // instead of standing between two K-loops.  Every thread must issue exactly 16 store instructions for that
+            // count to be safe, hence interior tiles only (no lane, hence no wave, skips a store).
+            if (g.ovl && tix + (int)gridDim.x < total_tiles && m0 + G2_BM <= g.M && n0 + G2_BN <= g.N && nk >= 4) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4_v regs[16];
+#pragma unroll
+                for (int it = 0; it < 16; ++it)
+                    regs[it] = *reinterpret_cast<const u32x4_v*>(smem + (it * 16 + wave * 2 + (lane >> 5)) * RS + (lane & 31) * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();  // every wave holds its share of the tile: LDS is free
+                __builtin_amdgcn_sched_barrier(0);
+                OutT* obase = out + (size_t)(m0 + wave * 2 + (lane >> 5)) * g.ldo + n0 + (lane & 31) * 8;
+                tile_coords(tix + gridDim.x);
+                setup_src();
+                if (g.bias && wave == 0) {
+                    int n = n0 + lane * 4;
+                    n = n + 4 <= g.N ? n : (g.N >= 4 ? g.N - 4 : 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + n),
+                                                     (__attribute__((address_space(3))) void*)(smem + G2_TILE_BYTES), 16, 0, 0);
+                }
+                issue_step(0);
+                issue_step(1);
+                issue_step(2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) *reinterpret_cast<u32x4_v*>(obase + (size_t)it * 16 * g.ldo) = regs[it];
+                __builtin_amdgcn_sched_barrier(0);
+                pre_issued = pre_issued_bias = pre4 = true;
+                return;
+            }
+#endif
             __syncthreads();
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
@@ -529,10 +587,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                 }
         }
     };
-    epilogue();
     pre_issued = false;
     pre_issued_bias = false;
-    if (tix + (int)gridDim.x < total_tiles) {
+    pre4 = false;
+    epilogue();
+    if (!pre_issued && tix + (int)gridDim.x < total_tiles) {
         __syncthreads();  // every wave has finished reading the epilogue tile out of LDS
         tile_coords(tix + gridDim.x);
         setup_src();
@@ -586,7 +645,24 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
         if (n_cu <= 0 || (n_cu & 7)) n_cu = 256;
     }
     if (persist && grid > n_cu) grid = n_cu;  // one workgroup per CU walks the tiles
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G2_THREADS), G2_LDS_BYTES, stream, g);
+    // 16-bit-output GEMMs: each workgroup does `tpw` tiles (tix, tix + grid, ...) so that all but its last epilogue drain under
+    // the next tile's first phases (overlapped drain in the kernel).  tpw = 2 adds no tile-quantisation (c_fc: 2400 tiles = 9.4 -> 10
+    // rounds either way) and keeps two streams interleaving at a granularity of two tiles.
+    static int tpw = -1;
+    if (tpw < 0) {
+        const char* e = getenv("ARP_GEMM_TPW");
+        tpw = e ? atoi(e) : 1;
+        if (tpw < 1) tpw = 1;
+    }
+    GemmArgs ga = g;
+#if ARP_G2_OVERLAP_DRAIN
+    if (sizeof(OutT) == 2 && tpw > 1 && !persist && grid >= 2 * n_cu) {
+        grid = (grid + tpw - 1) / tpw;
+        ga.ovl = 1;
+    }
+    if (sizeof(OutT) == 2 && persist) ga.ovl = 1;
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G2_THREADS), G2_LDS_BYTES, stream, ga);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
