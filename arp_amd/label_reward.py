@@ -146,10 +146,10 @@ def _prefetch(it, depth=4):
         yield x
 
 
-def _open_store(data_path):
+def _open_store(data_path, mode="a"):
     if data_path.endswith((".hdf5", ".h5")):
         from .h5store import H5Store  # ctypes over libhdf5 -- the library h5py wraps; ImportError if absent
-        return H5Store(data_path, "a"), True
+        return H5Store(data_path, mode), True
     raise ValueError(f"unsupported data file {data_path!r}: pass store=<mapping of arrays> instead")
 
 
@@ -323,7 +323,9 @@ def label_reward(
             if env_type != "none":
                 dirname += f"_{env_type}"
             data_path = os.path.join(base_path, dirname, "data.hdf5")
-        store, is_hdf5 = _open_store(data_path)
+        # one process: "a" as the reference (label_reward.py:69).  Sharded (one process per GPU): every rank READS through its own
+        # read-only handle -- HDF5 locks a file that is open for writing -- and rank 0 reopens it "a" for the single-writer step
+        store, is_hdf5 = _open_store(data_path, "a" if world == 1 else "r")
     _, num_frames, _ = trajectory_bounds(store)  # quirk Q2: the argument is overwritten from the file
 
     compute_reward = make_compute_reward(model_type)
@@ -346,11 +348,15 @@ def label_reward(
 
     results = label_store(store, clip_model, compute_reward, image_keys=image_keys, model_type=model_type,
                           inst_type=inst_type, use_crop=use_crop, rank=rank, world=world, text=text)
+    if is_hdf5 and world > 1:
+        store.close()  # before the gather: it is the barrier after which no rank holds the file
     per_rank = gather(results) if (world > 1 and gather is not None) else [results]
     if rank == 0:
+        if is_hdf5 and world > 1:
+            store, _ = _open_store(data_path, "a")
         for res in per_rank:
             write_results(store, res, is_hdf5, num_frames)
-    if is_hdf5:
+    if is_hdf5 and (world == 1 or rank == 0):
         store.close()
     if own_model:
         clip_model.close()

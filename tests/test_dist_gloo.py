@@ -56,6 +56,58 @@ def _label_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _label_h5_worker(rank, world, port, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arp_amd import label_reward as L
+
+    def gather(res):
+        out = [None] * world
+        dist.all_gather_object(out, res)
+        return out
+
+    L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=path, clip_model=_FakeClip(), tokens=np.zeros((1, 77), np.int32),
+                   rank=rank, world=world, gather=gather)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_labelling_of_an_hdf5_file(tmp_path):
+    """Two ranks read one recorder-style HDF5 file through read-only handles, rank 0 alone reopens it to write (HDF5 is
+    single-writer): the file ends up with the datasets a single process writes."""
+    import pytest
+    try:
+        from arp_amd import h5store
+        h5store.lib()
+    except ImportError as e:
+        pytest.skip(str(e))
+    from arp_amd import label_reward as L
+    lens, F = [5, 9, 3, 14, 2, 8], 8
+    rng = np.random.default_rng(4)
+    ob, done = [], []
+    for n in lens:
+        fr = rng.integers(0, 256, (n, 8, 8, 3), dtype=np.uint8)
+        idx = np.clip(np.arange(n)[:, None] + np.arange(-F + 1, 1)[None, :], 0, None)
+        d = np.zeros((n, F), np.float32); d[-1, -1] = 1
+        ob.append(fr[idx]); done.append(d)
+    ob, done = np.concatenate(ob), np.concatenate(done)
+    ref = {"ob": ob, "done": done}
+    L.label_reward("coinrun", "hard", 500, 0, "x", ".", store=ref, clip_model=_FakeClip(), tokens=np.zeros((1, 77), np.int32))
+    p = str(tmp_path / "data.hdf5")
+    with h5store.H5Store(p, "w") as f:
+        f.create_dataset("ob", data=ob, compression="gzip", chunks=(1, F, 8, 8, 3), maxshape=(None, F, 8, 8, 3))
+        f.create_dataset("done", data=done, compression="gzip", chunks=(1, F), maxshape=(None, F))
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_label_h5_worker, args=(r, 2, port, p)) for r in range(2)]
+    [q.start() for q in procs]
+    [q.join(120) for q in procs]
+    assert all(q.exitcode == 0 for q in procs)
+    with h5store.H5Store(p, "r") as f:
+        for k in ("ob_clip_reward", "ob_clip_pos_rtg"):
+            assert f[k].chunks == (1, F) and np.array_equal(f[k][...], np.asarray(ref[k])), k
+
+
 def test_sharded_labelling_equals_single_process():
     from arp_amd import label_reward as L
     ref = _store([5, 9, 3, 14, 2, 8], seed=4)
