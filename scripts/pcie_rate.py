@@ -7,7 +7,7 @@ from arp_amd import clip, synth
 
 cfg = clip.MODELS["ViT-B/32"]
 NS = int(os.environ.get("ARP_NS", "2"))
-m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), mode="bf16", max_batch=1024, n_streams=NS).set_text(synth.prompt_tokens(1, 8, seed=2))
+m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), max_batch=1024, n_streams=NS).set_text(synth.prompt_tokens(1, 8, seed=2))
 for n in (64, 256, 1024, 2048):
     fr = synth.procgen_like_frames(n, seed=3)
     m.label(fr)
