@@ -655,6 +655,12 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
         if (tpw < 1) tpw = 1;
     }
     GemmArgs ga = g;
+    static int group_env = -1;  // ARP_GEMM_GROUP_M: tile-rows per L2 group of the block -> tile walk (0 = the default, G2_GROUP_M)
+    if (group_env < 0) {
+        const char* e = getenv("ARP_GEMM_GROUP_M");
+        group_env = e ? atoi(e) : 0;
+    }
+    if (group_env > 0 && ga.group_m == 0) ga.group_m = group_env;
 #if ARP_G2_OVERLAP_DRAIN
     if (sizeof(OutT) == 2 && tpw > 1 && !persist && grid >= 2 * n_cu) {
         grid = (grid + tpw - 1) / tpw;
