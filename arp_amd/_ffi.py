@@ -46,6 +46,13 @@ class EncCfg(C.Structure):
                                           "attn_impl")]
 
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A labeller uses one stream per
+# batch part; with a SECOND handle in the process its streams landed on queues already in use and it ran at the single-stream rate
+# (78 k instead of 90 k frames/s, whichever handle came second); with 8 queues both run at 90 k.  Read by the runtime at its first
+# HIP call, so it has to be in the environment before that; an explicit setting of the user's wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(

@@ -358,8 +358,8 @@ def main():
 
     # bf16 operands on the same frames (BASELINE.json's configs[1] names bf16): parity beside the f16 line.  Its RATE is the f16
     # rate (same kernels on v_mfma_f32_16x16x32_bf16; profiles/r1_bench_label_bf16.json = `bench.py --mode bf16` on the same box);
-    # it is not re-timed here because a second handle in one process shares hardware queues with the first and runs at the
-    # single-stream rate (78 k vs 90 k frames/s, whichever mode comes second).
+    # it is not re-timed here (a second handle's streams shared hardware queues with the first's under the runtime's default of 4
+    # queues and ran at the single-stream rate, whichever mode came second; arp_amd._ffi now asks for 8).
     alt = None
     if rank == 0 and world == 1 and a.mode == "f16" and a.alt_bf16 and parity is not None:
         m2 = clip.ClipLabeller(cfg, weights, mode="bf16", device=local_rank, max_batch=a.batch, n_streams=1).set_text(tokens)
