@@ -233,6 +233,7 @@ struct arp_clip {
     // per-row loads and reductions land in the GEMM epilogues, which are the serialised part of every tile,
     // while the LayerNorm kernels they replace overlap with the other stream's GEMMs.  Off by default.
     bool ln_fold = false;
+    bool qkv_fused = true;      // QKV projection + attention in one kernel (qkvattn.h) where the geometry allows; ARP_QKV_FUSED=0 disables
     bool cls_only_last = true;  // vision tower: the last block computes only what ln_post reads (tower.h); ARP_CLS_ONLY=0 disables
     DevBuf stats;
 
@@ -248,6 +249,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.prof = &c->prof;
     t.attn_impl = c->cfg.attn_impl;
     t.gemm_force = c->gemm_force;
+    t.qkv_fused = c->qkv_fused;
     t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
     return t;
 }
@@ -306,8 +308,10 @@ static int get_staged(arp_clip* c, const std::string& name, std::vector<int64_t>
     return 0;
 }
 
-static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers, int heads, TowerW& tw, bool fold, int wmode = -1) {
+static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers, int heads, TowerW& tw, bool fold, int wmode = -1, int ntok = 0) {
     tw.width = d; tw.layers = layers; tw.heads = heads;
+    const int emode = wmode >= 0 ? wmode : c->cfg.mode;
+    const bool hm = c->qkv_fused && ntok > 0 && qkv_attn_supported(ntok, d, heads, emode == ARP_MODE_F32 ? 4 : 2);
     tw.L.resize(layers);
     for (int i = 0; i < layers; ++i) {
         const std::string p = prefix + "resblocks." + std::to_string(i) + ".";
@@ -319,6 +323,18 @@ static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers,
         ARP_TRY(get_staged(c, p + "ln_2.bias", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.ln2_b));
         ARP_TRY(get_staged(c, p + "attn.in_proj_weight", {3 * d, d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), 3 * d, d, false, &L.w_in, wmode));
         ARP_TRY(get_staged(c, p + "attn.in_proj_bias", {3 * d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_in));
+        if (hm) {  // head-major copies for the fused QKV + attention kernel (qkvattn.h): row h*192 + j = q | k | v row of head h
+            const HostTensor *w, *b;
+            ARP_TRY(get_staged(c, p + "attn.in_proj_weight", {3 * d, d}, &w)); ARP_TRY(get_staged(c, p + "attn.in_proj_bias", {3 * d}, &b));
+            std::vector<float> wp((size_t)3 * d * d), bp((size_t)3 * d);
+            for (int hh = 0; hh < heads; ++hh)
+                for (int j = 0; j < 192; ++j) {
+                    const int src = (j >> 6) * d + hh * 64 + (j & 63);
+                    memcpy(&wp[(size_t)(hh * 192 + j) * d], &w->data[(size_t)src * d], (size_t)d * 4);
+                    bp[hh * 192 + j] = b->data[src];
+                }
+            ARP_TRY(upload_mat(c, wp.data(), 3 * d, d, false, &L.w_in_hm, wmode)); ARP_TRY(upload_f32(c, bp, &L.b_in_hm));
+        }
         ARP_TRY(get_staged(c, p + "attn.out_proj.weight", {d, d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), d, d, false, &L.w_out, wmode));
         ARP_TRY(get_staged(c, p + "attn.out_proj.bias", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_out));
         ARP_TRY(get_staged(c, p + "mlp.c_fc.weight", {4 * d, d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), 4 * d, d, false, &L.w_fc, wmode));
@@ -669,6 +685,7 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     if (const char* e = getenv("ARP_GEMM")) c->gemm_force = atoi(e);
     if (const char* e = getenv("ARP_LN_FOLD")) c->ln_fold = atoi(e) != 0;
     if (const char* e = getenv("ARP_CLS_ONLY")) c->cls_only_last = atoi(e) != 0;
+    if (const char* e = getenv("ARP_QKV_FUSED")) c->qkv_fused = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail("hipStreamCreate failed");
@@ -736,7 +753,7 @@ int arp_clip_finalize_weights(arp_clip* c) {
     ARP_TRY(get_staged(c, "visual.ln_post.weight", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpost_w));
     ARP_TRY(get_staged(c, "visual.ln_post.bias", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpost_b));
     ARP_TRY(get_staged(c, "visual.proj", {D, E}, &t)); ARP_TRY(upload_mat(c, t->data.data(), D, E, true, &c->proj_t));
-    ARP_TRY(load_tower(c, "visual.transformer.", D, k.layers, k.heads, c->vis, c->ln_fold && k.mode == ARP_MODE_BF16 && (D & 127) == 0));
+    ARP_TRY(load_tower(c, "visual.transformer.", D, k.layers, k.heads, c->vis, c->ln_fold && k.mode == ARP_MODE_BF16 && (D & 127) == 0, -1, c->ntok()));
     ARP_TRY(get_staged(c, "token_embedding.weight", {k.vocab, Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->tok_emb));
     ARP_TRY(get_staged(c, "positional_embedding", {k.ctx, Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->tpos));
     ARP_TRY(get_staged(c, "ln_final.weight", {Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnf_w));

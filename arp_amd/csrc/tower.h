@@ -8,6 +8,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "gemm256.h"
+#include "qkvattn.h"
 #include "rowops.h"
 #include "runtime.h"
 
@@ -19,6 +20,9 @@ struct LayerW {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
     void *w_in, *w_out, *w_fc, *w_proj;
     // LayerNorm-folded operands (bf16 mode): W' = W diag(gamma), c = row sums of W', d = W beta + bias
+    // head-major in-proj operands of the fused QKV + attention kernel (qkvattn.h): rows h*192 + {q | k | v of head h}
+    void* w_in_hm = nullptr;
+    float* b_in_hm = nullptr;
     void *w_in_f = nullptr, *w_fc_f = nullptr;
     float *c_in = nullptr, *d_in = nullptr, *c_fc = nullptr, *d_fc = nullptr;
 };
@@ -106,6 +110,7 @@ struct TowerCtx {
     bool cls_only_last = false;
     int attn_impl = 0;   // 0 = MFMA attention where available, 1 = VALU kernel
     int gemm_force = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel
+    bool qkv_fused = true;  // QKV projection + attention in one kernel where qkvattn.h supports the geometry (ARP_QKV_FUSED=0 disables)
     // multi-scale export: after every block, one row per sample of the residual stream -- what the forward
     // hooks of finetune_module/utils.py:6-18 capture on each resblock output -- is copied to ms_out[b, layer*D ..]
     float* ms_out = nullptr;
@@ -209,6 +214,25 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
     return 0;
 }
 
+// ln_1 output -> attention output: the fused kernel where the geometry allows it, else projection + attention kernel
+template <typename T, int SITE>
+static int tower_qkv_attention(TowerCtx& c, const TowerW& tw, const LayerW& L, const char* s_qkv, const char* s_attn, const char* s_fused, const T* h,
+                               T* qkv, T* ao, int B, int N, int causal, int nq) {
+    const int D = tw.width, M = B * N;
+    if constexpr (sizeof(T) == 2) {
+        if (c.qkv_fused && L.w_in_hm && c.attn_impl == 0 && qkv_attn_supported(N, D, tw.heads, (int)sizeof(T))) {
+            QkvAttnArgs q;
+            q.A = h; q.W = L.w_in_hm; q.bias = L.b_in_hm; q.out = ao;
+            q.B = B; q.N = N; q.K = D; q.heads = tw.heads; q.lda = D; q.ldw = D; q.ldo = D; q.fpt = 0; q.nq = nq; q.causal = causal; q.scale = 0.f;
+            ProfScope ps(*c.prof, c.stream, s_fused);
+            return launch_qkv_attn<T>(q, c.stream);
+        }
+    }
+    ARP_TRY((tower_gemm<T, T, ACT_NONE, false, SITE>(c, s_qkv, h, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, D)));
+    ProfScope ps(*c.prof, c.stream, s_attn);
+    return launch_attention<T>(c.stream, c.attn_impl, qkv, ao, B, N, D, tw.heads, causal, nq);
+}
+
 // 12 x ResidualAttentionBlock (arp_dt/models/openai/layers.py:235-271) on the f32 residual stream x.
 // ACT: MLP activation (QuickGELU for CLIP, tanh-GELU for the M3AE encoder); eps: LayerNorm epsilon;
 // SB: site-id base so that every call site is its own kernel instantiation in a rocprof trace.
@@ -218,7 +242,7 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
     const int D = tw.width, M = B * N;
     const std::string t(tag);
     const std::string s_ln1 = t + ".ln_1", s_qkv = t + ".qkv", s_attn = t + ".attn", s_out = t + ".out_proj", s_ln2 = t + ".ln_2",
-                      s_fc1 = t + ".c_fc", s_fc2 = t + ".c_proj", s_st = t + ".ln_stats";
+                      s_fc1 = t + ".c_fc", s_fc2 = t + ".c_proj", s_st = t + ".ln_stats", s_qa = t + ".qkv_attn", s_qa1 = t + ".qkv_attn_cls";
     if (stats && tw.folded && sizeof(T) == 2 && (D & 127) == 0) {
         // LayerNorm folded into the consumer GEMMs: `h` holds the bf16 copy of the residual stream, `stats` its
         // per-128-column partial sums; both are re-emitted by the epilogue of every residual GEMM.  No LN kernel runs.
@@ -253,11 +277,7 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
                               s_fc21 = t + ".c_proj_cls";
             const int ND = N * D;  // row stride of the class-token rows inside the [B*N, D] buffers
             ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));  // K and V need every token
-            ARP_TRY((tower_gemm<T, T, ACT_NONE, false, SB + SITE_QKV>(c, s_qkv.c_str(), h, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, D)));
-            {
-                ProfScope ps(*c.prof, c.stream, s_attn1.c_str());
-                ARP_TRY(launch_attention<T>(c.stream, c.attn_impl, qkv, ao, B, N, D, tw.heads, causal, 1));
-            }
+            ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn1.c_str(), s_qa1.c_str(), h, qkv, ao, B, N, causal, 1)));
             ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out1.c_str(), ao, L.w_out, L.b_out, x, x, B, D, D, nullptr, ND, ND, ND)));
             ARP_TRY(tower_layernorm<T>(c, s_ln21.c_str(), x, ND, h, D, L.ln2_w, L.ln2_b, B, D, eps));
             ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc11.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, B, 4 * D, D)));
@@ -266,11 +286,7 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
             break;
         }
         ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));
-        ARP_TRY((tower_gemm<T, T, ACT_NONE, false, SB + SITE_QKV>(c, s_qkv.c_str(), h, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, D)));
-        {
-            ProfScope ps(*c.prof, c.stream, s_attn.c_str());
-            ARP_TRY(launch_attention<T>(c.stream, c.attn_impl, qkv, ao, B, N, D, tw.heads, causal));
-        }
+        ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn.c_str(), s_qa.c_str(), h, qkv, ao, B, N, causal, 0)));
         ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out.c_str(), ao, L.w_out, L.b_out, x, x, M, D, D)));
         ARP_TRY(tower_layernorm<T>(c, s_ln2.c_str(), x, D, h, D, L.ln2_w, L.ln2_b, M, D, eps));
         ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc1.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, M, 4 * D, D)));

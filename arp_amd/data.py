@@ -16,8 +16,25 @@ def get_clip_instruct(task):
 
 
 def get_clip_special_instruct(env_name, inst_type):
-    """data_procgen.py:296-300."""
+    """data_procgen.py:296-317, including the ValueError when no branch returns."""
     if inst_type == "random1":
         return "His voice echoed through the empty hallway."
     elif inst_type == "random2":
         return "NeurIPS 2023 will be held again at the at the New Orleans Ernest N. Morial Convention Center."
+    elif inst_type == "misinfo":
+        if "coinrun" in env_name:
+            return "The agent must go to the far right of the level."
+        elif env_name == "maze_aisc":
+            return "navigate a maze to reacth to the top right corner."
+        elif env_name == "maze_yellowline":
+            return "navigate a maze to collect yellow gem."
+    elif inst_type == "misinfo2":
+        if "coinrun" in env_name:
+            return "The goal is to collect the red strawberry."
+    elif inst_type == "misinfo3":
+        if "coinrun" in env_name:
+            return "The goal is to reach the saw."
+    elif inst_type == "misinfo4":
+        if "coinrun" in env_name:
+            return "The goal is to jump as high as you can."
+    raise ValueError("You must pass any condition.")

@@ -52,7 +52,8 @@ def stack_outputs(pos_outputs, num_frames):
 
 
 def trajectory_bounds(store, done_key=None):
-    """label_reward.py:71-87.  Returns (len_data, num_frames, [traj start indices..., end])."""
+    """label_reward.py:71-87, including the ``time`` fallback of :84-87 when the done-key path raises.
+    Returns (len_data, num_frames, [traj start indices..., end])."""
     if done_key is None:
         for k in ("done", "rewards", "is_terminal"):
             if k in store and store[k] is not None:
@@ -60,10 +61,16 @@ def trajectory_bounds(store, done_key=None):
                 break
         else:
             raise ValueError
-    d = store[done_key]
-    len_data, num_frames = d.shape[:2]
-    idx = list(np.nonzero(np.asarray(d[:, -1]))[0] + 1)
-    idx.insert(0, 0)
+    try:
+        d = store[done_key]
+        len_data, num_frames = d.shape[:2]
+        idx = list(np.nonzero(np.asarray(d[:, -1]))[0] + 1)
+        idx.insert(0, 0)
+    except Exception:  # label_reward.py:84-87: boundaries from the step counter (1.0 on the first step of a trajectory)
+        t = store["time"]
+        len_data, num_frames = t.shape[:2]
+        idx = list(np.where(np.asarray(t[:, -1, 0]) == 1.0)[0])
+        idx.append(len(t))
     return len_data, num_frames, idx
 
 
@@ -262,7 +269,9 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
         first = bounds[t0] if t0 < len(bounds) else len_data
         for k in target_keys:
             rows = np.concatenate(parts[k], axis=0) if parts[k] else np.zeros((0, num_frames), np.float32)
-            out[f"{img_key}_{k}"] = (first, rows.astype(np.float32))
+            # the reference stores what np.concatenate of the stacks gives: float32 for the CLIP logits, float64 for the
+            # goal-conditioned distances (label_reward.py:163 casts them to float64)
+            out[f"{img_key}_{k}"] = (first, rows if rows.dtype == np.float64 else rows.astype(np.float32))
     return out
 
 
@@ -279,7 +288,7 @@ def write_results(store, results, is_hdf5, num_frames):
                 existing.resize(first + rows.shape[0], axis=0)
                 existing[first:] = rows
         else:
-            prev = np.asarray(existing) if existing is not None else np.zeros((0, num_frames), np.float32)
+            prev = np.asarray(existing) if existing is not None else np.zeros((0, num_frames), rows.dtype)
             store[key] = np.concatenate([prev[:first], rows], axis=0)
 
 
@@ -350,7 +359,10 @@ def label_reward(
                           inst_type=inst_type, use_crop=use_crop, rank=rank, world=world, text=text)
     if is_hdf5 and world > 1:
         store.close()  # before the gather: it is the barrier after which no rank holds the file
-    per_rank = gather(results) if (world > 1 and gather is not None) else [results]
+    if world > 1 and gather is None:
+        raise ValueError("world > 1 needs gather=<callable returning every rank's results>: rank 0 alone would write a file "
+                         "shorter than len_data (the reference always labels the whole file)")
+    per_rank = gather(results) if world > 1 else [results]
     if rank == 0:
         if is_hdf5 and world > 1:
             store, _ = _open_store(data_path, "a")

@@ -1,7 +1,7 @@
 """Oracle (test infrastructure): the host-side plumbing of the reference's labelling loop.
 
 Follows /root/reference/arp_dt/label_reward.py:
-  * trajectory boundaries from ``done[:, -1]`` ............ :80-83
+  * trajectory boundaries from ``done[:, -1]`` ............ :80-83  (``time`` fallback :84-87)
   * ``discount_cumsum`` (reverse cumulative sum, gamma=1) .. :247-254
   * ``stack_outputs`` (sliding window of last num_frames
     values, first value left-padded) ...................... :232-245
@@ -9,7 +9,8 @@ Follows /root/reference/arp_dt/label_reward.py:
 
 Deliberately written the slow way the reference writes it (Python loops, deque) so that the
 product's vectorised versions are checked against an independent formulation.
-Parity status: unpinned by reference-held vectors (none exist).
+Parity status: pinned -- tests/golden/rtg.npz holds the datasets the reference FILE ITSELF wrote (tests/golden/make_golden.py
+executes /root/reference/arp_dt/label_reward.py under I/O stand-ins); tests/test_oracle.py checks this module against them.
 """
 from collections import deque
 
@@ -53,9 +54,14 @@ def label_file(store, compute_reward, image_keys="ob", model_type="clip", inst_t
     """The reference loop (label_reward.py:256-289) over an in-memory ``store`` (dict of numpy
     arrays standing in for the HDF5 file).  ``compute_reward(images_u8[N,H,W,3]) -> float32[N]``.
     Returns {dataset_key: float32 [len_data, num_frames]}."""
-    done = store["done"]
-    len_data, num_frames = done.shape[:2]
-    bounds = trajectory_bounds(done[:, -1])
+    try:
+        done = store["done"]
+        len_data, num_frames = done.shape[:2]
+        bounds = trajectory_bounds(done[:, -1])
+    except Exception:  # label_reward.py:84-87
+        len_data, num_frames = store["time"].shape[:2]
+        bounds = list(np.where(store["time"][:, -1, 0] == 1.0)[0])
+        bounds.append(len(store["time"]))
     target_keys = [f"{model_type}_reward", f"{model_type}_pos_rtg"]
     if inst_type != "none":
         target_keys = [f"{k}_{inst_type}" for k in target_keys]

@@ -137,7 +137,9 @@ def make_rtg():
 
     rng = np.random.default_rng(123)
     out = {}
-    for case, lens in (("a", [1, 3, 9, 17]), ("b", [8, 8]), ("c", [5])):
+    # case "t": the `time` fallback of label_reward.py:84-87 -- `done` exists but is 1-D, so unpacking its shape[:2] raises and
+    # the boundaries come from time[:, -1, 0] == 1.0 (first step of every trajectory)
+    for case, lens in (("a", [1, 3, 9, 17]), ("b", [8, 8]), ("c", [5]), ("t", [4, 1, 6])):
         nf = 8
         L = sum(lens)
         rewards = rng.standard_normal(L).astype(np.float32) * 3
@@ -148,10 +150,16 @@ def make_rtg():
         ends = np.cumsum(lens) - 1
         done[ends, -1] = 1
         f = _File(ob=_DS(ob), done=_DS(done))
+        if case == "t":
+            tm = np.zeros((L, nf, 1), np.float32)
+            for s0, n in zip(np.cumsum([0] + lens[:-1]), lens):
+                tm[s0 : s0 + n, -1, 0] = np.arange(1, n + 1)
+            f = _File(ob=_DS(ob), done=_DS(done[:, -1].copy()), time=_DS(tm))
+            out["t_time"] = tm
         store["file"] = f
         ref.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path="mem.hdf5", image_keys="ob", num_frames=nf,
                          env_type="none", model_type="clip", use_crop=False, inst_type="none")
-        keys = sorted(k for k in f if k not in ("ob", "done"))
+        keys = sorted(k for k in f if k not in ("ob", "done", "time"))
         out[f"{case}_rewards"] = rewards
         out[f"{case}_done"] = done
         out[f"{case}_keys"] = np.array(keys)

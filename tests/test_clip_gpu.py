@@ -231,6 +231,38 @@ def test_last_block_class_token_only_is_exact(gpu_lib, monkeypatch, mode):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_fused_qkv_attention_is_exact(gpu_lib, monkeypatch, mode):
+    """16-bit modes at head_dim 64 / N <= 64 run the QKV projection and the attention as ONE kernel (csrc/qkvattn.h: a
+    workgroup owns 5 whole frames x one head, q|k|v never leave the CU).  Every q/k/v value is the same MFMA chain rounded at
+    the same point and the attention arithmetic is attn_mfma_kernel's, so rewards, features and the multi-scale export must be
+    bit-identical to the two-kernel path (ARP_QKV_FUSED=0) -- on full tiles, a ragged last tile (37 = 7 x 5 + 2 frames), fewer
+    frames than one tile, and with the class-token-only last block on and off."""
+    from arp_amd import clip, synth
+    from oracle import clip_np as C
+    ocfg = C.ClipConfig(**MID)
+    Wt = synth.clip_weights(ocfg, seed=29)
+    tok = synth.prompt_tokens(1, 5, ctx=ocfg.ctx, vocab=ocfg.vocab, seed=4)
+    fr = synth.procgen_like_frames(37, seed=8)
+    ref = C.compute_reward(Wt, ocfg, fr[:5], tok)
+    for cls_only in ("1", "0"):
+        monkeypatch.setenv("ARP_CLS_ONLY", cls_only)
+        out = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("ARP_QKV_FUSED", flag)
+            m = clip.ClipLabeller(clip.ClipConfig(**MID), Wt, mode=mode, n_streams=1).set_text(tok)
+            m.profile(True)
+            out[flag] = (m.label(fr), m.label(fr[:3]), m.encode_image(fr)) + tuple(m.encode_image_multiscale(fr))
+            sites = m.profile_read()
+            assert ("vit.qkv_attn" in sites) == (flag == "1") and ("vit.attn" in sites) == (flag == "0"), sorted(sites)
+            if cls_only == "1":
+                assert ("vit.qkv_attn_cls" in sites) == (flag == "1")
+            m.close()
+        for a, b in zip(out["0"], out["1"]):
+            assert np.array_equal(a, b)
+        assert np.abs(out["1"][0][:5] - ref).max() / float(np.exp(Wt["logit_scale"])) < (2 * COS_TOL_F16 if mode == "f16" else COS_TOL_BF16)
+
+
 def test_label_reward_from_hdf5_file(gpu_lib, tmp_path):
     """SURVEY row N3 end to end on the GPU: recorder-style HDF5 file in, reward / rtg datasets out (gzip, chunks (1, num_frames)),
     equal to labelling the same frames from memory."""

@@ -134,12 +134,14 @@ def test_label_reward_mirror_matches_reference_goldens():
         def label(self, frames, use_crop=False):
             return frames[:, 0, 0, 0].astype(np.float32)
 
-    for case in "abc":
+    for case in "abct":
         rewards, done = g[f"{case}_rewards"], g[f"{case}_done"]
         Ln, nf = done.shape
         ob = np.zeros((Ln, nf, 1, 1, 3), np.float32)
         ob[:, -1, 0, 0, 0] = rewards
         st = {"ob": ob, "done": done}
+        if case == "t":  # boundaries from `time` when the done-key path raises (label_reward.py:84-87)
+            st = {"ob": ob, "done": done[:, -1].copy(), "time": g["t_time"]}
         L.label_reward("coinrun", "hard", 500, 0, "x", ".", store=st, clip_model=Fake(), tokens=np.zeros((1, 77), np.int32))
         for k in g[f"{case}_keys"]:
             assert (np.asarray(st[str(k)]) == g[f"{case}__{k}"]).all(), (case, k)
@@ -164,6 +166,22 @@ def test_label_reward_variants_and_errors():
         L.label_reward("coinrun", "hard", 500, 0, "x", ".", store=st, clip_model=_FakeClip())  # neither tokens nor tokenizer
     from arp_amd import data
     assert data.get_clip_instruct("coinrun") == "the goal is to collect the coin."
+    # data_procgen.py:296-317: every branch, and the ValueError when none returns
+    assert data.get_clip_special_instruct("coinrun_aisc", "misinfo") == "The agent must go to the far right of the level."
+    assert data.get_clip_special_instruct("maze_aisc", "misinfo") == "navigate a maze to reacth to the top right corner."
+    assert data.get_clip_special_instruct("maze_yellowline", "misinfo") == "navigate a maze to collect yellow gem."
+    assert data.get_clip_special_instruct("coinrun", "misinfo2") == "The goal is to collect the red strawberry."
+    assert data.get_clip_special_instruct("coinrun", "misinfo3") == "The goal is to reach the saw."
+    assert data.get_clip_special_instruct("coinrun", "misinfo4") == "The goal is to jump as high as you can."
+    for env, inst in (("maze", "misinfo"), ("maze", "misinfo2"), ("coinrun", "none"), ("coinrun", "bogus")):
+        with pytest.raises(ValueError, match="You must pass any condition"):
+            data.get_clip_special_instruct(env, inst)
+    # sharded call without a gather: refuse instead of writing a short file
+    with pytest.raises(ValueError, match="gather"):
+        L.label_reward("coinrun", "hard", 500, 0, "x", ".", store=_store([3, 4]), clip_model=_FakeClip(), tokens=np.zeros((1, 77), np.int32),
+                       rank=0, world=2)
+    # goal-conditioned rewards keep the float64 the reference's compute_reward returns (label_reward.py:163)
+    assert st["ob_clip_goal_conditioned_reward_random1"].dtype == np.float64
 
 
 def test_shard_trajectories_balanced_and_complete():

@@ -66,12 +66,14 @@ def test_rtg_oracle_matches_reference_goldens():
     """oracle/rtg.py against datasets written by the reference's own label_reward()."""
     from oracle import rtg
     g = np.load(os.path.join(G, "rtg.npz"))
-    for case in "abc":
+    for case in "abct":
         rewards, done = g[f"{case}_rewards"], g[f"{case}_done"]
         keys = list(g[f"{case}_keys"])
         assert keys == ["ob_clip_pos_rtg", "ob_clip_reward"]
         L, nf = done.shape
         store = {"done": done, "ob": np.zeros((L, nf, 1), np.float32)}
+        if case == "t":  # the `time` fallback (label_reward.py:84-87): a 1-D `done` makes the done-key path raise
+            store = {"done": done[:, -1].copy(), "time": g["t_time"], "ob": store["ob"]}
         store["ob"][:, -1, 0] = rewards
         out = rtg.label_file(store, lambda imgs: imgs[:, 0])
         for k in keys:
