@@ -1149,6 +1149,7 @@ extern "C" {
 
 int arp_op_gemm_bench(int mode, int kernel, int act, int resid, int out_f32, int M, int N, int K, int iters, float* avg_ms) {
     if (!avg_ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return fail("bad argument");
+    if (mode == ARP_MODE_F16) return op_gemm_bench<f16_t>(kernel, act, resid, out_f32, M, N, K, iters, avg_ms);
     return mode == ARP_MODE_BF16 ? op_gemm_bench<bf16_t>(kernel, act, resid, out_f32, M, N, K, iters, avg_ms)
                                  : op_gemm_bench<float>(kernel, act, resid, out_f32, M, N, K, iters, avg_ms);
 }

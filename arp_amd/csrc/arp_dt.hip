@@ -87,6 +87,12 @@ struct arp_dt {
     bool shadows_stale = true;
     // operand-type shadows of the big weights
     DevBuf W1s, W2s, W2t, Wis, Wit;
+    // f16 mode: image_text_input contracts K = 197 376 products of once-rounded operands; with 11-bit significands that rounding is
+    // ~1e-3 on the logits (measured 1.05-1.16e-3 vs north_star's 1e-3).  Both operands are therefore carried as hi + lo pairs
+    // (y = y_hi + y_lo, Wi = Wi_hi + Wi_lo, each part binary16) and the forward sums the three leading products
+    // y_hi.Wi_hi + y_lo.Wi_hi + y_hi.Wi_lo in one fixed-order split-K reduction: 2 x 6.5 GFLOP extra per step.
+    DevBuf Wis_lo, Y_lo;
+    bool split_iti() const { return cfg.mode == ARP_MODE_F16 && cfg.use_adapter; }
     // batch
     int B = 0;
     DevBuf enc32, action, rtg;
@@ -113,7 +119,11 @@ struct arp_dt {
     int graph_B = 0, graph_images = -1, eager_steps = 0;
     Profiler prof;
 
-    size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
+    size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
+    // Backward activations of the adapter path (dz -> dY -> dApre -> G, all stored in the operand type) are ~1e-7 at B = 32:
+    // below binary16's normal range.  In f16 mode they carry a power-of-two scale (exact), removed again where a gradient
+    // leaves for the f32 gradient buffer (GEMM alpha / split-K reduce / row sums).  bf16 and f32 have the range: scale 1.
+    float act_scale() const { return cfg.mode == ARP_MODE_F16 ? 16384.f : 1.f; }
     int R() const { return B * cfg.window; }
     int L() const { return 3 * cfg.window; }
     float* p(const std::string& n) { return params.as<float>() + infos[index.at(n)].off; }
@@ -247,8 +257,9 @@ int ew_bwd(arp_dt* c, const float* gr, const float* ref, float* out, size_t n, i
 // big NT GEMM on the MFMA kernels; OutT in {T, float}
 template <typename T, typename OutT, int ACT>
 int big_gemm(arp_dt* c, const char* site, const void* A, int lda, const void* W, int ldw, const float* bias, void* out, int ldo, int M, int N,
-             int K) {
+             int K, float alpha = 1.f) {
     GemmArgs g;
+    g.alpha = alpha;
     g.A = A; g.W = W; g.bias = bias; g.resid = nullptr; g.out = out;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = ldo; g.ldo = ldo;
     ProfScope ps(c->prof, c->stream, site);
@@ -257,7 +268,7 @@ int big_gemm(arp_dt* c, const char* site, const void* A, int lda, const void* W,
 // split-K NT GEMM: f32 partials [S][M][N] then a fixed-order reduce (+bias, act) into OutT
 template <typename T, typename OutT>
 int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void* W, int ldw, const float* bias, int act, OutT* out, int M, int N,
-                int K) {
+                int K, float alpha = 1.f, const void* A2 = nullptr, const void* W2 = nullptr, const void* A3 = nullptr, const void* W3 = nullptr) {
     constexpr int EPB = 128 / (int)sizeof(T);
     const int nk = K / EPB;
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
@@ -265,7 +276,10 @@ int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void*
     int S = std::max(1, std::min(nk, wg_target / std::max(tiles, 1)));
     const int per = (nk + S - 1) / S;
     S = (nk + per - 1) / per;  // every slice non-empty
-    ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
+    // extra operand pairs (A2.W2^T, A3.W3^T; same shapes) land in further slabs of the same partial buffer and are summed by the
+    // same fixed-order reduction
+    const int npairs = 1 + (A2 ? 1 : 0) + (A3 ? 1 : 0);
+    ARP_TRY(c->part.ensure((size_t)npairs * S * M * N * 4));
     GemmArgs g;
     g.A = A; g.W = W; g.bias = nullptr; g.resid = nullptr; g.out = c->part.p;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = N; g.ldo = N;
@@ -274,7 +288,16 @@ int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void*
     if (S == 1) g.ksplit = 1;
     ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_DT + 1>(g, c->stream)));
     const size_t MN = (size_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out);
+    const void* As[2] = {A2, A3};
+    const void* Ws[2] = {W2, W3};
+    for (int q = 0, slab = 1; q < 2; ++q)
+        if (As[q]) {
+            g.A = As[q]; g.W = Ws[q]; g.out = c->part.as<float>() + (size_t)slab * S * MN;
+            ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_DT + 1>(g, c->stream)));
+            ++slab;
+        }
+    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), npairs * S, MN, N, bias, act, out,
+                       nullptr, 0, alpha);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -301,6 +324,12 @@ template <typename T> int refresh_shadows(arp_dt* c) {
     }
     ARP_TRY((transpose_mask<float, float, T>(c, c->p("image_text_input/kernel"), (int)Kin, nullptr, nullptr, 1.f, c->Wis.as<T>(), (int)Kin,
                                              c->Wit.as<T>(), E, E, (int)Kin)));
+    if (c->split_iti()) {
+        ARP_TRY(c->Wis_lo.ensure(Kin * E * sizeof(T)));
+        hipLaunchKernelGGL((split_lo_kernel<T>), dim3(cdiv(Kin * E, 1024)), dim3(256), 0, c->stream, c->p("image_text_input/kernel"), c->Wis.as<T>(),
+                           c->Wis_lo.as<T>(), Kin * E);
+        ARP_HIP_OK(hipGetLastError());
+    }
     c->shadows_stale = false;
     return 0;
 }
@@ -397,6 +426,7 @@ int ensure_buffers(arp_dt* c, int B) {
     ARP_TRY(c->enc32.ensure(Mx * D * 4)); ARP_TRY(c->action.ensure(R * 4)); ARP_TRY(c->rtg.ensure(R * 4));
     DevBuf* tb[] = {&c->Xb, &c->H1, &c->A, &c->Y, &c->dY, &c->dApre, &c->G};
     for (auto* b : tb) ARP_TRY(b->ensure(Mx * D * e));
+    if (c->split_iti()) ARP_TRY(c->Y_lo.ensure(Mx * D * e));
     DevBuf* tt[] = {&c->XbT, &c->H1T, &c->dApreT, &c->dH1T};
     for (auto* b : tt) {
         ARP_TRY(b->ensure((size_t)D * Mxp * e));
@@ -471,13 +501,17 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc1", c->Xb.p, D, c->W1s.p, D, c->p("AdapterMLP_0/Dense_0/bias"), c->H1.p, D, (int)Mx, D, D)));
         ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc2", c->H1.p, D, c->W2s.p, D, c->p("AdapterMLP_0/Dense_1/bias"), c->A.p, D, (int)Mx, D, D)));
         ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
-        hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->Xb.as<T>(),
-                           c->p("residual_weight"), c->Y.as<T>(), Mx * D);
+        hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->enc32.as<float>(),
+                           c->p("residual_weight"), c->Y.as<T>(), c->split_iti() ? c->Y_lo.as<T>() : nullptr, Mx * D);
         ARP_HIP_OK(hipGetLastError());
         Yp = c->Y.as<T>();
     }
     // image_text_input + tanh (arp_dt/ARPDT.py:475-484): [R, tokens*dim] x [tokens*dim, E], split over K
-    ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
+    if (c->split_iti())
+        ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin,
+                                       1.f, c->Y_lo.p, c->Wis.p, Yp, c->Wis_lo.p)));
+    else
+        ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
     if (c->fused) {
         ProfScope ps(c->prof, c->stream, "dt.policy_fwd");
         ARP_TRY(policy_fused(c, with_bwd));
@@ -586,21 +620,22 @@ template <typename T> int backward(arp_dt* c) {
     }
     // ---- image_text_input: dW[E, Kin] = dz^T Y ;  dY[R, Kin] = dz Wi -------------------------------------
     const T* Yp = k.use_adapter ? c->Y.as<T>() : c->Xb.as<T>();
-    ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, 1.f, c->dzb.as<T>(), E, c->dzT.as<T>(), Rp, R, E)));
+    const float S = c->act_scale(), invS = 1.0f / S;
+    ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, S, c->dzb.as<T>(), E, c->dzT.as<T>(), Rp, R, E)));
     {
         ProfScope ps(c->prof, c->stream, "dt.Y_transpose");
         ARP_TRY((transpose_mask<T, T, T>(c, Yp, Kin, nullptr, nullptr, 1.f, nullptr, 0, c->YT.as<T>(), Rp, R, Kin)));
     }
-    ARP_TRY((big_gemm<T, float, ACT_NONE>(c, "dt.image_text_input_dW", c->dzT.p, Rp, c->YT.p, Rp, nullptr, c->g("image_text_input/kernel"), Kin, E, Kin, Rp)));
+    ARP_TRY((big_gemm<T, float, ACT_NONE>(c, "dt.image_text_input_dW", c->dzT.p, Rp, c->YT.p, Rp, nullptr, c->g("image_text_input/kernel"), Kin, E, Kin, Rp, invS)));
     if (!k.use_adapter) return 0;
     ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.image_text_input_dX", c->dzb.p, E, c->Wit.p, E, nullptr, c->dY.p, Kin, R, Kin, E)));
     // ---- adapter backward (y = res a + (1-res) x, x is stop_gradient'ed: arp_dt/ARPDT.py:462-472) --------
     {
         ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_elementwise");
         const int nb = 1024;
-        hipLaunchKernelGGL((adapter_dres_kernel<T>), dim3(nb), dim3(256), 0, c->stream, c->dY.as<T>(), c->A.as<T>(), c->Xb.as<T>(),
+        hipLaunchKernelGGL((adapter_dres_kernel<T>), dim3(nb), dim3(256), 0, c->stream, c->dY.as<T>(), c->A.as<T>(), c->enc32.as<float>(),
                            c->scal.as<float>() + 16, Mx * D);
-        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, nb, 1.0f, c->scal.as<float>() + 8, 0);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, nb, invS, c->scal.as<float>() + 8, 0);
         hipLaunchKernelGGL(dres_to_drw_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 8, c->p("residual_weight"), c->g("residual_weight"));
         // res = sigmoid(rw) as a device scalar for the masked transposes
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->p("residual_weight"), 1, 1.0f, c->scal.as<float>() + 9, 0);
@@ -614,15 +649,15 @@ template <typename T> int backward(arp_dt* c) {
                                          (int)Mx, D)));
         ARP_TRY((transpose_mask<T, T, T>(c, c->H1.as<T>(), D, nullptr, nullptr, 1.f, nullptr, 0, c->H1T.as<T>(), Mxp, (int)Mx, D)));
     }
-    ARP_TRY((splitk_gemm<T, float>(c, "dt.adapter_fc2_dW", c->dApreT.p, Mxp, c->H1T.p, Mxp, nullptr, ACT_NONE, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp)));
-    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(D), dim3(256), 0, c->stream, c->dApreT.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_1/bias"), D);
+    ARP_TRY((splitk_gemm<T, float>(c, "dt.adapter_fc2_dW", c->dApreT.p, Mxp, c->H1T.p, Mxp, nullptr, ACT_NONE, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp, invS)));
+    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(D), dim3(256), 0, c->stream, c->dApreT.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_1/bias"), D, invS);
     ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.adapter_fc2_dX", c->dApre.p, D, c->W2t.p, D, nullptr, c->G.p, D, (int)Mx, D, D)));
     {
         ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
         ARP_TRY((transpose_mask<T, T, T>(c, c->G.as<T>(), D, c->H1.as<T>(), nullptr, 1.f, nullptr, 0, c->dH1T.as<T>(), Mxp, (int)Mx, D)));
     }
-    ARP_TRY((splitk_gemm<T, float>(c, "dt.adapter_fc1_dW", c->dH1T.p, Mxp, c->XbT.p, Mxp, nullptr, ACT_NONE, c->g("AdapterMLP_0/Dense_0/kernel"), D, D, Mxp)));
-    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(D), dim3(256), 0, c->stream, c->dH1T.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_0/bias"), D);
+    ARP_TRY((splitk_gemm<T, float>(c, "dt.adapter_fc1_dW", c->dH1T.p, Mxp, c->XbT.p, Mxp, nullptr, ACT_NONE, c->g("AdapterMLP_0/Dense_0/kernel"), D, D, Mxp, invS)));
+    hipLaunchKernelGGL((rowsum_kernel<T>), dim3(D), dim3(256), 0, c->stream, c->dH1T.as<T>(), Mxp, (int)Mx, c->g("AdapterMLP_0/Dense_0/bias"), D, invS);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -747,11 +782,11 @@ extern "C" {
 int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (!cfg || !out) return fail("null argument");
     const arp_dt_cfg& k = *cfg;
-    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16) return fail("bad mode");
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16 && k.mode != ARP_MODE_F16) return fail("bad mode");
     if (k.emb <= 0 || k.heads <= 0 || k.emb % k.heads || k.emb % 4) return fail("emb must be a positive multiple of heads and of 4");
     const int hd = k.emb / k.heads;
     if (hd != 16 && hd != 32 && hd != 64) return fail("head_dim must be 16, 32 or 64");
-    const int kq = k.mode == ARP_MODE_BF16 ? 64 : 32;
+    const int kq = k.mode == ARP_MODE_F32 ? 32 : 64;
     if (k.enc_dim % kq || k.emb % kq) return fail("enc_dim and emb must be multiples of " + std::to_string(kq));
     if (k.window <= 0 || 3 * k.window > 64) return fail("window must be in 1..21");
     if (k.depth <= 0 || k.n_actions <= 0 || k.enc_tokens <= 0 || k.mlp_ratio <= 0) return fail("bad geometry");
@@ -788,7 +823,7 @@ int arp_dt_destroy(arp_dt* c) {
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->Wis_lo, &c->Y_lo, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,
@@ -916,7 +951,7 @@ int arp_dt_forward(arp_dt* c, float* action_logits, float* return_pred, float* m
     if (!c) return fail("null handle");
     if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : forward<float>(c));
+    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : (c->cfg.mode == ARP_MODE_F16 ? forward<f16_t>(c) : forward<float>(c)));
     const int R = c->R();
     if (action_logits) ARP_HIP_OK(hipMemcpyAsync(action_logits, c->logits.p, (size_t)R * c->cfg.n_actions * 4, hipMemcpyDeviceToHost, c->stream));
     if (return_pred) ARP_HIP_OK(hipMemcpyAsync(return_pred, c->ret.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
@@ -930,6 +965,7 @@ int arp_dt_backward(arp_dt* c) {
     if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(forward<bf16_t>(c, true)); ARP_TRY(backward<bf16_t>(c)); }
+    else if (c->cfg.mode == ARP_MODE_F16) { ARP_TRY(forward<f16_t>(c, true)); ARP_TRY(backward<f16_t>(c)); }
     else { ARP_TRY(forward<float>(c, true)); ARP_TRY(backward<float>(c)); }
     ARP_TRY(l2_penalty(c));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
@@ -940,6 +976,7 @@ int arp_dt_train_step_async(arp_dt* c, float lr) {
     if (!c) return fail("null handle");
     if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_F16) return step_impl<f16_t>(c, lr, nullptr);
     return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, nullptr) : step_impl<float>(c, lr, nullptr);
 }
 
@@ -947,6 +984,7 @@ int arp_dt_train_step(arp_dt* c, float lr, float* aux) {
     if (!c || !aux) return fail("null argument");
     if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_F16) return step_impl<f16_t>(c, lr, aux);
     return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, aux) : step_impl<float>(c, lr, aux);
 }
 
@@ -994,7 +1032,15 @@ int arp_dt_broadcast_state(arp_dt* c) {
     for (auto* b : fb)
         if (ncclResult_t r = rccl_api()->Broadcast(b->p, b->p, c->P, ncclFloat, 0, c->comm, c->stream); r != ncclSuccess)
             return rccl_fail("ncclBroadcast", r);
+    // ... and its step counter (rank 0's whole TrainState, main_procgen.py:94-101: optax's count drives the bias correction and
+    // the learning-rate schedule): 8 bytes through the scratch buffer
+    ARP_TRY(c->scal.ensure(4096 * 4));
+    long long st = c->step;
+    ARP_HIP_OK(hipMemcpyAsync(c->scal.p, &st, 8, hipMemcpyHostToDevice, c->stream));
+    if (ncclResult_t r = rccl_api()->Broadcast(c->scal.p, c->scal.p, 8, ncclChar, 0, c->comm, c->stream); r != ncclSuccess) return rccl_fail("ncclBroadcast(step)", r);
+    ARP_HIP_OK(hipMemcpyAsync(&st, c->scal.p, 8, hipMemcpyDeviceToHost, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    c->step = st;
     c->shadows_stale = true;
     return 0;
 }

@@ -76,7 +76,7 @@ struct arp_enc {
     Profiler prof;
     int gemm_force = 0;
     int tokens() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
-    size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
+    size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
 };
 
 namespace {
@@ -100,6 +100,10 @@ int up_kernel(arp_enc* c, const float* src, int in, int out_, void** out) {
     if (c->cfg.mode == ARP_MODE_BF16) {
         std::vector<bf16_t> hb(n);
         for (size_t i = 0; i < n; ++i) hb[i] = host_f2bf(t[i]);
+        ARP_HIP_OK(hipMemcpy(p, hb.data(), n * 2, hipMemcpyHostToDevice));
+    } else if (c->cfg.mode == ARP_MODE_F16) {
+        std::vector<f16_t> hb(n);
+        for (size_t i = 0; i < n; ++i) hb[i] = host_f2h(t[i]);
         ARP_HIP_OK(hipMemcpy(p, hb.data(), n * 2, hipMemcpyHostToDevice));
     } else {
         ARP_HIP_OK(hipMemcpy(p, t.data(), n * 4, hipMemcpyHostToDevice));
@@ -168,6 +172,7 @@ int enc_forward_on(arp_enc* c, hipStream_t stream, const float* images_dev, int 
     for (int off = 0; off < n; off += mb) {
         const int nb = std::min(mb, n - off);
         if (c->cfg.mode == ARP_MODE_BF16) ARP_TRY(forward_chunk<bf16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
+        else if (c->cfg.mode == ARP_MODE_F16) ARP_TRY(forward_chunk<f16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
         else ARP_TRY(forward_chunk<float>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
     }
     return 0;
@@ -185,9 +190,9 @@ extern "C" {
 int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
     if (!cfg || !out) return fail("null argument");
     const arp_enc_cfg& k = *cfg;
-    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16) return fail("bad mode");
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16 && k.mode != ARP_MODE_F16) return fail("bad mode");
     if (k.patch <= 0 || k.img_res % k.patch || k.width % k.heads || k.width % 4) return fail("bad geometry");
-    const int kq = k.mode == ARP_MODE_BF16 ? 64 : 32;
+    const int kq = k.mode == ARP_MODE_F32 ? 32 : 64;
     if (k.width % kq || (k.patch * k.patch * 3) % kq) return fail("width and 3*patch^2 must be multiples of " + std::to_string(kq));
     int ndev = 0;
     ARP_HIP_OK(hipGetDeviceCount(&ndev));

@@ -84,7 +84,7 @@ static __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) { s
 template <typename OutT>
 static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, size_t MN, int N,
                                                             const float* __restrict__ bias, int act, OutT* __restrict__ out,
-                                                            const float* __restrict__ resid = nullptr, int ldo = 0) {
+                                                            const float* __restrict__ resid = nullptr, int ldo = 0, float alpha = 1.f) {
     // 64 outputs per block, 4 slice groups per output (fixed order: group partials are added 0..3)
     __shared__ float red[4][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
@@ -106,7 +106,7 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* 
     red[y][x] = s;
     __syncthreads();
     if (y != 0 || i >= MN) return;
-    s = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+    s = alpha * ((red[0][x] + red[1][x]) + (red[2][x] + red[3][x]));
     if (bias) s += bias[i % N];
     if (act == ACT_TANH) s = tanhf(s);
     else if (act == ACT_RELU) s = fmaxf(s, 0.f);
@@ -187,25 +187,55 @@ __global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restric
 }
 
 // ---- adapter mix (arp_dt/ARPDT.py:466-472):  y = res*a + (1-res)*x,  res = sigmoid(residual_weight) -----
+// x is the f32 encoder output itself (not its operand-type copy: the skip term then carries no operand rounding); y_lo, when
+// given, receives the operand-type remainder y - T(y) so that image_text_input can contract (y_hi + y_lo) (arp_dt.hip).
 template <typename T>
-static __global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ a, const T* __restrict__ x, const float* __restrict__ rw,
-                                                          T* __restrict__ y, size_t n) {
+static __global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ a, const float* __restrict__ x, const float* __restrict__ rw,
+                                                          T* __restrict__ y, T* __restrict__ y_lo, size_t n) {
     const float res = 1.0f / (1.0f + expf(-rw[0]));
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
-        float av[4], xv[4];
+        float av[4], xv[4], yv[4], hv[4];
         load4(a + i, av);
         load4(x + i, xv);
-        store4(y + i, res * av[0] + (1.f - res) * xv[0], res * av[1] + (1.f - res) * xv[1], res * av[2] + (1.f - res) * xv[2],
-               res * av[3] + (1.f - res) * xv[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = res * av[j] + (1.f - res) * xv[j];
+        store4(y + i, yv[0], yv[1], yv[2], yv[3]);
+        if (y_lo) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T h;
+                Elem<T>::st(&h, yv[j]);
+                hv[j] = yv[j] - Elem<T>::ld(&h);
+            }
+            store4(y_lo + i, hv[0], hv[1], hv[2], hv[3]);
+        }
     } else {
-        for (size_t j = i; j < n; ++j) Elem<T>::st(y + j, res * Elem<T>::ld(a + j) + (1.f - res) * Elem<T>::ld(x + j));
+        for (size_t j = i; j < n; ++j) {
+            const float v = res * Elem<T>::ld(a + j) + (1.f - res) * x[j];
+            Elem<T>::st(y + j, v);
+            if (y_lo) Elem<T>::st(y_lo + j, v - Elem<T>::ld(y + j));
+        }
+    }
+}
+
+// lo[i] = T(w[i] - float(T(w[i])))  -- the operand-type remainder of an f32 matrix whose T copy is `hi`
+template <typename T>
+static __global__ __launch_bounds__(256) void split_lo_kernel(const float* __restrict__ w, const T* __restrict__ hi, T* __restrict__ lo, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float wv[4], hv[4];
+        load4(w + i, wv);
+        load4(hi + i, hv);
+        store4(lo + i, wv[0] - hv[0], wv[1] - hv[1], wv[2] - hv[2], wv[3] - hv[3]);
+    } else {
+        for (size_t j = i; j < n; ++j) Elem<T>::st(lo + j, w[j] - Elem<T>::ld(hi + j));
     }
 }
 
 // partial[b] = sum over the block's slice of dy * (a - x)      (d loss / d res; finished by reduce_sum)
 template <typename T>
-static __global__ __launch_bounds__(256) void adapter_dres_kernel(const T* __restrict__ dy, const T* __restrict__ a, const T* __restrict__ x,
+static __global__ __launch_bounds__(256) void adapter_dres_kernel(const T* __restrict__ dy, const T* __restrict__ a, const float* __restrict__ x,
                                                            float* __restrict__ partial, size_t n) {
     __shared__ float red[4];
     float s = 0.f;
@@ -219,7 +249,7 @@ static __global__ __launch_bounds__(256) void adapter_dres_kernel(const T* __res
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = (n4 << 2) + threadIdx.x;
-        s += Elem<T>::ld(dy + i) * (Elem<T>::ld(a + i) - Elem<T>::ld(x + i));
+        s += Elem<T>::ld(dy + i) * (Elem<T>::ld(a + i) - x[i]);
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -252,7 +282,7 @@ static __global__ void dres_to_drw_kernel(const float* __restrict__ dres, const 
 
 // ---- row sums of a [R, ld] matrix (bias gradients from the TRANSPOSED gradient: one row per output unit)
 template <typename T>
-static __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, int ld, int cols, float* __restrict__ out, int rows) {
+static __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ in, int ld, int cols, float* __restrict__ out, int rows, float alpha = 1.f) {
     __shared__ float red[4];
     const int row = blockIdx.x;  // one workgroup per row; ld % 4 == 0 (rows are 8/16-byte aligned)
     const T* r = in + (size_t)row * ld;
@@ -267,7 +297,7 @@ static __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict_
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[row] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) out[row] = alpha * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 // column sums of a small [R, C] f32 matrix: out[c] = sum_r in[r, c]
 __device__ __forceinline__ void colsum_tile(const float* __restrict__ in, int R, int C, float* __restrict__ out, int bx) {

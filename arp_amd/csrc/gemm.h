@@ -44,6 +44,8 @@ struct GemmArgs {
     int group_m = 0;          // gemm256: tile-rows per L2 group (0 = default)
     int stagger_groups = 0;   // >1: the first wave of workgroups starts in `stagger_groups` phase groups spread over
     int stagger_cycles = 0;   //     `stagger_cycles` shader cycles, so CUs do not all reach their store epilogue together
+    float alpha = 1.f;        // out = act(alpha * (A.W^T) + bias) (+ resid); honoured by gemm_nt_kernel only -- launch_gemm_auto routes
+                              // alpha != 1 there (power-of-two un-scaling of f16 gradient GEMMs, arp_dt.hip)
     int ovl = 0;              // gemm256, 16-bit output: a workgroup with another tile to do drains this tile's stores under that tile's first phases
 };
 
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
                     const int row = wr * 64 + mi * 16 + fr, col = wc * 64 + ni * 16 + fg * 4;
-                    float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+                    float v[4] = {acc[ni][mi][0] * g.alpha, acc[ni][mi][1] * g.alpha, acc[ni][mi][2] * g.alpha, acc[ni][mi][3] * g.alpha};
                     if (g.ln_stats && n0 + col < g.N) {
                         const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n0 + col);
                         v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     for (int ni = 0; ni < 4; ++ni) {
                         const int mi = 2 * p + mh;
                         const int lrow = wr * 32 + mh * 16 + fr, col = wc * 64 + ni * 16 + fg * 4;
-                        float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+                        float v[4] = {acc[ni][mi][0] * g.alpha, acc[ni][mi][1] * g.alpha, acc[ni][mi][2] * g.alpha, acc[ni][mi][3] * g.alpha};
                         if (g.bias && n0 + col < g.N) {
                             const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
                             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
         for (int ni = 0; ni < 4; ++ni) {
             const int n = n0 + wc * 64 + ni * 16 + fg * 4;
             if (n >= g.N) continue;
-            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            float v[4] = {acc[ni][mi][0] * g.alpha, acc[ni][mi][1] * g.alpha, acc[ni][mi][2] * g.alpha, acc[ni][mi][3] * g.alpha};
             if (vec_ok) {
                 if (g.bias) {
                     const float4 b = *reinterpret_cast<const float4*>(g.bias + n);

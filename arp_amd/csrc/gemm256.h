@@ -674,15 +674,21 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
 }
 
 }  // namespace arp
-#include "gemm_p.h"
+#include "gemm2w.h"
 namespace arp {
 
-// force: 0 = auto, 1 = 128x128 (2 WG/CU, two-phase), 2 = 256x256 (1 WG/CU, four-phase pipelined),
-// 3 = 256x128 paired (2 WG/CU, 3-deep ring).  Auto: a big-tile kernel when the grid fills the chip.
+// force: 0 = auto, 1 = 128x128 (2 WG/CU, simple double buffer), 2 = 256x256 (1 WG/CU, two-phase pipelined),
+// 3 = 128x192 two-workgroups-per-CU kernel (gemm2w.h; 16-bit operands, instantiated epilogues only -- anything else falls
+// through to auto).  Auto: a big-tile kernel when the grid fills the chip.
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
 inline int launch_gemm_auto(const GemmArgs& g, hipStream_t stream, int force = 0) {
     const long tiles256 = (long)((g.M + G2_BM - 1) / G2_BM) * ((g.N + G2_BN - 1) / G2_BN);
-    if (force == 3) return launch_gemm_p<T, OutT, ACT, RESID, SITE>(g, stream);
+    if constexpr (sizeof(T) == 2) {
+        if (force == 3 && gemm2w_has(__is_same(T, bf16_t) ? 1 : 2, sizeof(OutT) == 4 ? 1 : 0, ACT, RESID ? 1 : 0) && g.K % 64 == 0 && !(g.N & 7) &&
+            !(g.ldo & 7) && !(RESID && (g.ldr & 3)) && !g.ln_stats && !g.stats_out && !g.xb_out && g.ksplit <= 1 && g.alpha == 1.f)
+            return launch_gemm2w<T, OutT, ACT, RESID>(g, stream);
+    }
+    if (g.alpha != 1.f) return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, stream);  // the only kernel with the alpha epilogue
     if (force == 2) return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);
     if (force == 1) return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, stream);
     if (tiles256 >= 192) return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);

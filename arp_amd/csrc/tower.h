@@ -146,7 +146,11 @@ static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* 
     g.A = A; g.W = W; g.bias = bias; g.resid = resid; g.out = out;
     g.M = M; g.N = N; g.K = K; g.lda = lda ? lda : K; g.ldw = K; g.ldr = ldr ? ldr : N; g.ldo = ldo ? ldo : N;
     ProfScope ps(*c.prof, c.stream, site);
-    return launch_gemm_auto<T, OutT, ACT, RESID, SITE>(g, c.stream, c.gemm_force);
+    int force = c.gemm_force;
+    // out_proj (K = N = width, f32 residual epilogue) is the one big GEMM where the two-workgroups-per-CU kernel wins: its tiles
+    // are short (12 K-tiles) and epilogue-heavy, so a second resident workgroup pays (measured 57.7 vs 66.8 us at M = 25 600)
+    if (force == 0 && (SITE & 7) == SITE_OUT && M >= 4096) force = 3;
+    return launch_gemm_auto<T, OutT, ACT, RESID, SITE>(g, c.stream, force);
 }
 
 template <typename OutT>

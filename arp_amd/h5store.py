@@ -588,21 +588,32 @@ class H5Dataset:
                     jobs_rows.append((hi - 1, base + lo - r0, hi - lo))
                     hi = lo
                 base += r1 - r0
-            # cross-check the group that ends the trajectory against plain per-row reads of the same rows (first call per dataset)
+            # cross-check against plain per-row reads before trusting the sliding-window layout.  A group of ONE row proves nothing
+            # (a chunk's last frame always is its own row's last frame), so only groups of >= 2 rows count, the fullest ones
+            # first (cnt == F exercises every slot), up to three of them spread over the call; the verdict is latched for the
+            # dataset only once such a group has been checked.  A call made of one-row groups alone is per-row reading anyway.
             if not getattr(self, "_stack_checked", False):
-                row, lo, cnt = jobs_rows[0]
-                direct = self[row - cnt + 1 : row + 1, -1]
-                try:
-                    got = inflate((row, raw_of(row), lo, cnt))[2]
-                except (zlib.error, OSError):  # the pread path mis-addressed the chunk (e.g. a user block): library reads only
-                    os.close(fd)
-                    self._store._pread_fd = fd = None
-                    got = inflate((row, self._raw_chunk(row), lo, cnt))[2]
-                if got is None or not np.array_equal(direct.reshape(-1), got):
-                    self._stack_ok = False
+                best = max(cnt for _, _, cnt in jobs_rows)
+                if best >= 2:
+                    cand = [j for j in jobs_rows if j[2] == best]
+                    picks = [cand[0], cand[len(cand) // 2], cand[-1]] if len(cand) > 2 else cand
+                    ok = True
+                    for row, lo, cnt in dict.fromkeys(picks):
+                        direct = self[row - cnt + 1 : row + 1, -1]
+                        try:
+                            got = inflate((row, raw_of(row), lo, cnt))[2]
+                        except (zlib.error, OSError):  # the pread path mis-addressed the chunk (e.g. a user block): library reads only
+                            if fd is not None:
+                                os.close(fd)
+                            self._store._pread_fd = fd = None
+                            got = inflate((row, self._raw_chunk(row), lo, cnt))[2]
+                        if got is None or not np.array_equal(direct.reshape(-1), got):
+                            ok = False
+                            break
+                    self._stack_ok = ok
+                    self._stack_checked = True
                 else:
-                    self._stack_ok = True
-                self._stack_checked = True
+                    self._stack_ok = True  # this call only: nothing latched
             if not self._stack_ok:
                 return self.read_last_frames_spans(spans, threads=threads, stacked=False, native=native, native_threads=native_threads, out=out)
         else:

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _ffi
-from ._ffi import MODE_BF16, MODE_F32, check, lib
+from ._ffi import MODE_BF16, MODE_F16, MODE_F32, check, lib
 
 
 @dataclass(frozen=True)
@@ -41,7 +41,7 @@ class M3AEEncoder:
     def __init__(self, cfg, params, mode="bf16", device=0, max_frames=128, attn_impl=0):
         _ffi.require_gpu()
         self.cfg = cfg
-        c = _ffi.EncCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.mlp_ratio, cfg.img_res, {"bf16": MODE_BF16, "f32": MODE_F32}[mode],
+        c = _ffi.EncCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.mlp_ratio, cfg.img_res, {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32}[mode],
                         device, max_frames, attn_impl)
         h = C.c_void_p()
         check(lib.arp_enc_create(C.byref(c), C.byref(h)))

@@ -23,7 +23,7 @@ from dataclasses import asdict, dataclass
 import numpy as np
 
 from . import _ffi
-from ._ffi import MODE_BF16, MODE_F32, check, lib
+from ._ffi import MODE_BF16, MODE_F16, MODE_F32, check, lib
 
 AUX_KEYS = ("loss", "acc", "trans_loss", "return_loss", "weight_penalty", "weight_l2", "train_state_step", "learning_rate")
 
@@ -51,11 +51,13 @@ class PolicyConfig:
 class PolicyTrainer:
     """Owns one GPU's copy of the policy: parameters, Adam state, activations, RCCL communicator."""
 
-    def __init__(self, cfg, mode="bf16", device=0):
+    def __init__(self, cfg, mode="f16", device=0):
+        """mode: GEMM operand type of the adapter path -- "f16" (default: the 16-bit mode that meets north_star's 1e-3 on the
+        logits), "bf16" (8 significand bits: ~1e-2) or "f32" (f32-input MFMA, the parity mode)."""
         _ffi.require_gpu()
         self.cfg = cfg
         c = _ffi.DtCfg(cfg.emb, cfg.depth, cfg.heads, cfg.mlp_ratio, cfg.n_actions, cfg.window, cfg.enc_tokens, cfg.enc_dim,
-                       int(cfg.use_adapter), {"bf16": MODE_BF16, "f32": MODE_F32}[mode], device, 1, 0, cfg.lambda_ret,
+                       int(cfg.use_adapter), {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32}[mode], device, 1, 0, cfg.lambda_ret,
                        cfg.weight_decay, cfg.clip_norm, cfg.b1, cfg.b2, cfg.eps)
         h = C.c_void_p()
         check(lib.arp_dt_create(C.byref(c), C.byref(h)))
@@ -221,7 +223,7 @@ class TrainState:
         self._live = True
 
     @classmethod
-    def create(cls, model, params, mode="bf16", device=0):
+    def create(cls, model, params, mode="f16", device=0):
         cfg = model if isinstance(model, PolicyConfig) else PolicyConfig(**dict(model))
         tr = PolicyTrainer(cfg, mode=mode, device=device)
         tr.set_params(params)
@@ -244,8 +246,79 @@ def _batch_arrays(batch):
     return np.asarray(enc), np.asarray(batch["action"]), np.asarray(rtg)
 
 
-def create_train_step(model, learning_rate, weight_decay):
-    """main_procgen.py:104-141.  ``learning_rate`` is the schedule ``step -> lr`` (``:135``)."""
+def shard_batch(batch, rank, world, device_axis=False):
+    """This rank's part of a global batch: ``generate_batch``'s ``x.reshape(n_devices, -1, *x.shape[1:])[rank]``
+    (main_procgen.py:645-683) -- contiguous, equal parts of the leading axis, every leaf of the (nested) batch dict alike;
+    ``None`` leaves stay ``None``.  ``device_axis=True``: the batch already carries the reference's leading ``[n_devices, ...]``
+    axis (what its pmapped train_step_fn receives) and the rank's slice is ``x[rank]``."""
+    if world == 1 and not device_axis:
+        return batch
+
+    def cut(x):
+        x = np.asarray(x)
+        if device_axis:
+            if x.shape[0] != world:
+                raise ValueError(f"leading device axis is {x.shape[0]}, expected {world}")
+            return x[rank]
+        if x.shape[0] % world:
+            raise ValueError(f"global batch of {x.shape[0]} does not divide over {world} ranks")
+        per = x.shape[0] // world
+        return x[rank * per : (rank + 1) * per]
+
+    def walk(v):
+        if v is None:
+            return None
+        if isinstance(v, dict):
+            return {k: walk(x) for k, x in v.items()}
+        return cut(v)
+
+    return walk(batch)
+
+
+def torch_object_broadcast(dist):
+    """``bcast`` for :class:`DataParallel` on an initialised ``torch.distributed`` group (gloo control plane)."""
+
+    def bcast(obj, src=0):
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    return bcast
+
+
+class DataParallel:
+    """One process per GPU around a :class:`PolicyTrainer` -- the reference's ``pmap`` over devices (main_procgen.py:94-141):
+
+    * the RCCL unique id is made on rank 0 and handed to every rank over the control plane (``bcast``);
+    * ``sync_state_fn`` (``:94-101``): every rank takes rank 0's parameters, Adam moments and step counter, once, at start;
+    * a step = this rank's shard of the global batch (:func:`shard_batch`) through forward/backward, ONE all-reduce(sum) of
+      the flat gradient + one of the loss scalars inside the library (``pmean``, ``:132``; the 1/world is folded into the
+      update), then the identical clip + Adam update on every rank.  No other collective."""
+
+    def __init__(self, trainer, rank, world, bcast):
+        if not (0 <= rank < world):
+            raise ValueError(f"rank {rank} outside world {world}")
+        self.trainer, self.rank, self.world = trainer, int(rank), int(world)
+        uid = trainer.new_unique_id() if rank == 0 else None
+        uid = bcast(uid, 0)
+        if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+            raise ValueError("the control plane did not deliver rank 0's 128-byte RCCL unique id")
+        trainer.comm_init(bytes(uid), self.world, self.rank)
+        trainer.broadcast_state()
+
+    def set_global_batch(self, batch, device_axis=False):
+        self.trainer.set_batch(*_batch_arrays(shard_batch(batch, self.rank, self.world, device_axis)))
+
+    def train_step(self, batch, lr, device_axis=False):
+        """aux is the rank-averaged aux of the reference's pmean: identical on every rank."""
+        self.set_global_batch(batch, device_axis)
+        return self.trainer.train_step(lr)
+
+
+def create_train_step(model, learning_rate, weight_decay, *, rank=0, world=1, device_axis=False):
+    """main_procgen.py:104-141.  ``learning_rate`` is the schedule ``step -> lr`` (``:135``).  With ``world > 1`` (one process
+    per GPU, the state's trainer wrapped by :class:`DataParallel` beforehand) every call steps on this rank's shard of the
+    global batch it is given."""
     cfg = model if isinstance(model, PolicyConfig) else PolicyConfig(**dict(model))
     if abs(cfg.weight_decay - weight_decay) > 1e-12:
         cfg = PolicyConfig(**{**asdict(cfg), "weight_decay": float(weight_decay)})
@@ -256,7 +329,9 @@ def create_train_step(model, learning_rate, weight_decay):
         tr = state.trainer
         if abs(tr.cfg.weight_decay - cfg.weight_decay) > 1e-12:
             raise ValueError("state was created with a different weight_decay than create_train_step")
-        tr.set_batch(*_batch_arrays(batch))
+        if world > 1 and getattr(tr, "world", 1) != world:
+            raise ValueError("world > 1: wrap the state's trainer in DataParallel (RCCL communicator + state sync) first")
+        tr.set_batch(*_batch_arrays(shard_batch(batch, rank, world, device_axis)))
         aux = tr.train_step(learning_rate(tr.step))
         state._live = False
         return TrainState(tr), aux, rng  # dropout is 0 in the shipped config: the rng is carried through unused

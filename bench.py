@@ -31,6 +31,8 @@ def gemm_sites(cfg, batch):
     m, d, g = batch * cfg.tokens, cfg.width, cfg.grid
     return {
         "vit.patch_embed": 2.0 * batch * g * g * d * 3 * cfg.patch * cfg.patch,
+        # fused QKV projection + attention (csrc/qkvattn.h): the projection plus QK^T and PV of every (frame, head)
+        "vit.qkv_attn": 2.0 * m * 3 * d * d + 4.0 * batch * cfg.tokens * cfg.tokens * d,
         "vit.qkv": 2.0 * m * 3 * d * d,
         "vit.out_proj": 2.0 * m * d * d,
         "vit.c_fc": 2.0 * m * 4 * d * d,
@@ -57,6 +59,67 @@ def cpu_baseline(model, seconds, policy_batch=0, finetune_batch=0):
         return {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh copies of this script, one rank per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), BEFORE anything here has
+    initialised a GPU -- the parent stays a pure launcher.  Rank 0 prints the JSON line; the exit code is the worst child's."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT))
+    rc = 0
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(timeout=3600)))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = max(rc, 124)
+    if rc:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
+def gather_rates(dist, world, units, elapsed_local):
+    """per-rank units/s over the timed region (control plane, gloo)"""
+    if dist is None:
+        return [units / elapsed_local]
+    out = [None] * world
+    dist.all_gather_object(out, float(elapsed_local))
+    return [units / t for t in out]
+
+
+def policy_sites(cfg, B, n_params):
+    """Algorithmic work per launch of the policy step's call sites: ("mfma", FLOPs) or ("hbm", bytes)."""
+    R = B * cfg.window
+    Mx, D, E, Kin = R * cfg.enc_tokens, cfg.enc_dim, cfg.emb, cfg.enc_tokens * cfg.enc_dim
+    ad = 2.0 * Mx * D * D
+    iti = 2.0 * R * Kin * E
+    return {
+        "dt.adapter_fc1": ("mfma", ad), "dt.adapter_fc2": ("mfma", ad), "dt.adapter_fc2_dX": ("mfma", ad), "dt.adapter_fc2_dW": ("mfma", ad),
+        "dt.adapter_fc1_dW": ("mfma", ad), "dt.image_text_input": ("mfma", iti), "dt.image_text_input_dW": ("mfma", iti),
+        "dt.image_text_input_dX": ("mfma", iti),
+        # norms pass reads p, g; the update reads p, g, mu, nu and writes p, mu, nu: 9 x 4 B per parameter
+        "dt.clip_adam": ("hbm", 36.0 * n_params),
+    }
+
+
+def policy_step_flops(cfg, B):
+    R = B * cfg.window
+    Mx, D, E, H, Kin = R * cfg.enc_tokens, cfg.enc_dim, cfg.emb, cfg.mlp_ratio * cfg.emb, cfg.enc_tokens * cfg.enc_dim
+    adapter = 6 * 2.0 * Mx * D * D                                # fwd 2, bwd 4 GEMMs (the first layer needs no dX: enc is stop_gradient'ed)
+    iti = 3 * 2.0 * R * Kin * E                                   # image_text_input fwd, dW, dX
+    tok = 3 * 2.0 * (3 * R) * cfg.depth * (4 * E * E + 2 * E * H)  # 12-token transformer, fwd + 2x bwd
+    return adapter + iti + tok
+
+
 def bench_policy(a):
     """Secondary benchmark: ARPDT train_step (BASELINE.json configs[3]): B = 32 samples per GPU, T = 4, random-init
     M3AE-shaped encodings [B,4,257,768] resident in HBM, forward + backward + RCCL all-reduce + clip + Adam."""
@@ -64,23 +127,36 @@ def bench_policy(a):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     cpu = cpu_baseline(a.model, a.cpu_seconds, a.policy_batch) if (rank == 0 and world == 1 and a.cpu_seconds > 0) else None
+    import torch  # before arp_amd: one HIP runtime per process (arp_amd/_ffi.py); the parity gate and the control plane need it
     dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    from arp_amd import _ffi, clip, synth_policy as S
+    from arp_amd import _ffi, clip, synth_policy as S, train
     from arp_amd.train import PolicyConfig, PolicyTrainer
     _ffi.require_gpu()
-    local_rank %= _ffi.device_count()
+    if world > _ffi.device_count():
+        raise SystemExit(f"--path policy --gpus {world}: {_ffi.device_count()} GPU(s) visible; RCCL needs one GPU per rank")
     _ffi.check(_ffi.lib.arp_set_device(local_rank))
     cfg = PolicyConfig(lambda_ret=0.01)
+    # parity gate (rank 0): the mode timed below, real geometry (257 x 768 encodings, K = 197 376), B = 2, against the fp64 oracle
+    parity = None
+    if rank == 0 and a.parity_frames > 0:
+        from oracle import arpdt_torch as O
+        Pp = S.policy_params(cfg, seed=3)
+        enc, act, rtg = S.policy_batch(cfg, 2, seed=4)
+        ref = O.forward({k: torch.from_numpy(v).double() for k, v in Pp.items()}, O.PolicyConfig(lambda_ret=0.01), torch.from_numpy(enc).double(),
+                        torch.from_numpy(act).long(), torch.from_numpy(rtg).double())
+        t0 = PolicyTrainer(cfg, mode=a.mode, device=local_rank)
+        t0.set_params(Pp)
+        t0.set_batch(enc, act, rtg)
+        out = t0.forward()
+        t0.close()
+        parity = float(np.abs(out["action_pred"] - ref["action_pred"].numpy()).max())
     tr = PolicyTrainer(cfg, mode=a.mode, device=local_rank)
     tr.set_params(S.policy_params(cfg, seed=0))
-    if world > 1:
-        ids = [PolicyTrainer.new_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        tr.comm_init(ids[0], world, rank)
-        tr.broadcast_state()
+    if world > 1:  # RCCL id from rank 0 over gloo, communicator, sync_state_fn
+        train.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
     enc = None
     if a.with_encoder:
         from arp_amd import m3ae
@@ -105,9 +181,9 @@ def bench_policy(a):
     tr.sync()
     _ffi.check(_ffi.lib.arp_dev_synchronize())
     elapsed = time.perf_counter() - t0
+    per_rank = gather_rates(dist, world, a.policy_batch * a.steps, elapsed)
     if dist is not None:
         dist.barrier()
-        import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -124,22 +200,31 @@ def bench_policy(a):
         prof.update({k: {"ms": v["ms"] * a.steps, "calls": v["calls"] * a.steps} for k, v in enc.profile_read().items()})
     aux = tr.train_step(lr)
     if rank == 0:
-        Mx = a.policy_batch * cfg.window * cfg.enc_tokens
-        site = "dt.adapter_fc1"
-        flops = 2.0 * Mx * cfg.enc_dim * cfg.enc_dim
+        sites = policy_sites(cfg, a.policy_batch, tr.num_params)
+        known = {k: v for k, v in prof.items() if k in sites and v["calls"]}
+        site = max(known, key=lambda k: known[k]["ms"])  # the call site that takes the most time per step
+        kind, work = sites[site]
         avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
-        peak = PEAK_TFLOPS[a.mode]
+        peak = PEAK_TFLOPS[a.mode] if kind == "mfma" else 8000.0
+        achieved = work / (avg_ms * 1e-3) / (1e12 if kind == "mfma" else 1e9)
+        flops = policy_step_flops(cfg, a.policy_batch)
         print(json.dumps({
             "metric": "samples/sec ARPDT train_step (frames in, frozen M3AE encoder inside)" if enc is not None else
                       "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
             "config": {"workload": f"ARPDT policy train_step, {a.policy_batch} samples/GPU x window 4, random-init encodings [B,4,257,768] f32 "
-                                   f"resident in HBM, 26.9 M trainable params (BASELINE.json configs[3])", "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                         "frac": flops / (avg_ms * 1e-3) / 1e12 / peak, "traffic": None, "kernel": f"gemm @ {site}", "flops_per_launch": flops,
-                         "avg_launch_ms": avg_ms},
-            "cpu_baseline": cpu, "final_aux": aux,
+                                   f"resident in HBM, 26.9 M trainable params (BASELINE.json configs[3])", "parallelism": f"dp{world}",
+                       "collective": "one RCCL all-reduce(sum) of the flat f32 gradient (107.5 MB) + one of 4 scalars per step" if world > 1 else "none (1 rank)"},
+            "roofline": {"bound": kind, "achieved": achieved, "peak": peak, "unit": "TFLOP/s" if kind == "mfma" else "GB/s",
+                         "frac": achieved / peak, "traffic": None, "kernel": f"{'gemm' if kind == 'mfma' else 'norms_partial + adam_kernel'} @ {site}",
+                         ("flops_per_launch" if kind == "mfma" else "bytes_per_launch"): work, "avg_launch_ms": avg_ms,
+                         "note": "the call site with the largest share of the step (sites_ms_per_step)"},
+            "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12,
+                           "mfma_frac_of_peak": flops / (elapsed / a.steps) / 1e12 / PEAK_TFLOPS[a.mode]},
+            "parity": {"max_logit_err_vs_oracle": parity, "geometry": "B = 2, window 4, 257 x 768 encodings (K = 197 376)", "tolerance": 1e-3,
+                       "within_tolerance": None if parity is None else bool(parity < 1e-3)},
+            "cpu_baseline": cpu, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
     tr.close()
     if dist is not None:
@@ -244,9 +329,11 @@ def main():
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
     a = ap.parse_args()
     if a.mode is None:
-        a.mode = "f16" if a.path == "label" else "bf16"
-    if a.path != "label" and a.mode == "f16":
-        raise SystemExit("--mode f16 exists on the label path only")
+        a.mode = "bf16" if a.path == "finetune" else "f16"
+    if a.path == "finetune" and a.mode == "f16":
+        raise SystemExit("--mode f16: the fine-tune head kernels know bf16 / f32")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)  # plain `python bench.py --gpus N`: this process only launches the ranks (it never touches a GPU)
     if a.path == "policy":
         return bench_policy(a)
     if a.path == "finetune":
@@ -255,10 +342,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        a.gpus = world
+    a.gpus = world  # under torch.distributed.run / spawn_ranks the environment is authoritative
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
@@ -322,6 +406,7 @@ def main():
     barrier()
     elapsed = t1 - t0
     ev_ms = clip.elapsed_ms(e0, e1)
+    per_rank = gather_rates(dist, world, a.batch * a.steps, elapsed)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -366,11 +451,7 @@ def main():
         err2 = float(np.abs(m2.label(fr) - ref).max() / np.exp(float(weights["logit_scale"])))
         m2.close()
         alt = {"dtype": "bf16", "max_cosine_err_vs_oracle": err2, "within_tolerance": bool(err2 < 1e-4),
-               "note": "same kernels and frame rate on bf16 operands (bench.py --mode bf16); outside north_star's 1e-4, hence not the headline mode"}
-        try:
-            alt["value_separate_run"] = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_label_bf16.json")))["value"]
-        except Exception:
-            pass
+               "note": "parity of the same kernels on bf16 operands (rate: run bench.py --mode bf16); outside north_star's 1e-4, hence not the headline mode"}
     del weights
 
     if rank == 0:
@@ -394,6 +475,8 @@ def main():
                 traffic = None
         fps = world * a.batch * a.steps / elapsed
         flops_frame = clip.flops_per_frame(cfg)
+        exec_flops = flops_frame - (0 if os.environ.get("ARP_CLS_ONLY") == "0" else 2.0 * (cfg.tokens - 1) * 9 * cfg.width * cfg.width)
+        kname = {"vit.qkv_attn": "qkv_attn_kernel"}.get(dom, "gemm2w_kernel" if os.environ.get("ARP_GEMM") == "3" else "gemm256_nt_kernel")
         total_ms = sum(v["ms"] for v in prof.values())
         out = {
             "metric": "frames/sec CLIP reward-labelled (256x256 ViT-B/32)" if a.model == "ViT-B/32" else f"frames/sec CLIP reward-labelled (256x256 {a.model})",
@@ -416,7 +499,7 @@ def main():
                                     "f32": "f32-input MFMA"}[a.mode],
                        "parallelism": f"shard{world} (no collective)", "streams_per_gpu": nsplit},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": f"gemm256_nt_kernel @ {dom}",
+                         "traffic": traffic, "kernel": f"{kname} @ {dom}",
                          "note": (f"each launch covers {-(-a.batch // nsplit)} frames; with --streams {nsplit} that many such launches (the parts of a batch) share "
                                   "the chip, so a launch's HIP-event duration includes time it ran beside the other stream's kernels; "
                                   "--streams 1 gives the isolated per-kernel figure") if nsplit > 1 else "single stream", "flops_per_launch": sites[dom],
@@ -428,15 +511,16 @@ def main():
                 "note": f"same kernel @ {dom}, whole {a.batch}-frame batch per launch on a single stream (nothing else resident)"}),
             "cpu_baseline": cpu,
             "alt_dtype": alt,
-            "whole_pass": {"gflop_per_frame": flops_frame / 1e9, "mfma_frac_of_peak": fps / world * flops_frame / (peak * 1e12),
-                           # the last block runs out_proj + MLP on the class-token row only (tower.h): FLOPs actually issued
-                           "executed_gflop_per_frame": (flops_frame - (0 if os.environ.get("ARP_CLS_ONLY") == "0" else
-                                                        2.0 * (cfg.tokens - 1) * 9 * cfg.width * cfg.width)) / 1e9,
+            # mfma_frac_of_peak counts the FLOPs actually ISSUED (the last block runs out_proj + MLP on the class-token row only,
+            # tower.h); the nominal figure prices the pass at SURVEY section 8(d)'s 8.82 GFLOP/frame including that skipped work
+            "whole_pass": {"executed_gflop_per_frame": exec_flops / 1e9, "mfma_frac_of_peak": fps / world * exec_flops / (peak * 1e12),
+                           "nominal_gflop_per_frame": flops_frame / 1e9, "nominal_mfma_frac_of_peak": fps / world * flops_frame / (peak * 1e12),
                            "hip_event_ms_per_step": ev_ms / a.steps, "profiled_ms_per_step": prof_ms / a.steps},
             "parity": {"max_cosine_err_vs_oracle": parity, "frames": a.parity_frames, "tolerance": 1e-4,
                        "within_tolerance": None if parity is None else bool(parity < 1e-4)},
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             "sites_total_ms_per_step": total_ms / a.steps,
+            "per_rank_frames_per_s": [round(v, 1) for v in per_rank],
         }
         print(json.dumps(out))
     model.close()

@@ -1,5 +1,6 @@
 """world_size-2 gloo tests on CPU for the N > 1 host logic: labelling shards the trajectory stream with no
-data-path collective (rank 0 gathers + writes); the train step's pmean algebra over two ranks."""
+data-path collective (rank 0 gathers + writes); the train step's data-parallel plumbing (arp_amd.train.DataParallel /
+shard_batch: id exchange, state sync, device shards) on two ranks; the oracle's pmean algebra."""
 import os
 import socket
 
@@ -125,6 +126,113 @@ def test_sharded_labelling_equals_single_process():
         assert got[k].shape == np.asarray(ref[k]).shape and (got[k] == np.asarray(ref[k])).all(), k
 
 
+class _StubTrainer:
+    """Stands where PolicyTrainer stands (no GPU here): records what train.DataParallel / create_train_step ask of it, and
+    implements the library's collective contract on gloo -- all-reduce(sum) of a 'gradient' computed from the shard it was
+    given, 1/world folded into the update -- so the PRODUCT's sharding, id exchange and state-sync logic is what runs."""
+
+    def __init__(self, rank, seed):
+        self.rank, self.calls, self.world = rank, [], 1
+        self.state = np.random.default_rng(seed).standard_normal(5)  # differs per rank until broadcast_state
+        self.step = 3 * rank                                          # so does the step counter
+        from arp_amd.train import PolicyConfig
+        self.cfg = PolicyConfig()
+
+    def new_unique_id(self):
+        self.calls.append("new_unique_id")
+        return bytes([7 + self.rank]) * 128
+
+    def comm_init(self, uid, world, rank):
+        self.calls.append(("comm_init", uid, world, rank))
+        self.world = world
+
+    def broadcast_state(self):
+        self.calls.append("broadcast_state")
+        t = torch.from_numpy(np.concatenate([self.state, [float(self.step)]]))
+        dist.broadcast(t, src=0)
+        self.state, self.step = t.numpy()[:5].copy(), int(t[5])
+
+    def set_batch(self, enc, action, rtg):
+        self.calls.append(("set_batch", enc.shape, action.shape, rtg.shape))
+        self.batch = (enc, action, rtg)
+
+    def train_step(self, lr):
+        enc, action, rtg = self.batch
+        g = torch.tensor([float(enc.sum()), float(action.sum()), float(rtg.sum()), float(len(action)), 1.0], dtype=torch.float64)
+        dist.all_reduce(g)  # the one data-path collective
+        self.state = self.state - lr * (g.numpy() / self.world)
+        self.step += 1
+        return {"loss": float(g[0]) / self.world, "train_state_step": self.step - 1}
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arp_amd import train
+    rng = np.random.default_rng(0)  # the same GLOBAL batch on every rank
+    B, T = 6, 4
+    batch = {"image": {"ob": rng.standard_normal((B, T, 3, 8)).astype(np.float32)}, "action": rng.integers(0, 15, (B, T)),
+             "rtg": {"ob": rng.standard_normal((B, T, 1)).astype(np.float32), "ob2": rng.standard_normal((B, T, 1)).astype(np.float32)},
+             "instruct": None, "text_padding_mask": None}
+    tr = _StubTrainer(rank, seed=10 + rank)
+    dp = train.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
+    aux = dp.train_step(batch, 0.5)
+    # the reference hands its pmapped fn a batch with a leading [n_devices] axis: same shards through device_axis=True
+    pm = train.shard_batch({k: (None if v is None else ({kk: vv.reshape(world, -1, *vv.shape[1:]) for kk, vv in v.items()} if isinstance(v, dict)
+                                                       else v.reshape(world, -1, *v.shape[1:]))) for k, v in batch.items()}, rank, world, device_axis=True)
+    mine = train.shard_batch(batch, rank, world)
+    same = all(np.array_equal(pm[k][kk], mine[k][kk]) for k in ("image", "rtg") for kk in mine[k]) and np.array_equal(pm["action"], mine["action"])
+    q.put((rank, tr.calls, tr.state.tolist(), tr.step, aux, same, mine["action"].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_plumbing_two_ranks():
+    """P10 / P12 host logic of arp_amd/train.py on two gloo ranks (the reference: pmean main_procgen.py:128-139, sync_state_fn
+    :94-101, generate_batch's device reshape :645-683): rank 0's RCCL id reaches both ranks, comm_init comes before the state
+    broadcast, every rank ends up with rank 0's state AND step, the shards are the reference's contiguous device slices
+    (disjoint, covering the global batch, multi-view rtg averaged as ARPDT.py:285-290), and after one step both ranks hold the
+    same state = the full-batch update."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (r0, c0, s0, st0, a0, same0, act0), (r1, c1, s1, st1, a1, same1, act1) = res
+    assert c0[0] == "new_unique_id" and "new_unique_id" not in c1          # only rank 0 makes the id
+    ci0, ci1 = c0[1], c1[0]
+    assert ci0[0] == ci1[0] == "comm_init" and ci0[1] == ci1[1] == bytes([7]) * 128 and (ci0[2], ci0[3]) == (2, 0) and (ci1[2], ci1[3]) == (2, 1)
+    assert c0[2] == "broadcast_state" and c1[1] == "broadcast_state"         # state sync right after the communicator exists
+    assert c0[3][0] == "set_batch" and c0[3][1] == (3, 4, 3, 8) and c0[3][3] == (3, 4, 1)  # 6 samples -> 3 per rank; rtg views averaged
+    assert same0 and same1
+    rng = np.random.default_rng(0)
+    rng.standard_normal((6, 4, 3, 8)); act = rng.integers(0, 15, (6, 4))
+    assert act0 == act[:3].tolist() and act1 == act[3:].tolist()            # contiguous device slices, in order
+    assert s0 == s1 and st0 == st1 == 1 and a0 == a1                         # rank 0's step (0) won the sync, then +1; same aux
+    # full-batch reference of the stub's update
+    rng = np.random.default_rng(0)
+    enc = rng.standard_normal((6, 4, 3, 8)).astype(np.float32); act = rng.integers(0, 15, (6, 4))
+    r1_ = rng.standard_normal((6, 4, 1)).astype(np.float32); r2_ = rng.standard_normal((6, 4, 1)).astype(np.float32)
+    rtg = np.mean(np.stack([r1_, r2_]), axis=0)
+    g = np.array([sum(float(enc[i * 3:(i + 1) * 3].sum()) for i in range(2)), float(act.sum()), sum(float(rtg[i * 3:(i + 1) * 3].sum()) for i in range(2)), 6.0, 2.0]) / 2
+    want = np.random.default_rng(10).standard_normal(5) - 0.5 * g
+    assert np.allclose(s0, want, rtol=0, atol=1e-9)
+
+
+def test_shard_batch_errors_and_identity():
+    from arp_amd import train
+    b = {"action": np.zeros((5, 4), np.int32), "image": {"ob": np.zeros((5, 4, 2, 2), np.float32)}, "instruct": None}
+    assert train.shard_batch(b, 0, 1) is b
+    import pytest
+    with pytest.raises(ValueError, match="does not divide"):
+        train.shard_batch(b, 0, 2)
+    with pytest.raises(ValueError, match="leading device axis"):
+        train.shard_batch(b, 0, 2, device_axis=True)
+
+
 def _pmean_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -145,7 +253,9 @@ def _pmean_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gradient_allreduce_algebra_two_ranks():
+def test_oracle_shard_mean_equals_full_batch_gradient_two_ranks():
+    """Pins the ORACLE's pmean algebra (mean of per-shard gradients = full-batch gradient); the product's own world-2 logic
+    is test_data_parallel_plumbing_two_ranks above."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

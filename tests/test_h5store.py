@@ -119,6 +119,27 @@ def test_unstacked_file_falls_back_to_per_row_reads(tmp_path):
         assert not f["raw"].fast_path_ok() and np.array_equal(f["raw"].read_last_frames(2, 9), ob[2:9, -1])
 
 
+def test_unstacked_file_with_a_length_one_first_trajectory(tmp_path):
+    """the stacked fast path was trusted after checking ONE group, and a one-row group (first trajectory of length 1)
+    passes that check trivially.  Only a group of >= 2 rows may latch the verdict; a non-stacked file must still read as
+    g[key][rows, -1], whatever the first trajectory's length."""
+    p = str(tmp_path / "odd1.hdf5")
+    rng = np.random.default_rng(4)
+    ob = rng.integers(0, 256, (30, F, 8, 8, 3), dtype=np.uint8)  # independent frames in every slot: NOT a sliding window
+    with h5store.H5Store(p, "w") as f:
+        f.create_dataset("ob", data=ob, compression="gzip", chunks=(1, F, 8, 8, 3), maxshape=(None, F, 8, 8, 3))
+    spans = [(0, 1), (1, 2), (2, 13), (13, 30)]  # trajectories of length 1, 1, 11, 17
+    with h5store.H5Store(p, "r") as f:
+        d = f["ob"]
+        one = d.read_last_frames_spans(spans[:2])  # one-row groups only: correct, and nothing may be latched
+        assert np.array_equal(one, ob[0:2, -1]) and not getattr(d, "_stack_checked", False)
+        got = d.read_last_frames_spans(spans)
+        assert np.array_equal(got, ob[:, -1]) and d._stack_checked and d._stack_ok is False
+    with h5store.H5Store(p, "r") as f:  # fresh handle, whole file in one call (label_store's pattern)
+        d = f["ob"]
+        assert np.array_equal(d.read_last_frames_spans(spans), ob[:, -1]) and d._stack_ok is False
+
+
 @pytest.mark.parametrize("bool_done", [False, True])
 def test_label_reward_on_an_hdf5_file_matches_the_mapping_path(tmp_path, bool_done):
     """label_reward(data_path=...) end to end (fake model): same datasets as the store= path and as the oracle loop; created as

@@ -1,11 +1,14 @@
 """GPU parity of path (2) against the torch oracle, through the C ABI: forward (logits / return /
-losses), every gradient tensor, and multi-step training trajectories.  Tolerances: f32 mode tight;
-bf16 mode = north_star's "policy logits within 1e-3"."""
+losses), every gradient tensor, and multi-step training trajectories.  Tolerances: f32 mode tight; the 16-bit throughput
+mode is f16 (IEEE half MFMA operands, what bench.py --path policy times): north_star's "policy logits within 1e-3" is asserted
+for it; bf16 operands (8 significand bits) stay available with their measured ~1e-2."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+LOGIT_TOL_16BIT = 1e-3  # north_star: policy logits within 1e-3 in the 16-bit mode
 
 TINY = dict(emb=64, depth=2, heads=4, window=3, enc_tokens=5, enc_dim=64, lambda_ret=0.5)
 SMALL = dict(emb=128, depth=2, heads=8, window=4, enc_tokens=9, enc_dim=128, lambda_ret=0.01)
@@ -23,11 +26,19 @@ def _setup(kw, B, seed):
     return cfg, ocfg, P, (enc, act, rtg), Pt, tb
 
 
-@pytest.mark.parametrize("kw,B", [(TINY, 4), (SMALL, 6), (TINY, 1)])
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 3e-2)])
+FULL = dict(lambda_ret=0.01)  # PolicyConfig defaults = BASELINE configs[3]: emb 128, depth 2, 8 heads, window 4, 257 x 768 encodings
+
+
+@pytest.mark.parametrize("kw,B", [(TINY, 4), (SMALL, 6), (TINY, 1), (FULL, 2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("f16", LOGIT_TOL_16BIT), ("bf16", 3e-2)])
 def test_forward_parity(gpu_lib, kw, B, mode, tol):
+    """f16 (the default mode, timed by bench.py --path policy): north_star's 1e-3 on the logits at the REAL geometry (measured
+    4.9e-4).  The toy geometries contract 64..128 terms where the real one contracts 768 and 197 376 -- less averaging of the
+    operand rounding, measured 0.92-1.04e-3 -- and get 1.5e-3, as the labelling tests do for their toy geometry."""
     from arp_amd.train import PolicyTrainer
     from oracle import arpdt_torch as O
+    if mode == "f16" and kw is not FULL:
+        tol = 1.5e-3
     cfg, ocfg, P, (enc, act, rtg), Pt, tb = _setup(kw, B, 3)
     ref = O.forward(Pt, ocfg, *tb)
     tr = PolicyTrainer(cfg, mode=mode)
@@ -47,7 +58,7 @@ def test_forward_parity(gpu_lib, kw, B, mode, tol):
 
 
 @pytest.mark.parametrize("kw,B", [(TINY, 4), (SMALL, 6), (TINY, 3)])  # B = 3: 45 adapter rows, ragged for every 4-wide access
-@pytest.mark.parametrize("mode,rtol", [("f32", 2e-4), ("bf16", None)])
+@pytest.mark.parametrize("mode,rtol", [("f32", 2e-4), ("f16", None), ("bf16", None)])
 def test_gradient_parity(gpu_lib, kw, B, mode, rtol):
     from arp_amd.train import PolicyTrainer
     from oracle import arpdt_torch as O
@@ -70,7 +81,9 @@ def test_gradient_parity(gpu_lib, kw, B, mode, rtol):
             if np.linalg.norm(r) > 1e-7 and (a @ r) / (np.linalg.norm(a) * np.linalg.norm(r) + 1e-30) < 0.9:
                 bad.append((k, float((a @ r) / (np.linalg.norm(a) * np.linalg.norm(r)))))
         cos = num / np.sqrt(den1 * den2)
-        assert cos > 0.995 and abs(np.sqrt(den1 / den2) - 1) < 0.02, f"bf16 gradient: cosine {cos}, norm ratio {np.sqrt(den1 / den2)}"
+        cmin, nmax = (0.9999, 2e-3) if mode == "f16" else (0.995, 0.02)
+        print(f"{mode} gradient: cosine {cos:.6f}, norm ratio {np.sqrt(den1 / den2):.5f}")
+        assert cos > cmin and abs(np.sqrt(den1 / den2) - 1) < nmax, f"{mode} gradient: cosine {cos}, norm ratio {np.sqrt(den1 / den2)}"
     else:
         for k in P:
             r = g_ref[k].numpy()
@@ -82,7 +95,7 @@ def test_gradient_parity(gpu_lib, kw, B, mode, rtol):
     tr.close()
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 5e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 5e-5), ("f16", 2e-3), ("bf16", 2e-2)])
 def test_train_steps_match_oracle(gpu_lib, mode, tol):
     """3 steps incl. global-norm clipping active (clip_norm small) and a warm-up schedule starting at lr 0."""
     from arp_amd.train import PolicyTrainer, PolicyConfig
@@ -100,7 +113,7 @@ def test_train_steps_match_oracle(gpu_lib, mode, tol):
         assert aux["train_state_step"] == s and abs(aux["learning_rate"] - lr_fn(s)) < 1e-9
         for k in ("loss", "trans_loss", "return_loss", "weight_penalty", "weight_l2", "acc"):
             assert abs(aux[k] - oaux[k]) < max(tol, 1e-4 * abs(oaux[k])), (s, k, aux[k], oaux[k])
-        assert abs(aux["grad_norm"] - oaux["grad_norm"]) < (5e-2 * oaux["grad_norm"] if mode == "bf16" else 1e-4)
+        assert abs(aux["grad_norm"] - oaux["grad_norm"]) < ({"bf16": 5e-2, "f16": 5e-3}[mode] * oaux["grad_norm"] if mode != "f32" else 1e-4)
     got = tr.get_params()
     err = max(np.abs(got[k] - st["params"][k].numpy()).max() for k in P)
     # Adam's m/sqrt(v) update is sign-like on its first steps, so an element whose gradient is ~0 amplifies
@@ -109,9 +122,9 @@ def test_train_steps_match_oracle(gpu_lib, mode, tol):
     # max 5.8e-3 after 3 steps at lr <= 2e-3); the MEAN error stays small.
     assert err < (1e-4 if mode == "f32" else 1.2e-2), f"params after 3 steps: max err {err}"
     mean_err = float(np.mean([np.abs(got[k] - st["params"][k].numpy()).mean() for k in P]))
-    assert mean_err < (2e-6 if mode == "f32" else 6e-4), f"params after 3 steps: mean err {mean_err}"
+    assert mean_err < {"f32": 2e-6, "f16": 1e-4, "bf16": 6e-4}[mode], f"params after 3 steps: mean err {mean_err}"
     mu = tr.get_tensors(2)
-    assert max(np.abs(mu[k] - st["mu"][k].numpy()).max() for k in P) < (1e-5 if mode == "f32" else 2e-2)
+    assert max(np.abs(mu[k] - st["mu"][k].numpy()).max() for k in P) < {"f32": 1e-5, "f16": 2e-3, "bf16": 2e-2}[mode]
     tr.close()
 
 
@@ -214,7 +227,7 @@ def test_full_size_step_is_bitwise_reproducible(gpu_lib):
     batch = S.policy_batch(cfg, 32, seed=1)
     runs = []
     for _ in range(2):
-        tr = PolicyTrainer(cfg, mode="bf16")
+        tr = PolicyTrainer(cfg, mode="f16")
         tr.set_params(P)
         tr.set_batch(*batch)
         aux = [tr.train_step(5e-4) for _ in range(3)]
@@ -224,3 +237,61 @@ def test_full_size_step_is_bitwise_reproducible(gpu_lib):
     assert [a["loss"] for a in a0] == [a["loss"] for a in a1]
     assert all(np.array_equal(p0[k], p1[k]) for k in p0)
     assert a0[-1]["loss"] < a0[0]["loss"]  # and it learns on a fixed batch
+
+
+def test_full_geometry_matches_oracle(gpu_lib):
+    """The REAL shapes against the fp64 oracle: B = 2, window 4, enc_tokens 257, enc_dim 768 -- the 257-way
+    split-K over K = 197 376 of image_text_input, the adapter GEMMs at M = 2056, the transposed K-padded operand copies of the
+    weight-gradient GEMMs.  f32 mode: forward, every gradient tensor and one clipped Adam step; f16 mode (what bench.py --path
+    policy times): logits within north_star's 1e-3, gradient direction, and the same Adam step to its 16-bit tolerance."""
+    from arp_amd.train import PolicyTrainer
+    from oracle import arpdt_torch as O
+    cfg, ocfg, P, (enc, act, rtg), Pt, tb = _setup(FULL, 2, 21)
+    assert cfg.enc_tokens == 257 and cfg.enc_dim == 768 and cfg.window == 4
+    ref = O.forward(Pt, ocfg, *tb)
+    g_ref, _, _ = O.grads(Pt, ocfg, *tb)
+    lr = 1e-3
+    st, oaux = O.train_step(O.init_state(Pt), ocfg, [tb], lambda t: lr)
+    for mode, ltol, gtol in (("f32", 2e-5, 3e-4), ("f16", LOGIT_TOL_16BIT, None)):
+        tr = PolicyTrainer(cfg, mode=mode)
+        tr.set_params(P)
+        tr.set_batch(enc, act, rtg)
+        out = tr.forward()
+        e1 = np.abs(out["action_pred"] - ref["action_pred"].numpy()).max()
+        e2 = np.abs(out["return_pred"] - ref["return_pred"].numpy()).max()
+        print(f"full geometry {mode}: logits err {e1:.2e} return err {e2:.2e}")
+        assert e1 < ltol and e2 < ltol, f"full geometry {mode}: logits err {e1}, return err {e2}"
+        tr.backward()
+        g = tr.get_grads()
+        if gtol is not None:
+            # The adapter has 2 x 1.58 M ReLU inputs here; one or two of them sit within f32 noise of zero, and a flipped mask bit
+            # moves one row of a weight gradient by a single term (~1e-3 of the tensor's max).  An indexing bug moves EVERYTHING:
+            # so every tensor must agree in relative L2 norm, all but a sliver of its entries to gtol, and the tensors that do
+            # not sit behind a ReLU to gtol everywhere.
+            bad = []
+            for k in P:
+                r = g_ref[k].numpy()
+                err = np.abs(g[k] - r)
+                scale = max(np.abs(r).max(), 1e-9)
+                rel_l2 = float(np.linalg.norm(g[k] - r) / max(np.linalg.norm(r), 1e-30))
+                frac = float((err > gtol * scale).mean())
+                behind_relu = k.startswith("AdapterMLP_0/")
+                print(f"  {k}: max err {err.max() / scale:.2e}, rel L2 {rel_l2:.2e}, entries over tol {frac:.2e}")
+                if rel_l2 > 1e-4 or frac > (2e-3 if behind_relu else 0.0):
+                    bad.append((k, float(err.max() / scale), rel_l2, frac))
+            assert not bad, f"full geometry {mode} gradients: {bad}"
+        else:
+            num = sum(float(g[k].ravel().astype(np.float64) @ g_ref[k].numpy().ravel()) for k in P)
+            d1 = sum(float((g[k].astype(np.float64) ** 2).sum()) for k in P)
+            d2 = sum(float((g_ref[k].numpy() ** 2).sum()) for k in P)
+            cos = num / np.sqrt(d1 * d2)
+            print(f"full geometry {mode}: gradient cosine {cos:.6f}, norm ratio {np.sqrt(d1 / d2):.5f}")
+            assert cos > 0.9995 and abs(np.sqrt(d1 / d2) - 1) < 5e-3
+        aux = tr.train_step(lr)
+        assert abs(aux["loss"] - oaux["loss"]) < (1e-4 if mode == "f32" else 2e-3), (aux["loss"], oaux["loss"])
+        assert abs(aux["grad_norm"] - oaux["grad_norm"]) < (1e-4 if mode == "f32" else 5e-3) * max(1.0, oaux["grad_norm"])
+        got = tr.get_params()
+        # first Adam step = lr * sign-like update: compare the MEAN parameter error (a ~0 gradient may flip sign in any finite precision)
+        mean_err = float(np.mean([np.abs(got[k] - st["params"][k].numpy()).mean() for k in P]))
+        assert mean_err < (2e-5 if mode == "f32" else 2e-4), f"full geometry {mode}: mean param err after one step {mean_err}"
+        tr.close()
