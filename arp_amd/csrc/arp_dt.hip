@@ -87,12 +87,10 @@ struct arp_dt {
     bool shadows_stale = true;
     // operand-type shadows of the big weights
     DevBuf W1s, W2s, W2t, Wis, Wit;
-    // f16 mode: image_text_input contracts K = 197 376 products of once-rounded operands; with 11-bit significands that rounding is
-    // ~1e-3 on the logits (measured 1.05-1.16e-3 vs north_star's 1e-3).  Both operands are therefore carried as hi + lo pairs
-    // (y = y_hi + y_lo, Wi = Wi_hi + Wi_lo, each part binary16) and the forward sums the three leading products
-    // y_hi.Wi_hi + y_lo.Wi_hi + y_hi.Wi_lo in one fixed-order split-K reduction: 2 x 6.5 GFLOP extra per step.
-    DevBuf Wis_lo, Y_lo;
-    bool split_iti() const { return cfg.mode == ARP_MODE_F16 && cfg.use_adapter; }
+    // (f16 mode, measured on the real geometry with tests/probes/policy_rounding_probe.py: every operand rounding of the adapter
+    // path -- X, W1, H1, W2, A, Y, Wi -- costs 2.4-6.1e-4 on the logits and they combine to 4.9-8.4e-4 across seeds; with
+    // res = sigmoid(4) = 0.98 the adapter branch carries the signal, so carrying Y and Wi as hi + lo pairs, tried, bought
+    // nothing for +10 % step time and was removed.)
     // batch
     int B = 0;
     DevBuf enc32, action, rtg;
@@ -268,7 +266,7 @@ int big_gemm(arp_dt* c, const char* site, const void* A, int lda, const void* W,
 // split-K NT GEMM: f32 partials [S][M][N] then a fixed-order reduce (+bias, act) into OutT
 template <typename T, typename OutT>
 int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void* W, int ldw, const float* bias, int act, OutT* out, int M, int N,
-                int K, float alpha = 1.f, const void* A2 = nullptr, const void* W2 = nullptr, const void* A3 = nullptr, const void* W3 = nullptr) {
+                int K, float alpha = 1.f) {
     constexpr int EPB = 128 / (int)sizeof(T);
     const int nk = K / EPB;
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
@@ -276,10 +274,7 @@ int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void*
     int S = std::max(1, std::min(nk, wg_target / std::max(tiles, 1)));
     const int per = (nk + S - 1) / S;
     S = (nk + per - 1) / per;  // every slice non-empty
-    // extra operand pairs (A2.W2^T, A3.W3^T; same shapes) land in further slabs of the same partial buffer and are summed by the
-    // same fixed-order reduction
-    const int npairs = 1 + (A2 ? 1 : 0) + (A3 ? 1 : 0);
-    ARP_TRY(c->part.ensure((size_t)npairs * S * M * N * 4));
+    ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
     GemmArgs g;
     g.A = A; g.W = W; g.bias = nullptr; g.resid = nullptr; g.out = c->part.p;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = N; g.ldo = N;
@@ -288,15 +283,7 @@ int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void*
     if (S == 1) g.ksplit = 1;
     ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_DT + 1>(g, c->stream)));
     const size_t MN = (size_t)M * N;
-    const void* As[2] = {A2, A3};
-    const void* Ws[2] = {W2, W3};
-    for (int q = 0, slab = 1; q < 2; ++q)
-        if (As[q]) {
-            g.A = As[q]; g.W = Ws[q]; g.out = c->part.as<float>() + (size_t)slab * S * MN;
-            ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_DT + 1>(g, c->stream)));
-            ++slab;
-        }
-    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), npairs * S, MN, N, bias, act, out,
+    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out,
                        nullptr, 0, alpha);
     ARP_HIP_OK(hipGetLastError());
     return 0;
@@ -324,12 +311,6 @@ template <typename T> int refresh_shadows(arp_dt* c) {
     }
     ARP_TRY((transpose_mask<float, float, T>(c, c->p("image_text_input/kernel"), (int)Kin, nullptr, nullptr, 1.f, c->Wis.as<T>(), (int)Kin,
                                              c->Wit.as<T>(), E, E, (int)Kin)));
-    if (c->split_iti()) {
-        ARP_TRY(c->Wis_lo.ensure(Kin * E * sizeof(T)));
-        hipLaunchKernelGGL((split_lo_kernel<T>), dim3(cdiv(Kin * E, 1024)), dim3(256), 0, c->stream, c->p("image_text_input/kernel"), c->Wis.as<T>(),
-                           c->Wis_lo.as<T>(), Kin * E);
-        ARP_HIP_OK(hipGetLastError());
-    }
     c->shadows_stale = false;
     return 0;
 }
@@ -426,7 +407,6 @@ int ensure_buffers(arp_dt* c, int B) {
     ARP_TRY(c->enc32.ensure(Mx * D * 4)); ARP_TRY(c->action.ensure(R * 4)); ARP_TRY(c->rtg.ensure(R * 4));
     DevBuf* tb[] = {&c->Xb, &c->H1, &c->A, &c->Y, &c->dY, &c->dApre, &c->G};
     for (auto* b : tb) ARP_TRY(b->ensure(Mx * D * e));
-    if (c->split_iti()) ARP_TRY(c->Y_lo.ensure(Mx * D * e));
     DevBuf* tt[] = {&c->XbT, &c->H1T, &c->dApreT, &c->dH1T};
     for (auto* b : tt) {
         ARP_TRY(b->ensure((size_t)D * Mxp * e));
@@ -502,16 +482,12 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc2", c->H1.p, D, c->W2s.p, D, c->p("AdapterMLP_0/Dense_1/bias"), c->A.p, D, (int)Mx, D, D)));
         ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
         hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->enc32.as<float>(),
-                           c->p("residual_weight"), c->Y.as<T>(), c->split_iti() ? c->Y_lo.as<T>() : nullptr, Mx * D);
+                           c->p("residual_weight"), c->Y.as<T>(), Mx * D);
         ARP_HIP_OK(hipGetLastError());
         Yp = c->Y.as<T>();
     }
     // image_text_input + tanh (arp_dt/ARPDT.py:475-484): [R, tokens*dim] x [tokens*dim, E], split over K
-    if (c->split_iti())
-        ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin,
-                                       1.f, c->Y_lo.p, c->Wis.p, Yp, c->Wis_lo.p)));
-    else
-        ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
+    ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
     if (c->fused) {
         ProfScope ps(c->prof, c->stream, "dt.policy_fwd");
         ARP_TRY(policy_fused(c, with_bwd));
@@ -823,7 +799,7 @@ int arp_dt_destroy(arp_dt* c) {
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->Wis_lo, &c->Y_lo, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,

@@ -187,49 +187,20 @@ __global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restric
 }
 
 // ---- adapter mix (arp_dt/ARPDT.py:466-472):  y = res*a + (1-res)*x,  res = sigmoid(residual_weight) -----
-// x is the f32 encoder output itself (not its operand-type copy: the skip term then carries no operand rounding); y_lo, when
-// given, receives the operand-type remainder y - T(y) so that image_text_input can contract (y_hi + y_lo) (arp_dt.hip).
+// x is the f32 encoder output itself, not its operand-type copy: the skip term then carries no operand rounding.
 template <typename T>
 static __global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ a, const float* __restrict__ x, const float* __restrict__ rw,
-                                                          T* __restrict__ y, T* __restrict__ y_lo, size_t n) {
+                                                          T* __restrict__ y, size_t n) {
     const float res = 1.0f / (1.0f + expf(-rw[0]));
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
-        float av[4], xv[4], yv[4], hv[4];
+        float av[4], xv[4];
         load4(a + i, av);
         load4(x + i, xv);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) yv[j] = res * av[j] + (1.f - res) * xv[j];
-        store4(y + i, yv[0], yv[1], yv[2], yv[3]);
-        if (y_lo) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                T h;
-                Elem<T>::st(&h, yv[j]);
-                hv[j] = yv[j] - Elem<T>::ld(&h);
-            }
-            store4(y_lo + i, hv[0], hv[1], hv[2], hv[3]);
-        }
+        store4(y + i, res * av[0] + (1.f - res) * xv[0], res * av[1] + (1.f - res) * xv[1], res * av[2] + (1.f - res) * xv[2],
+               res * av[3] + (1.f - res) * xv[3]);
     } else {
-        for (size_t j = i; j < n; ++j) {
-            const float v = res * Elem<T>::ld(a + j) + (1.f - res) * x[j];
-            Elem<T>::st(y + j, v);
-            if (y_lo) Elem<T>::st(y_lo + j, v - Elem<T>::ld(y + j));
-        }
-    }
-}
-
-// lo[i] = T(w[i] - float(T(w[i])))  -- the operand-type remainder of an f32 matrix whose T copy is `hi`
-template <typename T>
-static __global__ __launch_bounds__(256) void split_lo_kernel(const float* __restrict__ w, const T* __restrict__ hi, T* __restrict__ lo, size_t n) {
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i + 3 < n) {
-        float wv[4], hv[4];
-        load4(w + i, wv);
-        load4(hi + i, hv);
-        store4(lo + i, wv[0] - hv[0], wv[1] - hv[1], wv[2] - hv[2], wv[3] - hv[3]);
-    } else {
-        for (size_t j = i; j < n; ++j) Elem<T>::st(lo + j, w[j] - Elem<T>::ld(hi + j));
+        for (size_t j = i; j < n; ++j) Elem<T>::st(y + j, res * Elem<T>::ld(a + j) + (1.f - res) * x[j]);
     }
 }
 

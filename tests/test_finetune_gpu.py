@@ -306,3 +306,53 @@ def test_full_size_head_step_is_bitwise_reproducible(gpu_lib):
     assert [a["loss"] for a in a0] == [a["loss"] for a in a1]
     assert all(np.array_equal(p0[k], p1[k]) for k in probe)
     assert a0[1]["loss"] < a0[0]["loss"]
+
+
+def test_full_geometry_head_matches_oracle(gpu_lib):
+    """The REAL head: 12 layers, widths 768 / 512, hidden 1024 -> 476 M parameters, B = 4, f32 mode,
+    against the fp64 torch oracle: losses, every gradient tensor (9216- and 6656-wide contractions, the split-K weight-streaming
+    GEMMs, the K-padded transposed operand copies of the weight-gradient GEMMs) and one AdamW step.  B = 4 keeps the oracle to
+    seconds; the shapes that could hide an indexing bug do not depend on B."""
+    from arp_amd import finetune as FT
+    from oracle import finetune_torch as O
+    fcfg = FT.FinetuneConfig(weight_decay=0.01)
+    cfg = O.HeadConfig(logit_scale=fcfg.logit_scale)
+    assert (cfg.layers, cfg.width_v, cfg.width_t, cfg.embed, cfg.hidden) == (12, 768, 512, 512, 1024)
+    P = FT.synth_params(fcfg, seed=11)
+    assert set(P) == set(O.param_shapes(cfg)) and sum(int(np.prod(v.shape)) for v in P.values()) > 470e6
+    batch = FT.synth_batch(fcfg, 4, seed=12)
+    g_ref, aux = O.grads(P, cfg, batch)
+    tr = FT.FinetuneTrainer(fcfg, mode="f32")
+    tr.set_params(P)
+    tr.set_batch(*batch)
+    out = tr.forward()
+    for k in ("loss", "vip_loss", "id_loss"):
+        assert abs(out[k] - aux[k]) < 1e-4 * max(1.0, abs(aux[k])), (k, out[k], aux[k])
+    tr.backward()
+    import ctypes as C
+    from arp_amd import _ffi
+    bad = []
+    for k in P:  # tensor by tensor: the whole gradient dict would be another 1.9 GB of host memory
+        a = np.empty(tr.shapes[k], np.float32)
+        _ffi.check(_ffi.lib.arp_ft_get_tensor(tr._h, k.encode(), 1, _ffi.as_ptr(a, C.c_float)))
+        r = g_ref[k]
+        err = float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-9))
+        rel_l2 = float(np.linalg.norm(a.astype(np.float64) - r) / max(np.linalg.norm(r), 1e-30))
+        print(f"  {k}: max err {err:.2e}, rel L2 {rel_l2:.2e}")
+        # ReLU ties (a pre-activation within f32 noise of zero) move a few entries by one term; an indexing bug moves everything
+        if rel_l2 > 1e-4 or err > 5e-3:
+            bad.append((k, err, rel_l2))
+    assert not bad, bad
+    del g_ref
+    lr = 1e-3
+    P1, aux1 = O.train_steps(P, cfg, [batch], lr, 0.01, 1)
+    st = tr.train_step(lr)
+    assert abs(st["loss"] - aux1[0]["loss"]) < 1e-4 * max(1.0, abs(aux1[0]["loss"]))
+    errs = []
+    for k in P:
+        a = np.empty(tr.shapes[k], np.float32)
+        _ffi.check(_ffi.lib.arp_ft_get_tensor(tr._h, k.encode(), 0, _ffi.as_ptr(a, C.c_float)))
+        errs.append(float(np.abs(a - P1[k]).mean()))
+    print(f"mean abs parameter error after one AdamW step: {np.mean(errs):.2e}")
+    assert np.mean(errs) < 2e-5  # first Adam step = lr * sign-like update: a ~0 gradient may flip sign, compare on average
+    tr.close()
