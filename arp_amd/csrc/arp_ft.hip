@@ -343,9 +343,18 @@ int apply_update(arp_ft* c, float lr) {
     ProfScope ps(c->prof, c->stream, "ft.adamw");
     const double t = (double)(c->step + 1);
     const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
+    // parameters that received no gradient this step are left alone, as torch does for .grad is None
+    size_t s0lo = 0, s0hi = 0, s1lo = 0, s1hi = 0;
+    if (!c->cfg.use_id) {
+        const FtParam& a = c->infos[c->index.at("inverse_layer.layers.0.weight")];
+        const FtParam& b = c->infos[c->index.at("inverse_layer.layers.3.bias")];
+        const FtParam& l = c->infos[c->index.at("lambda_id")];
+        s0lo = a.off; s0hi = b.off + ((b.size + 3) & ~(size_t)3);
+        s1lo = l.off; s1hi = l.off + 4;
+    }
     hipLaunchKernelGGL(ft_adamw_kernel, dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(), c->mu.as<float>(),
                        c->nu.as<float>(), 1.0f, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P,
-                       c->cfg.mode == ARP_MODE_BF16 ? c->mirror.as<bf16_t>() : nullptr);
+                       c->cfg.mode == ARP_MODE_BF16 ? c->mirror.as<bf16_t>() : nullptr, s0lo, s0hi, s1lo, s1hi);
     ARP_HIP_OK(hipGetLastError());
     c->step += 1;
     c->transposed_stale = true;

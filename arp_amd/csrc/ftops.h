@@ -163,9 +163,13 @@ static __global__ __launch_bounds__(256) void ft_mix_norm_bwd_kernel(const float
 // forward GEMMs need no separate conversion pass over the f32 parameters.
 static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
                                                               float* __restrict__ nu, float gscale, float lr, float wd, float b1, float b2,
-                                                              float eps, float bc1, float bc2, size_t n, bf16_t* __restrict__ mirror) {
+                                                              float eps, float bc1, float bc2, size_t n, bf16_t* __restrict__ mirror,
+                                                              size_t skip0_lo, size_t skip0_hi, size_t skip1_lo, size_t skip1_hi) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // torch.optim.AdamW skips parameters whose .grad is None -- no decay, no moment update (with use_id_loss off the inverse
+    // model and lambda_id never receive a gradient: finetune.py:141 + clip_multiscale_adapter.py:177-250)
+    if ((i >= skip0_lo && i < skip0_hi) || (i >= skip1_lo && i < skip1_hi)) return;
     const float gi = g[i] * gscale;
     const float m = b1 * mu[i] + (1.f - b1) * gi;
     const float v = b2 * nu[i] + (1.f - b2) * gi * gi;

@@ -37,6 +37,7 @@ struct QkvAttnArgs {
     int nq;             // query rows produced per frame (N, or 1 when only the class token is consumed)
     int causal;
     float scale;
+    int group_m = 0;    // frame-tiles per L2 group of the block -> tile walk (0 = default; ARP_QA_GROUP_M overrides)
 };
 
 // usable when: 16-bit operands, head_dim 64, N <= 64, K a multiple of 64

@@ -1,6 +1,8 @@
 // Fused QKV projection + attention kernel (see qkvattn.h), compiled as its own translation unit.
 #include "qkvattn.h"
 
+#include <cstdlib>
+
 #include "attention.h"
 #include "gemm.h"
 #include "gemm256.h"
@@ -34,10 +36,11 @@ __global__ __launch_bounds__(QA_THREADS, 2) void qkv_attn_kernel(QkvAttnArgs g) 
     int mt, head;
     {
         int t = xcd_remap(blockIdx.x, m_tiles * n_tiles);
-        const int per_group = G2_GROUP_M * n_tiles;
+        const int group_m = g.group_m > 0 ? g.group_m : G2_GROUP_M;
+        const int per_group = group_m * n_tiles;
         const int grp = t / per_group;
-        const int first_m = grp * G2_GROUP_M;
-        const int gsize = min(m_tiles - first_m, G2_GROUP_M);
+        const int first_m = grp * group_m;
+        const int gsize = min(m_tiles - first_m, group_m);
         t -= grp * per_group;
         mt = first_m + t % gsize;
         head = t / gsize;
@@ -326,6 +329,8 @@ static int launch_qkv_attn_impl(QkvAttnArgs g, hipStream_t stream) {
     g.fpt = 256 / g.N;
     if (g.nq <= 0 || g.nq > g.N) g.nq = g.N;
     g.scale = 1.0f / sqrtf(64.0f);
+    static const int group_env = getenv("ARP_QA_GROUP_M") ? atoi(getenv("ARP_QA_GROUP_M")) : 0;
+    if (group_env > 0) g.group_m = group_env;
     auto kern = qkv_attn_kernel<T>;
     static bool attr_set = false;
     if (!attr_set) {

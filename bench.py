@@ -466,11 +466,9 @@ def main():
             try:
                 rec = json.load(open(tpath)).get(dom, {})
                 traffic = rec.get("hbm_bytes_per_launch")
-                # the committed PMC run may have used a different launch size: scale by workgroup count
-                exp_grid = 512 * (-(-(-(-a.batch // nsplit) * cfg.tokens) // 256)) * {
-                    "vit.c_fc": 4 * cfg.width, "vit.qkv": 3 * cfg.width}.get(dom, cfg.width) // 256
-                if traffic and rec.get("grid_threads") and rec["grid_threads"] != exp_grid:
-                    traffic = traffic * exp_grid / rec["grid_threads"]
+                # the committed PMC run may have used a different launch size: algorithmic and measured bytes scale with the frames
+                if traffic and rec.get("frames_per_launch"):
+                    traffic = traffic * (-(-a.batch // nsplit)) / rec["frames_per_launch"]
             except Exception:
                 traffic = None
         fps = world * a.batch * a.steps / elapsed

@@ -132,14 +132,20 @@ def grads(P, cfg, batch, dtype=torch.float64):
     out = forward(Pt, cfg, *[torch.as_tensor(b, dtype=dtype) for b in batch[:5]], torch.as_tensor(batch[5], dtype=torch.long))
     out["loss"].backward()
     g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy() for k, v in Pt.items()}
-    return g, {k: float(out[k].detach()) for k in ("loss", "vip_loss", "id_loss")}
+    aux = {k: float(out[k].detach()) for k in ("loss", "vip_loss", "id_loss")}
+    aux["no_grad"] = tuple(k for k, v in Pt.items() if v.grad is None)  # torch.optim.AdamW leaves these untouched
+    return g, aux
 
 
-def adamw_step(P, M, V, G, step, lr, weight_decay, b1=0.9, b2=0.999, eps=1e-8):
-    """torch.optim.AdamW semantics (decoupled decay on every parameter, bias correction with t = step + 1)."""
+def adamw_step(P, M, V, G, step, lr, weight_decay, b1=0.9, b2=0.999, eps=1e-8, no_grad=()):
+    """torch.optim.AdamW semantics (decoupled decay on every parameter THAT HAS A GRADIENT -- one whose .grad is None is skipped
+    entirely: no decay, no moment update -- bias correction with t = step + 1)."""
     t = step + 1
     out_p, out_m, out_v = {}, {}, {}
     for k in P:
+        if k in no_grad:
+            out_p[k], out_m[k], out_v[k] = np.asarray(P[k], np.float64), M[k], V[k]
+            continue
         p = np.asarray(P[k], np.float64) * (1.0 - lr * weight_decay)
         m = b1 * np.asarray(M[k], np.float64) + (1 - b1) * G[k]
         v = b2 * np.asarray(V[k], np.float64) + (1 - b2) * G[k] * G[k]
@@ -157,5 +163,5 @@ def train_steps(P, cfg, batches, lr, weight_decay, n_steps):
     for i in range(n_steps):
         g, a = grads(P, cfg, batches[i % len(batches)])
         aux.append(a)
-        P, M, V = adamw_step(P, M, V, g, i, lr, weight_decay)
+        P, M, V = adamw_step(P, M, V, g, i, lr, weight_decay, no_grad=a["no_grad"])
     return P, aux

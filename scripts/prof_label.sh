@@ -1,8 +1,8 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py (run on the GPU box through gpurun).  Writes under gpurun_out/.
+# rocprofv3 evidence for bench.py (label path): kernel-trace stats + FETCH_SIZE / WRITE_SIZE passes (run on the GPU box through gpurun).  Writes under gpurun_out/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r1}
+TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 3 --cpu-seconds 0 --parity-frames 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_trace.log 2>&1

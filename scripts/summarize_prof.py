@@ -22,14 +22,18 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
-# bench site -> kernel-name substring (template arguments ACT, RESID, SITE of gemm_nt_kernel)
+# bench site -> substrings that identify its kernel instantiation (round 2: the QKV projection + attention run as qkv_attn_kernel,
+# out_proj on the two-workgroups-per-CU kernel; template arguments of gemm256_nt_kernel are <T, OutT, ACT, RESID, SITE>)
 SITES = {
-    "vit.c_fc": "1, false, 3>",
-    "vit.c_proj": "0, true, 4>",
-    "vit.qkv": "0, false, 1>",
-    "vit.out_proj": "0, true, 2>",
-    "vit.patch_embed": "0, false, 0>",
+    "vit.c_fc": ("gemm256_nt_kernel", "1, false, 3>"),
+    "vit.c_proj": ("gemm256_nt_kernel", "0, true, 4>"),
+    "vit.qkv_attn": ("qkv_attn_kernel",),
+    "vit.qkv": ("gemm256_nt_kernel", "0, false, 1>"),
+    "vit.out_proj": ("gemm2w_kernel", "float, 0, true>"),
+    "vit.patch_embed": ("gemm256_nt_kernel", "0, false, 0>"),
+    "vit.ln": ("layernorm_kernel",),
 }
+FRAMES_PER_LAUNCH = int(os.environ.get("FRAMES_PER_LAUNCH", "1024"))  # the largest grid of a site = bench.py's single-stream (isolated) pass: 1024 frames per launch
 
 
 def one(pattern):
@@ -63,12 +67,13 @@ for e in summary.values():
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
 
 traffic = {}
-for site, sub in SITES.items():
-    cands = [e for e in summary.values() if sub in e["kernel"] and "gemm" in e["kernel"] and "hbm_bytes_per_launch" in e]
+for site, subs in SITES.items():
+    cands = [e for e in summary.values() if all(x in e["kernel"] for x in subs) and "hbm_bytes_per_launch" in e]
     if cands:
-        e = max(cands, key=lambda x: x["grid_threads"])
+        e = max(cands, key=lambda x: x["grid_threads"])  # the full-size launches (the class-token-only last block has small grids)
         traffic[site] = {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "fetch_KiB": e["FETCH_SIZE_KiB_avg"],
                          "write_KiB": e["WRITE_SIZE_KiB_avg"], "kernel": e["kernel"], "grid_threads": e["grid_threads"],
+                         "frames_per_launch": FRAMES_PER_LAUNCH, "round": tag,
                          "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/{tag}_pmc_summary.json"}
 json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic, indent=1))

@@ -356,3 +356,26 @@ def test_full_geometry_head_matches_oracle(gpu_lib):
     print(f"mean abs parameter error after one AdamW step: {np.mean(errs):.2e}")
     assert np.mean(errs) < 2e-5  # first Adam step = lr * sign-like update: a ~0 gradient may flip sign, compare on average
     tr.close()
+
+
+def test_adamw_leaves_gradientless_parameters_alone(gpu_lib):
+    """use_id_loss off: inverse_layer.* and lambda_id get no gradient; torch.optim.AdamW (finetune.py:141) skips parameters whose
+    .grad is None -- no decay, no moment update.  Three steps against the oracle (pinned on torch.optim.AdamW for this case)."""
+    from arp_amd import finetune as FT
+    from oracle import finetune_torch as O
+    cfg = O.HeadConfig(**MID, use_id=False)
+    P = O.init_params(cfg, seed=9)
+    fcfg = FT.FinetuneConfig(**MID, weight_decay=0.05, use_id=False, logit_scale=cfg.logit_scale)
+    batch = FT.synth_batch(fcfg, 5, seed=10)
+    P_ref, _ = O.train_steps(P, cfg, [batch], 1e-3, 0.05, 3)
+    tr = FT.FinetuneTrainer(fcfg, mode="f32")
+    tr.set_params(P)
+    for _ in range(3):
+        tr.set_batch(*batch)
+        tr.train_step(1e-3)
+    got = tr.get_params()
+    for k in P:
+        if k.startswith("inverse_layer.") or k == "lambda_id":
+            assert np.array_equal(got[k], P[k]), k  # bit for bit untouched
+    assert float(np.mean([np.abs(got[k] - P_ref[k]).mean() for k in P])) < 2e-5
+    tr.close()

@@ -62,9 +62,14 @@ def test_vip_exponent_broadcasts_to_a_matrix():
     assert abs(np.log(1e-8 + per_sample) - np.log(1e-8 + mat.mean())) > 1e-6  # a per-sample reading would differ
 
 
-def test_adamw_matches_torch():
+@pytest.mark.parametrize("use_id", [True, False])
+def test_adamw_matches_torch(use_id):
+    """incl. use_id_loss off: the inverse model and lambda_id then have .grad None and torch.optim.AdamW leaves them untouched
+    (no decoupled decay either) -- ADVICE r1."""
+    import dataclasses
     from oracle import finetune_torch as O
     cfg, P, _, batch, _ = load_golden()
+    cfg = dataclasses.replace(cfg, use_id=use_id)
     Pt = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in P.items()}
     opt = torch.optim.AdamW(list(Pt.values()), lr=1e-3, weight_decay=0.01)
     for _ in range(3):
@@ -75,3 +80,5 @@ def test_adamw_matches_torch():
     got, _ = O.train_steps(P, cfg, [batch], 1e-3, 0.01, 3)
     for k in P:
         assert np.abs(got[k] - Pt[k].detach().numpy()).max() < 1e-9, k
+    if not use_id:
+        assert all(np.array_equal(got[k], np.asarray(P[k], np.float64)) for k in P if k.startswith("inverse_layer.") or k == "lambda_id")
