@@ -22,6 +22,7 @@
 #include "enc_internal.h"
 #include "gemm.h"
 #include "gemm256.h"
+#include "gemm_tn.h"
 #include "policy_fused.h"
 #include "runtime.h"
 
@@ -86,7 +87,16 @@ struct arp_dt {
     long long step = 0;
     bool shadows_stale = true;
     // operand-type shadows of the big weights
-    DevBuf W1s, W2s, W2t, Wis, Wit;
+    // Forward-layout operands of the three big Dense kernels: the f32 parameters themselves (f32 mode) or `mirror`, their
+    // operand-type copy over the flat prefix [0, n_mirror) that the Adam kernel keeps current; the transposed ones (dX = dY.W)
+    // are rebuilt from it once per step.
+    DevBuf mirror, W2t, Wit;
+    size_t n_mirror = 0;
+    bool mirror_stale = true;  // the host wrote parameters (or a broadcast did): rebuild the mirror from f32
+    const void* fwd_w(const std::string& n) {
+        const size_t off = infos[index.at(n)].off;
+        return cfg.mode == ARP_MODE_F32 ? (const void*)(params.as<float>() + off) : (const void*)(static_cast<char*>(mirror.p) + off * 2);
+    }
     // (f16 mode, measured on the real geometry with tests/probes/policy_rounding_probe.py: every operand rounding of the adapter
     // path -- X, W1, H1, W2, A, Y, Wi -- costs 2.4-6.1e-4 on the logits and they combine to 4.9-8.4e-4 across seeds; with
     // res = sigmoid(4) = 0.98 the adapter branch carries the signal, so carrying Y and Wi as hi + lo pairs, tried, bought
@@ -122,6 +132,13 @@ struct arp_dt {
     // below binary16's normal range.  In f16 mode they carry a power-of-two scale (exact), removed again where a gradient
     // leaves for the f32 gradient buffer (GEMM alpha / split-K reduce / row sums).  bf16 and f32 have the range: scale 1.
     float act_scale() const { return cfg.mode == ARP_MODE_F16 ? 16384.f : 1.f; }
+    // 16-bit modes with 128-aligned widths: weight gradients on the TN kernel (gemm_tn.h) straight from the row-major operands --
+    // no transposed, K-padded copies.  Other geometries (and the f32 parity mode) keep the transposed-copy path.
+    bool use_tn() const {
+        static const bool off = getenv("ARP_DT_TN") && atoi(getenv("ARP_DT_TN")) == 0;
+        return !off && cfg.mode != ARP_MODE_F32 && cfg.enc_dim % 128 == 0 && cfg.emb % 128 == 0;
+    }
+    DevBuf colpart;  // column partial sums of mask_copy_colsum_kernel
     int R() const { return B * cfg.window; }
     int L() const { return 3 * cfg.window; }
     float* p(const std::string& n) { return params.as<float>() + infos[index.at(n)].off; }
@@ -261,6 +278,8 @@ int big_gemm(arp_dt* c, const char* site, const void* A, int lda, const void* W,
     g.A = A; g.W = W; g.bias = bias; g.resid = nullptr; g.out = out;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldr = ldo; g.ldo = ldo;
     ProfScope ps(c->prof, c->stream, site);
+    // (the two-workgroups-per-CU kernel, which wins on the ViT's out_proj, measured 2-10 % slower here on the adapter's
+    //  768 x 768 x 32 896 GEMMs: bias/ReLU epilogues are cheap, nothing for a second workgroup to hide)
     return launch_gemm_auto<T, OutT, ACT, false, SITE_DT>(g, c->stream, 0);
 }
 // split-K NT GEMM: f32 partials [S][M][N] then a fixed-order reduce (+bias, act) into OutT
@@ -304,13 +323,18 @@ template <typename T> int refresh_shadows(arp_dt* c) {
     const int D = k.enc_dim, E = k.emb;
     const size_t Kin = (size_t)k.enc_tokens * D;
     ProfScope ps(c->prof, c->stream, "dt.refresh_shadows");
-    if (k.use_adapter) {
-        // device layout of a Dense kernel is [out, in]
-        ARP_TRY((transpose_mask<float, float, T>(c, c->p("AdapterMLP_0/Dense_0/kernel"), D, nullptr, nullptr, 1.f, c->W1s.as<T>(), D, nullptr, 0, D, D)));
-        ARP_TRY((transpose_mask<float, float, T>(c, c->p("AdapterMLP_0/Dense_1/kernel"), D, nullptr, nullptr, 1.f, c->W2s.as<T>(), D, c->W2t.as<T>(), D, D, D)));
+    if constexpr (sizeof(T) == 2) {
+        if (c->mirror_stale) {
+            hipLaunchKernelGGL((convert_kernel<T>), dim3(cdiv(c->n_mirror, 1024)), dim3(256), 0, c->stream, c->params.as<float>(), c->mirror.as<T>(), c->n_mirror);
+            ARP_HIP_OK(hipGetLastError());
+            c->mirror_stale = false;
+        }
     }
-    ARP_TRY((transpose_mask<float, float, T>(c, c->p("image_text_input/kernel"), (int)Kin, nullptr, nullptr, 1.f, c->Wis.as<T>(), (int)Kin,
-                                             c->Wit.as<T>(), E, E, (int)Kin)));
+    // device layout of a Dense kernel is [out, in]; the transposed shadows come from the operand-type copy (half the bytes)
+    const T* W2 = static_cast<const T*>(c->fwd_w("AdapterMLP_0/Dense_1/kernel"));
+    const T* Wi = static_cast<const T*>(c->fwd_w("image_text_input/kernel"));
+    if (k.use_adapter) ARP_TRY((transpose_mask<T, T, T>(c, W2, D, nullptr, nullptr, 1.f, nullptr, 0, c->W2t.as<T>(), D, D, D)));
+    ARP_TRY((transpose_mask<T, T, T>(c, Wi, (int)Kin, nullptr, nullptr, 1.f, nullptr, 0, c->Wit.as<T>(), E, E, (int)Kin)));
     c->shadows_stale = false;
     return 0;
 }
@@ -405,8 +429,15 @@ int ensure_buffers(arp_dt* c, int B) {
     const size_t R = (size_t)B * T, Mx = R * k.enc_tokens, BL = R * 3, Kin = (size_t)k.enc_tokens * D;
     const size_t Mxp = (Mx + 63) / 64 * 64, Rp = (R + 63) / 64 * 64;
     ARP_TRY(c->enc32.ensure(Mx * D * 4)); ARP_TRY(c->action.ensure(R * 4)); ARP_TRY(c->rtg.ensure(R * 4));
+    // TN path: these are GEMM operands whose contraction index is the ROW -- rows up to the next multiple of 64 must read as zeros
+    const size_t Rp64 = (R + 63) / 64 * 64;
+    const size_t rowpad = std::max(Mxp * (size_t)D, Rp64 * Kin);
     DevBuf* tb[] = {&c->Xb, &c->H1, &c->A, &c->Y, &c->dY, &c->dApre, &c->G};
-    for (auto* b : tb) ARP_TRY(b->ensure(Mx * D * e));
+    for (auto* b : tb) {
+        ARP_TRY(b->ensure(rowpad * e));
+        ARP_HIP_OK(hipMemsetAsync(b->p, 0, rowpad * e, c->stream));
+    }
+    ARP_TRY(c->colpart.ensure((Mxp / 64) * (size_t)D * 4));
     DevBuf* tt[] = {&c->XbT, &c->H1T, &c->dApreT, &c->dH1T};
     for (auto* b : tt) {
         ARP_TRY(b->ensure((size_t)D * Mxp * e));
@@ -414,8 +445,8 @@ int ensure_buffers(arp_dt* c, int B) {
     }
     ARP_TRY(c->YT.ensure(Kin * Rp * e)); ARP_HIP_OK(hipMemsetAsync(c->YT.p, 0, Kin * Rp * e, c->stream));
     ARP_TRY(c->dzT.ensure((size_t)E * Rp * e)); ARP_HIP_OK(hipMemsetAsync(c->dzT.p, 0, (size_t)E * Rp * e, c->stream));
-    ARP_TRY(c->dzb.ensure(R * E * e));
-    ARP_TRY(c->scal.ensure(4096 * 4));
+    ARP_TRY(c->dzb.ensure(Rp64 * E * e)); ARP_HIP_OK(hipMemsetAsync(c->dzb.p, 0, Rp64 * E * e, c->stream));
+    ARP_TRY(c->scal.ensure((4096 + (size_t)cdiv(D, 256) * (Mxp / 64 + 1)) * 4));
     auto f32 = [&](DevBuf& b, size_t n) { return b.ensure(std::max<size_t>(n, 4) * 4); };
     c->xs.resize(k.depth + 1); c->ln0.resize(k.depth); c->qkv.resize(k.depth); c->att.resize(k.depth); c->hmid.resize(k.depth);
     c->ln1.resize(k.depth); c->u.resize(k.depth); c->gl.resize(k.depth);
@@ -473,13 +504,13 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     {   // enc f32 -> operand type, both layouts (the transposed one feeds the weight-gradient GEMM)
         ProfScope ps(c->prof, c->stream, "dt.enc_convert");
         ARP_TRY((transpose_mask<float, float, T>(c, c->enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D,
-                                                 k.use_adapter ? c->XbT.as<T>() : nullptr, Mxp, (int)Mx, D)));
+                                                 (k.use_adapter && !c->use_tn()) ? c->XbT.as<T>() : nullptr, Mxp, (int)Mx, D)));
     }
     const T* Yp = c->Xb.as<T>();
     if (k.use_adapter) {
         // AdapterMLP: relu(relu(x W1 + b1) W2 + b2)   (arp_dt/models/adapter/layers.py:19-30)
-        ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc1", c->Xb.p, D, c->W1s.p, D, c->p("AdapterMLP_0/Dense_0/bias"), c->H1.p, D, (int)Mx, D, D)));
-        ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc2", c->H1.p, D, c->W2s.p, D, c->p("AdapterMLP_0/Dense_1/bias"), c->A.p, D, (int)Mx, D, D)));
+        ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc1", c->Xb.p, D, c->fwd_w("AdapterMLP_0/Dense_0/kernel"), D, c->p("AdapterMLP_0/Dense_0/bias"), c->H1.p, D, (int)Mx, D, D)));
+        ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc2", c->H1.p, D, c->fwd_w("AdapterMLP_0/Dense_1/kernel"), D, c->p("AdapterMLP_0/Dense_1/bias"), c->A.p, D, (int)Mx, D, D)));
         ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
         hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->enc32.as<float>(),
                            c->p("residual_weight"), c->Y.as<T>(), Mx * D);
@@ -487,7 +518,7 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         Yp = c->Y.as<T>();
     }
     // image_text_input + tanh (arp_dt/ARPDT.py:475-484): [R, tokens*dim] x [tokens*dim, E], split over K
-    ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->Wis.p, Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
+    ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->fwd_w("image_text_input/kernel"), Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
     if (c->fused) {
         ProfScope ps(c->prof, c->stream, "dt.policy_fwd");
         ARP_TRY(policy_fused(c, with_bwd));
@@ -525,6 +556,72 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
                            c->rtg.as<float>(), R, NA, k.lambda_ret, c->metrics.as<float>(), c->dlogits.as<float>(), c->dret.as<float>());
         ARP_HIP_OK(hipGetLastError());
     }
+    return 0;
+}
+
+// ---- adapter + image_text_input backward, 16-bit modes, TN weight-gradient GEMMs (gemm_tn.h) ---------------------------------
+// Same math as the tail of backward<T>() below; the operands of the three weight-gradient contractions stay row-major
+// (no transposed K-padded copies): dWi = dz^T Y, dW2 = dApre^T H1, dW1 = dH1^T X.
+template <typename T> int tn_gemm(arp_dt* c, const char* site, const T* A, int lda, const T* B, int ldb, float* out, int M, int N, int K, float alpha) {
+    const int tcode = __is_same(T, bf16_t) ? 1 : 2;
+    const int tiles = (M / 128) * (N / 128), nk = K / 64;
+    int S = std::max(1, std::min(nk, 512 / std::max(tiles, 1)));  // one resident round of workgroups, as splitk_gemm
+    const int per = (nk + S - 1) / S;
+    S = (nk + per - 1) / per;
+    GemmTnArgs g;
+    g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ksplit = S;
+    ProfScope ps(c->prof, c->stream, site);
+    if (S == 1) {
+        g.out = out; g.ldo = N; g.slice_stride = 0; g.alpha = alpha;
+        return launch_gemm_tn(tcode, g, c->stream);
+    }
+    ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
+    g.out = c->part.as<float>(); g.ldo = N; g.slice_stride = (size_t)M * N; g.alpha = 1.f;
+    ARP_TRY(launch_gemm_tn(tcode, g, c->stream));
+    const size_t MN = (size_t)M * N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, nullptr, ACT_NONE, out,
+                       nullptr, 0, alpha);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename T> int backward_adapter_tn(arp_dt* c) {
+    const arp_dt_cfg& k = c->cfg;
+    const int E = k.emb, D = k.enc_dim;
+    const int R = c->R();
+    const size_t Mx = (size_t)R * k.enc_tokens;
+    const int Kin = k.enc_tokens * D;
+    const int Mxp = (int)((Mx + 63) / 64 * 64), Rp64 = (R + 63) / 64 * 64;
+    const float S = c->act_scale(), invS = 1.0f / S;
+    const T* Yp = k.use_adapter ? c->Y.as<T>() : c->Xb.as<T>();
+    // dz (f32) -> operand type, scaled (rows R..Rp64 of dzb stay zero)
+    ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, S, c->dzb.as<T>(), E, nullptr, 0, R, E)));
+    // dWi[E, Kin] = dz^T Y: contraction over the R rows, written straight into the gradient buffer
+    ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS)));
+    if (!k.use_adapter) return 0;
+    ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.image_text_input_dX", c->dzb.p, E, c->Wit.p, E, nullptr, c->dY.p, Kin, R, Kin, E)));
+    const int prow = Mxp / 64, ncb = cdiv(D, 256);
+    {   // dApre = res * dY * (A > 0), row-major; its column sums = the Dense_1 bias gradient; sum dY * (A - x) = d loss / d res
+        ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->p("residual_weight"), 1, 1.0f, c->scal.as<float>() + 9, 0);
+        hipLaunchKernelGGL(sigmoid_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 9);
+        hipLaunchKernelGGL((mask_copy_colsum_kernel<T>), dim3(ncb, prow), dim3(256), 0, c->stream, c->dY.as<T>(), c->A.as<T>(),
+                           c->scal.as<float>() + 9, 1.f, c->dApre.as<T>(), c->colpart.as<float>(), (int)Mx, D, c->enc32.as<float>(), c->scal.as<float>() + 16);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), prow, D, c->g("AdapterMLP_0/Dense_1/bias"), invS);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, ncb * prow, invS, c->scal.as<float>() + 8, 0);
+        hipLaunchKernelGGL(dres_to_drw_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 8, c->p("residual_weight"), c->g("residual_weight"));
+        ARP_HIP_OK(hipGetLastError());
+    }
+    ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc2_dW", c->dApre.as<T>(), D, c->H1.as<T>(), D, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp, invS)));
+    ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.adapter_fc2_dX", c->dApre.p, D, c->W2t.p, D, nullptr, c->G.p, D, (int)Mx, D, D)));
+    {   // dH1 = G * (H1 > 0), row-major (in the buffer the other path uses for its transposed copy), + the Dense_0 bias gradient
+        ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
+        hipLaunchKernelGGL((mask_copy_colsum_kernel<T>), dim3(cdiv(D, 256), prow), dim3(256), 0, c->stream, c->G.as<T>(), c->H1.as<T>(), nullptr, 1.f,
+                           c->dH1T.as<T>(), c->colpart.as<float>(), (int)Mx, D);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), prow, D, c->g("AdapterMLP_0/Dense_0/bias"), invS);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc1_dW", c->dH1T.as<T>(), D, c->Xb.as<T>(), D, c->g("AdapterMLP_0/Dense_0/kernel"), D, D, Mxp, invS)));
     return 0;
 }
 
@@ -593,6 +690,9 @@ template <typename T> int backward(arp_dt* c) {
         ARP_TRY(ew_bwd(c, c->dimg.as<float>(), c->img.as<float>(), c->dz.as<float>(), (size_t)R * E, EW_TANH_BWD));
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(E, 64)), dim3(256), 0, c->stream, c->dz.as<float>(), R, E, c->g("image_text_input/bias"));
         ARP_HIP_OK(hipGetLastError());
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (c->use_tn()) return backward_adapter_tn<T>(c);
     }
     // ---- image_text_input: dW[E, Kin] = dz^T Y ;  dY[R, Kin] = dz Wi -------------------------------------
     const T* Yp = k.use_adapter ? c->Y.as<T>() : c->Xb.as<T>();
@@ -664,9 +764,14 @@ int apply_update(arp_dt* c, float lr) {
     hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, pp, nb, 1.0f, c->scal.as<float>() + 1, 0);
     const double t = (double)(c->step + 1);
     const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
-    hipLaunchKernelGGL(adam_kernel, dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(), c->mu.as<float>(),
-                       c->nu.as<float>(), c->scal.as<float>(), gscale, c->cfg.weight_decay, c->n_decay, c->cfg.clip_norm, lr, c->cfg.b1, c->cfg.b2,
-                       c->cfg.eps, bc1, bc2, c->P);
+#define ARP_ADAM(TM)                                                                                                                    \
+    hipLaunchKernelGGL((adam_kernel<TM>), dim3(cdiv(c->P / 4, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(),        \
+                       c->mu.as<float>(), c->nu.as<float>(), c->scal.as<float>(), gscale, c->cfg.weight_decay, c->n_decay, c->cfg.clip_norm, lr, \
+                       c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P, c->mirror.as<TM>(), c->mirror_stale ? (size_t)0 : c->n_mirror)
+    if (c->cfg.mode == ARP_MODE_BF16) ARP_ADAM(bf16_t);
+    else if (c->cfg.mode == ARP_MODE_F16) ARP_ADAM(f16_t);
+    else ARP_ADAM(float);
+#undef ARP_ADAM
     ARP_HIP_OK(hipGetLastError());
     c->step += 1;
     c->shadows_stale = true;
@@ -688,6 +793,12 @@ template <typename T> int fwd_bwd_graphed(arp_dt* c) {
         (void)hipGraphExecDestroy(c->graph_exec);
         c->graph_exec = nullptr;
         c->eager_steps = 0;
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (c->mirror_stale) {  // a host write since the last step: rebuild the operand mirror eagerly, never inside the captured chain
+            c->shadows_stale = true;
+            ARP_TRY(refresh_shadows<T>(c));
+        }
     }
     if (!c->graph_exec) {
         if (c->eager_steps < 2) {
@@ -783,8 +894,10 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
             ARP_HIP_OK(hipMemset(b->p, 0, c->P * 4));
         }
         const size_t e = c->esz(), D = k.enc_dim, Kin = (size_t)k.enc_tokens * D;
-        if (k.use_adapter) { ARP_TRY(c->W1s.ensure(D * D * e)); ARP_TRY(c->W2s.ensure(D * D * e)); ARP_TRY(c->W2t.ensure(D * D * e)); }
-        ARP_TRY(c->Wis.ensure(Kin * k.emb * e)); ARP_TRY(c->Wit.ensure(Kin * k.emb * e));
+        c->n_mirror = c->infos[c->index.at("action_input/embedding")].off;  // flat prefix = (W1, W2,) Wi: the big Dense kernels
+        if (k.mode != ARP_MODE_F32) ARP_TRY(c->mirror.ensure(c->n_mirror * e));
+        if (k.use_adapter) ARP_TRY(c->W2t.ensure(D * D * e));
+        ARP_TRY(c->Wit.ensure(Kin * k.emb * e));
         return 0;
     };
     if (body() != 0) { arp_dt_destroy(c); return -1; }
@@ -799,7 +912,7 @@ int arp_dt_destroy(arp_dt* c) {
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->W1s, &c->W2s, &c->W2t, &c->Wis, &c->Wit, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->W2t, &c->Wit, &c->colpart, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,
@@ -852,7 +965,7 @@ static int tensor_io(arp_dt* c, const char* name, int which, float* host, int wr
             memcpy(tmp.data(), host, pi.size * 4);
         }
         ARP_HIP_OK(hipMemcpy(dev, tmp.data(), pi.size * 4, hipMemcpyHostToDevice));
-        if (which == 0) c->shadows_stale = true;
+        if (which == 0) c->shadows_stale = c->mirror_stale = true;
     } else {
         ARP_HIP_OK(hipMemcpy(tmp.data(), dev, pi.size * 4, hipMemcpyDeviceToHost));
         if (pi.dense) {
@@ -1017,7 +1130,7 @@ int arp_dt_broadcast_state(arp_dt* c) {
     ARP_HIP_OK(hipMemcpyAsync(&st, c->scal.p, 8, hipMemcpyDeviceToHost, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     c->step = st;
-    c->shadows_stale = true;
+    c->shadows_stale = c->mirror_stale = true;
     return 0;
 }
 

@@ -271,7 +271,7 @@ static __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict_
     if (threadIdx.x == 0) out[row] = alpha * ((red[0] + red[1]) + (red[2] + red[3]));
 }
 // column sums of a small [R, C] f32 matrix: out[c] = sum_r in[r, c]
-__device__ __forceinline__ void colsum_tile(const float* __restrict__ in, int R, int C, float* __restrict__ out, int bx) {
+__device__ __forceinline__ void colsum_tile(const float* __restrict__ in, int R, int C, float* __restrict__ out, int bx, float alpha = 1.f) {
     // 64 columns per block (lane = column: coalesced rows), rows split over the 4 waves with 4 independent
     // accumulators each, then a fixed-order combine
     __shared__ float red[4][64];
@@ -290,10 +290,61 @@ __device__ __forceinline__ void colsum_tile(const float* __restrict__ in, int R,
     }
     red[y][x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (y == 0 && c < C) out[c] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+    if (y == 0 && c < C) out[c] = alpha * ((red[0][x] + red[1][x]) + (red[2][x] + red[3][x]));
 }
-static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
-    colsum_tile(in, R, C, out, blockIdx.x);
+static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out, float alpha = 1.f) {
+    colsum_tile(in, R, C, out, blockIdx.x, alpha);
+}
+
+// ---- masked, scaled ROW-major copy with column partial sums (16-bit modes: operand of the TN weight-gradient GEMM) ----------
+//   out[r,c] = scale * in[r,c] * (mask[r,c] > 0)          part[blockIdx.y][c] = sum over the block's 64 rows of out[r,c]
+// The partial sums (of the ROUNDED values, as the transposed-copy path's row sums were) give the bias gradient after one
+// colsum_kernel over gridDim.y rows: fixed order, no atomics.  C % 4 == 0; rows >= R are not written (callers keep them zero).
+template <typename T>
+static __global__ __launch_bounds__(256) void mask_copy_colsum_kernel(const T* __restrict__ in, const T* __restrict__ mask, const float* __restrict__ scale_ptr,
+                                                               float scale, T* __restrict__ out, float* __restrict__ part, int R, int C,
+                                                               const float* __restrict__ x32 = nullptr, float* __restrict__ dres_part = nullptr) {
+    // x32 / dres_part (the adapter's first masked copy): also the block's share of d loss / d res = sum in * (mask - x32), i.e.
+    // dY * (A - x) of y = res*A + (1-res)*x (arp_dt/ARPDT.py:466-472), so that dY and A are read once for both results
+    __shared__ float red[4][256];
+    __shared__ float dred[4];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + tx * 4;
+    const float s = scale_ptr ? scale * scale_ptr[0] : scale;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float dsum = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int r = blockIdx.y * 64 + i * 4 + ty;
+            if (r >= R) break;
+            float v[4], m[4];
+            load4(in + (size_t)r * C + c, v);
+            load4(mask + (size_t)r * C + c, m);
+            if (x32) {
+                float x[4];
+                load4(x32 + (size_t)r * C + c, x);
+                dsum += (v[0] * (m[0] - x[0]) + v[1] * (m[1] - x[1])) + (v[2] * (m[2] - x[2]) + v[3] * (m[3] - x[3]));
+            }
+            T o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Elem<T>::st(&o[e], m[e] > 0.f ? v[e] * s : 0.f);
+                acc[e] += Elem<T>::ld(&o[e]);
+            }
+            *reinterpret_cast<uint2*>(out + (size_t)r * C + c) = *reinterpret_cast<const uint2*>(o);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[ty][tx * 4 + e] = acc[e];
+    if (dres_part) {
+        dsum = wave_sum(dsum);
+        if (tx == 0) dred[ty] = dsum;
+    }
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < C) part[(size_t)blockIdx.y * C + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (dres_part && threadIdx.x == 0) dres_part[blockIdx.y * gridDim.x + blockIdx.x] = (dred[0] + dred[1]) + (dred[2] + dred[3]);
 }
 
 // ---- LayerNorm forward (f32 in/out, saves nothing: backward recomputes the statistics) ------------------
@@ -542,16 +593,19 @@ static __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* 
 // averaged over ranks), pp[b] = sum p^2 over i < n_decay (weight_l2 of main_procgen.py:114-117).
 static __global__ __launch_bounds__(256) void norms_partial_kernel(const float* __restrict__ g, const float* __restrict__ p, size_t n, size_t n_decay,
                                                                    float gscale, float wd, float* __restrict__ pg, float* __restrict__ pp) {
+    // n and n_decay are multiples of 4 (every tensor's offset is): 16-byte accesses, fixed grid-stride order
     __shared__ float red[2][4];
     float sg = 0.f, sp = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float gi = g[i] * gscale;
-        if (i < n_decay) {
-            const float pi = p[i];
-            gi += wd * pi;
-            sp += pi * pi;
+    const size_t n4 = n >> 2, d4 = n_decay >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float g0 = gv.x * gscale, g1 = gv.y * gscale, g2 = gv.z * gscale, g3 = gv.w * gscale;
+        if (i < d4) {
+            const float4 pv = reinterpret_cast<const float4*>(p)[i];
+            g0 += wd * pv.x; g1 += wd * pv.y; g2 += wd * pv.z; g3 += wd * pv.w;
+            sp += (pv.x * pv.x + pv.y * pv.y) + (pv.z * pv.z + pv.w * pv.w);
         }
-        sg += gi * gi;
+        sg += (g0 * g0 + g1 * g1) + (g2 * g2 + g3 * g3);
     }
     sg = wave_sum(sg);
     sp = wave_sum(sp);
@@ -572,19 +626,36 @@ static __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restric
 // the adamw decay mask of the reference is all-False, so no decoupled decay.
 // The L2 term's gradient wd*p (first n_decay entries) is added here, not materialised: g holds the raw (rank-summed) loss
 // gradient, scal[0] the squared norm of g*gscale + wd*p from norms_partial_kernel.
+// mirror (16-bit modes): the operand-type copy of the first n_mirror parameters (the three big Dense kernels, device layout
+// [out, in] = the NT operand layout), written here so that the next step's forward needs no conversion pass over them.
+template <typename TM>
 static __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
                                                    float* __restrict__ nu, const float* __restrict__ scal, float gscale, float wd, size_t n_decay,
-                                                   float clip, float lr, float b1, float b2, float eps, float bc1, float bc2, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+                                                   float clip, float lr, float b1, float b2, float eps, float bc1, float bc2, size_t n,
+                                                   TM* __restrict__ mirror, size_t n_mirror) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 per thread; n, n_decay, n_mirror are multiples of 4
+    if (i >= (n >> 2)) return;
     const float gnorm = sqrtf(scal[0]);
     const float s = (gnorm < clip) ? 1.0f : clip / gnorm;
-    const float gi = (g[i] * gscale + (i < n_decay ? wd * p[i] : 0.f)) * s;
-    const float m = b1 * mu[i] + (1.f - b1) * gi;
-    const float v = b2 * nu[i] + (1.f - b2) * gi * gi;
-    mu[i] = m;
-    nu[i] = v;
-    p[i] -= lr * (m / bc1) / (sqrtf(v / bc2) + eps);
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    float4 mv = reinterpret_cast<float4*>(mu)[i];
+    float4 vv = reinterpret_cast<float4*>(nu)[i];
+    const float dw = (i < (n_decay >> 2)) ? wd : 0.f;
+    float gg[4] = {gv.x, gv.y, gv.z, gv.w}, pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w}, nn[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gi = (gg[e] * gscale + dw * pp[e]) * s;
+        mm[e] = b1 * mm[e] + (1.f - b1) * gi;
+        nn[e] = b2 * nn[e] + (1.f - b2) * gi * gi;
+        pp[e] -= lr * (mm[e] / bc1) / (sqrtf(nn[e] / bc2) + eps);
+    }
+    reinterpret_cast<float4*>(mu)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(nu)[i] = make_float4(nn[0], nn[1], nn[2], nn[3]);
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    if constexpr (sizeof(TM) == 2) {
+        if (mirror && i < (n_mirror >> 2)) store4(mirror + 4 * i, pp[0], pp[1], pp[2], pp[3]);
+    }
 }
 
 }  // namespace arp
