@@ -141,6 +141,8 @@ SIGNATURES = {
     "arp_ft_train_step": (_i, [_vp, C.c_float, _fp]),
     "arp_ft_train_step_async": (_i, [_vp, C.c_float]),
     "arp_ft_sync": (_i, [_vp]),
+    "arp_ft_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "arp_ft_broadcast_state": (_i, [_vp]),
     "arp_ft_event_record": (_i, [_vp, _vp]),
     "arp_ft_profile_enable": (_i, [_vp, _i]),
     "arp_ft_profile_reset": (_i, [_vp]),

@@ -4,8 +4,6 @@
 //
 // Boundary this round: the frozen M3AE encoder output `enc` [B,T,tokens,dim] is an
 // INPUT (BASELINE.json configs[3]: "random-init M3AE encodings"); everything trainable is inside.
-#include <dlfcn.h>
-#include <rccl/rccl.h>  // types only: librccl is dlopen'ed at arp_dt_comm_init, never linked (see rccl_api())
 
 #include <algorithm>
 #include <cmath>
@@ -24,44 +22,12 @@
 #include "gemm256.h"
 #include "gemm_tn.h"
 #include "policy_fused.h"
+#include "rccl_dl.h"
 #include "runtime.h"
 
 using namespace arp;
 
 namespace {
-
-// RCCL is bound at run time.  Linking it would make every process that loads libarp_hip.so also load
-// /opt/rocm's librccl next to the copy PyTorch-ROCm bundles (same SONAME, different file) -- two RCCLs in one
-// process abort in glibc at exit.  dlopen("librccl.so.1") returns whichever copy is already loaded, else the
-// system one.
-struct RcclApi {
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    bool ok = false;
-};
-RcclApi* rccl_api() {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.ok ? &api : nullptr;
-    tried = true;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return nullptr;
-    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
-    api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(h, "ncclBroadcast"));
-    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    api.ok = api.GetErrorString && api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Broadcast;
-    return api.ok ? &api : nullptr;
-}
-
-int rccl_fail(const char* what, ncclResult_t r) { return fail(std::string(what) + ": " + rccl_api()->GetErrorString(r)); }
 
 enum { SITE_DT = 16 };
 

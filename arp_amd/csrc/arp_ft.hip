@@ -30,6 +30,7 @@
 #include "ftops.h"
 #include "gemm.h"
 #include "gemm256.h"
+#include "rccl_dl.h"
 #include "runtime.h"
 
 using namespace arp;
@@ -66,6 +67,10 @@ struct arp_ft {
         dres_part[2];
     DevBuf scores, ds, C, CT_, Ct, Hinv, logits, dlogits, dHinv, dHinvT_, dHinvt, dC, metrics, scal, part;
     Profiler prof;
+    // data parallelism (BASELINE configs[4]: DP = 8): one process per GPU, one all-reduce(sum) of the flat gradient per step
+    ncclComm_t comm = nullptr;
+    bool has_comm = false;
+    int world = 1, rank = 0;
 
     size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
     int Dv() const { return cfg.layers * cfg.width_v; }
@@ -353,7 +358,7 @@ int apply_update(arp_ft* c, float lr) {
         s1lo = l.off; s1hi = l.off + 4;
     }
     hipLaunchKernelGGL(ft_adamw_kernel, dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(), c->mu.as<float>(),
-                       c->nu.as<float>(), 1.0f, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P,
+                       c->nu.as<float>(), 1.0f / (float)std::max(c->world, 1), lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P,
                        c->cfg.mode == ARP_MODE_BF16 ? c->mirror.as<bf16_t>() : nullptr, s0lo, s0hi, s1lo, s1hi);
     ARP_HIP_OK(hipGetLastError());
     c->step += 1;
@@ -364,10 +369,20 @@ int apply_update(arp_ft* c, float lr) {
 template <typename T> int step_impl(arp_ft* c, float lr, float* aux) {
     ARP_TRY(forward<T>(c));
     ARP_TRY(backward<T>(c));
+    if (c->has_comm && c->world > 1) {
+        // data parallel: every rank ran its shard; ONE all-reduce(sum) of the flat f32 gradient (1.9 GB at full size) plus one of
+        // the 4 loss scalars -- the mean over ranks is taken by the 1/world factor inside the AdamW kernel
+        ProfScope ps(c->prof, c->stream, "ft.allreduce");
+        if (rccl_api()->AllReduce(c->grads.p, c->grads.p, c->P, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(grads) failed");
+        if (rccl_api()->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(metrics) failed");
+    }
     ARP_TRY(apply_update(c, lr));
     if (aux) {
         ARP_HIP_OK(hipMemcpyAsync(aux, c->metrics.p, 16, hipMemcpyDeviceToHost, c->stream));
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
+        const float inv = 1.0f / (float)std::max(c->world, 1);
+        for (int i = 0; i < 3; ++i) aux[i] *= inv;  // loss, vip_loss, id_loss: rank means; lambda_id is the same everywhere
+        if (c->world > 1) aux[3] *= inv;
     }
     return 0;
 }
@@ -416,6 +431,7 @@ int arp_ft_destroy(arp_ft* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
     c->prof.destroy();
     DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->sV1t, &c->r, &c->action, &c->scores, &c->ds, &c->C, &c->CT_, &c->Ct, &c->Hinv, &c->logits,
                      &c->dlogits, &c->dHinv, &c->dHinvT_, &c->dHinvt, &c->dC, &c->metrics, &c->scal, &c->part};
@@ -581,6 +597,41 @@ int arp_ft_event_record(arp_ft* c, arp_event* e) {
     ARP_HIP_OK(hipEventRecord(e->e, c->stream));
     return 0;
 }
+// Data parallelism (BASELINE configs[4]): the id comes from arp_dt_comm_unique_id (one RCCL id serves any handle type)
+int arp_ft_comm_init(arp_ft* c, const void* id128, int world, int rank) {
+    if (!c || !id128 || world <= 0 || rank < 0 || rank >= world) return fail("bad argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) == 128, "unexpected ncclUniqueId size");
+    memcpy(&id, id128, 128);
+    if (!rccl_api()) return fail("librccl.so.1 could not be loaded");
+    if (ncclResult_t r = rccl_api()->CommInitRank(&c->comm, world, id, rank); r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
+    c->has_comm = true;
+    c->world = world;
+    c->rank = rank;
+    return 0;
+}
+
+// every rank takes rank 0's parameters, AdamW moments and step counter (what loading one checkpoint on every rank gives)
+int arp_ft_broadcast_state(arp_ft* c) {
+    if (!c) return fail("null handle");
+    if (!c->has_comm) return 0;
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    DevBuf* fb[] = {&c->params, &c->mu, &c->nu};
+    for (auto* b : fb)
+        if (ncclResult_t r = rccl_api()->Broadcast(b->p, b->p, c->P, ncclFloat, 0, c->comm, c->stream); r != ncclSuccess) return rccl_fail("ncclBroadcast", r);
+    ARP_TRY(c->scal.ensure(64));
+    long long st = c->step;
+    ARP_HIP_OK(hipMemcpyAsync(c->scal.p, &st, 8, hipMemcpyHostToDevice, c->stream));
+    if (ncclResult_t r = rccl_api()->Broadcast(c->scal.p, c->scal.p, 8, ncclChar, 0, c->comm, c->stream); r != ncclSuccess) return rccl_fail("ncclBroadcast(step)", r);
+    ARP_HIP_OK(hipMemcpyAsync(&st, c->scal.p, 8, hipMemcpyDeviceToHost, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    c->step = st;
+    c->shadows_stale = true;
+    c->transposed_stale = true;
+    return 0;
+}
+
 int arp_ft_profile_enable(arp_ft* c, int on) {
     if (!c) return fail("null handle");
     c->prof.on = on != 0;

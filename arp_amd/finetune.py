@@ -202,6 +202,21 @@ class FinetuneTrainer:
     def sync(self):
         check(lib.arp_ft_sync(self._h))
 
+    # -- data parallelism (BASELINE configs[4]: DP = 8; one process per GPU, RCCL over xGMI) ------------------------------------
+    @staticmethod
+    def new_unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib.arp_dt_comm_unique_id(buf))  # one RCCL id serves any handle type
+        return buf.raw
+
+    def comm_init(self, unique_id, world, rank):
+        check(lib.arp_ft_comm_init(self._h, C.create_string_buffer(unique_id, 128), world, rank))
+        self.world, self.rank = world, rank
+
+    def broadcast_state(self):
+        """every rank takes rank 0's parameters, AdamW moments and step (= loading one checkpoint everywhere)"""
+        check(lib.arp_ft_broadcast_state(self._h))
+
     def record(self, event):
         check(lib.arp_ft_event_record(self._h, event.ptr))
 
@@ -300,3 +315,39 @@ def synth_batch(cfg, B, seed=0):
     return (rng.standard_normal((3, B, cfg.d_img), dtype=np.float32), rng.standard_normal((3, B, cfg.embed), dtype=np.float32),
             rng.standard_normal((B, cfg.d_txt), dtype=np.float32), rng.standard_normal((B, cfg.embed), dtype=np.float32),
             rng.integers(0, 2, (B,)).astype(np.float32), rng.integers(0, cfg.n_actions, (B,)).astype(np.int32))
+
+
+def shard_batch(batch, rank, world):
+    """This rank's contiguous part of a global fine-tune batch ``(img_inter [3,B,..], img_final [3,B,..], txt_inter [B,..],
+    txt_final [B,..], r [B], action [B])``: samples [rank*B/world, (rank+1)*B/world) of every array.  The VIP term couples the
+    samples of a batch through its [B,B] matrix (clip_multiscale_adapter.py:177-250), so data parallelism -- as for any
+    in-batch contrastive loss -- optimises the mean of the per-shard losses, not the loss of the undivided batch."""
+    if world == 1:
+        return batch
+    B = np.asarray(batch[5]).shape[0]
+    if B % world:
+        raise ValueError(f"global batch of {B} does not divide over {world} ranks")
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    return tuple(np.asarray(a)[:, sl] if i < 2 else np.asarray(a)[sl] for i, a in enumerate(batch))
+
+
+class DataParallel:
+    """One process per GPU around a :class:`FinetuneTrainer`: rank 0's RCCL id over the control plane, state broadcast, then
+    every step = this rank's shard, ONE all-reduce(sum) of the flat gradient inside the library, identical AdamW update on all
+    ranks (the scheme of arp_amd.train.DataParallel; bcast as there, e.g. ``train.torch_object_broadcast(dist)``)."""
+
+    def __init__(self, trainer, rank, world, bcast):
+        if not (0 <= rank < world):
+            raise ValueError(f"rank {rank} outside world {world}")
+        self.trainer, self.rank, self.world = trainer, int(rank), int(world)
+        uid = trainer.new_unique_id() if rank == 0 else None
+        uid = bcast(uid, 0)
+        if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+            raise ValueError("the control plane did not deliver rank 0's 128-byte RCCL unique id")
+        trainer.comm_init(bytes(uid), self.world, self.rank)
+        trainer.broadcast_state()
+
+    def train_step(self, batch, lr):
+        self.trainer.set_batch(*shard_batch(batch, self.rank, self.world))
+        return self.trainer.train_step(lr)

@@ -235,12 +235,25 @@ def bench_finetune(a):
     """Secondary benchmark: the CLIP multi-scale adapter fine-tune head step (BASELINE.json configs[4]):
     B = 64 samples x 3 frames, frozen-tower features resident in HBM, forward + backward + AdamW over 476 M parameters.
     Single GPU, as the reference (finetune_module/finetune.py)."""
-    cpu = cpu_baseline(a.model, a.cpu_seconds, finetune_batch=a.finetune_batch) if a.cpu_seconds > 0 else None
-    from arp_amd import _ffi, finetune as FT
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu = cpu_baseline(a.model, a.cpu_seconds, finetune_batch=a.finetune_batch) if (a.cpu_seconds > 0 and rank == 0 and world == 1) else None
+    dist = None
+    if world > 1:  # DP = N (BASELINE configs[4] names DP = 8): one rank per GPU, one RCCL all-reduce of the 1.9 GB gradient per step
+        import torch  # noqa: F401  -- before arp_amd: one HIP runtime per process
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arp_amd import _ffi, finetune as FT, train
     _ffi.require_gpu()
+    if world > _ffi.device_count():
+        raise SystemExit(f"--path finetune --gpus {world}: {_ffi.device_count()} GPU(s) visible; RCCL needs one GPU per rank")
+    _ffi.check(_ffi.lib.arp_set_device(local_rank))
     cfg = FT.FinetuneConfig()
-    tr = FT.FinetuneTrainer(cfg, mode=a.mode, device=0)
+    tr = FT.FinetuneTrainer(cfg, mode=a.mode, device=local_rank)
     tr.set_params(FT.synth_params(cfg, seed=0))
+    if world > 1:
+        FT.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
     B = a.finetune_batch
     lr = 1e-4
     towers = None
@@ -248,10 +261,10 @@ def bench_finetune(a):
         # frames in: the frozen CLIP ViT-B/16 towers (random init) produce the per-block CLS / EOT features every step;
         from arp_amd import clip, synth
         ccfg = clip.MODELS["ViT-B/16"]
-        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=0, max_batch=3 * B)
+        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=local_rank, max_batch=3 * B)
         frames = np.concatenate([synth.procgen_like_frames(B, seed=200 + k) for k in range(3)])  # image0 | image1 | image2
         tokens = synth.prompt_tokens(B, [8] * B, seed=203)
-        rb = FT.synth_batch(cfg, B, seed=100)
+        rb = FT.synth_batch(cfg, B, seed=100 + rank)
         fbufs = tr.feature_buffers(B)
 
         def step():
@@ -259,13 +272,15 @@ def bench_finetune(a):
             tr.set_batch_device(fbufs, rb[4], rb[5])
             tr.train_step_async(lr)
     else:
-        tr.set_batch(*FT.synth_batch(cfg, B, seed=100))
+        tr.set_batch(*FT.synth_batch(cfg, B, seed=100 + rank))
 
         def step():
             tr.train_step_async(lr)
     for _ in range(a.warmup):
         step()
     tr.sync()
+    if dist is not None:
+        dist.barrier()
     _ffi.check(_ffi.lib.arp_dev_synchronize())
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -273,6 +288,13 @@ def bench_finetune(a):
     tr.sync()
     _ffi.check(_ffi.lib.arp_dev_synchronize())
     elapsed = time.perf_counter() - t0
+    per_rank = gather_rates(dist, world, a.finetune_batch * a.steps, elapsed)
+    if dist is not None:
+        import torch
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     tr.profile(True)
     tr.profile_reset()
     for _ in range(a.steps):
@@ -285,21 +307,28 @@ def bench_finetune(a):
     nbytes = 28.0 * tr.n_params
     avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
     flops = FT.flops_per_sample(cfg) * a.finetune_batch
+    if rank != 0:
+        tr.close()
+        dist.destroy_process_group()
+        return
     print(json.dumps({
         "metric": "samples/sec CLIP multi-scale adapter fine-tune step (frames in: frozen ViT-B/16 towers + head)" if towers is not None else
-                  "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": a.finetune_batch * a.steps / elapsed,
-        "unit": "samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+                  "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": world * a.finetune_batch * a.steps / elapsed,
+        "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
         "config": {"workload": f"CLIPMultiscaleAdapter head train step, {a.finetune_batch} samples x 3 frames, ViT-B/16-shaped tower features "
                                f"[3,B,9216]+[3,B,512] / [B,6144]+[B,512] resident in HBM, {tr.n_params / 1e6:.0f} M trainable params "
-                               f"(BASELINE.json configs[4])", "parallelism": "single GPU (as the reference)"},
+                               f"(BASELINE.json configs[4])", "parallelism": "single GPU (as the reference)" if world == 1 else f"dp{world}: one RCCL all-reduce(sum) of the "
+                               f"flat f32 gradient ({tr.n_params * 4 / 1e9:.1f} GB) per step"},
         "roofline": {"bound": "hbm", "achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": f"ft_adamw_kernel @ {site}",
                      "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms},
         "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12},
-        "cpu_baseline": cpu, "final_aux": aux,
+        "cpu_baseline": cpu, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
         "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
     tr.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():

@@ -241,6 +241,11 @@ int arp_ft_train_step(arp_ft* h, float lr, float* aux4); /* forward + backward +
 int arp_ft_train_step_async(arp_ft* h, float lr);
 int arp_ft_sync(arp_ft* h);
 int arp_ft_event_record(arp_ft* h, arp_event* e);
+/* Data parallelism for the head step (BASELINE.json configs[4]: DP = 8; the reference's finetune.py is single-GPU): one process
+ * per GPU, id from arp_dt_comm_unique_id on rank 0, then every step all-reduces the flat f32 gradient once (sum; the mean is
+ * folded into the AdamW kernel) -- the scheme of the policy step (main_procgen.py:128-139). */
+int arp_ft_comm_init(arp_ft* h, const void* id128, int world, int rank);
+int arp_ft_broadcast_state(arp_ft* h);
 int arp_ft_profile_enable(arp_ft* h, int on);
 int arp_ft_profile_reset(arp_ft* h);
 int arp_ft_profile_json(arp_ft* h, char* buf, int buf_len);

@@ -222,6 +222,63 @@ def test_data_parallel_plumbing_two_ranks():
     assert np.allclose(s0, want, rtol=0, atol=1e-9)
 
 
+def _ft_dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arp_amd import finetune as FT, train
+
+    class Stub:
+        def __init__(self):
+            self.calls = []
+
+        def new_unique_id(self):
+            self.calls.append("id")
+            return bytes([3]) * 128
+
+        def comm_init(self, uid, world, rank):
+            self.calls.append(("comm_init", uid, world, rank))
+
+        def broadcast_state(self):
+            self.calls.append("broadcast_state")
+
+        def set_batch(self, *b):
+            self.calls.append(("set_batch",) + tuple(np.asarray(x).shape for x in b))
+            self.b = b
+
+        def train_step(self, lr):
+            t = torch.tensor([float(np.asarray(self.b[5]).sum()), float(len(self.b[5]))], dtype=torch.float64)
+            dist.all_reduce(t)
+            return {"loss": float(t[0] / t[1])}
+
+    cfg = FT.FinetuneConfig(layers=2, width_v=8, width_t=8, embed=8, hidden=8)
+    batch = FT.synth_batch(cfg, 6, seed=1)  # the same global batch on both ranks
+    st = Stub()
+    dp = FT.DataParallel(st, rank, world, train.torch_object_broadcast(dist))
+    aux = dp.train_step(batch, 1e-3)
+    q.put((rank, st.calls, aux))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_finetune_data_parallel_plumbing_two_ranks():
+    """configs[4]'s DP wrapper (arp_amd.finetune.DataParallel / shard_batch) on two gloo ranks: id from rank 0, communicator,
+    state broadcast, contiguous sample shards of all six batch arrays, identical aux on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ft_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, c0, a0), (_, c1, a1) = res
+    assert c0[0] == "id" and "id" not in c1 and c0[1][0] == "comm_init" and c0[1][1] == c1[0][1] == bytes([3]) * 128
+    assert (c0[1][2], c0[1][3]) == (2, 0) and (c1[0][2], c1[0][3]) == (2, 1) and c0[2] == c1[1] == "broadcast_state"
+    sb = c0[3]
+    assert sb[0] == "set_batch" and sb[1] == (3, 3, 16) and sb[2] == (3, 3, 8) and sb[3] == (3, 16) and sb[6] == (3,)
+    assert a0 == a1
+
+
 def test_shard_batch_errors_and_identity():
     from arp_amd import train
     b = {"action": np.zeros((5, 4), np.int32), "image": {"ob": np.zeros((5, 4, 2, 2), np.float32)}, "instruct": None}

@@ -379,3 +379,26 @@ def test_adamw_leaves_gradientless_parameters_alone(gpu_lib):
             assert np.array_equal(got[k], P[k]), k  # bit for bit untouched
     assert float(np.mean([np.abs(got[k] - P_ref[k]).mean() for k in P])) < 2e-5
     tr.close()
+
+
+def test_single_rank_comm_and_shards(gpu_lib):
+    """RCCL communicator with world = 1 on the fine-tune head: all-reduce / broadcast are exercised and are identities (the
+    DP = 8 of BASELINE configs[4] needs 8 GPUs; the two-rank host logic is tests/test_dist_gloo.py)."""
+    from arp_amd import finetune as FT
+    from oracle import finetune_torch as O
+    cfg = O.HeadConfig(**MID)
+    P = O.init_params(cfg, seed=13)
+    fcfg = FT.FinetuneConfig(**MID, logit_scale=cfg.logit_scale)
+    batch = FT.synth_batch(fcfg, 6, seed=14)
+    a = FT.FinetuneTrainer(fcfg, mode="f32"); a.set_params(P); a.set_batch(*batch)
+    b = FT.FinetuneTrainer(fcfg, mode="f32"); b.set_params(P)
+    dp = FT.DataParallel(b, 0, 1, lambda obj, src=0: obj)
+    x, y = a.train_step(1e-3), dp.train_step(batch, 1e-3)
+    assert x == y
+    pa, pb = a.get_params(), b.get_params()
+    assert all(np.array_equal(pa[k], pb[k]) for k in pa)
+    s0, s1 = FT.shard_batch(batch, 0, 2), FT.shard_batch(batch, 1, 2)
+    assert s0[0].shape[1] == 3 and np.array_equal(np.concatenate([s0[0], s1[0]], 1), batch[0]) and np.array_equal(np.concatenate([s0[5], s1[5]]), batch[5])
+    with pytest.raises(ValueError, match="does not divide"):
+        FT.shard_batch(batch, 0, 4)
+    a.close(); b.close()
