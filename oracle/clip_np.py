@@ -20,7 +20,7 @@ reference's own in-tree Flax mirror of it line by line:
   * weight names / layouts (openai state dict) . arp_dt/models/openai/model.py:220-314
 
 Parity status: UNPINNED by reference-held vectors (the reference has none).  Pinned instead by
-``tests/test_oracle_clip.py`` against HuggingFace ``CLIPModel`` (quick_gelu) on the same weights.
+``tests/test_oracle.py`` against HuggingFace ``CLIPModel`` (quick_gelu) on the same weights.
 """
 from dataclasses import dataclass
 

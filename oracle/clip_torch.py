@@ -5,7 +5,7 @@ independent cross-check of oracle/clip_np.py.
 It runs the pass the way the reference's CPU branch does (/root/reference/arp_dt/label_reward.py:89,
 132-146): a per-frame PIL transform loop (:109-121,134) followed by one batched fp32 forward of the
 openai/CLIP architecture (nn.MultiheadAttention semantics, QuickGELU, LayerNorm eps 1e-5).
-Parity status: unpinned by reference-held vectors; agrees with clip_np.py (tests/test_oracle_clip.py).
+Parity status: unpinned by reference-held vectors; agrees with clip_np.py (tests/test_oracle.py::test_torch_port_matches_numpy_oracle).
 """
 import numpy as np
 import torch

@@ -8,7 +8,7 @@ Follows /root/reference/arp_dt/label_reward.py:109-121 (default transform) and :
 
 torchvision's ``Resize`` on a PIL image is ``PIL.Image.resize`` (antialiased two-pass resample with
 22-bit fixed-point coefficients and a uint8 round/clamp after each pass).  The recipe below is the
-one in SURVEY.md Appendix A; ``tests/test_oracle_preprocess.py`` pins it bit-exactly against
+one in SURVEY.md Appendix A; ``tests/test_oracle.py`` pins it bit-exactly against
 Pillow itself.  Parity status: pinned against PIL (the library the reference calls), not against a
 reference-held fixture -- the reference has none.
 """

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses the rocprofv3 outputs of scripts/prof_r1.sh (gpurun_out/prof_<tag>_*) into the small
+"""Condenses the rocprofv3 outputs of scripts/prof_label.sh (gpurun_out/prof_<tag>_*) into the small
 files that are committed under profiles/:
 
   profiles/<tag>_kernel_stats.csv   -- rocprofv3 --kernel-trace --stats summary (as emitted)
