@@ -14,6 +14,11 @@
 //   * split-K over gridDim.y into f32 partial slabs (fixed-order reduction by splitk_reduce_kernel -- no atomics);
 //   * 16-bit operands only (the transposing read is a 16-bit instruction); the f32 parity mode keeps the transposed-copy path.
 //
+// Tried on the policy step's 768 x 768 x 32 896 weight gradients (0.075 ms each as built) and not kept: 32-row K-tiles at higher
+// occupancy (0.09 ms), four stages / one workgroup per CU (0.107 ms), every K-slice's tiles on one XCD for L2 sharing (0.10 ms with
+// 16 slices = 72 workgroups per XCD, 0.08 ms with 32-row tiles).  The contraction is bound by operand re-reads: 36 tiles x K x
+// 512 B = 606 MB per GEMM past L2; 256 x 256 tiles would halve that.
+//
 // Requirements: M, N multiples of 128; K a multiple of 64 with rows [K_valid, K) of BOTH operands zero (callers pad).
 #pragma once
 #include "common.h"
