@@ -72,7 +72,10 @@ struct arp_ft {
     bool has_comm = false;
     int world = 1, rank = 0;
 
-    size_t esz() const { return cfg.mode == ARP_MODE_BF16 ? 2 : 4; }
+    size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
+    // f16 mode: every gradient is seeded with this power-of-two factor (ft_loss_kernel) and carries it to the f32 gradient buffer;
+    // AdamW's gscale and arp_ft_get_tensor(which = 1) take it out.  bf16 / f32 have the range: 1.
+    float grad_scale() const { return cfg.mode == ARP_MODE_F16 ? 1024.f : 1.f; }
     int Dv() const { return cfg.layers * cfg.width_v; }
     int Dt() const { return cfg.layers * cfg.width_t; }
     int F() const { return cfg.layers * cfg.width_t + cfg.embed; }
@@ -278,7 +281,7 @@ template <typename T> int forward(arp_ft* c) {
                   Hi, Hi));
     hipLaunchKernelGGL(ft_loss_kernel, dim3(1), dim3(256), 0, c->stream, c->scores.as<float>(), c->r.as<float>(), c->logits.as<float>(), c->action.as<int>(),
                        B, NA, k.gamma, c->p("lambda_id"), k.use_vip, k.use_id, c->metrics.as<float>(), c->ds.as<float>(), c->dlogits.as<float>(),
-                       c->g("lambda_id"));
+                       c->g("lambda_id"), c->grad_scale());
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -357,9 +360,15 @@ int apply_update(arp_ft* c, float lr) {
         s0lo = a.off; s0hi = b.off + ((b.size + 3) & ~(size_t)3);
         s1lo = l.off; s1hi = l.off + 4;
     }
-    hipLaunchKernelGGL(ft_adamw_kernel, dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(), c->mu.as<float>(),
-                       c->nu.as<float>(), 1.0f / (float)std::max(c->world, 1), lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P,
-                       c->cfg.mode == ARP_MODE_BF16 ? c->mirror.as<bf16_t>() : nullptr, s0lo, s0hi, s1lo, s1hi);
+    const float gscale = 1.0f / ((float)std::max(c->world, 1) * c->grad_scale());
+#define ARP_FT_ADAMW(TM)                                                                                                                          \
+    hipLaunchKernelGGL((ft_adamw_kernel<TM>), dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(),        \
+                       c->mu.as<float>(), c->nu.as<float>(), gscale, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P, \
+                       c->mirror.as<TM>(), s0lo, s0hi, s1lo, s1hi)
+    if (c->cfg.mode == ARP_MODE_BF16) ARP_FT_ADAMW(bf16_t);
+    else if (c->cfg.mode == ARP_MODE_F16) ARP_FT_ADAMW(f16_t);
+    else ARP_FT_ADAMW(float);
+#undef ARP_FT_ADAMW
     ARP_HIP_OK(hipGetLastError());
     c->step += 1;
     c->transposed_stale = true;
@@ -395,9 +404,9 @@ extern "C" {
 int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
     if (!cfg || !out) return fail("null argument");
     const arp_ft_cfg& k = *cfg;
-    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16) return fail("bad mode");
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16 && k.mode != ARP_MODE_F16) return fail("bad mode");
     if (k.layers <= 0 || k.width_v <= 0 || k.width_t <= 0 || k.embed <= 0 || k.hidden <= 0 || k.n_actions <= 0) return fail("bad geometry");
-    const int kq = k.mode == ARP_MODE_BF16 ? 64 : 32;
+    const int kq = k.mode == ARP_MODE_F32 ? 32 : 64;
     const int F = k.layers * k.width_t + k.embed;
     // every contraction length of an MFMA GEMM must be a whole number of K-tiles
     for (int d : {k.layers * k.width_v, k.layers * k.width_t, F, k.hidden * (k.layers + 1), k.hidden})
@@ -417,7 +426,7 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
             ARP_HIP_OK(hipMemset(b->p, 0, c->P * 4));
         }
         const size_t e = c->esz(), Fd = c->F(), Hd = c->Hd(), Hi = k.hidden;
-        if (k.mode == ARP_MODE_BF16) ARP_TRY(c->mirror.ensure(c->P * e));
+        if (k.mode != ARP_MODE_F32) ARP_TRY(c->mirror.ensure(c->P * e));
         for (int w = 0; w < 2; ++w) { ARP_TRY(c->sW1t[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2t[w].ensure(Hd * Fd * e)); }
         ARP_TRY(c->sV1t.ensure(Hi * 4 * Fd * e));
         return 0;
@@ -482,6 +491,10 @@ static int ft_tensor_io(arp_ft* c, const char* name, int which, float* host, int
         if (which == 0) c->shadows_stale = true;
     } else {
         ARP_HIP_OK(hipMemcpy(host, dev, pi.size * 4, hipMemcpyDeviceToHost));
+        if (which == 1 && c->grad_scale() != 1.f) {  // gradients carry the f16 mode's seed scale on the device
+            const float inv = 1.0f / c->grad_scale();
+            for (size_t i = 0; i < pi.size; ++i) host[i] *= inv;
+        }
     }
     return 0;
 }
@@ -539,7 +552,7 @@ int arp_ft_forward(arp_ft* c, float* metrics4, float* scores, float* logits) {
     if (!c) return fail("null handle");
     if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : forward<float>(c));
+    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : (c->cfg.mode == ARP_MODE_F16 ? forward<f16_t>(c) : forward<float>(c)));
     if (metrics4) ARP_HIP_OK(hipMemcpyAsync(metrics4, c->metrics.p, 16, hipMemcpyDeviceToHost, c->stream));
     if (scores) ARP_HIP_OK(hipMemcpyAsync(scores, c->scores.p, (size_t)3 * c->B * 4, hipMemcpyDeviceToHost, c->stream));
     if (logits) ARP_HIP_OK(hipMemcpyAsync(logits, c->logits.p, (size_t)c->B * c->cfg.n_actions * 4, hipMemcpyDeviceToHost, c->stream));
@@ -559,6 +572,7 @@ int arp_ft_encode(arp_ft* c, int which, const float* inter, const float* final_f
     ARP_HIP_OK(hipMemcpyAsync(c->x_in[which].p, inter, (size_t)n * Din * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipMemcpyAsync(c->x_fin[which].p, final_feat, (size_t)n * c->cfg.embed * 4, hipMemcpyHostToDevice, c->stream));
     if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(refresh_shadows<bf16_t>(c)); ARP_TRY(encode_tower<bf16_t>(c, which, n)); }
+    else if (c->cfg.mode == ARP_MODE_F16) { ARP_TRY(refresh_shadows<f16_t>(c)); ARP_TRY(encode_tower<f16_t>(c, which, n)); }
     else { ARP_TRY(refresh_shadows<float>(c)); ARP_TRY(encode_tower<float>(c, which, n)); }
     ARP_HIP_OK(hipMemcpyAsync(out, c->a[which].p, (size_t)n * c->F() * 4, hipMemcpyDeviceToHost, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
@@ -570,6 +584,7 @@ int arp_ft_backward(arp_ft* c) {
     if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(forward<bf16_t>(c)); ARP_TRY(backward<bf16_t>(c)); }
+    else if (c->cfg.mode == ARP_MODE_F16) { ARP_TRY(forward<f16_t>(c)); ARP_TRY(backward<f16_t>(c)); }
     else { ARP_TRY(forward<float>(c)); ARP_TRY(backward<float>(c)); }
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
@@ -579,12 +594,14 @@ int arp_ft_train_step_async(arp_ft* c, float lr) {
     if (!c) return fail("null handle");
     if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_F16) return step_impl<f16_t>(c, lr, nullptr);
     return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, nullptr) : step_impl<float>(c, lr, nullptr);
 }
 int arp_ft_train_step(arp_ft* c, float lr, float* aux4) {
     if (!c || !aux4) return fail("null argument");
     if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (c->cfg.mode == ARP_MODE_F16) return step_impl<f16_t>(c, lr, aux4);
     return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, aux4) : step_impl<float>(c, lr, aux4);
 }
 int arp_ft_sync(arp_ft* c) {

@@ -62,7 +62,9 @@ static __global__ __launch_bounds__(256) void ft_loss_kernel(const float* __rest
                                                              const int* __restrict__ action, int B, int NA, float gamma,
                                                              const float* __restrict__ lambda_id, int use_vip, int use_id,
                                                              float* __restrict__ metrics, float* __restrict__ ds, float* __restrict__ dlogits,
-                                                             float* __restrict__ dlambda) {
+                                                             float* __restrict__ dlambda, float gs = 1.f) {
+    // gs: power-of-two scale on every gradient this kernel seeds (f16 mode: the 16-bit gradient activations downstream would sit
+    // below binary16's normal range otherwise); everything after it is linear, AdamW / arp_ft_get_tensor take it out again
     __shared__ float red[4];
     const float lam = lambda_id[0];
     float s0 = 0.f, er = 0.f, ee = 0.f, ce = 0.f;
@@ -78,7 +80,7 @@ static __global__ __launch_bounds__(256) void ft_loss_kernel(const float* __rest
         const float lse = logf(sum) + mx;
         ce += lse - l[action[b]];
         for (int c = 0; c < NA; ++c)
-            dlogits[(size_t)b * NA + c] = use_id ? lam * (expf(l[c] - lse) - (c == action[b] ? 1.f : 0.f)) / (float)B : 0.f;
+            dlogits[(size_t)b * NA + c] = use_id ? gs * lam * (expf(l[c] - lse) - (c == action[b] ? 1.f : 0.f)) / (float)B : 0.f;
     }
     s0 = ft_block_sum(s0, red);
     er = ft_block_sum(er, red);
@@ -90,16 +92,16 @@ static __global__ __launch_bounds__(256) void ft_loss_kernel(const float* __rest
     for (int b = threadIdx.x; b < B; b += 256) {
         const float e = expf(-(gamma * s[2 * B + b] - s[B + b]));
         const float w = use_vip ? Rm * e / ((float)B * (1e-8f + Z)) : 0.f;
-        ds[b] = use_vip ? -(1.f - gamma) / (float)B : 0.f;
-        ds[B + b] = w;
-        ds[2 * B + b] = -gamma * w;
+        ds[b] = use_vip ? gs * -(1.f - gamma) / (float)B : 0.f;
+        ds[B + b] = gs * w;
+        ds[2 * B + b] = gs * -gamma * w;
     }
     if (threadIdx.x == 0) {
         metrics[0] = (use_vip ? vip : 0.f) + (use_id ? lam * idl : 0.f);
         metrics[1] = vip;
         metrics[2] = idl;
         metrics[3] = lam;
-        dlambda[0] = use_id ? idl : 0.f;
+        dlambda[0] = use_id ? gs * idl : 0.f;
     }
 }
 
@@ -161,9 +163,10 @@ static __global__ __launch_bounds__(256) void ft_mix_norm_bwd_kernel(const float
 // torch.optim.AdamW: decoupled decay on EVERY parameter (finetune.py:141 passes model.parameters()), bias correction
 // mirror (bf16 mode): the operand-type copy of the whole flat parameter vector, refreshed here so that the next step's
 // forward GEMMs need no separate conversion pass over the f32 parameters.
+template <typename TM>
 static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
                                                               float* __restrict__ nu, float gscale, float lr, float wd, float b1, float b2,
-                                                              float eps, float bc1, float bc2, size_t n, bf16_t* __restrict__ mirror,
+                                                              float eps, float bc1, float bc2, size_t n, TM* __restrict__ mirror,
                                                               size_t skip0_lo, size_t skip0_hi, size_t skip1_lo, size_t skip1_hi) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -178,7 +181,9 @@ static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict_
     const float pd = p[i] * (1.f - lr * wd);
     const float pn = pd - (lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + eps);
     p[i] = pn;
-    if (mirror) mirror[i] = f2bf(pn);
+    if constexpr (sizeof(TM) == 2) {
+        if (mirror) Elem<TM>::st(mirror + i, pn);
+    }
 }
 
 }  // namespace arp

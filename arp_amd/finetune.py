@@ -16,7 +16,7 @@ import numpy as np
 from . import _ffi
 from ._ffi import check, lib
 
-MODES = {"f32": _ffi.MODE_F32, "bf16": _ffi.MODE_BF16}
+MODES = {"f32": _ffi.MODE_F32, "bf16": _ffi.MODE_BF16, "f16": _ffi.MODE_F16}
 AUX_KEYS = ("loss", "vip_loss", "id_loss", "lambda_id")
 
 
@@ -248,7 +248,7 @@ class FinetunedClip:
         cw = {k[len("clip_model."):]: v for k, v in sd.items() if k.startswith("clip_model.")}
         ccfg = aclip.MODELS[model] if isinstance(model, str) else model
         towers = aclip.ClipLabeller(ccfg, cw, mode=mode, device=device)  # "f16" applies to the towers only
-        mode = "bf16" if mode == "f16" else mode                         # the head kernels know bf16 / f32
+        # (the head has its own f16 mode since round 2: the same operand type end to end)
         ls = float(cw["logit_scale"]) if logit_scale is None else float(logit_scale)  # model.logit_scale = clip's, detached (:95)
         hidden = sd["inverse_layer.layers.0.weight"].shape[0]
         head = FinetuneTrainer(FinetuneConfig(layers=ccfg.layers, width_v=ccfg.width, width_t=ccfg.txt_width, embed=ccfg.embed, hidden=hidden,

@@ -358,9 +358,7 @@ def main():
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
     a = ap.parse_args()
     if a.mode is None:
-        a.mode = "bf16" if a.path == "finetune" else "f16"
-    if a.path == "finetune" and a.mode == "f16":
-        raise SystemExit("--mode f16: the fine-tune head kernels know bf16 / f32")
+        a.mode = "f16"  # IEEE-half MFMA operands on every path: the 16-bit mode that meets the parity bars (bf16 stays selectable)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(a.gpus)  # plain `python bench.py --gpus N`: this process only launches the ranks (it never touches a GPU)
     if a.path == "policy":

@@ -61,27 +61,33 @@ def test_gradients_match_oracle(gpu_lib, use_vip, use_id):
     tr.close()
 
 
-def test_bf16_mode_tracks_oracle(gpu_lib):
+@pytest.mark.parametrize("mode,ltol,cmin", [("bf16", 5e-2, 0.99), ("f16", 5e-3, 0.9999)])
+def test_16bit_modes_track_oracle(gpu_lib, mode, ltol, cmin):
+    """f16 (round 2: IEEE-half operands, gradients seeded with a power-of-two scale that AdamW / get_tensor take out again) is
+    ~10x closer to the fp64 oracle than bf16 at the same MFMA rate."""
     from arp_amd import finetune as FT
     from oracle import finetune_torch as O
     cfg = O.HeadConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64)
     P = O.init_params(cfg, seed=5)
     batch = FT.synth_batch(FT.FinetuneConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64), 6, seed=6)
     g_ref, aux = O.grads(P, cfg, batch)
-    tr = _trainer(cfg, "bf16")
+    tr = _trainer(cfg, mode)
     tr.set_params(P)
     tr.set_batch(*batch)
     out = tr.forward()
-    assert abs(out["loss"] - aux["loss"]) < 5e-2 * max(1.0, abs(aux["loss"]))
+    print(f"{mode}: loss err {abs(out['loss'] - aux['loss']):.2e}")
+    assert abs(out["loss"] - aux["loss"]) < ltol * max(1.0, abs(aux["loss"]))
     tr.backward()
     g = tr.get_grads()
     num = sum(float(g[k].ravel().astype(np.float64) @ g_ref[k].ravel()) for k in g_ref)
     den = np.sqrt(sum(float((g[k].astype(np.float64) ** 2).sum()) for k in g_ref) * sum(float((g_ref[k] ** 2).sum()) for k in g_ref))
-    assert num / den > 0.99, num / den
+    nr = np.sqrt(sum(float((g[k].astype(np.float64) ** 2).sum()) for k in g_ref) / sum(float((g_ref[k] ** 2).sum()) for k in g_ref))
+    print(f"{mode}: gradient cosine {num / den:.6f}, norm ratio {nr:.5f}")
+    assert num / den > cmin and abs(nr - 1) < (5e-3 if mode == "f16" else 5e-2), (num / den, nr)
     tr.close()
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 5e-3)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("f16", 1e-3), ("bf16", 5e-3)])
 def test_train_steps_match_torch_adamw(gpu_lib, mode, tol):
     from arp_amd import finetune as FT
     from oracle import finetune_torch as O
