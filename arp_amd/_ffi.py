@@ -83,6 +83,7 @@ SIGNATURES = {
     "arp_clip_create": (_i, [C.POINTER(ClipCfg), C.POINTER(_vp)]),
     "arp_clip_destroy": (_i, [_vp]),
     "arp_clip_load_weight": (_i, [_vp, C.c_char_p, _fp, _i64p, _i]),
+    "arp_clip_set_fp8_mlp": (_i, [_vp, _i]),
     "arp_clip_finalize_weights": (_i, [_vp]),
     "arp_clip_set_text": (_i, [_vp, _i32p, _i]),
     "arp_clip_get_text_features": (_i, [_vp, _fp]),
@@ -159,6 +160,7 @@ SIGNATURES = {
     "arp_h5_inflate_last_frames": (_i, [_i, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _u8p, C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _u8p, _i]),
     "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
+    "arp_op_gemm_fp8": (_i, [_i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _f]),
     "arp_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "arp_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f]),
     "arp_op_attention": (_i, [_i, _i, _fp, _fp, _i, _i, _i, _i, _i]),

@@ -111,7 +111,10 @@ class ClipLabeller:
     the fp32 reference at the bf16 rate), "bf16" (same rate, 8-bit significands: 3-8e-4) or "f32" (f32-input MFMA, 1e-7).
     """
 
-    def __init__(self, cfg, state_dict, mode="f16", device=0, max_batch=1024, attn_impl=0, n_streams=3):
+    def __init__(self, cfg, state_dict, mode="f16", device=0, max_batch=1024, attn_impl=0, n_streams=3, fp8_mlp=False):
+        """fp8_mlp: run the vision tower's c_fc / c_proj GEMMs on e4m3 operands (scaled fp8 MFMA, twice the 16-bit rate) -- the
+        "fp8 MFMA GEMMs" of BASELINE configs[4]: a throughput mode for the FROZEN towers of the fine-tune step (features ~1e-2 off
+        the f32 towers), never the labelling default (1e-4 needs the 11 significand bits of f16)."""
         _ffi.require_gpu()
         self.cfg = cfg
         self.mode = {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32}[mode]
@@ -128,6 +131,8 @@ class ClipLabeller:
             a = np.require(np.asarray(val, dtype=np.float32), requirements="C")  # keeps 0-d (logit_scale) 0-d
             shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
             check(lib.arp_clip_load_weight(h, name.encode(), _ffi.as_ptr(a, C.c_float), shape, a.ndim))
+        if fp8_mlp:
+            check(lib.arp_clip_set_fp8_mlp(h, 1))
         check(lib.arp_clip_finalize_weights(h))
 
     def close(self):

@@ -233,6 +233,7 @@ struct arp_clip {
     // per-row loads and reductions land in the GEMM epilogues, which are the serialised part of every tile,
     // while the LayerNorm kernels they replace overlap with the other stream's GEMMs.  Off by default.
     bool ln_fold = false;
+    bool fp8_mlp = false;       // vision tower MLP GEMMs on the scaled fp8 MFMA (arp_clip_set_fp8_mlp before finalize; tower.h)
     bool qkv_fused = true;      // QKV projection + attention in one kernel (qkvattn.h) where the geometry allows; ARP_QKV_FUSED=0 disables
     bool cls_only_last = true;  // vision tower: the last block computes only what ln_post reads (tower.h); ARP_CLS_ONLY=0 disables
     DevBuf stats;
@@ -250,6 +251,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.attn_impl = c->cfg.attn_impl;
     t.gemm_force = c->gemm_force;
     t.qkv_fused = c->qkv_fused;
+    t.fp8_mlp = c->fp8_mlp;
     t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
     return t;
 }
@@ -341,6 +343,33 @@ static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers,
         ARP_TRY(get_staged(c, p + "mlp.c_fc.bias", {4 * d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_fc));
         ARP_TRY(get_staged(c, p + "mlp.c_proj.weight", {d, 4 * d}, &t)); ARP_TRY(upload_mat(c, t->data.data(), d, 4 * d, false, &L.w_proj, wmode));
         ARP_TRY(get_staged(c, p + "mlp.c_proj.bias", {d}, &t)); ARP_TRY(upload_f32(c, t->data, &L.b_proj));
+        if (c->fp8_mlp && ntok > 0 && emode != ARP_MODE_F32 && d % 128 == 0) {  // vision tower only (ntok is passed for it alone)
+            auto put8 = [&](const std::vector<float>& w, void** out, float* scale) -> int {
+                float mx = 0.f;
+                for (float v : w) mx = std::max(mx, fabsf(v));
+                const float sc = mx > 0.f ? exp2f(floorf(log2f(240.f / mx))) : 1.f;  // power of two: the largest weight lands in [120, 240]
+                std::vector<fp8_t> q(w.size());
+                for (size_t i = 0; i < w.size(); ++i) q[i] = host_f2fp8(w[i] * sc);
+                void* dp = nullptr;
+                ARP_HIP_OK(hipMalloc(&dp, q.size()));
+                ARP_HIP_OK(hipMemcpy(dp, q.data(), q.size(), hipMemcpyHostToDevice));
+                c->owned.push_back(dp);
+                *out = dp;
+                *scale = sc;
+                return 0;
+            };
+            const HostTensor *w1, *w2, *lw, *lb;
+            float s1 = 1.f, s2 = 1.f;
+            ARP_TRY(get_staged(c, p + "mlp.c_fc.weight", {4 * d, d}, &w1)); ARP_TRY(put8(w1->data, &L.w_fc8, &s1));
+            ARP_TRY(get_staged(c, p + "mlp.c_proj.weight", {d, 4 * d}, &w2)); ARP_TRY(put8(w2->data, &L.w_proj8, &s2));
+            L.a_fc = 1.0f / (FP8_S_H * s1);
+            L.a_proj = 1.0f / (FP8_S_G * s2);
+            ARP_TRY(get_staged(c, p + "ln_2.weight", {d}, &lw)); ARP_TRY(get_staged(c, p + "ln_2.bias", {d}, &lb));
+            std::vector<float> g8(lw->data), b8(lb->data);
+            for (auto& v : g8) v *= FP8_S_H;
+            for (auto& v : b8) v *= FP8_S_H;
+            ARP_TRY(upload_f32(c, g8, &L.ln2_w8)); ARP_TRY(upload_f32(c, b8, &L.ln2_b8));
+        }
         if (fold) {  // LayerNorm folded into in_proj (ln_1) and c_fc (ln_2): tower.h fold_layernorm
             const HostTensor *w, *b, *lw, *lb;
             std::vector<bf16_t> wf;
@@ -956,6 +985,15 @@ int arp_preprocess(const uint8_t* frames, int n, int H, int W, int use_crop, int
     return rc;
 }
 
+int arp_clip_set_fp8_mlp(arp_clip* c, int on) {
+    if (!c) return fail("null handle");
+    if (c->finalized) return fail("arp_clip_set_fp8_mlp must come before arp_clip_finalize_weights (the e4m3 weight copies are made there)");
+    if (on && c->cfg.mode == ARP_MODE_F32) return fail("fp8 MLP needs a 16-bit mode for the rest of the tower");
+    if (on && c->cfg.width % 128) return fail("fp8 MLP needs width % 128 == 0");
+    c->fp8_mlp = on != 0;
+    return 0;
+}
+
 int arp_clip_set_streams(arp_clip* c, int n_streams) {
     if (!c || n_streams < 0 || n_streams > 4) return fail("n_streams must be 0..4");
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
@@ -1098,6 +1136,60 @@ int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const floa
     if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0) return fail("bad argument");
     if (mode == ARP_MODE_F16) return op_gemm<f16_t>(act, A, W, bias, resid, out, M, N, K);
     return mode == ARP_MODE_BF16 ? op_gemm<bf16_t>(act, A, W, bias, resid, out, M, N, K) : op_gemm<float>(act, A, W, bias, resid, out, M, N, K);
+}
+
+}  // extern "C"
+
+// e4m3 bits -> f32 on the host (test hook below)
+static float host_fp82f(uint8_t b) {
+    const int sign = b >> 7, e = (b >> 3) & 15, m = b & 7;
+    float v;
+    if (e == 15 && m == 7) v = NAN;
+    else if (e == 0) v = ldexpf((float)m, -9);
+    else v = ldexpf(1.0f + m / 8.0f, e - 7);
+    return sign ? -v : v;
+}
+
+extern "C" {
+
+// Test hook for the fp8 instances of gemm256_nt_kernel: A [M,K] and W [N,K] are rounded to e4m3 on the host (pass values that are
+// already representable for an exact check), out = act(alpha * A.W^T + bias) (+ resid) as f32, or (out_fp8) quantised to e4m3 after
+// a multiplication by out_scale and returned decoded.
+int arp_op_gemm_fp8(int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N, int K, float alpha,
+                    int out_fp8, float out_scale) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || K % 128 || N % 16) return fail("bad argument (K % 128, N % 16)");
+    if (out_fp8 && resid) return fail("fp8 output has no residual epilogue");
+    DevBuf dA, dW, dB, dR, dO;
+    auto body = [&]() -> int {
+        std::vector<fp8_t> qa((size_t)M * K), qw((size_t)N * K);
+        for (size_t i = 0; i < qa.size(); ++i) qa[i] = host_f2fp8(A[i]);
+        for (size_t i = 0; i < qw.size(); ++i) qw[i] = host_f2fp8(W[i]);
+        ARP_TRY(dA.ensure(qa.size())); ARP_TRY(dW.ensure(qw.size()));
+        ARP_HIP_OK(hipMemcpy(dA.p, qa.data(), qa.size(), hipMemcpyHostToDevice));
+        ARP_HIP_OK(hipMemcpy(dW.p, qw.data(), qw.size(), hipMemcpyHostToDevice));
+        if (bias) ARP_TRY(to_dev<float>(bias, N, dB));
+        if (resid) ARP_TRY(to_dev<float>(resid, (size_t)M * N, dR));
+        ARP_TRY(dO.ensure((size_t)M * N * 4));
+        GemmArgs g;
+        g.A = dA.p; g.W = dW.p; g.bias = bias ? dB.as<float>() : nullptr; g.resid = resid ? dR.as<float>() : nullptr; g.out = dO.p;
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N; g.alpha = alpha; g.out_scale = out_scale;
+        int rc;
+        if (out_fp8) rc = act == ACT_QGELU ? launch_gemm256_nt<fp8_t, fp8_t, ACT_QGELU, false, SITE_OP>(g, nullptr) : launch_gemm256_nt<fp8_t, fp8_t, ACT_NONE, false, SITE_OP>(g, nullptr);
+        else if (act != ACT_NONE) return fail("f32 output: act must be ACT_NONE");
+        else rc = resid ? launch_gemm256_nt<fp8_t, float, ACT_NONE, true, SITE_OP>(g, nullptr) : launch_gemm256_nt<fp8_t, float, ACT_NONE, false, SITE_OP>(g, nullptr);
+        ARP_TRY(rc);
+        ARP_HIP_OK(hipDeviceSynchronize());
+        if (out_fp8) {
+            std::vector<uint8_t> hb((size_t)M * N);
+            ARP_HIP_OK(hipMemcpy(hb.data(), dO.p, hb.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < hb.size(); ++i) out[i] = host_fp82f(hb[i]);
+            return 0;
+        }
+        return from_dev<float>(out, (size_t)M * N, dO);
+    };
+    const int rc = body();
+    dA.release(); dW.release(); dB.release(); dR.release(); dO.release();
+    return rc;
 }
 
 }  // extern "C"

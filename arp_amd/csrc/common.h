@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -10,6 +11,9 @@ namespace arp {
 typedef uint16_t bf16_t;  // raw bf16 bits; arithmetic always happens in f32
 // raw IEEE binary16 bits as a distinct type (ARP_MODE_F16: same MFMA rate as bf16, 11 significand bits instead of 8)
 struct f16_t { uint16_t b; };
+// raw OCP e4m3fn bits (no infinities, max 448, NaN = 0x7f / 0xff): operand type of the scaled fp8 MFMA (BASELINE configs[4])
+struct fp8_t { uint8_t b; };
+typedef __attribute__((ext_vector_type(8))) int i32x8_v;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_v;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_v;
@@ -63,6 +67,25 @@ template <typename T> __device__ __forceinline__ f32x4_v mfma16(u32x4_v a, u32x4
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
 }
 
+// ---- fp8 (e4m3fn) helpers: conversions saturate to +-448 (the format has no infinity; an overflow would read back as NaN) -------
+constexpr float FP8_MAX = 448.f;
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -FP8_MAX, FP8_MAX); b = __builtin_amdgcn_fmed3f(b, -FP8_MAX, FP8_MAX);
+    c = __builtin_amdgcn_fmed3f(c, -FP8_MAX, FP8_MAX); d = __builtin_amdgcn_fmed3f(d, -FP8_MAX, FP8_MAX);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+// one v_mfma_scale_f32_16x16x128_f8f6f4 on e4m3 operands with unit block scales: 32 bytes of K per lane and operand, twice the
+// FLOPs per cycle of the 16-bit 16x16x32 form.  The two 16-byte halves may hold ANY 32 of the 128 k-values as long as both
+// operands use the same assignment (the product is a sum over k).
+__device__ __forceinline__ f32x4_v mfma_fp8(u32x4_v a0, u32x4_v a1, u32x4_v b0, u32x4_v b1, f32x4_v c) {
+    const i32x8_v a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+    const i32x8_v b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);  // cbsz = blgp = 0: e4m3; scale 2^0
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -77,6 +100,17 @@ template <> struct Elem<f16_t> {
     static __device__ __forceinline__ float ld(const f16_t* p) { return h2f(*p); }
     static __device__ __forceinline__ void st(f16_t* p, float v) { *p = f2h(v); }
 };
+
+template <> struct Elem<fp8_t> {
+    static __device__ __forceinline__ float ld(const fp8_t* p) { return __builtin_amdgcn_cvt_f32_fp8((int)p->b, 0); }
+    static __device__ __forceinline__ void st(fp8_t* p, float v) { p->b = (uint8_t)(pack_fp8x4(v, 0.f, 0.f, 0.f) & 0xffu); }
+};
+__device__ __forceinline__ void store4(fp8_t* p, float a, float b, float c, float d) { *reinterpret_cast<uint32_t*>(p) = pack_fp8x4(a, b, c, d); }
+__device__ __forceinline__ void load4(const fp8_t* p, float (&v)[4]) {
+    const int w = *reinterpret_cast<const int*>(p);
+    v[0] = __builtin_amdgcn_cvt_f32_fp8(w, 0); v[1] = __builtin_amdgcn_cvt_f32_fp8(w, 1);
+    v[2] = __builtin_amdgcn_cvt_f32_fp8(w, 2); v[3] = __builtin_amdgcn_cvt_f32_fp8(w, 3);
+}
 
 // store 4 consecutive values (16-B aligned for float, 8-B aligned for bf16)
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
@@ -167,6 +201,29 @@ static inline f16_t host_f2h(float f) {
     if (rem > half || (rem == half && (q & 1u))) ++q;
     uint32_t h = e >= -14 ? (((uint32_t)(e + 15) << 10) + (q - 0x400u)) : q;  // carries propagate into the exponent
     return f16_t{(uint16_t)(sign | h)};
+}
+
+// host-side f32 -> e4m3fn (RNE, saturating at +-448, subnormals down to 2^-9)
+static inline fp8_t host_f2fp8(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+    float a = fabsf(f);
+    if (!(a == a)) return fp8_t{(uint8_t)(sign | 0x7f)};  // NaN
+    if (a >= 448.f) return fp8_t{(uint8_t)(sign | 0x7e)};   // saturate: 0x7e = 448
+    if (a < 0.0009765625f) return fp8_t{sign};              // < 2^-10: rounds to zero (half the smallest subnormal 2^-9)
+    int e;
+    const float m = frexpf(a, &e);                          // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                                          // a = (2m) * 2^E, 2m in [1, 2)
+    if (E < -6) {                                           // subnormal: units of 2^-9
+        const float q = nearbyintf(a * 512.f);              // RNE (default rounding mode)
+        const int qi = (int)q;
+        return fp8_t{(uint8_t)(sign | (qi >= 8 ? 0x08 : qi))};  // 8 units = the smallest normal
+    }
+    float q = nearbyintf((2.f * m - 1.f) * 8.f);            // 3 mantissa bits
+    if (q >= 8.f) { q = 0.f; E += 1; }
+    if (E > 8 || (E == 8 && q > 6.f)) return fp8_t{(uint8_t)(sign | 0x7e)};
+    return fp8_t{(uint8_t)(sign | ((E + 7) << 3) | (int)q)};
 }
 
 }  // namespace arp

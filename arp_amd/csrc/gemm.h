@@ -44,8 +44,9 @@ struct GemmArgs {
     int group_m = 0;          // gemm256: tile-rows per L2 group (0 = default)
     int stagger_groups = 0;   // >1: the first wave of workgroups starts in `stagger_groups` phase groups spread over
     int stagger_cycles = 0;   //     `stagger_cycles` shader cycles, so CUs do not all reach their store epilogue together
-    float alpha = 1.f;        // out = act(alpha * (A.W^T) + bias) (+ resid); honoured by gemm_nt_kernel only -- launch_gemm_auto routes
-                              // alpha != 1 there (power-of-two un-scaling of f16 gradient GEMMs, arp_dt.hip)
+    float alpha = 1.f;        // out = act(alpha * (A.W^T) + bias) (+ resid); honoured by gemm_nt_kernel (launch_gemm_auto routes alpha != 1
+                              // there: power-of-two un-scaling of f16 gradient GEMMs, arp_dt.hip) and by the fp8 instances of gemm256
+    float out_scale = 1.f;    // fp8 output only: the stored value is out_scale * act(...) (the consumer's alpha takes it out again)
     int ovl = 0;              // gemm256, 16-bit output: a workgroup with another tile to do drains this tile's stores under that tile's first phases
 };
 

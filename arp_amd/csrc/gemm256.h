@@ -201,6 +201,10 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                 for (int mi = 0; mi < 4; ++mi) {
                     if constexpr (sizeof(T) == 2) {
                         acc[mq][nq][ni][mi] = mfma16<T>(breg[nq][ni][ks], areg[mi][ks], acc[mq][nq][ni][mi]);
+                    } else if constexpr (sizeof(T) == 1) {
+                        // fp8: the K-tile's 128 bytes per row are ONE 16x16x128 step; both register halves go into a single MFMA
+                        if (ks == 0)
+                            acc[mq][nq][ni][mi] = mfma_fp8(breg[nq][ni][0], breg[nq][ni][1], areg[mi][0], areg[mi][1], acc[mq][nq][ni][mi]);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -400,9 +404,41 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     // leaves the CU as 16-byte-per-lane stores of 512 B (bf16) / 1 KiB (f32) contiguous runs -- whole
     // 128-B lines -- instead of 32 eight-byte stores per lane into 32-B row fragments; the residual is
     // read the same way.  (Direct per-fragment stores measured 118 us of a 358 us c_fc launch.)
-    const bool staged = vec_ok && ((g.N | g.ldo) & 7) == 0 && !(g.flags & 2);
+    const bool staged = vec_ok && ((g.N | g.ldo) & (sizeof(OutT) == 1 ? 15 : 7)) == 0 && !(g.flags & 2);
     if (staged) {
-        if constexpr (sizeof(OutT) == 2) {
+        if constexpr (sizeof(OutT) == 1) {
+            // fp8 output (the MLP's hidden activation): out_scale * act(alpha * acc + bias), 4 values per dword, 256-B rows out
+            constexpr int RS8 = 256 + 16;
+#pragma unroll
+            for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    const int row = wr * 128 + mq * 64 + mi * 16 + fr;
+#pragma unroll
+                    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
+                            const f32x4_v a4 = acc[mq][nq][ni][mi];
+                            float v[4] = {a4[0] * g.alpha, a4[1] * g.alpha, a4[2] * g.alpha, a4[3] * g.alpha};
+                            if (g.bias && n0 + col < g.N) {
+                                const float4 b = *reinterpret_cast<const float4*>(bias_s + col);
+                                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, true>(v[j]) * g.out_scale;
+                            *reinterpret_cast<uint32_t*>(smem + row * RS8 + col) = pack_fp8x4(v[0], v[1], v[2], v[3]);
+                        }
+                }
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 32 + wave * 4 + (lane >> 4);
+                const int m = m0 + r, n = n0 + (lane & 15) * 16;
+                if (m < g.M && n < g.N)
+                    *reinterpret_cast<u32x4_v*>(reinterpret_cast<char*>(out) + (size_t)m * g.ldo + n) = *reinterpret_cast<const u32x4_v*>(smem + r * RS8 + (lane & 15) * 16);
+            }
+        } else if constexpr (sizeof(OutT) == 2) {
             constexpr int RS = 256 * 2 + 16;  // +16 B pad: fragment rows land on different banks
 #pragma unroll
             for (int mq = 0; mq < 2; ++mq)
@@ -418,6 +454,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                             const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
                             const f32x4_v a4 = acc[mq][nq][ni][mi];
                             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                            if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
                             if (g.ln_stats && n0 + col < g.N) {
                                 const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n0 + col);
                                 v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
@@ -428,7 +465,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                             }
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                            for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) <= 2>(v[j]);
                             *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
                         }
                 }
@@ -510,12 +547,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                             const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
                             const f32x4_v a4 = acc[p][nq][ni][mi];
                             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                            if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
                             if (g.bias && n0 + col < g.N) {
                                 const float4 b = *reinterpret_cast<const float4*>(bias_s + col);
                                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                             }
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                            for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) <= 2>(v[j]);
                             *reinterpret_cast<float4*>(smem + lrow * RSF + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                 __syncthreads();
@@ -562,13 +600,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                     if (n >= g.N) continue;
                     const f32x4_v a4 = acc[mq][nq][ni][mi];
                     float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                    if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
                     if (vec_ok) {
                         if (g.bias) {
                             const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
                             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) == 2>(v[j]);
+                        for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) <= 2>(v[j]);
                         if constexpr (RESID) {
                             const float4 r = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
                             v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
@@ -579,7 +618,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                         for (int j = 0; j < 4; ++j) {
                             if (n + j >= g.N) break;
                             float x = v[j] + (g.bias ? g.bias[n + j] : 0.f);
-                            x = apply_act<ACT, sizeof(T) == 2>(x);
+                            x = apply_act<ACT, sizeof(T) <= 2>(x);
                             if constexpr (RESID) x += g.resid[(size_t)m * g.ldr + n + j];
                             Elem<OutT>::st(out + (size_t)m * g.ldo + n + j, x);
                         }

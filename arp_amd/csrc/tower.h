@@ -20,6 +20,11 @@ struct LayerW {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *b_in, *b_out, *b_fc, *b_proj;
     void *w_in, *w_out, *w_fc, *w_proj;
     // LayerNorm-folded operands (bf16 mode): W' = W diag(gamma), c = row sums of W', d = W beta + bias
+    // fp8 MLP (BASELINE configs[4] "fp8 MFMA GEMMs"; TowerCtx::fp8_mlp): e4m3 copies of c_fc / c_proj scaled by per-tensor powers
+    // of two, ln_2's gain and bias pre-multiplied by the activation scale, and the factors that take the scales out again
+    void *w_fc8 = nullptr, *w_proj8 = nullptr;
+    float *ln2_w8 = nullptr, *ln2_b8 = nullptr;
+    float a_fc = 1.f, a_proj = 1.f;
     // head-major in-proj operands of the fused QKV + attention kernel (qkvattn.h): rows h*192 + {q | k | v of head h}
     void* w_in_hm = nullptr;
     float* b_in_hm = nullptr;
@@ -110,6 +115,10 @@ struct TowerCtx {
     bool cls_only_last = false;
     int attn_impl = 0;   // 0 = MFMA attention where available, 1 = VALU kernel
     int gemm_force = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel
+    // c_fc / c_proj on the scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4: twice the 16-bit rate): ln_2 writes e4m3 (x 32), c_fc
+    // reads it and writes QuickGELU x 16 as e4m3, c_proj reads that; accumulation, bias, residual stream stay f32.  Three
+    // significand bits: a lower-precision THROUGHPUT mode for the frozen towers of the fine-tune step, not the labelling default.
+    bool fp8_mlp = false;
     bool qkv_fused = true;  // QKV projection + attention in one kernel where qkvattn.h supports the geometry (ARP_QKV_FUSED=0 disables)
     // multi-scale export: after every block, one row per sample of the residual stream -- what the forward
     // hooks of finetune_module/utils.py:6-18 capture on each resblock output -- is copied to ms_out[b, layer*D ..]
@@ -239,6 +248,30 @@ static int tower_qkv_attention(TowerCtx& c, const TowerW& tw, const LayerW& L, c
     return launch_attention<T>(c.stream, c.attn_impl, qkv, ao, B, N, D, tw.heads, causal, nq);
 }
 
+constexpr float FP8_S_H = 32.f, FP8_S_G = 16.f;  // activation scales of the fp8 MLP: LayerNorm output, QuickGELU output
+
+// ln_2 -> c_fc -> c_proj on fp8 operands (256 x 256 kernel only: M >= 1 row block of the big GEMMs)
+template <typename T, int ACT, int SB>
+static int tower_mlp_fp8(TowerCtx& c, const LayerW& L, const char* s_ln2, const char* s_fc1, const char* s_fc2, float* x, T* h, T* fc, int M, int D, float eps) {
+    fp8_t* h8 = reinterpret_cast<fp8_t*>(h);
+    fp8_t* fc8 = reinterpret_cast<fp8_t*>(fc);
+    ARP_TRY(tower_layernorm<fp8_t>(c, s_ln2, x, D, h8, D, L.ln2_w8, L.ln2_b8, M, D, eps));
+    GemmArgs g;
+    g.A = h8; g.W = L.w_fc8; g.bias = L.b_fc; g.resid = nullptr; g.out = fc8;
+    g.M = M; g.N = 4 * D; g.K = D; g.lda = D; g.ldw = D; g.ldr = 4 * D; g.ldo = 4 * D;
+    g.alpha = L.a_fc; g.out_scale = FP8_S_G;
+    {
+        ProfScope ps(*c.prof, c.stream, s_fc1);
+        ARP_TRY((launch_gemm256_nt<fp8_t, fp8_t, ACT, false, SB + SITE_FC1>(g, c.stream)));
+    }
+    GemmArgs q;
+    q.A = fc8; q.W = L.w_proj8; q.bias = L.b_proj; q.resid = x; q.out = x;
+    q.M = M; q.N = D; q.K = 4 * D; q.lda = 4 * D; q.ldw = 4 * D; q.ldr = D; q.ldo = D;
+    q.alpha = L.a_proj;
+    ProfScope ps(*c.prof, c.stream, s_fc2);
+    return launch_gemm256_nt<fp8_t, float, ACT_NONE, true, SB + SITE_FC2>(q, c.stream);
+}
+
 // 12 x ResidualAttentionBlock (arp_dt/models/openai/layers.py:235-271) on the f32 residual stream x.
 // ACT: MLP activation (QuickGELU for CLIP, tanh-GELU for the M3AE encoder); eps: LayerNorm epsilon;
 // SB: site-id base so that every call site is its own kernel instantiation in a rocprof trace.
@@ -294,9 +327,14 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
         ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));
         ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn.c_str(), s_qa.c_str(), h, qkv, ao, B, N, causal, 0)));
         ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out.c_str(), ao, L.w_out, L.b_out, x, x, M, D, D)));
-        ARP_TRY(tower_layernorm<T>(c, s_ln2.c_str(), x, D, h, D, L.ln2_w, L.ln2_b, M, D, eps));
-        ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc1.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, M, 4 * D, D)));
-        ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_FC2>(c, s_fc2.c_str(), fc, L.w_proj, L.b_proj, x, x, M, D, 4 * D)));
+        if (sizeof(T) == 2 && c.fp8_mlp && L.w_fc8 && (D % 128) == 0) {
+            const std::string s_fc18 = t + ".c_fc_fp8", s_fc28 = t + ".c_proj_fp8";
+            ARP_TRY((tower_mlp_fp8<T, ACT, SB>(c, L, s_ln2.c_str(), s_fc18.c_str(), s_fc28.c_str(), x, h, fc, M, D, eps)));
+        } else {
+            ARP_TRY(tower_layernorm<T>(c, s_ln2.c_str(), x, D, h, D, L.ln2_w, L.ln2_b, M, D, eps));
+            ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc1.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, M, 4 * D, D)));
+            ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_FC2>(c, s_fc2.c_str(), fc, L.w_proj, L.b_proj, x, x, M, D, 4 * D)));
+        }
         ARP_TRY(tower_export_rows(c, x, D, i, B, N));
     }
     return 0;

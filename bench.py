@@ -261,7 +261,7 @@ def bench_finetune(a):
         # frames in: the frozen CLIP ViT-B/16 towers (random init) produce the per-block CLS / EOT features every step;
         from arp_amd import clip, synth
         ccfg = clip.MODELS["ViT-B/16"]
-        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=local_rank, max_batch=3 * B)
+        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=local_rank, max_batch=3 * B, fp8_mlp=a.fp8_mlp)
         frames = np.concatenate([synth.procgen_like_frames(B, seed=200 + k) for k in range(3)])  # image0 | image1 | image2
         tokens = synth.prompt_tokens(B, [8] * B, seed=203)
         rb = FT.synth_batch(cfg, B, seed=100 + rank)
@@ -316,7 +316,8 @@ def bench_finetune(a):
                   "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": world * a.finetune_batch * a.steps / elapsed,
         "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
-        "config": {"workload": f"CLIPMultiscaleAdapter head train step, {a.finetune_batch} samples x 3 frames, ViT-B/16-shaped tower features "
+        "config": {"towers": None if towers is None else ("ViT-B/16, " + a.mode + (" + fp8 (e4m3) c_fc / c_proj" if a.fp8_mlp else "")),
+                   "workload": f"CLIPMultiscaleAdapter head train step, {a.finetune_batch} samples x 3 frames, ViT-B/16-shaped tower features "
                                f"[3,B,9216]+[3,B,512] / [B,6144]+[B,512] resident in HBM, {tr.n_params / 1e6:.0f} M trainable params "
                                f"(BASELINE.json configs[4])", "parallelism": "single GPU (as the reference)" if world == 1 else f"dp{world}: one RCCL all-reduce(sum) of the "
                                f"flat f32 gradient ({tr.n_params * 4 / 1e9:.1f} GB) per step"},
@@ -351,6 +352,8 @@ def main():
                     help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary); "
                          "finetune = CLIP multi-scale adapter head step (configs[4], secondary)")
     ap.add_argument("--finetune-batch", type=int, default=64, help="samples per step (finetune.py:25)")
+    ap.add_argument("--fp8-mlp", action="store_true", help="label path / finetune --with-towers: the vision tower's c_fc / c_proj GEMMs on e4m3 "
+                    "operands (scaled fp8 MFMA; BASELINE configs[4] 'fp8 MFMA GEMMs'): a lower-precision throughput mode, its parity is printed")
     ap.add_argument("--with-towers", action="store_true", help="finetune path: run the frozen CLIP ViT-B/16 towers inside the timed step "
                     "(uint8 frames + tokens in) instead of feeding pre-computed tower features")
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
@@ -390,7 +393,7 @@ def main():
     cfg = clip.MODELS[a.model]
     weights = synth.clip_weights(cfg, seed=0)
     tokens = synth.prompt_tokens(1, 8, seed=2)
-    model = clip.ClipLabeller(cfg, weights, mode=a.mode, device=local_rank, max_batch=a.batch, n_streams=a.streams).set_text(tokens)
+    model = clip.ClipLabeller(cfg, weights, mode=a.mode, device=local_rank, max_batch=a.batch, n_streams=a.streams, fp8_mlp=a.fp8_mlp).set_text(tokens)
 
     # parity gate on a few frames (rank 0): the thing timed below is the thing checked here
     parity = None
@@ -521,7 +524,8 @@ def main():
                        "operands": {"f16": "IEEE half MFMA operands (same 2.5 PF dense rate as bf16), f32 accumulate / residual / LayerNorm / softmax; "
                                            "rewards within north_star's 1e-4 of the fp32 oracle -- bf16 operands are not (alt_dtype)",
                                     "bf16": "bf16 MFMA operands, f32 accumulate / residual / LayerNorm / softmax",
-                                    "f32": "f32-input MFMA"}[a.mode],
+                                    "f32": "f32-input MFMA"}[a.mode] + (" -- PLUS c_fc / c_proj of blocks 1..11 on e4m3 operands (--fp8-mlp: NOT the "
+                                    "headline configuration; see parity)" if a.fp8_mlp else ""),
                        "parallelism": f"shard{world} (no collective)", "streams_per_gpu": nsplit},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "kernel": f"{kname} @ {dom}",

@@ -74,6 +74,11 @@ int arp_clip_destroy(arp_clip* h);
 /* One tensor of an openai/CLIP state dict (names and layouts: arp_dt/models/openai/model.py:220-314,
  * SURVEY.md Appendix B), f32 host data, row-major.  Call arp_clip_finalize_weights() after the last. */
 int arp_clip_load_weight(arp_clip* h, const char* name, const float* data, const int64_t* shape, int ndim);
+/* Before arp_clip_finalize_weights: run the vision tower's c_fc / c_proj GEMMs on the scaled fp8 MFMA (e4m3 operands, f32 accumulate;
+ * BASELINE.json configs[4] "bf16 with fp8 MFMA GEMMs").  A THROUGHPUT mode for the frozen towers of the fine-tune step
+ * (finetune_module/clip_multiscale_adapter.py:134-175): 3 significand bits, features ~1e-2 off the f32 towers -- not for labelling
+ * to 1e-4.  16-bit modes only, width % 128 == 0. */
+int arp_clip_set_fp8_mlp(arp_clip* h, int on);
 int arp_clip_finalize_weights(arp_clip* h);
 
 /* clip.tokenize output [n_prompts, ctx] int32 -> runs the text tower ONCE and caches the normalised
@@ -292,6 +297,10 @@ int arp_h5_inflate_last_frames(int fd, int n, const uint64_t* addr, const uint64
 
 /* ---- single-operator entry points (host buffers; used by the per-kernel parity tests) ---------- */
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid), operands rounded to bf16 in ARP_MODE_BF16. */
+/* fp8 (e4m3) instances of the 256x256 GEMM: operands rounded to e4m3 on the host; f32 output (+ residual) or e4m3 output
+ * (out_scale * act(...), returned decoded).  K % 128 == 0, N % 16 == 0. */
+int arp_op_gemm_fp8(int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N, int K, float alpha,
+                    int out_fp8, float out_scale);
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,
                    float* out, int M, int N, int K);
 /* Times `iters` launches of the GEMM on device-resident random operands (HIP events); kernel: 1 = 128x128,

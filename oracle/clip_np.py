@@ -86,17 +86,40 @@ def mha(x, w_in, b_in, w_out, b_out, heads, causal):
     return o @ w_out.T + b_out
 
 
-def resblock(x, W, pre, heads, causal):
+def quant_e4m3(x):
+    """Round to OCP e4m3fn (4 exponent bits, bias 7, 3 mantissa bits, subnormals down to 2^-9, NO infinities: saturates at 448),
+    round-to-nearest-even -- what v_cvt_pk_fp8_f32 behind a clamp produces.  Emulation for the product's optional fp8 MLP mode."""
+    x = np.asarray(x, np.float64)
+    a = np.minimum(np.abs(x), 448.0)
+    e = np.floor(np.log2(np.maximum(a, 2.0 ** -20)))
+    e = np.clip(e, -6, 8)                    # below 2^-6 the spacing stays 2^-9 (subnormals)
+    step = 2.0 ** (e - 3)
+    q = np.round(a / step) * step            # numpy rounds half to even
+    return np.sign(x) * np.minimum(q, 448.0)
+
+
+def _pow2_scale(w):
+    return 2.0 ** np.floor(np.log2(240.0 / np.abs(w).max()))
+
+
+def resblock(x, W, pre, heads, causal, mlp_fp8=False):
     g = lambda k: W[pre + k]
     h = layer_norm(x, g("ln_1.weight"), g("ln_1.bias"))
     x = x + mha(h, g("attn.in_proj_weight"), g("attn.in_proj_bias"), g("attn.out_proj.weight"),
                 g("attn.out_proj.bias"), heads, causal)
     h = layer_norm(x, g("ln_2.weight"), g("ln_2.bias"))
+    if mlp_fp8:
+        # the product's fp8 MLP (csrc/tower.h::tower_mlp_fp8): e4m3 activations x 32 / x 16, e4m3 weights x a per-tensor power of two
+        w1, w2 = g("mlp.c_fc.weight"), g("mlp.c_proj.weight")
+        s1, s2 = _pow2_scale(w1), _pow2_scale(w2)
+        u = (quant_e4m3(h * 32.0) @ quant_e4m3(w1 * s1).T) / (32.0 * s1) + g("mlp.c_fc.bias")
+        h = quant_e4m3(quick_gelu(u) * 16.0)
+        return x + (h @ quant_e4m3(w2 * s2).T) / (16.0 * s2) + g("mlp.c_proj.bias")
     h = quick_gelu(h @ g("mlp.c_fc.weight").T + g("mlp.c_fc.bias"))
     return x + h @ g("mlp.c_proj.weight").T + g("mlp.c_proj.bias")
 
 
-def encode_image(W, cfg, x_nchw, return_tokens=False):
+def encode_image(W, cfg, x_nchw, return_tokens=False, mlp_fp8=False):
     """x_nchw: float [n,3,R,R] already normalised.  Returns un-normalised features [n, embed]."""
     n = x_nchw.shape[0]
     P, G, D = cfg.patch, cfg.grid, cfg.width
@@ -107,7 +130,8 @@ def encode_image(W, cfg, x_nchw, return_tokens=False):
     x = np.concatenate([cls, x], axis=1) + W["visual.positional_embedding"]
     x = layer_norm(x, W["visual.ln_pre.weight"], W["visual.ln_pre.bias"])
     for i in range(cfg.layers):
-        x = resblock(x, W, f"visual.transformer.resblocks.{i}.", cfg.heads, causal=False)
+        # (the product keeps the class-token-only last block on 16-bit operands: its row count is below the fp8 kernel's tile)
+        x = resblock(x, W, f"visual.transformer.resblocks.{i}.", cfg.heads, causal=False, mlp_fp8=mlp_fp8 and i < cfg.layers - 1)
     if return_tokens:
         return x
     c = layer_norm(x[:, 0], W["visual.ln_post.weight"], W["visual.ln_post.bias"])

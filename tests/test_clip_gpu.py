@@ -302,6 +302,38 @@ def test_heavy_tailed_weights_f16_stays_finite_and_in_tolerance(gpu_lib):
     m32.close(); m16.close()
 
 
+def test_fp8_mlp_mode(gpu_lib):
+    """BASELINE configs[4] names "fp8 MFMA GEMMs": the vision tower's c_fc / c_proj on e4m3 operands (v_mfma_scale_f32_16x16x128_f8f6f4).
+    Two checks: (1) KERNEL correctness -- against the oracle with the same e4m3 roundings inserted (activations x 32 / x 16, weights x
+    a per-tensor power of two) the features agree to 16-bit-mode accuracy; (2) the PRICE of three significand bits -- the feature
+    error against the plain fp64 oracle is reported and bounded (a throughput mode for the frozen towers of the fine-tune step)."""
+    from arp_amd import clip, synth
+    from oracle import clip_np as C, preprocess as P
+    kw = dict(MID, width=256, heads=4, layers=3)  # width % 128 == 0; K = 256 (c_fc) and 1024 (c_proj): 2 and 8 fp8 K-tiles
+    ocfg = C.ClipConfig(**kw)
+    Wt = synth.clip_weights(ocfg, seed=41)
+    fr = synth.procgen_like_frames(40, seed=42)   # 2000 rows: several 256-row tiles, the last one ragged
+    Wd = C.cast_weights(Wt, np.float64)
+    x = P.preprocess(fr).astype(np.float64)
+    f_ref = C.encode_image(Wd, ocfg, x)
+    f_emul = C.encode_image(Wd, ocfg, x, mlp_fp8=True)
+    m16 = clip.ClipLabeller(clip.ClipConfig(**kw), Wt, mode="f16", n_streams=1)
+    m8 = clip.ClipLabeller(clip.ClipConfig(**kw), Wt, mode="f16", n_streams=1, fp8_mlp=True)
+    m8.profile(True)
+    f16, f8 = m16.encode_image(fr), m8.encode_image(fr)
+    assert "vit.c_fc_fp8" in m8.profile_read() and np.isfinite(f8).all()
+    cos = lambda a, b: float(np.min(np.sum(a * b, 1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    print(f"fp8 MLP: vs e4m3-emulating oracle rel {rel(f8, f_emul):.2e} (f16 path vs plain oracle {rel(f16, f_ref):.2e}); "
+          f"vs plain oracle rel {rel(f8, f_ref):.2e}, min cosine {cos(f8, f_ref):.5f}")
+    # The kernels themselves are checked EXACTLY in test_ops_gpu.py::test_gemm_fp8_exact_on_representable_operands.  End to end an
+    # f16-level difference in a LayerNorm / QuickGELU output that crosses an e4m3 rounding boundary moves that value by a whole
+    # step (6 %), so the product agrees with the emulating oracle only to a fraction of the quantisation error itself.
+    assert rel(f8, f_emul) < 0.6 * rel(f_emul, f_ref) and rel(f8, f_emul) < 2e-2
+    assert cos(f8, f_ref) > 0.995 and cos(f8, f_emul) > 0.9995
+    m16.close(); m8.close()
+
+
 def test_label_reward_from_hdf5_file(gpu_lib, tmp_path):
     """SURVEY row N3 end to end on the GPU: recorder-style HDF5 file in, reward / rtg datasets out (gzip, chunks (1, num_frames)),
     equal to labelling the same frames from memory."""

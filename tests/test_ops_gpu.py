@@ -155,3 +155,35 @@ def test_preprocess_bit_exact(gpu_lib, case):
     assert got.shape == ref.shape
     nbad = int((got != ref).sum())
     assert nbad == 0, f"{nbad} of {ref.size} f32 values differ; max abs diff {np.abs(got - ref).max()}"
+
+
+@pytest.mark.parametrize("shape", [(300, 512, 256), (256, 256, 128), (1030, 768, 3072), (77, 1024, 384)])
+def test_gemm_fp8_exact_on_representable_operands(gpu_lib, shape):
+    """The fp8 instances of the 256x256 kernel (v_mfma_scale_f32_16x16x128_f8f6f4, BASELINE configs[4]).  Operands that are exactly
+    representable in e4m3 make the check EXACT up to f32 summation: any error in the fragment layout, the k-slot assignment of the
+    two register halves, the unit block scales or the alpha / bias / residual epilogue shows up at O(1), not at the 6 % of an
+    e4m3 rounding step.  The e4m3 OUTPUT path (QuickGELU, out_scale, saturating convert) is checked against the oracle's rounding."""
+    from oracle import clip_np as O
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    A = O.quant_e4m3(rng.standard_normal((M, K)) * 4).astype(np.float32)
+    W = O.quant_e4m3(rng.standard_normal((N, K)) * 8).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    alpha = 1.0 / 64
+    ref = alpha * (A.astype(np.float64) @ W.astype(np.float64).T)
+    out = np.empty((M, N), np.float32)
+    gpu_lib.check(gpu_lib.lib.arp_op_gemm_fp8(0, _fp(A), _fp(W), _fp(bias), _fp(resid), _fp(out), M, N, K, alpha, 0, 1.0))
+    r = ref + bias + resid
+    # the error scales with the magnitude of the TERMS (they cancel), not of the result; measured 4e-6 of sum |a||w| -- the scaled
+    # fp8 MFMA does not carry a full f32 significand through its 128-term sum -- against O(1) for any layout / k-slot mistake
+    tol = 2e-5 * alpha * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T) + 2e-6 * (np.abs(r) + 1.0)
+    assert (np.abs(out - r) <= tol).all(), float((np.abs(out - r) / tol).max())
+    gpu_lib.check(gpu_lib.lib.arp_op_gemm_fp8(0, _fp(A), _fp(W), None, None, _fp(out), M, N, K, alpha, 0, 1.0))
+    assert (np.abs(out - ref) <= tol).all(), float((np.abs(out - ref) / tol).max())
+    # e4m3 output: 0.25 * quickgelu(alpha * acc + bias), saturating; allow one rounding step where f32 noise crosses a boundary
+    gpu_lib.check(gpu_lib.lib.arp_op_gemm_fp8(1, _fp(A), _fp(W), _fp(bias), None, _fp(out), M, N, K, alpha, 1, 0.25))
+    want = O.quant_e4m3(0.25 * _act(ref + bias, 1))
+    step = np.maximum(np.abs(want), 2.0 ** -6) / 8
+    bad = np.abs(out - want) > 1e-6
+    assert bad.mean() < 2e-3 and (np.abs(out - want) <= step * 1.01 + 1e-6).all(), (bad.mean(), np.abs(out - want).max())
