@@ -175,6 +175,37 @@ template <int ACT, bool FAST = false> __device__ __forceinline__ float apply_act
     }
 }
 
+// Four fragment values at once.  In the 16-bit GEMM epilogues the activation is VALU-issue-bound (two transcendental and five
+// plain instructions per element); written on float2 pairs the scale, the +1 and the final product become v_pk_mul_f32 /
+// v_pk_add_f32 -- two elements per issue slot -- and the arithmetic per element is exactly apply_act<ACT, true>'s.
+typedef __attribute__((ext_vector_type(2))) float f32x2_v;
+template <int ACT, bool FAST> __device__ __forceinline__ void apply_act4(float (&v)[4]) {
+    if constexpr (FAST && (ACT == ACT_QGELU || ACT == ACT_GELU_TANH)) {
+        f32x2_v a = {v[0], v[1]}, b = {v[2], v[3]};
+        f32x2_v ta, tb;
+        if constexpr (ACT == ACT_QGELU) {
+            ta = a * -2.4554669595930157f;
+            tb = b * -2.4554669595930157f;
+        } else {
+            const float c = 0.7978845608028654f;
+            ta = (c * (a + 0.044715f * a * a * a)) * -2.8853900817779268f;
+            tb = (c * (b + 0.044715f * b * b * b)) * -2.8853900817779268f;
+        }
+        f32x2_v ea = {__builtin_amdgcn_exp2f(ta[0]), __builtin_amdgcn_exp2f(ta[1])};
+        f32x2_v eb = {__builtin_amdgcn_exp2f(tb[0]), __builtin_amdgcn_exp2f(tb[1])};
+        ea = ea + 1.0f;
+        eb = eb + 1.0f;
+        const f32x2_v ra = {__builtin_amdgcn_rcpf(ea[0]), __builtin_amdgcn_rcpf(ea[1])};
+        const f32x2_v rb = {__builtin_amdgcn_rcpf(eb[0]), __builtin_amdgcn_rcpf(eb[1])};
+        a = a * ra;
+        b = b * rb;
+        v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, FAST>(v[j]);
+    }
+}
+
 // host-side f32 -> bf16 (RNE)
 static inline bf16_t host_f2bf(float f) {
     uint32_t u;

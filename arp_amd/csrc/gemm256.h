@@ -42,6 +42,9 @@ namespace arp {
 #ifndef ARP_G2_OVERLAP_DRAIN
 #define ARP_G2_OVERLAP_DRAIN 0
 #endif
+// K-loop variants measured in round 2 with the standalone harness scripts/gemm256_bench.hip (10 s per build) and NOT kept: moving
+// U1 / U2 of phase B's six LDS-DMA issues in between that phase's MFMAs (3-7 % slower on every shape, 4096^3 1250 -> 1172 TF),
+// issuing the LDS-DMA ahead of the phase's fragment reads, dropping s_setprio around the MFMA segments (both within +-1.5 % noise).
 constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
 constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * 128;  // one K-tile: 64 KiB
 static_assert(256 * (256 * 2 + 16) >= 2 * G2_BUF_BYTES && 256 * (256 * 2 + 16) >= 128 * (256 * 4 + 16), "epilogue tile must cover the K-tile ring");
@@ -66,6 +69,9 @@ __device__ __forceinline__ void wait_units(int allow) {
     else wait_vmcnt<0>();
 }
 
+#ifdef ARP_G2_STAMPS
+__device__ long long* arp_g2_stamps = nullptr;  // scripts/gemm256_bench.hip: per-tile, per-wave phase time stamps
+#endif
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,6 +285,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     bool pre_issued_bias = false;
     bool pre4 = false;  // this tile's steps 0..2 were issued by the previous tile's overlapped epilogue, AHEAD of that tile's 16 stores
     for (int tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
+#ifdef ARP_G2_STAMPS
+    long long st_[6];
+    st_[0] = __builtin_amdgcn_s_memtime();
+#define ARP_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define ARP_STAMP(i)
+#endif
     tile_coords(tix);
     setup_src();
     // the tile's bias slice (256 floats) goes to LDS by one LDS-DMA of wave 0, issued ahead of the operand units (so every
@@ -382,9 +395,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    ARP_STAMP(1);
     auto epilogue = [&]() {
     // ---- epilogue ------------------------------------------------------------------------------------
     OutT* out = static_cast<OutT*>(g.out);  // may alias g.resid (in-place residual add)
+#ifdef ARP_G2_EXPERIMENT_SAME_TILE
+    if (g.flags & 16) out -= (size_t)m0 * g.ldo + n0;  // every tile stores to tile (0,0): takes HBM write bandwidth out of the picture
+#endif
     const bool vec_ok = ((g.N | g.ldo | g.ldr) & 3) == 0;
     if (g.flags & 1) {  // ablation: keep the accumulators live, store (almost) nothing
         float sacc = 0.f;
@@ -406,6 +423,16 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     // read the same way.  (Direct per-fragment stores measured 118 us of a 358 us c_fc launch.)
     const bool staged = vec_ok && ((g.N | g.ldo) & (sizeof(OutT) == 1 ? 15 : 7)) == 0 && !(g.flags & 2);
     if (staged) {
+        // The thread's four bias fragments are read ONCE, ahead of the staging loop (they depend on the fragment column only).
+        // Reading them per fragment inside the loop -- behind a per-fragment `n < N` branch -- put 32 dependent LDS round trips
+        // and 64 exec-mask branches on the staging path: 6.0 k of a 45.8 k-cycle qkv tile (in-kernel s_memtime stamps,
+        // scripts/gemm256_bench.hip -DARP_G2_STAMPS).  Columns past N hold the clamped load's finite values and are never stored.
+        float4 bq[2][2];
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                bq[nq][ni] = g.bias ? *reinterpret_cast<const float4*>(bias_s + wc * 64 + nq * 32 + ni * 16 + fg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (sizeof(OutT) == 1) {
             // fp8 output (the MLP's hidden activation): out_scale * act(alpha * acc + bias), 4 values per dword, 256-B rows out
             constexpr int RS8 = 256 + 16;
@@ -420,11 +447,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                         for (int ni = 0; ni < 2; ++ni) {
                             const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
                             const f32x4_v a4 = acc[mq][nq][ni][mi];
-                            float v[4] = {a4[0] * g.alpha, a4[1] * g.alpha, a4[2] * g.alpha, a4[3] * g.alpha};
-                            if (g.bias && n0 + col < g.N) {
-                                const float4 b = *reinterpret_cast<const float4*>(bias_s + col);
-                                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                            }
+                            const float4 b = bq[nq][ni];
+                            float v[4] = {a4[0] * g.alpha + b.x, a4[1] * g.alpha + b.y, a4[2] * g.alpha + b.z, a4[3] * g.alpha + b.w};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, true>(v[j]) * g.out_scale;
                             *reinterpret_cast<uint32_t*>(smem + row * RS8 + col) = pack_fp8x4(v[0], v[1], v[2], v[3]);
@@ -440,35 +464,38 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
             }
         } else if constexpr (sizeof(OutT) == 2) {
             constexpr int RS = 256 * 2 + 16;  // +16 B pad: fragment rows land on different banks
+            auto stage16 = [&](auto LN) {  // LN: the folded-LayerNorm correction is compiled out of the ordinary path
 #pragma unroll
-            for (int mq = 0; mq < 2; ++mq)
+                for (int mq = 0; mq < 2; ++mq)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    const int row = wr * 128 + mq * 64 + mi * 16 + fr;
-                    float mu = 0.f, rs = 1.f;
-                    if (g.ln_stats) ln_row_stats(g, min(m0 + row, g.M - 1), mu, rs);  // folded LayerNorm (gemm.h)
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int row = wr * 128 + mq * 64 + mi * 16 + fr;
+                        float mu = 0.f, rs = 1.f;
+                        if constexpr (LN.value) ln_row_stats(g, min(m0 + row, g.M - 1), mu, rs);  // folded LayerNorm (gemm.h)
 #pragma unroll
-                    for (int nq = 0; nq < 2; ++nq)
+                        for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
-                            const f32x4_v a4 = acc[mq][nq][ni][mi];
-                            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-                            if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
-                            if (g.ln_stats && n0 + col < g.N) {
-                                const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n0 + col);
-                                v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
-                                v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
-                            }
-                            if (g.bias && n0 + col < g.N) {
-                                const float4 b = *reinterpret_cast<const float4*>(bias_s + col);
+                            for (int ni = 0; ni < 2; ++ni) {
+                                const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
+                                const f32x4_v a4 = acc[mq][nq][ni][mi];
+                                float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                                if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
+                                if constexpr (LN.value) {
+                                    if (n0 + col < g.N) {
+                                        const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n0 + col);
+                                        v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
+                                        v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
+                                    }
+                                }
+                                const float4 b = bq[nq][ni];
                                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                                apply_act4<ACT, sizeof(T) <= 2>(v);
+                                *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
                             }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) <= 2>(v[j]);
-                            *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
-                        }
-                }
+                    }
+            };
+            if (g.ln_stats) stage16(std::true_type{});
+            else stage16(std::false_type{});
 #if ARP_G2_TWO_PHASE && ARP_G2_OVERLAP_DRAIN
             // ---- overlapped drain (a workgroup that has another tile to do; interior tiles only) --------------------------
             // The tile's bytes move LDS -> registers (64 VGPRs: the accumulators are dead), the barrier releases LDS, the NEXT
@@ -510,7 +537,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                 return;
             }
 #endif
+            ARP_STAMP(2);
             __syncthreads();
+            ARP_STAMP(3);
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
                 const int r = it * 16 + wave * 2 + (lane >> 5);
@@ -548,10 +577,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
                             const f32x4_v a4 = acc[p][nq][ni][mi];
                             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
                             if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
-                            if (g.bias && n0 + col < g.N) {
-                                const float4 b = *reinterpret_cast<const float4*>(bias_s + col);
-                                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                            }
+                            const float4 b = bq[nq][ni];
+                            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = apply_act<ACT, sizeof(T) <= 2>(v[j]);
                             *reinterpret_cast<float4*>(smem + lrow * RSF + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -630,6 +657,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
     pre_issued_bias = false;
     pre4 = false;
     epilogue();
+#ifdef ARP_G2_STAMPS
+    ARP_STAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ARP_STAMP(5);
+    if (arp_g2_stamps && (threadIdx.x & 63) == 0) {
+        long long* d = arp_g2_stamps + ((size_t)tix * 8 + wave) * 8;
+        for (int i = 0; i < 6; ++i) d[i] = st_[i];
+    }
+#endif
     if (!pre_issued && tix + (int)gridDim.x < total_tiles) {
         __syncthreads();  // every wave has finished reading the epilogue tile out of LDS
         tile_coords(tix + gridDim.x);

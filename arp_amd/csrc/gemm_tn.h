@@ -34,6 +34,8 @@ struct GemmTnArgs {
     int ksplit;
     size_t slice_stride;
     float alpha;
+    int tile256 = 0;     // 1: the 256 x 256-tile kernel (M, N multiples of 256; K a multiple of 64; four-stage ring)
+    int xcd_slices = 0;  // 1 (tile256 only): ksplit is a multiple of 8 and each XCD runs ksplit / 8 whole K-slices
 };
 
 // tcode: 1 = bf16, 2 = f16 (defined in gemm_tn.hip)

@@ -117,9 +117,223 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(GemmTnArgs g) {
         }
 }
 
+// ---- 256 x 256 tile variant (the adapter's 768 x 768 x 32 896 weight gradients) ------------------------------------------------
+// The 128 x 128 kernel above re-reads each operand six times past L2 (36 tiles x K x 512 B = 606 MB for 100 MB of operands) and
+// waits for a whole K-tile's loads at the end of every iteration.  Here: 512 threads (8 waves as 2 x 4, 128 x 64 per wave), K-tiles
+// of 32 rows (two 16-KiB operand tiles with 512-B rows), FOUR stages (128 KiB) with three K-tiles of loads in flight behind a counted
+// vmcnt, one barrier per K-tile, and the nine tiles of one K-slice placed on ONE XCD (blockIdx % 8 selects the XCD) so that the
+// slice's operand rows come from memory once and are shared through that XCD's L2.
+#ifdef ARP_TN_STAMPS
+__device__ long long* arp_tn_stamps = nullptr;  // scripts/gemm_tn_bench.hip: K-loop shader cycles / 100 MHz ticks / K-tiles per workgroup
+#endif
+constexpr int TW_BM = 256, TW_BN = 256, TW_BK = 32, TW_THREADS = 512, TW_STAGES = 4;
+constexpr int TW_OP_BYTES = TW_BK * 512;          // 32 rows x 512 B
+constexpr int TW_STAGE_BYTES = 2 * TW_OP_BYTES;   // 32 KiB
+constexpr int TW_LDS_BYTES = TW_STAGES * TW_STAGE_BYTES;
+
+template <typename T>
+__global__ __launch_bounds__(TW_THREADS) void gemm_tn256_kernel(GemmTnArgs g, int tiles, int slices_per_xcd) {
+    static_assert(sizeof(T) == 2, "16-bit operand types only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // physical workgroup p runs on XCD p % 8; that XCD owns slices [xcd * spx, (xcd + 1) * spx) and all their tiles
+    int slice, tile;
+    if (slices_per_xcd > 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        if (idx >= slices_per_xcd * tiles) return;
+        slice = xcd * slices_per_xcd + idx / tiles;
+        tile = idx % tiles;
+        if (slice >= g.ksplit) return;
+    } else {
+        slice = blockIdx.x / tiles;
+        tile = blockIdx.x % tiles;
+    }
+    const int n_tiles = g.N / TW_BN;
+    const int m0 = (tile / n_tiles) * TW_BM, n0 = (tile % n_tiles) * TW_BN;
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ B = static_cast<const T*>(g.B);
+
+    int nk = g.K / TW_BK, kt0 = 0;
+    {
+        const int per = (nk + g.ksplit - 1) / g.ksplit;
+        kt0 = slice * per;
+        nk = max(min(per, nk - kt0), 0);
+    }
+    // ---- LDS-DMA: a piece = 2 rows x 512 B; wave w fills pieces 2w, 2w+1 of each operand tile -------------------------------------
+    // lane -> (row in piece = lane / 32, physical 16-B chunk = lane % 32); physical 32-B slot s holds logical slot s ^ (row & 15)
+    const int prow = lane >> 5, pc = lane & 31;
+    const T* srcA[2];
+    const T* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 2 + prow;
+        const int lc = ((((pc >> 1) ^ (row & 15)) << 1) | (pc & 1)) * 8;
+        srcA[i] = A + (size_t)(kt0 * TW_BK + row) * g.lda + m0 + lc;
+        srcB[i] = B + (size_t)(kt0 * TW_BK + row) * g.ldb + n0 + lc;
+    }
+    auto stage = [&](int kt) {
+#if defined(TW_ABL) && (TW_ABL & 2)
+        if (kt >= TW_STAGES - 1) return;  // ablation: prologue loads only
+#endif
+        char* base = smem + (kt & (TW_STAGES - 1)) * TW_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* dst = base + (wave * 2 + i) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (size_t)kt * TW_BK * g.lda),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (size_t)kt * TW_BK * g.ldb),
+                                             (__attribute__((address_space(3))) void*)(dst + TW_OP_BYTES), 16, 0, 0);
+        }
+    };
+    // Transposing fragment reads as in the 128-tile kernel (rows of 512 B, slot swizzle by (row & 15)), but issued as inline asm with
+    // hand-counted lgkmcnt waits: behind the builtin, hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS read that follows an
+    // LDS-DMA issue (it cannot tell the ring slots apart), which drains the whole prefetch ring once per K-tile -- the 128-tile
+    // kernel's 1.9 k cycles per K-tile.  A fragment = rows r0 and r0 + 16 (same swizzle: +8192 B as an instruction offset).
+    const int fr = lane & 15, fg = lane >> 4;
+    const int trq = fr >> 2, trp = fr & 3;
+    const int r0 = 4 * fg + trq;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    uint32_t a_off[8], b_off[4];  // per-lane byte offsets inside an operand tile
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_off[i] = lds0 + r0 * 512 + (((wr * 8 + i) ^ (r0 & 15)) << 5) + trp * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_off[i] = lds0 + TW_OP_BYTES + r0 * 512 + (((wc * 4 + i) ^ (r0 & 15)) << 5) + trp * 8;
+    // A fragment's two halves stay two 64-bit values until its wait has been passed: the 128-bit MFMA operand is assembled only
+    // there, so that any register copy the compiler needs for the tuple reads data that has arrived.
+    struct Frag { u32x2_v lo, hi; };
+    auto frag = [&](uint32_t addr) {
+        Frag f;
+#if defined(TW_ABL) && (TW_ABL & 1)
+        asm volatile("v_mov_b32 %0, %1" : "=&v"(f.lo[0]) : "v"(addr));  // ablation: no LDS reads
+        f.lo[1] = f.lo[0]; f.hi = f.lo;
+#else
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:8192" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr));
+#endif
+        return f;
+    };
+    auto op = [](const Frag& f) { return u32x4_v{f.lo[0], f.lo[1], f.hi[0], f.hi[1]}; };
+#define TW_WAIT4(cnt, x)                                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(" #cnt ")"                                                                                    \
+                 : "+v"(x[0].lo), "+v"(x[0].hi), "+v"(x[1].lo), "+v"(x[1].hi), "+v"(x[2].lo), "+v"(x[2].hi), "+v"(x[3].lo), "+v"(x[3].hi))
+
+    f32x4_v acc[4][8];  // [ni][mi]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+
+    // Software pipeline across the per-tile barrier: a K-tile's MFMAs run as two halves of 16 (m-blocks 0-3, then 4-7).  The
+    // fragments of the second half are fetched behind the first half's MFMAs; the NEXT tile's B and first-half A fragments are
+    // fetched (after the wait + barrier that publish that tile) behind the second half's.
+    auto step = [&](int kt, Frag (&bfc)[4], Frag (&alc)[4], Frag (&bfn)[4], Frag (&aln)[4]) {
+        // Every non-MFMA instruction of the step sits in the gap behind an MFMA (the matrix pipe runs 16 cycles per instruction, the
+        // wave issues LDS reads / LDS-DMA / address arithmetic meanwhile): with the reads and the DMA issue bunched at the phase
+        // boundaries, where every wave of the workgroup stands at the same point, a K-tile took 1.7 k cycles for 1.0 k of MFMA.
+        const uint32_t cur = (kt & (TW_STAGES - 1)) * TW_STAGE_BYTES;
+        const bool next = kt + 1 < nk;
+        Frag ah[4];
+        TW_WAIT4(0, bfc);  // this step's B and first-half A fragments (fetched behind the previous step's second half)
+        TW_WAIT4(0, alc);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4_v b4[4], a4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { b4[i] = op(bfc[i]); a4[i] = op(alc[i]); }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                acc[ni][mi] = mfma16<T>(b4[ni], a4[mi], acc[ni][mi]);
+                if (ni == 0) ah[mi] = frag(a_off[4 + mi] + cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        TW_WAIT4(0, ah);  // this wave's last reads of tile kt have returned (also what lets the slot be overwritten two barriers on)
+        if (next) {
+            // tile kt+1 must have landed; tile kt+2 (4 LDS-DMA instructions per wave) may stay in flight
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(TW_ABL) && (TW_ABL & 4))
+            __builtin_amdgcn_s_barrier();
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t nxt = ((kt + 1) & (TW_STAGES - 1)) * TW_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = op(ah[i]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                acc[ni][4 + mi] = mfma16<T>(b4[ni], a4[mi], acc[ni][4 + mi]);
+                const int j = mi * 4 + ni;
+                if (next) {
+                    if (j == 1 && kt + TW_STAGES - 1 < nk) stage(kt + TW_STAGES - 1);  // into tile kt-1's slot: every wave finished it a barrier ago
+                    if (j >= 2 && j < 6) bfn[j - 2] = frag(b_off[j - 2] + nxt);
+                    if (j >= 6 && j < 10) aln[j - 6] = frag(a_off[j - 6] + nxt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+#ifdef ARP_TN_STAMPS
+    const long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (nk > 0) {
+        for (int s = 0; s < TW_STAGES - 1 && s < nk; ++s) stage(s);
+        if (nk >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (nk == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        Frag bf0[4], al0[4], bf1[4], al1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf0[i] = frag(b_off[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) al0[i] = frag(a_off[i]);
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, bf0, al0, bf1, al1);
+            if (kt + 1 < nk) step(kt + 1, bf1, al1, bf0, al0);
+        }
+    }
+#undef TW_WAIT4
+#ifdef ARP_TN_STAMPS
+    if (tid == 0 && arp_tn_stamps) {
+        arp_tn_stamps[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memtime() - st0;
+        arp_tn_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        arp_tn_stamps[blockIdx.x * 4 + 2] = nk;
+    }
+#endif
+    float* out = g.out + (size_t)slice * g.slice_stride;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int m = m0 + wr * 128 + mi * 16 + fr, n = n0 + wc * 64 + ni * 16 + fg * 4;
+            const f32x4_v a4 = acc[ni][mi];
+            *reinterpret_cast<float4*>(out + (size_t)m * g.ldo + n) = make_float4(a4[0] * g.alpha, a4[1] * g.alpha, a4[2] * g.alpha, a4[3] * g.alpha);
+        }
+}
+
 template <typename T> static int launch_impl(const GemmTnArgs& g, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.M % TN_BM || g.N % TN_BN || g.K % TN_BK || g.lda % 8 || g.ldb % 8 || g.ldo % 4 || g.ksplit < 1)
         return fail("gemm_tn: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) + " K=" + std::to_string(g.K));
+    if (g.tile256) {
+        if (g.M % TW_BM || g.N % TW_BN || (g.ksplit > 1 && !g.slice_stride)) return fail("gemm_tn: the 256-tile kernel needs M, N multiples of 256");
+        auto kern = gemm_tn256_kernel<T>;
+        static bool attr256 = false;
+        if (!attr256) {
+            ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
+            attr256 = true;
+        }
+        const int tiles = (g.M / TW_BM) * (g.N / TW_BN);
+        // XCD placement when the slices divide over the eight XCDs and an XCD's share fits its 32 CUs
+        const int spx = (g.ksplit % 8 == 0 && (g.ksplit / 8) * tiles <= 32 && g.xcd_slices) ? g.ksplit / 8 : 0;
+        const int grid = spx ? 8 * spx * tiles : tiles * g.ksplit;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TW_THREADS), TW_LDS_BYTES, stream, g, tiles, spx);
+        ARP_HIP_OK(hipGetLastError());
+        return 0;
+    }
     auto kern = gemm_tn_kernel<T>;
     static bool attr_set = false;
     if (!attr_set) {

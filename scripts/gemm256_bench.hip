@@ -1,0 +1,96 @@
+// Standalone timing / checksum harness for gemm256.h variants (kernel development loop: 20 s per build instead of the library's 4 min):
+//   cd arp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++20 -I. [-DARP_G2_...=..] ../../scripts/gemm256_bench.hip -o ../../scripts/gemm256_bench.bin
+// Prints microseconds, TFLOP/s and an FNV checksum of the output per shape (variants that keep the MFMA order must agree bit for bit).
+#include <cstdio>
+#include <vector>
+
+#include "gemm256.h"
+
+namespace arp {
+static thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; fprintf(stderr, "error: %s\n", m.c_str()); return -1; }
+void set_error(const std::string& m) { g_err = m; }
+int launch_gemm2w_dyn(int, int, int, int, const GemmArgs&, hipStream_t) { return fail("gemm2w is not linked into this harness"); }
+bool gemm2w_has(int, int, int, int) { return false; }
+}  // namespace arp
+using namespace arp;
+
+static uint64_t fnv(const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+template <typename OutT, int ACT, bool RESID> static void run(const char* name, int M, int N, int K) {
+    std::vector<f16_t> hA((size_t)M * K), hW((size_t)N * K);
+    std::vector<float> hb(N);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hA) v = host_f2h(rnd());
+    for (auto& v : hW) v = host_f2h(rnd() * 0.05f);
+    for (auto& v : hb) v = rnd();
+    void *dA, *dW, *dO, *dR;
+    float* dB;
+    hipMalloc(&dA, hA.size() * 2); hipMalloc(&dW, hW.size() * 2); hipMalloc(&dB, N * 4); hipMalloc(&dO, (size_t)M * N * 4); hipMalloc(&dR, (size_t)M * N * 4);
+    hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dB, hb.data(), N * 4, hipMemcpyHostToDevice);
+    hipMemset(dR, 0, (size_t)M * N * 4);
+    GemmArgs g;
+    g.A = dA; g.W = dW; g.bias = dB; g.resid = RESID ? (float*)dR : nullptr; g.out = RESID ? dR : dO;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
+    if (const char* e = getenv("G256_FLAGS")) g.flags = atoi(e);  // 1 = ablate the epilogue stores (K loop only), 2 = unstaged stores
+#ifdef ARP_G2_STAMPS
+    const int ntile = ((M + 255) / 256) * ((N + 255) / 256);
+    long long* dS;
+    hipMalloc(&dS, (size_t)ntile * 64 * 8);
+    hipMemset(dS, 0, (size_t)ntile * 64 * 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(arp_g2_stamps), &dS, sizeof(dS));
+#endif
+    auto go = [&]() { return launch_gemm256_nt<f16_t, OutT, ACT, RESID, 6>(g, nullptr); };
+    go();
+    hipDeviceSynchronize();
+#ifdef ARP_G2_STAMPS
+    {   // per-tile phase durations in shader cycles, averaged over tiles and waves: K loop | stage | barrier | copy-out issue | drain
+        std::vector<long long> h((size_t)ntile * 64);
+        hipMemcpy(h.data(), dS, h.size() * 8, hipMemcpyDeviceToHost);
+        double d[5] = {0, 0, 0, 0, 0};
+        for (int t = 0; t < ntile; ++t)
+            for (int w = 0; w < 8; ++w)
+                for (int i = 0; i < 5; ++i) d[i] += (double)(h[((size_t)t * 8 + w) * 8 + i + 1] - h[((size_t)t * 8 + w) * 8 + i]);
+        printf("  stamps %-10s: kloop %.0f | stage %.0f | barrier %.0f | copy-out issue %.0f | drain %.0f cycles\n", name, d[0] / ntile / 8, d[1] / ntile / 8,
+               d[2] / ntile / 8, d[3] / ntile / 8, d[4] / ntile / 8);
+        hipFree(dS);
+    }
+    return;
+#endif
+    std::vector<uint8_t> out((size_t)M * N * sizeof(OutT));
+    hipMemcpy(out.data(), g.out, out.size(), hipMemcpyDeviceToHost);
+    const uint64_t sum = fnv(out.data(), out.size());
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) go();
+    const int iters = 20;
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) go();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= iters;
+    printf("%-10s M=%d N=%d K=%d: %8.1f us %7.1f TFLOP/s  fnv %016llx\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9, (unsigned long long)sum);
+    hipFree(dA); hipFree(dW); hipFree(dB); hipFree(dO); hipFree(dR);
+}
+
+int main() {
+    run<f16_t, ACT_NONE, false>("qkv", 51200, 2304, 768);
+    run<f16_t, ACT_QGELU, false>("c_fc", 51200, 3072, 768);
+    run<f16_t, ACT_NONE, false>("c_fc_noact", 51200, 3072, 768);
+    run<float, ACT_NONE, true>("c_proj", 51200, 768, 3072);
+    run<float, ACT_NONE, true>("out_proj", 51200, 768, 768);
+    run<f16_t, ACT_QGELU, false>("c_fc_half", 25600, 3072, 768);
+    run<float, ACT_NONE, true>("c_proj_half", 25600, 768, 3072);
+    run<f16_t, ACT_NONE, false>("sq4096", 4096, 4096, 4096);
+    run<f16_t, ACT_NONE, false>("ragged", 1000, 520, 192);
+    return 0;
+}

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512) void store_kernel(u4* out, int row_bytes, int 
 }
 
 int main() {
-    const size_t cap = (size_t)2 << 30;
+    const size_t cap = (size_t)14 << 30;
     u4* out;
     long long* cyc;
     hipMalloc(&out, cap);
@@ -56,21 +56,23 @@ int main() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(store_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(store_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(store_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-    const int grids[] = {1, 8, 32, 64, 128, 256};
+    const int grids[] = {1, 32, 256};
+    // ld_mul = 1: the tile's rows are contiguous (a 128-KiB block); 12: rows 6 KiB apart, as the 256 x 256 tile of a [M, 3072] f16 output
+    for (int ld_mul : {1, 12})
     for (int mode = 0; mode < 3; ++mode)
         for (int rb : {512, 1024}) {
             if (mode == 2 && rb == 512) continue;
             for (int grid : grids) {
                 const int tiles = 8;
-                const size_t need = (size_t)grid * tiles * 256 * rb;
+                const size_t need = (size_t)grid * tiles * 256 * rb * ld_mul;
                 if (need > cap) continue;
                 float best = 1e9f;
                 std::vector<long long> h(grid);
                 for (int rep = 0; rep < 5; ++rep) {
                     hipEventRecord(e0);
-                    if (mode == 0) hipLaunchKernelGGL(store_kernel<0>, dim3(grid), dim3(512), 140 * 1024, 0, out, rb, rb, tiles, cyc);
-                    if (mode == 1) hipLaunchKernelGGL(store_kernel<1>, dim3(grid), dim3(512), 140 * 1024, 0, out, rb, rb, tiles, cyc);
-                    if (mode == 2) hipLaunchKernelGGL(store_kernel<2>, dim3(grid), dim3(512), 140 * 1024, 0, out, rb, rb, tiles, cyc);
+                    if (mode == 0) hipLaunchKernelGGL(store_kernel<0>, dim3(grid), dim3(512), 140 * 1024, 0, out, rb, rb * ld_mul, tiles, cyc);
+                    if (mode == 1) hipLaunchKernelGGL(store_kernel<1>, dim3(grid), dim3(512), 140 * 1024, 0, out, rb, rb * ld_mul, tiles, cyc);
+                    if (mode == 2) hipLaunchKernelGGL(store_kernel<2>, dim3(grid), dim3(512), 140 * 1024, 0, out, rb, rb * ld_mul, tiles, cyc);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                     float ms;
@@ -82,7 +84,7 @@ int main() {
                 for (auto c : h) avg += (double)c;
                 avg /= grid;
                 const double bytes_wg = (double)tiles * 256 * rb * (mode == 2 ? 2 : 1);
-                printf("mode %d row_bytes %4d grid %3d: %8.1f us  %7.2f TB/s chip  %6.1f B/clk per WG (in-kernel %0.0f cyc per tile)\n", mode, rb, grid, best * 1e3,
+                printf("ld x%2d mode %d row_bytes %4d grid %3d: %8.1f us  %7.2f TB/s chip  %6.1f B/clk per WG (in-kernel %0.0f cyc per tile)\n", ld_mul, mode, rb, grid, best * 1e3,
                        bytes_wg * grid / (best * 1e-3) / 1e12, bytes_wg / avg, avg / tiles);
             }
         }
