@@ -20,6 +20,7 @@
 #include "enc_internal.h"
 #include "gemm.h"
 #include "gemm256.h"
+#include "adapter_bwd.h"
 #include "gemm_tn.h"
 #include "policy_fused.h"
 #include "rccl_dl.h"
@@ -104,7 +105,17 @@ struct arp_dt {
         static const bool off = getenv("ARP_DT_TN") && atoi(getenv("ARP_DT_TN")) == 0;
         return !off && cfg.mode != ARP_MODE_F32 && cfg.enc_dim % 128 == 0 && cfg.emb % 128 == 0;
     }
+    // ... and, with the adapter on, the gradient through image_text_input fused with the adapter's first mask (adapter_bwd.h)
+    bool use_fused_dy() const {
+        static const bool off = getenv("ARP_DT_FUSED_DY") && atoi(getenv("ARP_DT_FUSED_DY")) == 0;
+        return !off && use_tn() && cfg.use_adapter && adapter_dy_supported(cfg.emb, cfg.enc_dim, (long long)cfg.enc_tokens * cfg.enc_dim);
+    }
+    bool fuse_relu_bwd() const {
+        static const bool off = getenv("ARP_DT_FUSE_RELU_BWD") && atoi(getenv("ARP_DT_FUSE_RELU_BWD")) == 0;
+        return !off;
+    }
     DevBuf colpart;  // column partial sums of mask_copy_colsum_kernel
+    DevBuf dres_part;  // per-workgroup d loss / d res partials of adapter_dy_kernel
     int R() const { return B * cfg.window; }
     int L() const { return 3 * cfg.window; }
     float* p(const std::string& n) { return params.as<float>() + infos[index.at(n)].off; }
@@ -300,7 +311,8 @@ template <typename T> int refresh_shadows(arp_dt* c) {
     const T* W2 = static_cast<const T*>(c->fwd_w("AdapterMLP_0/Dense_1/kernel"));
     const T* Wi = static_cast<const T*>(c->fwd_w("image_text_input/kernel"));
     if (k.use_adapter) ARP_TRY((transpose_mask<T, T, T>(c, W2, D, nullptr, nullptr, 1.f, nullptr, 0, c->W2t.as<T>(), D, D, D)));
-    ARP_TRY((transpose_mask<T, T, T>(c, Wi, (int)Kin, nullptr, nullptr, 1.f, nullptr, 0, c->Wit.as<T>(), E, E, (int)Kin)));
+    // the fused dY kernel reads Wi as it lies; only the unfused path wants the [Kin, E] copy
+    if (!c->use_fused_dy()) ARP_TRY((transpose_mask<T, T, T>(c, Wi, (int)Kin, nullptr, nullptr, 1.f, nullptr, 0, c->Wit.as<T>(), E, E, (int)Kin)));
     c->shadows_stale = false;
     return 0;
 }
@@ -528,24 +540,38 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
 // ---- adapter + image_text_input backward, 16-bit modes, TN weight-gradient GEMMs (gemm_tn.h) ---------------------------------
 // Same math as the tail of backward<T>() below; the operands of the three weight-gradient contractions stay row-major
 // (no transposed K-padded copies): dWi = dz^T Y, dW2 = dApre^T H1, dW1 = dH1^T X.
-template <typename T> int tn_gemm(arp_dt* c, const char* site, const T* A, int lda, const T* B, int ldb, float* out, int M, int N, int K, float alpha) {
+template <typename T>
+int tn_gemm(arp_dt* c, const char* site, const T* A, int lda, const T* B, int ldb, float* out, int M, int N, int K, float alpha) {
+    hipStream_t st = c->stream;
+    DevBuf& part = c->part;
     const int tcode = __is_same(T, bf16_t) ? 1 : 2;
-    const int tiles = (M / 128) * (N / 128), nk = K / 64;
-    int S = std::max(1, std::min(nk, 512 / std::max(tiles, 1)));  // one resident round of workgroups, as splitk_gemm
-    const int per = (nk + S - 1) / S;
-    S = (nk + per - 1) / per;
     GemmTnArgs g;
+    int S;
+    // a long contraction into a few 256 x 256 tiles (the adapter's 768 x 768 x 32 896): the 256-tile kernel, whole K-slices per XCD
+    const int t256 = (M % 256 == 0 && N % 256 == 0) ? (M / 256) * (N / 256) : 0;
+    const int spx = t256 > 0 && t256 <= 32 ? 32 / t256 : 0;
+    static const bool allow256 = [] { const char* e = getenv("ARP_DT_TN256"); return !e || atoi(e) != 0; }();
+    if (allow256 && spx > 0 && K / 32 >= 8 * spx * 8) {
+        S = 8 * spx;
+        g.tile256 = 1;
+        g.xcd_slices = 1;
+    } else {
+        const int tiles = (M / 128) * (N / 128), nk = K / 64;
+        S = std::max(1, std::min(nk, 512 / std::max(tiles, 1)));  // one resident round of workgroups, as splitk_gemm
+        const int per = (nk + S - 1) / S;
+        S = (nk + per - 1) / per;
+    }
     g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ksplit = S;
-    ProfScope ps(c->prof, c->stream, site);
+    ProfScope ps(c->prof, st, site);
     if (S == 1) {
         g.out = out; g.ldo = N; g.slice_stride = 0; g.alpha = alpha;
-        return launch_gemm_tn(tcode, g, c->stream);
+        return launch_gemm_tn(tcode, g, st);
     }
-    ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
-    g.out = c->part.as<float>(); g.ldo = N; g.slice_stride = (size_t)M * N; g.alpha = 1.f;
-    ARP_TRY(launch_gemm_tn(tcode, g, c->stream));
+    ARP_TRY(part.ensure((size_t)S * M * N * 4));
+    g.out = part.as<float>(); g.ldo = N; g.slice_stride = (size_t)M * N; g.alpha = 1.f;
+    ARP_TRY(launch_gemm_tn(tcode, g, st));
     const size_t MN = (size_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, nullptr, ACT_NONE, out,
+    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(cdiv(MN, 64)), dim3(256), 0, st, part.as<float>(), S, MN, N, nullptr, ACT_NONE, out,
                        nullptr, 0, alpha);
     ARP_HIP_OK(hipGetLastError());
     return 0;
@@ -565,9 +591,29 @@ template <typename T> int backward_adapter_tn(arp_dt* c) {
     // dWi[E, Kin] = dz^T Y: contraction over the R rows, written straight into the gradient buffer
     ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS)));
     if (!k.use_adapter) return 0;
-    ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.image_text_input_dX", c->dzb.p, E, c->Wit.p, E, nullptr, c->dY.p, Kin, R, Kin, E)));
     const int prow = Mxp / 64, ncb = cdiv(D, 256);
-    {   // dApre = res * dY * (A > 0), row-major; its column sums = the Dense_1 bias gradient; sum dY * (A - x) = d loss / d res
+    if (c->use_fused_dy()) {
+        // dY = dz Wi, dApre = res * dY * (A > 0), its column sums and sum dY * (A - x) in ONE pass (adapter_bwd.h): no transposed
+        // shadow of Wi, no dY round trip
+        ProfScope ps(c->prof, c->stream, "dt.adapter_dy_fused");
+        const int nrb = adapter_dy_row_blocks(R), nct = Kin / 128;
+        ARP_TRY(c->colpart.ensure((size_t)nrb * k.enc_tokens * D * 4));
+        ARP_TRY(c->dres_part.ensure((size_t)nrb * nct * 4));
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->p("residual_weight"), 1, 1.0f, c->scal.as<float>() + 9, 0);
+        hipLaunchKernelGGL(sigmoid_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 9);
+        AdapterDyArgs a;
+        a.dz = c->dzb.p; a.Wi = c->fwd_w("image_text_input/kernel"); a.A = c->A.p; a.x32 = c->enc32.as<float>(); a.res = c->scal.as<float>() + 9;
+        a.dApre = c->dApre.p; a.colpart = c->colpart.as<float>(); a.dres_part = c->dres_part.as<float>();
+        a.R = R; a.E = E; a.Kin = Kin; a.D = D;
+        ARP_TRY(launch_adapter_dy(__is_same(T, bf16_t) ? 1 : 2, a, c->stream));
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), nrb * k.enc_tokens, D,
+                           c->g("AdapterMLP_0/Dense_1/bias"), invS);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->dres_part.as<float>(), nrb * nct, invS, c->scal.as<float>() + 8, 0);
+        hipLaunchKernelGGL(dres_to_drw_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 8, c->p("residual_weight"), c->g("residual_weight"));
+        ARP_HIP_OK(hipGetLastError());
+    } else {
+        ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.image_text_input_dX", c->dzb.p, E, c->Wit.p, E, nullptr, c->dY.p, Kin, R, Kin, E)));
+        // dApre = res * dY * (A > 0), row-major; its column sums = the Dense_1 bias gradient; sum dY * (A - x) = d loss / d res
         ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->p("residual_weight"), 1, 1.0f, c->scal.as<float>() + 9, 0);
         hipLaunchKernelGGL(sigmoid_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 9);
@@ -579,8 +625,24 @@ template <typename T> int backward_adapter_tn(arp_dt* c) {
         ARP_HIP_OK(hipGetLastError());
     }
     ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc2_dW", c->dApre.as<T>(), D, c->H1.as<T>(), D, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp, invS)));
-    ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.adapter_fc2_dX", c->dApre.p, D, c->W2t.p, D, nullptr, c->G.p, D, (int)Mx, D, D)));
-    {   // dH1 = G * (H1 > 0), row-major (in the buffer the other path uses for its transposed copy), + the Dense_0 bias gradient
+    const long tiles256 = (long)cdiv((int)Mx, 256) * cdiv(D, 256);
+    if (tiles256 >= 192 && D % 8 == 0 && c->fuse_relu_bwd()) {
+        // dH1 = (dApre W2) * (H1 > 0) and its column sums (the Dense_0 bias gradient) in the GEMM's own epilogue (gemm256.h)
+        GemmArgs g;
+        g.A = c->dApre.p; g.W = c->W2t.p; g.out = c->dH1T.p; g.M = (int)Mx; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldr = D; g.ldo = D;
+        g.mask = c->H1.p; g.ldm = D; g.colsum_part = c->colpart.as<float>();
+        const int mt = cdiv((int)Mx, 256);
+        ARP_TRY(c->colpart.ensure((size_t)mt * D * 4));
+        g.colsum_part = c->colpart.as<float>();
+        {
+            ProfScope ps(c->prof, c->stream, "dt.adapter_fc2_dX");
+            ARP_TRY((launch_gemm256_nt<T, T, ACT_NONE, false, SITE_DT>(g, c->stream)));
+        }
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), mt, D, c->g("AdapterMLP_0/Dense_0/bias"), invS);
+        ARP_HIP_OK(hipGetLastError());
+    } else {
+        ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.adapter_fc2_dX", c->dApre.p, D, c->W2t.p, D, nullptr, c->G.p, D, (int)Mx, D, D)));
+        // dH1 = G * (H1 > 0), row-major (in the buffer the other path uses for its transposed copy), + the Dense_0 bias gradient
         ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
         hipLaunchKernelGGL((mask_copy_colsum_kernel<T>), dim3(cdiv(D, 256), prow), dim3(256), 0, c->stream, c->G.as<T>(), c->H1.as<T>(), nullptr, 1.f,
                            c->dH1T.as<T>(), c->colpart.as<float>(), (int)Mx, D);
@@ -603,10 +665,13 @@ template <typename T> int backward(arp_dt* c) {
     if (c->fused) {
         // activation gradients came out of policy_fused_kernel; every parameter gradient of the transformer, the
         // heads, the LayerNorms and the embeddings is produced by three launches
-        ProfScope ps(c->prof, c->stream, "dt.policy_bwd");
-        hipLaunchKernelGGL(grouped_small_gemm_kernel, dim3(c->gemm_tiles), dim3(256), 0, c->stream, c->gtab.as<SmallGemm>(), c->gprefix.as<int>(), c->n_gemm);
-        hipLaunchKernelGGL(grouped_colsum_kernel, dim3(c->cs_tiles), dim3(256), 0, c->stream, c->ctab.as<ColSumJob>(), c->cprefix.as<int>(), c->n_cs);
-        hipLaunchKernelGGL(tokens_bwd_par_kernel, dim3(NA + 1), dim3(256), 0, c->stream, c->dtok.as<float>(), c->rtg.as<float>(), c->action.as<int>(),
+        // (Tried: these three launches and two of the weight-gradient contractions on a second stream, forked / joined with events
+        // so that the step's hipGraph holds them as parallel branches: 1.33 ms per step against 0.99 ms on one stream.)
+        hipStream_t st = c->stream;
+        ProfScope ps(c->prof, st, "dt.policy_bwd");
+        hipLaunchKernelGGL(grouped_small_gemm_kernel, dim3(c->gemm_tiles), dim3(256), 0, st, c->gtab.as<SmallGemm>(), c->gprefix.as<int>(), c->n_gemm);
+        hipLaunchKernelGGL(grouped_colsum_kernel, dim3(c->cs_tiles), dim3(256), 0, st, c->ctab.as<ColSumJob>(), c->cprefix.as<int>(), c->n_cs);
+        hipLaunchKernelGGL(tokens_bwd_par_kernel, dim3(NA + 1), dim3(256), 0, st, c->dtok.as<float>(), c->rtg.as<float>(), c->action.as<int>(),
                            c->g("rtg_input/kernel"), c->g("action_input/embedding"), R, E, NA);
         ARP_HIP_OK(hipGetLastError());
     } else {

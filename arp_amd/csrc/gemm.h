@@ -21,13 +21,13 @@
 namespace arp {
 
 struct GemmArgs {
-    const void* A;      // [M, lda] T
-    const void* W;      // [N, ldw] T
-    const float* bias;  // [N] or nullptr
-    const float* resid; // [M, ldr] f32 or nullptr (may alias out when OutT == float)
-    void* out;          // [M, ldo] OutT
-    int M, N, K;
-    int lda, ldw, ldr, ldo;
+    const void* A = nullptr;      // [M, lda] T
+    const void* W = nullptr;      // [N, ldw] T
+    const float* bias = nullptr;  // [N] or nullptr
+    const float* resid = nullptr; // [M, ldr] f32 or nullptr (may alias out when OutT == float)
+    void* out = nullptr;          // [M, ldo] OutT
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldw = 0, ldr = 0, ldo = 0;
     int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only)
     int ksplit = 1;     // split-K: gridDim.y slices of K; slice s writes to out + s * slice_stride (bias/resid ignored by callers)
     size_t slice_stride = 0;
@@ -47,6 +47,10 @@ struct GemmArgs {
     float alpha = 1.f;        // out = act(alpha * (A.W^T) + bias) (+ resid); honoured by gemm_nt_kernel (launch_gemm_auto routes alpha != 1
                               // there: power-of-two un-scaling of f16 gradient GEMMs, arp_dt.hip) and by the fp8 instances of gemm256
     float out_scale = 1.f;    // fp8 output only: the stored value is out_scale * act(...) (the consumer's alpha takes it out again)
+    // gemm256, 16-bit output, staged epilogue only (a ReLU backward fused into the producing GEMM: arp_dt.hip's adapter):
+    const void* mask = nullptr;       // [M, ldm] OutT: out = (mask > 0) ? value : 0
+    int ldm = 0;
+    float* colsum_part = nullptr;     // [ceil(M / 256)][N] f32: column sums of the ROUNDED masked output over each tile's rows
     int ovl = 0;              // gemm256, 16-bit output: a workgroup with another tile to do drains this tile's stores under that tile's first phases
 };
 

@@ -49,7 +49,8 @@ constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
 constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * 128;  // one K-tile: 64 KiB
 static_assert(256 * (256 * 2 + 16) >= 2 * G2_BUF_BYTES && 256 * (256 * 2 + 16) >= 128 * (256 * 4 + 16), "epilogue tile must cover the K-tile ring");
 constexpr int G2_TILE_BYTES = 256 * (256 * 2 + 16);  // 132 KiB: 2 K-tile buffers (128 KiB) or the padded epilogue tile
-constexpr int G2_LDS_BYTES = G2_TILE_BYTES + 1024;   // + this tile's 256 bias values, fetched while the K loop runs
+constexpr int G2_RED_OFF = G2_TILE_BYTES + 1024;     // + this tile's 256 bias values, fetched while the K loop runs
+constexpr int G2_LDS_BYTES = G2_RED_OFF + 8 * 256 * 4;  // + the eight waves' column sums of the masked epilogue (GemmArgs::colsum_part)
 constexpr int G2_B_REGION = G2_BM * 128;             // W rows start here inside a buffer
 constexpr int G2_GROUP_M = 8;
 
@@ -540,6 +541,53 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
             ARP_STAMP(2);
             __syncthreads();
             ARP_STAMP(3);
+            if (g.mask) {
+                // out = (mask > 0) ? value : 0 on whole 16-byte row segments, plus the tile's column sums of what was stored (the bias
+                // gradient of the layer whose ReLU this is): one more 16-byte read per store instead of a separate pass over both tensors
+                const OutT* __restrict__ mk = static_cast<const OutT*>(g.mask);
+                float colacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int it = 0; it < 16; ++it) {
+                    const int r = it * 16 + wave * 2 + (lane >> 5);
+                    const int m = m0 + r, n = n0 + (lane & 31) * 8;
+                    if (m < g.M && n < g.N) {
+                        u32x4_v v = *reinterpret_cast<const u32x4_v*>(smem + r * RS + (lane & 31) * 16);
+                        const u32x4_v mv = *reinterpret_cast<const u32x4_v*>(mk + (size_t)m * g.ldm + n);
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            // per 16-bit half: keep = magnitude non-zero and sign clear (bf16 and f16 alike; a NaN mask keeps, as NaN > 0
+                            // never occurs behind a ReLU)
+                            const uint32_t mag = mv[w] & 0x7fff7fffu;
+                            const uint32_t nz = ((mag & 0xffffu) ? 0xffffu : 0u) | ((mag >> 16) ? 0xffff0000u : 0u);
+                            const uint32_t pos = ((mv[w] & 0x8000u) ? 0u : 0xffffu) | ((mv[w] & 0x80000000u) ? 0u : 0xffff0000u);
+                            const uint32_t kept = v[w] & nz & pos;
+                            v[w] = kept;
+                            OutT pr[2];
+                            memcpy(pr, &kept, 4);
+                            colacc[2 * w] += Elem<OutT>::ld(&pr[0]);
+                            colacc[2 * w + 1] += Elem<OutT>::ld(&pr[1]);
+                        }
+                        *reinterpret_cast<u32x4_v*>(out + (size_t)m * g.ldo + n) = v;
+                    }
+                }
+                if (g.colsum_part) {
+                    float* red = reinterpret_cast<float*>(smem + G2_RED_OFF);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) colacc[e] += __shfl_xor(colacc[e], 32, 64);
+                    if (lane < 32) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) red[wave * 256 + lane * 8 + e] = colacc[e];
+                    }
+                    __syncthreads();
+                    if (tid < 256 && n0 + tid < g.N) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) t += red[w * 256 + tid];
+                        g.colsum_part[(size_t)(m0 / G2_BM) * g.N + n0 + tid] = t;
+                    }
+                }
+                return;
+            }
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
                 const int r = it * 16 + wave * 2 + (lane >> 5);
@@ -700,6 +748,8 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     if (g.N <= 0 || g.K % EPB != 0 || g.K <= 0 || g.lda % (16 / (int)sizeof(T)) != 0 || g.ldw % (16 / (int)sizeof(T)) != 0)
         return fail("gemm256_nt: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) +
                     " K=" + std::to_string(g.K));
+    if (g.mask && (sizeof(OutT) != 2 || ((g.N | g.ldo | g.ldm | g.ldr) & 7) || (g.flags & 3)))
+        return fail("gemm256_nt: the masked epilogue needs a 16-bit output and N, ldo, ldm multiples of 8");
     auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -1,6 +1,8 @@
 // TN weight-gradient GEMM (design notes in gemm_tn.h); its own translation unit.
 #include "gemm_tn.h"
 
+#include <type_traits>
+
 #include "attention.h"  // tr_b64_v
 #include "gemm.h"       // xcd_remap
 
@@ -178,14 +180,16 @@ __global__ __launch_bounds__(TW_THREADS) void gemm_tn256_kernel(GemmTnArgs g, in
 #if defined(TW_ABL) && (TW_ABL & 2)
         if (kt >= TW_STAGES - 1) return;  // ablation: prologue loads only
 #endif
-        char* base = smem + (kt & (TW_STAGES - 1)) * TW_STAGE_BYTES;
+        // ring layout: A slots at [0, 64 KiB), B slots at [64 KiB, 128 KiB), 16 KiB each -- every fragment read of either operand is
+        // then one per-lane base register plus an instruction offset (slot * 16 KiB [+ 8 KiB] < 64 KiB)
+        char* base = smem + (kt & (TW_STAGES - 1)) * TW_OP_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             char* dst = base + (wave * 2 + i) * 1024;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (size_t)kt * TW_BK * g.lda),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (size_t)kt * TW_BK * g.ldb),
-                                             (__attribute__((address_space(3))) void*)(dst + TW_OP_BYTES), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + TW_STAGES * TW_OP_BYTES), 16, 0, 0);
         }
     };
     // Transposing fragment reads as in the 128-tile kernel (rows of 512 B, slot swizzle by (row & 15)), but issued as inline asm with
@@ -196,21 +200,24 @@ __global__ __launch_bounds__(TW_THREADS) void gemm_tn256_kernel(GemmTnArgs g, in
     const int trq = fr >> 2, trp = fr & 3;
     const int r0 = 4 * fg + trq;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    uint32_t a_off[8], b_off[4];  // per-lane byte offsets inside an operand tile
+    // per-lane byte addresses inside ring slot 0 of each operand; the slot and a fragment's second half are instruction offsets
+    uint32_t a_lo[8], b_lo[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a_off[i] = lds0 + r0 * 512 + (((wr * 8 + i) ^ (r0 & 15)) << 5) + trp * 8;
+    for (int i = 0; i < 8; ++i) a_lo[i] = lds0 + r0 * 512 + (((wr * 8 + i) ^ (r0 & 15)) << 5) + trp * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b_off[i] = lds0 + TW_OP_BYTES + r0 * 512 + (((wc * 4 + i) ^ (r0 & 15)) << 5) + trp * 8;
+    for (int i = 0; i < 4; ++i) b_lo[i] = lds0 + TW_STAGES * TW_OP_BYTES + r0 * 512 + (((wc * 4 + i) ^ (r0 & 15)) << 5) + trp * 8;
     // A fragment's two halves stay two 64-bit values until its wait has been passed: the 128-bit MFMA operand is assembled only
     // there, so that any register copy the compiler needs for the tuple reads data that has arrived.
     struct Frag { u32x2_v lo, hi; };
-    auto frag = [&](uint32_t addr) {
+    auto frag = [&]<int OFF>(uint32_t addr, std::integral_constant<int, OFF>) {
         Frag f;
 #if defined(TW_ABL) && (TW_ABL & 1)
         asm volatile("v_mov_b32 %0, %1" : "=&v"(f.lo[0]) : "v"(addr));  // ablation: no LDS reads
         f.lo[1] = f.lo[0]; f.hi = f.lo;
 #else
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:8192" : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=&v"(f.lo), "=&v"(f.hi)
+                     : "v"(addr), "n"(OFF), "n"(OFF + 8192));
 #endif
         return f;
     };
@@ -227,13 +234,18 @@ __global__ __launch_bounds__(TW_THREADS) void gemm_tn256_kernel(GemmTnArgs g, in
 
     // Software pipeline across the per-tile barrier: a K-tile's MFMAs run as two halves of 16 (m-blocks 0-3, then 4-7).  The
     // fragments of the second half are fetched behind the first half's MFMAs; the NEXT tile's B and first-half A fragments are
-    // fetched (after the wait + barrier that publish that tile) behind the second half's.
-    auto step = [&](int kt, Frag (&bfc)[4], Frag (&alc)[4], Frag (&bfn)[4], Frag (&aln)[4]) {
-        // Every non-MFMA instruction of the step sits in the gap behind an MFMA (the matrix pipe runs 16 cycles per instruction, the
-        // wave issues LDS reads / LDS-DMA / address arithmetic meanwhile): with the reads and the DMA issue bunched at the phase
-        // boundaries, where every wave of the workgroup stands at the same point, a K-tile took 1.7 k cycles for 1.0 k of MFMA.
-        const uint32_t cur = (kt & (TW_STAGES - 1)) * TW_STAGE_BYTES;
-        const bool next = kt + 1 < nk;
+    // fetched (after the wait + barrier that publish that tile) behind the second half's.  Every non-MFMA instruction of the step
+    // sits in the gap behind an MFMA: the SIMD's vector issue port, shared by the two resident waves, is what the loop is bound by
+    // (an MFMA holds it for 8 of its 16 cycles; an LDS read ~4, an LDS-DMA piece ~60), so the steady-state step (FULL) is branch-free
+    // and carries the ring slot (SLOT = kt % 4) as a compile-time constant -- no address arithmetic, no loop-end tests.
+    auto step = [&]<int SLOT, bool FULL>(int kt, Frag (&bfc)[4], Frag (&alc)[4], Frag (&bfn)[4], Frag (&aln)[4], std::integral_constant<int, SLOT>,
+                                         std::bool_constant<FULL>) {
+        constexpr int NS = (SLOT + 1) & 3;
+        constexpr int coff = SLOT * TW_OP_BYTES, noff = NS * TW_OP_BYTES;
+        const uint32_t(&a_c)[8] = a_lo;
+        const uint32_t(&a_n)[8] = a_lo;
+        const uint32_t(&b_n)[4] = b_lo;
+        const bool next = FULL || kt + 1 < nk;
         Frag ah[4];
         TW_WAIT4(0, bfc);  // this step's B and first-half A fragments (fetched behind the previous step's second half)
         TW_WAIT4(0, alc);
@@ -246,20 +258,19 @@ __global__ __launch_bounds__(TW_THREADS) void gemm_tn256_kernel(GemmTnArgs g, in
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 acc[ni][mi] = mfma16<T>(b4[ni], a4[mi], acc[ni][mi]);
-                if (ni == 0) ah[mi] = frag(a_off[4 + mi] + cur);
+                if (ni == 0) ah[mi] = frag(a_c[4 + mi], std::integral_constant<int, coff>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
         TW_WAIT4(0, ah);  // this wave's last reads of tile kt have returned (also what lets the slot be overwritten two barriers on)
         if (next) {
             // tile kt+1 must have landed; tile kt+2 (4 LDS-DMA instructions per wave) may stay in flight
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (FULL || kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if !(defined(TW_ABL) && (TW_ABL & 4))
             __builtin_amdgcn_s_barrier();
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
-        const uint32_t nxt = ((kt + 1) & (TW_STAGES - 1)) * TW_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) a4[i] = op(ah[i]);
 #pragma unroll
@@ -269,9 +280,9 @@ __global__ __launch_bounds__(TW_THREADS) void gemm_tn256_kernel(GemmTnArgs g, in
                 acc[ni][4 + mi] = mfma16<T>(b4[ni], a4[mi], acc[ni][4 + mi]);
                 const int j = mi * 4 + ni;
                 if (next) {
-                    if (j == 1 && kt + TW_STAGES - 1 < nk) stage(kt + TW_STAGES - 1);  // into tile kt-1's slot: every wave finished it a barrier ago
-                    if (j >= 2 && j < 6) bfn[j - 2] = frag(b_off[j - 2] + nxt);
-                    if (j >= 6 && j < 10) aln[j - 6] = frag(a_off[j - 6] + nxt);
+                    if (j == 1 && (FULL || kt + TW_STAGES - 1 < nk)) stage(kt + TW_STAGES - 1);  // into tile kt-1's slot: every wave finished it a barrier ago
+                    if (j >= 2 && j < 6) bfn[j - 2] = frag(b_n[j - 2], std::integral_constant<int, noff>{});
+                    if (j >= 6 && j < 10) aln[j - 6] = frag(a_n[j - 6], std::integral_constant<int, noff>{});
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -288,12 +299,23 @@ __global__ __launch_bounds__(TW_THREADS) void gemm_tn256_kernel(GemmTnArgs g, in
         __builtin_amdgcn_sched_barrier(0);
         Frag bf0[4], al0[4], bf1[4], al1[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bf0[i] = frag(b_off[i]);
+        for (int i = 0; i < 4; ++i) bf0[i] = frag(b_lo[i], std::integral_constant<int, 0>{});
 #pragma unroll
-        for (int i = 0; i < 4; ++i) al0[i] = frag(a_off[i]);
-        for (int kt = 0; kt < nk; kt += 2) {
-            step(kt, bf0, al0, bf1, al1);
-            if (kt + 1 < nk) step(kt + 1, bf1, al1, bf0, al0);
+        for (int i = 0; i < 4; ++i) al0[i] = frag(a_lo[i], std::integral_constant<int, 0>{});
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        int kt = 0;
+        for (; kt + 3 + TW_STAGES - 1 < nk; kt += 4) {  // four steady-state tiles: each still has a tile to prefetch
+            step(kt, bf0, al0, bf1, al1, I0{}, std::true_type{});
+            step(kt + 1, bf1, al1, bf0, al0, I1{}, std::true_type{});
+            step(kt + 2, bf0, al0, bf1, al1, I2{}, std::true_type{});
+            step(kt + 3, bf1, al1, bf0, al0, I3{}, std::true_type{});
+        }
+        for (; kt < nk; kt += 4) {
+            step(kt, bf0, al0, bf1, al1, I0{}, std::false_type{});
+            if (kt + 1 < nk) step(kt + 1, bf1, al1, bf0, al0, I1{}, std::false_type{});
+            if (kt + 2 < nk) step(kt + 2, bf0, al0, bf1, al1, I2{}, std::false_type{});
+            if (kt + 3 < nk) step(kt + 3, bf1, al1, bf0, al0, I3{}, std::false_type{});
         }
     }
 #undef TW_WAIT4

@@ -82,7 +82,55 @@ template <typename OutT, int ACT, bool RESID> static void run(const char* name, 
     hipFree(dA); hipFree(dW); hipFree(dB); hipFree(dO); hipFree(dR);
 }
 
+// the masked epilogue (out = value * (mask > 0), column sums of the stored values per 256-row tile) against a CPU reference
+static bool check_masked(int M, int N, int K) {
+    std::vector<f16_t> hA((size_t)M * K), hW((size_t)N * K), hM((size_t)M * N);
+    uint32_t s = 4242u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hA) v = host_f2h(rnd());
+    for (auto& v : hW) v = host_f2h(rnd() * 0.05f);
+    for (auto& v : hM) { const float r = rnd(); v = host_f2h(r > 0.f ? r : (r < -0.9f ? -0.0f : 0.f)); }  // relu-like: positives, +0 and a few -0
+    const int mt = (M + 255) / 256;
+    void *dA, *dW, *dO, *dM;
+    float* dC;
+    hipMalloc(&dA, hA.size() * 2); hipMalloc(&dW, hW.size() * 2); hipMalloc(&dO, (size_t)M * N * 2); hipMalloc(&dM, hM.size() * 2); hipMalloc(&dC, (size_t)mt * N * 4);
+    hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dM, hM.data(), hM.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(dO, 0xff, (size_t)M * N * 2);
+    GemmArgs g;
+    g.A = dA; g.W = dW; g.out = dO; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
+    g.mask = dM; g.ldm = N; g.colsum_part = dC;
+    if (launch_gemm256_nt<f16_t, f16_t, ACT_NONE, false, 6>(g, nullptr)) return false;
+    if (hipDeviceSynchronize() != hipSuccess) { printf("masked M=%d N=%d K=%d: launch failed\n", M, N, K); return false; }
+    std::vector<f16_t> hO((size_t)M * N);
+    std::vector<float> hC((size_t)mt * N);
+    hipMemcpy(hO.data(), dO, hO.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost);
+    auto h2f = [](f16_t h) { _Float16 x; memcpy(&x, &h, 2); return (float)x; };
+    double maxerr = 0, maxc = 0;
+    long bad_mask = 0;
+    std::vector<double> cs((size_t)mt * N, 0.0);
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) {
+            const float o = h2f(hO[(size_t)m * N + n]);
+            cs[(size_t)(m / 256) * N + n] += o;
+            if (!(h2f(hM[(size_t)m * N + n]) > 0.f)) { bad_mask += (o != 0.f); continue; }
+            if ((m * 7 + n) % 13) continue;
+            double r = 0;
+            for (int k = 0; k < K; ++k) r += (double)h2f(hA[(size_t)m * K + k]) * h2f(hW[(size_t)n * K + k]);
+            maxerr = std::max(maxerr, std::fabs(r - o) / (1.0 + std::fabs(r)));
+        }
+    for (size_t i = 0; i < cs.size(); ++i) maxc = std::max(maxc, std::fabs(cs[i] - hC[i]) / (1.0 + std::fabs(cs[i])));
+    const bool ok = bad_mask == 0 && maxerr < 2e-3 && maxc < 1e-4;
+    printf("masked M=%d N=%d K=%d: max rel err %.2e, unmasked-where-masked %ld, column-sum rel err %.2e  %s\n", M, N, K, maxerr, bad_mask, maxc, ok ? "OK" : "FAILED");
+    hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dM); hipFree(dC);
+    return ok;
+}
+
 int main() {
+#ifndef ARP_G2_STAMPS
+    bool ok = check_masked(512, 256, 128) & check_masked(1000, 520, 192) & check_masked(32896, 768, 768);
+    if (!ok) return 1;
+#endif
     run<f16_t, ACT_NONE, false>("qkv", 51200, 2304, 768);
     run<f16_t, ACT_QGELU, false>("c_fc", 51200, 3072, 768);
     run<f16_t, ACT_NONE, false>("c_fc_noact", 51200, 3072, 768);
