@@ -21,7 +21,7 @@ struct AdapterDyArgs {
     const void* Wi;     // [E, Kin] T: image_text_input/kernel in device layout [out, in], operand-type copy
     const void* A;      // [R, Kin] T: the adapter MLP's output (post-ReLU), = [R * tokens, D]
     const float* x32;   // [R, Kin] f32: the stop-gradient encodings
-    const float* res;   // device scalar sigmoid(residual_weight)
+    const float* rw;    // device scalar residual_weight (res = sigmoid(rw) is formed in the kernel)
     void* dApre;        // [R, Kin] T out
     float* colpart;     // [row_blocks * tokens, D] f32 out
     float* dres_part;   // [row_blocks * Kin / 128] f32 out

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(AD_THREADS) void adapter_dy_kernel(AdapterDyArgs g)
     // ---- row-contiguous pass: 16-byte loads of A, 32-byte loads of x, 16-byte stores of dApre ----------------------------------------
     const T* __restrict__ Ap = static_cast<const T*>(g.A);
     T* __restrict__ out = static_cast<T*>(g.dApre);
-    const float s = g.res[0];
+    const float s = 1.0f / (1.0f + expf(-g.rw[0]));  // res = sigmoid(residual_weight), as adapter_mix computes it
     const int chunk = tid & 15, rowl = tid >> 4;
     float colacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dsum = 0.f;

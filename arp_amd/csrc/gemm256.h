@@ -49,6 +49,8 @@ constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
 constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * 128;  // one K-tile: 64 KiB
 static_assert(256 * (256 * 2 + 16) >= 2 * G2_BUF_BYTES && 256 * (256 * 2 + 16) >= 128 * (256 * 4 + 16), "epilogue tile must cover the K-tile ring");
 constexpr int G2_TILE_BYTES = 256 * (256 * 2 + 16);  // 132 KiB: 2 K-tile buffers (128 KiB) or the padded epilogue tile
+// call sites >= 16 (the policy step's: arp_dt.hip SITE_DT) carry the masked epilogue (GemmArgs::mask)
+constexpr bool G2_MASK_SITE(int site) { return site >= 16; }
 constexpr int G2_RED_OFF = G2_TILE_BYTES + 1024;     // + this tile's 256 bias values, fetched while the K loop runs
 constexpr int G2_LDS_BYTES = G2_RED_OFF + 8 * 256 * 4;  // + the eight waves' column sums of the masked epilogue (GemmArgs::colsum_part)
 constexpr int G2_B_REGION = G2_BM * 128;             // W rows start here inside a buffer
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
             ARP_STAMP(2);
             __syncthreads();
             ARP_STAMP(3);
-            if (g.mask) {
+            if (G2_MASK_SITE(SITE) && g.mask) {  // compiled into the policy step's instances only: the ViT kernels keep their register budget
                 // out = (mask > 0) ? value : 0 on whole 16-byte row segments, plus the tile's column sums of what was stored (the bias
                 // gradient of the layer whose ReLU this is): one more 16-byte read per store instead of a separate pass over both tensors
                 const OutT* __restrict__ mk = static_cast<const OutT*>(g.mask);
@@ -748,7 +750,7 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     if (g.N <= 0 || g.K % EPB != 0 || g.K <= 0 || g.lda % (16 / (int)sizeof(T)) != 0 || g.ldw % (16 / (int)sizeof(T)) != 0)
         return fail("gemm256_nt: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) +
                     " K=" + std::to_string(g.K));
-    if (g.mask && (sizeof(OutT) != 2 || ((g.N | g.ldo | g.ldm | g.ldr) & 7) || (g.flags & 3)))
+    if (g.mask && (!G2_MASK_SITE(SITE) || sizeof(OutT) != 2 || ((g.N | g.ldo | g.ldm | g.ldr) & 7) || (g.flags & 3)))
         return fail("gemm256_nt: the masked epilogue needs a 16-bit output and N, ldo, ldm multiples of 8");
     auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE>;
     static bool attr_set = false;

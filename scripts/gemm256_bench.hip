@@ -100,7 +100,7 @@ static bool check_masked(int M, int N, int K) {
     GemmArgs g;
     g.A = dA; g.W = dW; g.out = dO; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
     g.mask = dM; g.ldm = N; g.colsum_part = dC;
-    if (launch_gemm256_nt<f16_t, f16_t, ACT_NONE, false, 6>(g, nullptr)) return false;
+    if (launch_gemm256_nt<f16_t, f16_t, ACT_NONE, false, 16>(g, nullptr)) return false;
     if (hipDeviceSynchronize() != hipSuccess) { printf("masked M=%d N=%d K=%d: launch failed\n", M, N, K); return false; }
     std::vector<f16_t> hO((size_t)M * N);
     std::vector<float> hC((size_t)mt * N);
