@@ -239,7 +239,7 @@ def test_full_size_step_is_bitwise_reproducible(gpu_lib):
     assert a0[-1]["loss"] < a0[0]["loss"]  # and it learns on a fixed batch
 
 
-def test_full_geometry_matches_oracle(gpu_lib):
+def test_full_geometry_matches_oracle(gpu_lib, monkeypatch):
     """The REAL shapes against the fp64 oracle: B = 2, window 4, enc_tokens 257, enc_dim 768 -- the 257-way
     split-K over K = 197 376 of image_text_input, the adapter GEMMs at M = 2056, the transposed K-padded operand copies of the
     weight-gradient GEMMs.  f32 mode: forward, every gradient tensor and one clipped Adam step; f16 mode (what bench.py --path
@@ -252,7 +252,12 @@ def test_full_geometry_matches_oracle(gpu_lib):
     g_ref, _, _ = O.grads(Pt, ocfg, *tb)
     lr = 1e-3
     st, oaux = O.train_step(O.init_state(Pt), ocfg, [tb], lambda t: lr)
-    for mode, ltol, gtol in (("f32", 2e-5, 3e-4), ("f16", LOGIT_TOL_16BIT, None)):
+    # "f16+": the same with the ReLU backward + bias column sums forced into gemm256's epilogue (what B = 32 runs; at B = 2 the grid
+    # is below the size where that kernel is chosen by itself)
+    for mode, ltol, gtol in (("f32", 2e-5, 3e-4), ("f16", LOGIT_TOL_16BIT, None), ("f16+", LOGIT_TOL_16BIT, None)):
+        if mode.endswith("+"):
+            monkeypatch.setenv("ARP_DT_FUSE_RELU_BWD", "2")
+            mode = mode[:-1]
         tr = PolicyTrainer(cfg, mode=mode)
         tr.set_params(P)
         tr.set_batch(enc, act, rtg)
@@ -287,6 +292,20 @@ def test_full_geometry_matches_oracle(gpu_lib):
             cos = num / np.sqrt(d1 * d2)
             print(f"full geometry {mode}: gradient cosine {cos:.6f}, norm ratio {np.sqrt(d1 / d2):.5f}")
             assert cos > 0.9995 and abs(np.sqrt(d1 / d2) - 1) < 5e-3
+            # ... and tensor by tensor (the 25 M-entry image_text_input kernel would hide a wrong bias gradient in the global cosine):
+            # direction and size of every gradient tensor to 16-bit-operand accuracy
+            bad = []
+            for k in P:
+                a, r = g[k].ravel().astype(np.float64), g_ref[k].numpy().ravel().astype(np.float64)
+                nr = np.linalg.norm(r)
+                if nr < 1e-12:
+                    continue
+                ck = float(a @ r / max(np.linalg.norm(a) * nr, 1e-300))
+                rel = float(np.linalg.norm(a - r) / nr)
+                print(f"  {k}: cosine {ck:.6f}, rel L2 {rel:.2e}")
+                if ck < 0.999 or rel > 3e-2:
+                    bad.append((k, ck, rel))
+            assert not bad, f"full geometry {mode} per-tensor gradients: {bad}"
         aux = tr.train_step(lr)
         assert abs(aux["loss"] - oaux["loss"]) < (1e-4 if mode == "f32" else 2e-3), (aux["loss"], oaux["loss"])
         assert abs(aux["grad_norm"] - oaux["grad_norm"]) < (1e-4 if mode == "f32" else 5e-3) * max(1.0, oaux["grad_norm"])
