@@ -227,7 +227,6 @@ struct arp_clip {
     bool is_sibling = false;
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;  // one per sibling
-    bool join_pending = false;        // sibling work recorded in ev_join that the primary stream has not been made to wait for yet
     int gemm_force = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (ARP_GEMM env)
     // Fold LayerNorm into the consumer GEMMs of the vision tower in bf16 mode (ARP_LN_FOLD=1).  Numerically fine
     // (cosine error 3.6e-4 vs 4.8e-4 unfused) but MEASURED SLOWER on MI355X (74.2 k vs 79.7 k frames/s): the extra
@@ -648,21 +647,10 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
                                       hipMemcpyHostToDevice, s->stream));
         ARP_TRY(label_dev_single(s, frames_dev + (size_t)b0 * H * W * 3, nb, H, W, use_crop, rewards_dev + b0));
         if (i > 0) {
-            // LAZY join: the primary stream waits for this only where a caller can observe results (join_siblings: sync, event
-            // record, the host path's download).  Back-to-back asynchronous batches then do not drain the chip at every batch
-            // boundary, and the parts drift out of phase instead of running the same kernel side by side.
             ARP_HIP_OK(hipEventRecord(c->ev_join[i - 1], s->stream));
-            c->join_pending = true;
+            ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join[i - 1], 0));
         }
     }
-    return 0;
-}
-
-// the primary stream waits for everything the sibling streams have been given so far
-static int join_siblings(arp_clip* c) {
-    if (!c->join_pending) return 0;
-    for (hipEvent_t e : c->ev_join) ARP_HIP_OK(hipStreamWaitEvent(c->stream, e, 0));
-    c->join_pending = false;
     return 0;
 }
 
@@ -820,9 +808,6 @@ int arp_clip_set_text(arp_clip* c, const int32_t* tokens, int n_prompts) {
     ARP_TRY(check_ready(c, false));
     if (!tokens || n_prompts <= 0) return fail("set_text: need at least one prompt");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    // parts of an asynchronous batch may still be reading the cached prompt features on the sibling streams
-    ARP_TRY(join_siblings(c));
-    for (arp_clip* sib : c->siblings) ARP_HIP_OK(hipStreamSynchronize(sib->stream));
     // 16-bit handles: the cached prompt features come from the f32 copy of the text tower (arp_clip::txt32); ARP_TEXT_F32=0 keeps
     // the handle's own operand type (A/B measurements)
     static const bool text32 = [] { const char* e = getenv("ARP_TEXT_F32"); return !e || atoi(e) != 0; }();
@@ -846,7 +831,6 @@ int arp_clip_label_dev_async(arp_clip* c, const uint8_t* frames_dev, int n, int 
 
 int arp_clip_sync(arp_clip* c) {
     if (!c) return fail("null handle");
-    ARP_TRY(join_siblings(c));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -864,7 +848,6 @@ int arp_clip_label(arp_clip* c, const uint8_t* frames, int n, int H, int W, int 
     for (int off = 0; off < n; off += mb) {
         const int nb = std::min(mb, n - off);
         ARP_TRY(label_dev(c, c->frames_in.as<uint8_t>(), nb, H, W, use_crop, c->rewards.as<float>(), frames + (size_t)off * fb));
-        ARP_TRY(join_siblings(c));
         ARP_HIP_OK(hipMemcpyAsync(rewards + off, c->rewards.p, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
     }
@@ -1070,7 +1053,6 @@ int arp_event_destroy(arp_event* e) {
 }
 int arp_clip_event_record(arp_clip* c, arp_event* e) {
     if (!c || !e) return fail("null argument");
-    ARP_TRY(join_siblings(c));
     ARP_HIP_OK(hipEventRecord(e->e, c->stream));
     return 0;
 }
