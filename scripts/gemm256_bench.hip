@@ -39,6 +39,7 @@ template <typename OutT, int ACT, bool RESID> static void run(const char* name, 
     GemmArgs g;
     g.A = dA; g.W = dW; g.bias = dB; g.resid = RESID ? (float*)dR : nullptr; g.out = RESID ? dR : dO;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
+    if (getenv("G256_LDA0")) g.lda = 0;  // every A row is row 0: the A stream comes from cache (isolates memory latency from loop mechanics)
     if (const char* e = getenv("G256_FLAGS")) g.flags = atoi(e);  // 1 = ablate the epilogue stores (K loop only), 2 = unstaged stores
 #ifdef ARP_G2_STAMPS
     const int ntile = ((M + 255) / 256) * ((N + 255) / 256);
@@ -140,5 +141,11 @@ int main() {
     run<float, ACT_NONE, true>("c_proj_half", 25600, 768, 3072);
     run<f16_t, ACT_NONE, false>("sq4096", 4096, 4096, 4096);
     run<f16_t, ACT_NONE, false>("ragged", 1000, 520, 192);
+    if (getenv("G256_MALL")) {  // is the c_proj A stream's home (Infinity Cache vs HBM) visible?  one / two full rounds of 255 tiles
+        run<float, ACT_NONE, true>("cproj_1rnd", 21760, 768, 3072);   // A = 134 MB: stays in the 256 MiB Infinity Cache between launches
+        run<float, ACT_NONE, true>("cproj_2rnd", 43520, 768, 3072);   // A = 267 MB: does not
+        run<f16_t, ACT_QGELU, false>("cfc_1rnd", 5376, 3072, 768);     // 21 x 12 = 252 tiles
+        run<f16_t, ACT_QGELU, false>("cfc_8rnd", 43520, 3072, 768);    // 170 x 12 = 2040 tiles = 8 rounds
+    }
     return 0;
 }
