@@ -18,6 +18,13 @@ constexpr int QA_V_OFF = QA_K_OFF + QA_KV_ROWS * 128;
 static_assert(QA_V_OFF + QA_KV_ROWS * 128 <= 2 * QA_BUF_BYTES, "q/k/v images must fit the K-tile ring");
 constexpr int QA_LDS_BYTES = 2 * QA_BUF_BYTES + 192 * 4;
 
+#ifdef ARP_QA_STAMPS
+__device__ long long* arp_qa_stamps = nullptr;  // scripts/qkvattn_bench.hip: per-workgroup, per-wave phase time stamps
+#define QA_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define QA_STAMP(i)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(QA_THREADS, 2) void qkv_attn_kernel(QkvAttnArgs g) {
     static_assert(sizeof(T) == 2, "16-bit operand types only");
@@ -55,8 +62,13 @@ __global__ __launch_bounds__(QA_THREADS, 2) void qkv_attn_kernel(QkvAttnArgs g) 
     const T* __restrict__ A = static_cast<const T*>(g.A);
     const T* __restrict__ W = static_cast<const T*>(g.W);
 
+#ifdef ARP_QA_STAMPS
+    long long st_[5];
+#endif
+    QA_STAMP(0);
     f32x4_v acc[2][3][4];  // [mq][ni][mi]
     kloop_256x192<T>(smem, A, W, g.bias, g.lda, g.ldw, m0, n0, Mtot, g.heads * 192, g.K, acc);
+    QA_STAMP(1);
     const int fr = lane & 15, fg = lane >> 4;
     float* bias_s = reinterpret_cast<float*>(smem + K192_RING_BYTES);
 
@@ -82,6 +94,7 @@ __global__ __launch_bounds__(QA_THREADS, 2) void qkv_attn_kernel(QkvAttnArgs g) 
             }
         }
     __syncthreads();
+    QA_STAMP(2);
 
     // ---- attention from LDS: one (frame, 16-query block) per wave at a time (code of attn_mfma_kernel) ----------------------
     const char* Ks = smem + QA_K_OFF;
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(QA_THREADS, 2) void qkv_attn_kernel(QkvAttnArgs g) 
             }
         }
     }
+    QA_STAMP(3);
     __syncthreads();
     // ---- whole 128-B row segments out ---------------------------------------------------------------------------------------
     T* out = static_cast<T*>(g.out);
@@ -182,6 +196,14 @@ __global__ __launch_bounds__(QA_THREADS, 2) void qkv_attn_kernel(QkvAttnArgs g) 
             *reinterpret_cast<u32x4_v*>(out + (size_t)(m0 + row) * g.ldo + head * 64 + ch * 8) = v;
         }
     }
+#ifdef ARP_QA_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    QA_STAMP(4);
+    if (arp_qa_stamps && lane == 0) {
+        long long* d = arp_qa_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 5; ++i) d[i] = st_[i];
+    }
+#endif
 }
 
 template <typename T>
