@@ -59,6 +59,24 @@ def cpu_baseline(model, seconds, policy_batch=0, finetune_batch=0):
         return {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries print there too (gloo's "[Gloo] Rank 0 is connected to ..." banner at
+    rendezvous, ROCm notices): from here on file descriptor 1 points at stderr and the JSON line goes to the saved real stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh copies of this script, one rank per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), BEFORE anything here has
@@ -72,7 +90,9 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT))
+        # the children get the REAL stdout as their fd 1 (this process's own fd 1 points at stderr since claim_stdout)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=_JSON_FD if _JSON_FD is not None else None))
     rc = 0
     for p in procs:
         try:
@@ -208,7 +228,7 @@ def bench_policy(a):
         peak = PEAK_TFLOPS[a.mode] if kind == "mfma" else 8000.0
         achieved = work / (avg_ms * 1e-3) / (1e12 if kind == "mfma" else 1e9)
         flops = policy_step_flops(cfg, a.policy_batch)
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "samples/sec ARPDT train_step (frames in, frozen M3AE encoder inside)" if enc is not None else
                       "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -311,7 +331,7 @@ def bench_finetune(a):
         tr.close()
         dist.destroy_process_group()
         return
-    print(json.dumps({
+    emit(json.dumps({
         "metric": "samples/sec CLIP multi-scale adapter fine-tune step (frames in: frozen ViT-B/16 towers + head)" if towers is not None else
                   "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": world * a.finetune_batch * a.steps / elapsed,
         "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
@@ -333,6 +353,7 @@ def bench_finetune(a):
 
 
 def main():
+    claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -551,7 +572,7 @@ def main():
             "sites_total_ms_per_step": total_ms / a.steps,
             "per_rank_frames_per_s": [round(v, 1) for v in per_rank],
         }
-        print(json.dumps(out))
+        emit(json.dumps(out))
     model.close()
     if dist is not None:
         dist.destroy_process_group()
