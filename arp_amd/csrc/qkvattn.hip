@@ -97,6 +97,8 @@ __global__ __launch_bounds__(QA_THREADS, 2) void qkv_attn_kernel(QkvAttnArgs g) 
     QA_STAMP(2);
 
     // ---- attention from LDS: one (frame, 16-query block) per wave at a time (code of attn_mfma_kernel) ----------------------
+    // (Three units per wave walked stage by stage, so that their dependent chains interleave, measured 7.4 k cycles for the phase
+    //  against 6.5 k: the phase is bound by issue throughput -- LDS reads, exp, MFMAs of two resident waves -- not by one chain's latency.)
     const char* Ks = smem + QA_K_OFF;
     const char* Vs = smem + QA_V_OFF;
     const int N = g.N;
