@@ -162,6 +162,9 @@ SIGNATURES = {
     "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
     "arp_op_gemm_fp8": (_i, [_i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _f]),
     "arp_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
+    "arp_op_gemm_tn": (_i, [_i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _f]),
+    "arp_op_gemm_relu_bwd": (_i, [_i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
+    "arp_op_adapter_dy": (_i, [_i, _fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _i, _i, _i, _i]),
     "arp_op_layernorm": (_i, [_fp, _fp, _fp, _fp, _i, _i, _f]),
     "arp_op_attention": (_i, [_i, _i, _fp, _fp, _i, _i, _i, _i, _i]),
 }

@@ -1174,6 +1174,153 @@ int arp_dt_broadcast_state(arp_dt* c) {
     return 0;
 }
 
+// ---- single-kernel entry points of the train step's own kernels (host buffers; tests/test_ops_gpu.py) ----------------------------
+}  // extern "C"
+
+namespace {
+// host f32 -> device operand type T (rounded on the device by the step's own conversion kernel)
+template <typename T> int upload_as(DevBuf& stage, DevBuf& dst, const float* src, size_t n) {
+    ARP_TRY(stage.ensure(n * 4));
+    ARP_TRY(dst.ensure(n * sizeof(T)));
+    ARP_HIP_OK(hipMemcpy(stage.p, src, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((convert_kernel<T>), dim3(cdiv(n, 1024)), dim3(256), 0, nullptr, stage.as<float>(), dst.as<T>(), n);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+template <typename T> __global__ void widen_kernel(const T* __restrict__ in, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = Elem<T>::ld(in + i);
+}
+template <typename T> int download_from(DevBuf& stage, const DevBuf& src, float* dst, size_t n) {
+    ARP_TRY(stage.ensure(n * 4));
+    hipLaunchKernelGGL((widen_kernel<T>), dim3(cdiv(n, 256)), dim3(256), 0, nullptr, src.as<T>(), stage.as<float>(), n);
+    ARP_HIP_OK(hipGetLastError());
+    ARP_HIP_OK(hipMemcpy(dst, stage.p, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+template <typename T> int op_gemm_tn(int tile256, int ksplit, const float* A, const float* B, float* out, int M, int N, int K, float alpha) {
+    DevBuf st, dA, dB, dP, dO;
+    auto body = [&]() -> int {
+        ARP_TRY(upload_as<T>(st, dA, A, (size_t)K * M));
+        ARP_TRY(upload_as<T>(st, dB, B, (size_t)K * N));
+        const size_t MN = (size_t)M * N;
+        ARP_TRY(dP.ensure((size_t)ksplit * MN * 4));
+        ARP_TRY(dO.ensure(MN * 4));
+        GemmTnArgs g;
+        g.A = dA.p; g.B = dB.p; g.M = M; g.N = N; g.K = K; g.lda = M; g.ldb = N; g.ldo = N; g.ksplit = ksplit; g.tile256 = tile256;
+        g.xcd_slices = tile256 && ksplit % 8 == 0;
+        const int tcode = __is_same(T, bf16_t) ? 1 : 2;
+        if (ksplit == 1) {
+            g.out = dO.as<float>(); g.slice_stride = 0; g.alpha = alpha;
+            ARP_TRY(launch_gemm_tn(tcode, g, nullptr));
+        } else {
+            g.out = dP.as<float>(); g.slice_stride = MN; g.alpha = 1.f;
+            ARP_TRY(launch_gemm_tn(tcode, g, nullptr));
+            hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(cdiv(MN, 64)), dim3(256), 0, nullptr, dP.as<float>(), ksplit, MN, N, nullptr, ACT_NONE,
+                               dO.as<float>(), nullptr, 0, alpha);
+            ARP_HIP_OK(hipGetLastError());
+        }
+        ARP_HIP_OK(hipMemcpy(out, dO.p, MN * 4, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    const int rc = body();
+    st.release(); dA.release(); dB.release(); dP.release(); dO.release();
+    return rc;
+}
+
+template <typename T>
+int op_gemm_relu_bwd(const float* A, const float* W, const float* mask, float* out, float* colsum, int M, int N, int K) {
+    DevBuf st, dA, dW, dM, dO, dC, dS;
+    auto body = [&]() -> int {
+        ARP_TRY(upload_as<T>(st, dA, A, (size_t)M * K));
+        ARP_TRY(upload_as<T>(st, dW, W, (size_t)N * K));
+        ARP_TRY(upload_as<T>(st, dM, mask, (size_t)M * N));
+        const int mt = cdiv(M, 256);
+        ARP_TRY(dO.ensure((size_t)M * N * sizeof(T)));
+        ARP_TRY(dC.ensure((size_t)mt * N * 4));
+        ARP_TRY(dS.ensure((size_t)N * 4));
+        GemmArgs g;
+        g.A = dA.p; g.W = dW.p; g.out = dO.p; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
+        g.mask = dM.p; g.ldm = N; g.colsum_part = dC.as<float>();
+        ARP_TRY((launch_gemm256_nt<T, T, ACT_NONE, false, SITE_DT>(g, nullptr)));
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, nullptr, dC.as<float>(), mt, N, dS.as<float>(), 1.f);
+        ARP_HIP_OK(hipGetLastError());
+        ARP_TRY(download_from<T>(st, dO, out, (size_t)M * N));
+        ARP_HIP_OK(hipMemcpy(colsum, dS.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    const int rc = body();
+    st.release(); dA.release(); dW.release(); dM.release(); dO.release(); dC.release(); dS.release();
+    return rc;
+}
+
+template <typename T>
+int op_adapter_dy(const float* dz, const float* Wi, const float* A, const float* x, float rw, float* dApre, float* colsum, float* dres, int R, int E,
+                  int tokens, int D) {
+    const size_t Kin = (size_t)tokens * D;
+    DevBuf st, ddz, dWi, dA, dx, drw, dO, dC, dP, dS;
+    auto body = [&]() -> int {
+        ARP_TRY(upload_as<T>(st, ddz, dz, (size_t)R * E));
+        ARP_TRY(upload_as<T>(st, dWi, Wi, (size_t)E * Kin));
+        ARP_TRY(upload_as<T>(st, dA, A, (size_t)R * Kin));
+        ARP_TRY(dx.ensure((size_t)R * Kin * 4));
+        ARP_HIP_OK(hipMemcpy(dx.p, x, (size_t)R * Kin * 4, hipMemcpyHostToDevice));
+        ARP_TRY(drw.ensure(16));
+        ARP_HIP_OK(hipMemcpy(drw.p, &rw, 4, hipMemcpyHostToDevice));
+        const int nrb = adapter_dy_row_blocks(R), nct = (int)(Kin / 128);
+        ARP_TRY(dO.ensure((size_t)R * Kin * sizeof(T)));
+        ARP_TRY(dC.ensure((size_t)nrb * tokens * D * 4));
+        ARP_TRY(dP.ensure((size_t)nrb * nct * 4));
+        ARP_TRY(dS.ensure((size_t)(D + 4) * 4));
+        AdapterDyArgs a;
+        a.dz = ddz.p; a.Wi = dWi.p; a.A = dA.p; a.x32 = dx.as<float>(); a.rw = drw.as<float>(); a.dApre = dO.p; a.colpart = dC.as<float>();
+        a.dres_part = dP.as<float>(); a.R = R; a.E = E; a.Kin = (int)Kin; a.D = D;
+        ARP_TRY(launch_adapter_dy(__is_same(T, bf16_t) ? 1 : 2, a, nullptr));
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, nullptr, dC.as<float>(), nrb * tokens, D, dS.as<float>(), 1.f);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, nullptr, dP.as<float>(), nrb * nct, 1.f, dS.as<float>() + D, 0);
+        ARP_HIP_OK(hipGetLastError());
+        ARP_TRY(download_from<T>(st, dO, dApre, (size_t)R * Kin));
+        ARP_HIP_OK(hipMemcpy(colsum, dS.p, (size_t)D * 4, hipMemcpyDeviceToHost));
+        ARP_HIP_OK(hipMemcpy(dres, dS.as<float>() + D, 4, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    const int rc = body();
+    for (DevBuf* b : {&st, &ddz, &dWi, &dA, &dx, &drw, &dO, &dC, &dP, &dS}) b->release();
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+
+// C[M,N] = alpha * sum_k A[k,m] B[k,n] on the TN weight-gradient kernels (gemm_tn.h): A [K,M], B [K,N] row-major, rounded to the
+// 16-bit operand type of `mode`; tile256 = 0 (128 x 128 tiles: M, N % 128, K % 64) or 1 (256 x 256 tiles: M, N % 256, K % 64);
+// ksplit > 1 runs the split-K slabs + fixed-order reduction of the train step.
+int arp_op_gemm_tn(int mode, int tile256, int ksplit, const float* A, const float* B, float* out, int M, int N, int K, float alpha) {
+    if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || ksplit < 1) return fail("bad argument");
+    if (mode == ARP_MODE_F16) return op_gemm_tn<f16_t>(tile256, ksplit, A, B, out, M, N, K, alpha);
+    if (mode == ARP_MODE_BF16) return op_gemm_tn<bf16_t>(tile256, ksplit, A, B, out, M, N, K, alpha);
+    return fail("arp_op_gemm_tn: 16-bit modes only");
+}
+// out[M,N] = (A[M,K] . W[N,K]^T) * (mask[M,N] > 0) in the operand type (returned widened), colsum[N] = column sums of the stored
+// values: the ReLU-backward epilogue of the 256 x 256 GEMM (gemm256.h, GemmArgs::mask).  N % 8 == 0, K % 64 == 0.
+int arp_op_gemm_relu_bwd(int mode, const float* A, const float* W, const float* mask, float* out, float* colsum, int M, int N, int K) {
+    if (!A || !W || !mask || !out || !colsum || M <= 0 || N <= 0 || K <= 0) return fail("bad argument");
+    if (mode == ARP_MODE_F16) return op_gemm_relu_bwd<f16_t>(A, W, mask, out, colsum, M, N, K);
+    if (mode == ARP_MODE_BF16) return op_gemm_relu_bwd<bf16_t>(A, W, mask, out, colsum, M, N, K);
+    return fail("arp_op_gemm_relu_bwd: 16-bit modes only");
+}
+// The fused adapter-backward pass (adapter_bwd.h): dApre[R, tokens*D] = sigmoid(rw) * (dz[R,E] . Wi[E, tokens*D]) * (A > 0) in the
+// operand type (returned widened), colsum[D] = its sums over rows and tokens, dres = sum (dz . Wi) * (A - x).
+int arp_op_adapter_dy(int mode, const float* dz, const float* Wi, const float* A, const float* x, float rw, float* dApre, float* colsum, float* dres,
+                      int R, int E, int tokens, int D) {
+    if (!dz || !Wi || !A || !x || !dApre || !colsum || !dres || R <= 0 || tokens <= 0) return fail("bad argument");
+    if (!adapter_dy_supported(E, D, (long long)tokens * D)) return fail("arp_op_adapter_dy: unsupported geometry (E in {32, 64, 128}, D % 128 == 0)");
+    if (mode == ARP_MODE_F16) return op_adapter_dy<f16_t>(dz, Wi, A, x, rw, dApre, colsum, dres, R, E, tokens, D);
+    if (mode == ARP_MODE_BF16) return op_adapter_dy<bf16_t>(dz, Wi, A, x, rw, dApre, colsum, dres, R, E, tokens, D);
+    return fail("arp_op_adapter_dy: 16-bit modes only");
+}
+
 int arp_dt_profile_enable(arp_dt* c, int on) {
     if (!c) return fail("null handle");
     c->prof.on = on != 0;

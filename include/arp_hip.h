@@ -303,6 +303,16 @@ int arp_op_gemm_fp8(int act, const float* A, const float* W, const float* bias, 
                     int out_fp8, float out_scale);
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,
                    float* out, int M, int N, int K);
+/* Kernels of the policy train step (16-bit modes; reference math: arp_dt/ARPDT.py:462-484 and its autodiff).
+ * arp_op_gemm_tn: C[M,N] = alpha * sum_k A[k,m] B[k,n], A [K,M] and B [K,N] row-major (weight gradients dW = dY^T X);
+ *   tile256 = 0: 128x128 tiles (M, N % 128), 1: 256x256 tiles (M, N % 256); K % 64; ksplit >= 1 K-slices.
+ * arp_op_gemm_relu_bwd: out = (A . W^T) * (mask > 0) rounded to the operand type, colsum[N] = column sums of out (N % 8, K % 64).
+ * arp_op_adapter_dy: dApre[R, tokens*D] = sigmoid(rw) * (dz[R,E] . Wi[E, tokens*D]) * (A > 0), colsum[D] = sums of dApre over rows
+ *   and tokens, dres[0] = sum (dz . Wi) * (A - x); E in {32, 64, 128}, D % 128 == 0. */
+int arp_op_gemm_tn(int mode, int tile256, int ksplit, const float* A, const float* B, float* out, int M, int N, int K, float alpha);
+int arp_op_gemm_relu_bwd(int mode, const float* A, const float* W, const float* mask, float* out, float* colsum, int M, int N, int K);
+int arp_op_adapter_dy(int mode, const float* dz, const float* Wi, const float* A, const float* x, float rw, float* dApre, float* colsum,
+                      float* dres, int R, int E, int tokens, int D);
 /* Times `iters` launches of the GEMM on device-resident random operands (HIP events); kernel: 1 = 128x128,
  * 2 = 256x256 pipelined, 0 = auto.  act/resid/out_f32 select the epilogue.  Returns the average ms per launch. */
 int arp_op_gemm_bench(int mode, int kernel, int act, int resid, int out_f32, int M, int N, int K, int iters, float* avg_ms);

@@ -187,3 +187,99 @@ def test_gemm_fp8_exact_on_representable_operands(gpu_lib, shape):
     step = np.maximum(np.abs(want), 2.0 ** -6) / 8
     bad = np.abs(out - want) > 1e-6
     assert bad.mean() < 2e-3 and (np.abs(out - want) <= step * 1.01 + 1e-6).all(), (bad.mean(), np.abs(out - want).max())
+
+
+# ---- kernels of the policy train step (round 2): TN weight-gradient GEMMs, the ReLU-backward GEMM epilogue, the fused dY pass ----
+
+def _rnd16(mode):
+    return {1: bf16_round, 2: lambda x: x.astype(np.float16).astype(np.float32)}[mode]
+
+
+def _ulp16(mode):
+    return {1: 2.0 ** -8, 2: 2.0 ** -11}[mode]  # half a unit in the last place, relative, of a value stored in the operand type
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("case", [  # M, N, K, ksplit, tile256
+    (128, 128, 64, 1, 0), (256, 384, 704, 3, 0), (128, 256, 1344, 5, 0),
+    (256, 256, 64, 1, 1), (256, 256, 128, 1, 1), (256, 512, 704, 1, 1), (512, 256, 1344, 5, 1), (768, 768, 2112, 8, 1),
+    (768, 768, 2112, 16, 1), (768, 768, 2112, 24, 1), (256, 256, 192, 3, 1),
+])
+def test_gemm_tn(gpu_lib, mode, case):
+    """dW = alpha * A^T B from two ROW-major operands (gemm_tn.hip): the 128-tile kernel and the pipelined 256-tile kernel (ring of
+    four K-tiles, hand-counted waits), K-tile counts below / at / above the ring depth, ragged K-splits, the per-XCD slice placement
+    (ksplit % 8 == 0).  Exact up to f32 summation: operands are pre-rounded to the operand type."""
+    M, N, K, S, t256 = case
+    rng = np.random.default_rng(M + 3 * N + 7 * K + S)
+    rnd = _rnd16(mode)
+    A = rnd(rng.standard_normal((K, M)).astype(np.float32))
+    B = rnd((rng.standard_normal((K, N)) * 0.25).astype(np.float32))
+    alpha = 0.5
+    out = np.full((M, N), np.nan, np.float32)
+    gpu_lib.check(gpu_lib.lib.arp_op_gemm_tn(mode, t256, S, _fp(A), _fp(B), _fp(out), M, N, K, alpha))
+    ref = alpha * (A.astype(np.float64).T @ B.astype(np.float64))
+    tol = 2e-6 * alpha * (np.abs(A).astype(np.float64).T @ np.abs(B).astype(np.float64)) + 1e-6
+    assert np.isfinite(out).all()
+    assert (np.abs(out - ref) <= tol).all(), float((np.abs(out - ref) / tol).max())
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("shape", [(512, 256, 128), (1000, 520, 192), (2056, 768, 768), (255, 8, 64)])
+def test_gemm_relu_bwd_epilogue(gpu_lib, mode, shape):
+    """out = (A W^T) * (mask > 0) and the column sums of what was stored -- gemm256's masked epilogue (the adapter's dH1 and Dense_0
+    bias gradient).  The mask holds positives, +0 and -0 (a ReLU output can be either zero); masked entries must be EXACT zeros, kept
+    entries within a rounding step of the operand type, the column sums equal to the sums of the returned values."""
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    rnd = _rnd16(mode)
+    A = rnd(rng.standard_normal((M, K)).astype(np.float32))
+    W = rnd((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    r = rng.standard_normal((M, N)).astype(np.float32)
+    mask = np.where(r > 0, r, np.where(r < -1.0, -0.0, 0.0)).astype(np.float32)
+    mask = rnd(mask)
+    out = np.full((M, N), np.nan, np.float32)
+    cs = np.full(N, np.nan, np.float32)
+    gpu_lib.check(gpu_lib.lib.arp_op_gemm_relu_bwd(mode, _fp(A), _fp(W), _fp(mask), _fp(out), _fp(cs), M, N, K))
+    keep = mask > 0
+    assert keep.any() and (~keep).any() and np.signbit(mask[~keep]).any()
+    assert (out[~keep] == 0).all()
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    tol = 1.01 * _ulp16(mode) * np.abs(ref) + 2e-6 * (np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T) + 1e-7
+    assert (np.abs(out - ref)[keep] <= tol[keep]).all(), float((np.abs(out - ref)[keep] / tol[keep]).max())
+    want = out.astype(np.float64).sum(0)
+    assert (np.abs(cs - want) <= 2e-6 * np.abs(out).astype(np.float64).sum(0) + 1e-6).all()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("geom", [(8, 128, 5, 128), (130, 64, 3, 256), (128, 128, 9, 768), (40, 32, 2, 128), (257, 128, 2, 384)])
+def test_adapter_dy_fused(gpu_lib, mode, geom):
+    """The fused adapter-backward pass (adapter_bwd.hip; arp_dt/ARPDT.py:462-484 differentiated): dY = dz Wi, dApre = res dY (A > 0),
+    Dense_1's bias gradient (column sums over rows and tokens of the ROUNDED dApre) and d loss / d res = sum dY (A - x).  Row counts
+    below, at and across the 128-row block, every supported E, widths of one to six 128-column tiles, -0 in the mask."""
+    R, E, tokens, D = geom
+    Kin = tokens * D
+    rng = np.random.default_rng(R * 13 + E + tokens * 5 + D)
+    rnd = _rnd16(mode)
+    dz = rnd((rng.standard_normal((R, E)) * 4).astype(np.float32))
+    Wi = rnd((rng.standard_normal((E, Kin)) / np.sqrt(E)).astype(np.float32))
+    r = rng.standard_normal((R, Kin)).astype(np.float32)
+    A = rnd(np.where(r > 0, r, np.where(r < -1.2, -0.0, 0.0)).astype(np.float32))
+    x = rng.standard_normal((R, Kin)).astype(np.float32)
+    rw = float(rng.standard_normal())
+    out = np.full((R, Kin), np.nan, np.float32)
+    cs = np.full(D, np.nan, np.float32)
+    dres = np.full(1, np.nan, np.float32)
+    gpu_lib.check(gpu_lib.lib.arp_op_adapter_dy(mode, _fp(dz), _fp(Wi), _fp(A), _fp(x), rw, _fp(out), _fp(cs), _fp(dres), R, E, tokens, D))
+    res = 1.0 / (1.0 + np.exp(-np.float64(np.float32(rw))))
+    dY = dz.astype(np.float64) @ Wi.astype(np.float64)
+    mag = np.abs(dz).astype(np.float64) @ np.abs(Wi).astype(np.float64)
+    keep = A > 0
+    assert (out[~keep] == 0).all() and np.signbit(A[~keep]).any()
+    ref = res * dY
+    tol = 1.01 * _ulp16(mode) * np.abs(ref) + 3e-6 * mag + 1e-7
+    assert (np.abs(out - ref)[keep] <= tol[keep]).all(), float((np.abs(out - ref)[keep] / tol[keep]).max())
+    want_cs = out.astype(np.float64).reshape(R, tokens, D).sum((0, 1))
+    assert (np.abs(cs - want_cs) <= 3e-6 * np.abs(out).astype(np.float64).reshape(R, tokens, D).sum((0, 1)) + 1e-6).all()
+    want_dres = float((dY * (A.astype(np.float64) - x)).sum())
+    tol_dres = 3e-6 * float((mag * np.abs(A.astype(np.float64) - x)).sum()) + 1e-6
+    assert abs(float(dres[0]) - want_dres) <= tol_dres, (float(dres[0]), want_dres, tol_dres)
