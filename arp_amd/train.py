@@ -41,6 +41,7 @@ class PolicyConfig:
     enc_dim: int = 768
     use_adapter: bool = True
     lambda_ret: float = 1.0
+    use_symlog: bool = False  # config.use_symlog (ARPDT.py:55): symlog of every return-to-go view before their mean
     weight_decay: float = 5e-5
     clip_norm: float = 10.0
     b1: float = 0.9
@@ -238,11 +239,23 @@ class TrainState:
         return self.trainer.get_params()
 
 
-def _batch_arrays(batch):
+def symlog(x):
+    """``sign(x) * log(1 + |x|)`` (arp_dt/utils.py:445-446)."""
+    x = np.asarray(x, np.float32)
+    return np.sign(x) * np.log1p(np.abs(x))
+
+
+def _batch_arrays(batch, use_symlog=False):
+    """(encodings, actions, return-to-go) of a reference batch dict.  ``batch["rtg"]`` holds one array per image view; the model
+    embeds -- and regresses onto -- their MEAN, each view passed through symlog first when ``config.use_symlog``
+    (arp_dt/ARPDT.py:251-258,281-293).  Both uses see the same array, so the transform is applied here, once, on the host."""
     image = batch["image"]
     enc = next(iter(image.values())) if isinstance(image, dict) else image
     rtg = batch["rtg"]
-    rtg = np.mean(np.stack([np.asarray(v, np.float32) for v in rtg.values()]), axis=0) if isinstance(rtg, dict) else rtg
+    views = [np.asarray(v, np.float32) for v in rtg.values()] if isinstance(rtg, dict) else [np.asarray(rtg, np.float32)]
+    if use_symlog:
+        views = [symlog(v) for v in views]
+    rtg = np.mean(np.stack(views), axis=0) if isinstance(rtg, dict) else views[0]
     return np.asarray(enc), np.asarray(batch["action"]), np.asarray(rtg)
 
 
@@ -307,7 +320,7 @@ class DataParallel:
         trainer.broadcast_state()
 
     def set_global_batch(self, batch, device_axis=False):
-        self.trainer.set_batch(*_batch_arrays(shard_batch(batch, self.rank, self.world, device_axis)))
+        self.trainer.set_batch(*_batch_arrays(shard_batch(batch, self.rank, self.world, device_axis), self.trainer.cfg.use_symlog))
 
     def train_step(self, batch, lr, device_axis=False):
         """aux is the rank-averaged aux of the reference's pmean: identical on every rank."""
@@ -331,7 +344,7 @@ def create_train_step(model, learning_rate, weight_decay, *, rank=0, world=1, de
             raise ValueError("state was created with a different weight_decay than create_train_step")
         if world > 1 and getattr(tr, "world", 1) != world:
             raise ValueError("world > 1: wrap the state's trainer in DataParallel (RCCL communicator + state sync) first")
-        tr.set_batch(*_batch_arrays(shard_batch(batch, rank, world, device_axis)))
+        tr.set_batch(*_batch_arrays(shard_batch(batch, rank, world, device_axis), tr.cfg.use_symlog))
         aux = tr.train_step(learning_rate(tr.step))
         state._live = False
         return TrainState(tr), aux, rng  # dropout is 0 in the shipped config: the rng is carried through unused

@@ -222,3 +222,24 @@ def test_trajectory_batching_changes_nothing():
     calls.clear()
     L.label_store(st, Counting(), L.make_compute_reward("clip_goal_conditioned"), model_type="clip_goal_conditioned", batch_frames=8)
     assert calls == []  # goal-conditioned goes through encode_image, one trajectory at a time
+
+
+def test_policy_batch_rtg_views_mean_and_symlog():
+    """batch["rtg"] holds one array per image view; the policy consumes their mean, each view through symlog first when
+    config.use_symlog (arp_dt/ARPDT.py:251-258,281-293; symlog = arp_dt/utils.py:445-446)."""
+    from arp_amd.train import _batch_arrays, symlog
+    rng = np.random.default_rng(5)
+    enc = rng.standard_normal((2, 4, 3, 8)).astype(np.float32)
+    act = rng.integers(0, 15, (2, 4))
+    views = {"ob": rng.standard_normal((2, 4, 1)).astype(np.float32) * 30, "ob2": rng.standard_normal((2, 4, 1)).astype(np.float32) * 30}
+    batch = {"image": {"ob": enc}, "action": act, "rtg": views}
+    e, a, r = _batch_arrays(batch)
+    assert e is not None and np.array_equal(a, act)
+    np.testing.assert_allclose(r, (views["ob"] + views["ob2"]) / 2, rtol=1e-6)
+    _, _, rs = _batch_arrays(batch, use_symlog=True)
+    want = np.mean([np.sign(v) * np.log(1 + np.abs(v)) for v in views.values()], axis=0)
+    np.testing.assert_allclose(rs, want, rtol=1e-6)
+    assert not np.allclose(rs, r)
+    np.testing.assert_allclose(symlog(np.array([-np.e + 1, 0.0, np.e - 1])), [-1.0, 0.0, 1.0], atol=1e-6)
+    _, _, r1 = _batch_arrays({"image": enc, "action": act, "rtg": views["ob"]}, use_symlog=True)  # a bare array = one view
+    np.testing.assert_allclose(r1, symlog(views["ob"]), rtol=1e-6)
