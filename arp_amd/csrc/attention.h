@@ -74,6 +74,14 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
 // so V is staged exactly like K -- no 2-byte transposing stores.
 typedef __attribute__((ext_vector_type(4))) short tr_b64_v;
 
+#ifdef ARP_ATTN_STAMPS
+__device__ long long* arp_attn_stamps = nullptr;  // scripts/attn_bench.hip: per-workgroup, per-wave cycles per phase
+#define AT_T() __builtin_amdgcn_s_memtime()
+#define AT_ACC(i) { const long long t_ = AT_T(); at_[i] += t_ - at_last; at_last = t_; }
+#else
+#define AT_ACC(i)
+#endif
+
 template <typename T, int NT>
 __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int D,
                                                         int heads, float scale, int causal, int nq) {
@@ -85,19 +93,30 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const size_t ld = 3 * (size_t)D;
     const T* base = qkv + (size_t)b * N * ld + h * 64;
+#ifdef ARP_ATTN_STAMPS
+    long long at_[5] = {0, 0, 0, 0, 0};
+    long long at_last = AT_T();
+#endif
 
-    for (int i = tid; i < NP * 8; i += 256) {  // pad keys are zero-filled
-        const int key = i >> 3, ch = i & 7;
-        u32x4_v kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (key < N) {
-            kv = *reinterpret_cast<const u32x4_v*>(base + key * ld + D + ch * 8);
-            vv = *reinterpret_cast<const u32x4_v*>(base + key * ld + 2 * D + ch * 8);
+    // K and V images by LDS-DMA, every piece in flight at once: a wave instruction fills 8 rows (1 KiB); lane -> (row, PHYSICAL 16-byte
+    // chunk), which holds logical chunk (physical ^ (key & 7)), so the swizzle sits on the source address.  (Staged through registers
+    // -- load, then ds_write -- the 66 KB of an N = 257 head took 15 k of the workgroup's 48 k cycles: the loads went out a few at a
+    // time.)  Pad keys (>= N) alias key N-1: they are masked out of the softmax, and their probabilities are exactly 0 in P.V.
+    {
+        const int prow = lane >> 3, pch = lane & 7;
+        for (int p = wave; p < NP / 8; p += 4) {
+            const int key = p * 8 + prow;
+            const int kk = key < N ? key : N - 1;
+            const T* src = base + (size_t)kk * ld + ((pch ^ (key & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + D),
+                                             (__attribute__((address_space(3))) void*)(Ks + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * D),
+                                             (__attribute__((address_space(3))) void*)(Vs + p * 1024), 16, 0, 0);
         }
-        const int off = key * 128 + ((ch ^ (key & 7)) << 4);
-        *reinterpret_cast<u32x4_v*>(Ks + off) = kv;
-        *reinterpret_cast<u32x4_v*>(Vs + off) = vv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    AT_ACC(0);
 
     const int fr = lane & 15, fg = lane >> 4;
     const int nqb = (nq + 15) >> 4;  // query rows >= nq are not produced (last ViT block: only the class token is read)
@@ -125,6 +144,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
                 s[kt] = mfma16<T>(kf, qf[ks], s[kt]);
             }
         }
+        AT_ACC(1);
         const int qidx = qb * 16 + fr;
         const int klim = causal ? (qidx < N ? qidx + 1 : N) : N;
         float mx = -INFINITY;
@@ -152,6 +172,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
+        AT_ACC(2);
 
         // O^T[d][q] = sum_key V^T[d][key] * P^T[key][q].  k-slot (fg, j) of step st <-> key 32*st + 16*(j>>2) + 4*fg + (j&3):
         // the B operand comes straight from s[2st], s[2st+1]; the A operand is two transposing reads of V.
@@ -178,13 +199,21 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
                 o[dt] = mfma16<T>(va, pb, o[dt]);
             }
         }
+        AT_ACC(3);
         if (qvalid && qidx < nq) {
             T* orow = out + ((size_t)b * N + qidx) * D + h * 64;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 store4(orow + dt * 16 + fg * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
         }
+        AT_ACC(4);
     }
+#ifdef ARP_ATTN_STAMPS
+    if (arp_attn_stamps && lane == 0) {
+        long long* d = arp_attn_stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 5; ++i) d[i] = at_[i];
+    }
+#endif
 }
 
 }  // namespace arp
