@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
     // transposing-read addressing: lane 4q+p of a 16-lane group points at row (key0 + q), columns 4p..4p+3 of the
     // 16-column block [16*dt, 16*dt+16); lane i receives column i of the four rows
     const int trq = fr >> 2, trp = fr & 3;
+    // (Two query blocks per wave at a time, so that each K / V^T fragment read feeds two MFMAs: 245-256 VGPRs plus accumulation
+    //  registers -- one workgroup per CU instead of two, 100 us against 51 us at N = 197.  The full score row of a block, NT x 4
+    //  registers, is what makes this kernel register-bound.)
     for (int qb = wave; qb < nqb; qb += 4) {
         int qrow = qb * 16 + fr;
         const int qvalid = qrow < N;
