@@ -228,6 +228,15 @@ def bench_policy(a):
         peak = PEAK_TFLOPS[a.mode] if kind == "mfma" else 8000.0
         achieved = work / (avg_ms * 1e-3) / (1e12 if kind == "mfma" else 1e9)
         flops = policy_step_flops(cfg, a.policy_batch)
+        # HBM bytes of the dominant site from the PMC counters (scripts/prof_policy_pmc.sh -> profiles/pmc_traffic_policy.json; measured
+        # at the default geometry, B = 32 per GPU)
+        traffic = None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_policy.json")))["sites"].get(site)
+            if rec and a.policy_batch == 32:
+                traffic = rec["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         emit(json.dumps({
             "metric": "samples/sec ARPDT train_step (frames in, frozen M3AE encoder inside)" if enc is not None else
                       "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
@@ -237,7 +246,7 @@ def bench_policy(a):
                                    f"resident in HBM, 26.9 M trainable params (BASELINE.json configs[3])", "parallelism": f"dp{world}",
                        "collective": "one RCCL all-reduce(sum) of the flat f32 gradient (107.5 MB) + one of 4 scalars per step" if world > 1 else "none (1 rank)"},
             "roofline": {"bound": kind, "achieved": achieved, "peak": peak, "unit": "TFLOP/s" if kind == "mfma" else "GB/s",
-                         "frac": achieved / peak, "traffic": None, "kernel": f"{'gemm' if kind == 'mfma' else 'norms_partial + adam_kernel'} @ {site}",
+                         "frac": achieved / peak, "traffic": traffic, "kernel": f"{'gemm' if kind == 'mfma' else 'norms_partial + adam_kernel'} @ {site}",
                          ("flops_per_launch" if kind == "mfma" else "bytes_per_launch"): work, "avg_launch_ms": avg_ms,
                          "note": "the call site with the largest share of the step (sites_ms_per_step)"},
             "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12,
