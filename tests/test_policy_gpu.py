@@ -314,3 +314,29 @@ def test_full_geometry_matches_oracle(gpu_lib, monkeypatch):
         mean_err = float(np.mean([np.abs(got[k] - st["params"][k].numpy()).mean() for k in P]))
         assert mean_err < (2e-5 if mode == "f32" else 2e-4), f"full geometry {mode}: mean param err after one step {mean_err}"
         tr.close()
+
+
+def test_f16_training_tracks_f32_over_many_steps(gpu_lib):
+    """The timed 16-bit mode against the f32 parity mode over a TRAINING RUN, not one step: 150 clipped Adam steps on a fixed batch at
+    the real geometry (B = 8).  The f16 operand rounding perturbs every gradient (adapter tensors to ~2e-2 relative, see the
+    full-geometry test), the 2^14 gradient scale must neither overflow nor flush gradients to zero as the loss falls -- so the two
+    loss curves have to stay together all the way down, and both have to learn."""
+    from arp_amd.train import PolicyTrainer
+    cfg, _, P, (enc, act, rtg), _, _ = _setup(FULL, 8, 77)
+    curves = {}
+    for mode in ("f32", "f16"):
+        tr = PolicyTrainer(cfg, mode=mode)
+        tr.set_params(P)
+        tr.set_batch(enc, act, rtg)
+        losses = []
+        for step in range(150):
+            aux = tr.train_step(3e-4)
+            assert np.isfinite(aux["loss"]) and np.isfinite(aux["grad_norm"]), (mode, step, aux)
+            losses.append(aux["loss"])
+        curves[mode] = np.array(losses)
+        tr.close()
+    a, b = curves["f32"], curves["f16"]
+    print("loss f32:", a[[0, 9, 49, 99, 149]], " f16:", b[[0, 9, 49, 99, 149]])
+    assert a[-1] < 0.5 * a[0] and b[-1] < 0.5 * b[0], "both modes must learn the fixed batch"
+    rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-3)
+    assert rel[:20].max() < 5e-3 and rel.max() < 5e-2, (float(rel[:20].max()), float(rel.max()))
