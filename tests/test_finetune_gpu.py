@@ -408,3 +408,31 @@ def test_single_rank_comm_and_shards(gpu_lib):
     with pytest.raises(ValueError, match="does not divide"):
         FT.shard_batch(batch, 0, 4)
     a.close(); b.close()
+
+
+def test_f16_head_training_tracks_f32_over_many_steps(gpu_lib):
+    """The head's 16-bit mode (gradients seeded x1024 in the loss kernel, un-scaled in AdamW) against the f32 mode over 60 AdamW steps on
+    two alternating batches: finite throughout, both learn, and the loss curves stay together."""
+    from arp_amd import finetune as FT
+    from oracle import finetune_torch as O
+    cfg = O.HeadConfig(**MID)
+    P = O.init_params(cfg, seed=11)
+    fcfg = FT.FinetuneConfig(**MID, weight_decay=0.01, logit_scale=cfg.logit_scale)
+    batches = [FT.synth_batch(fcfg, 6, seed=30 + i) for i in range(2)]
+    curves = {}
+    for mode in ("f32", "f16"):
+        tr = FT.FinetuneTrainer(fcfg, mode=mode)
+        tr.set_params(P)
+        losses = []
+        for i in range(60):
+            tr.set_batch(*batches[i % 2])
+            aux = tr.train_step(3e-4)
+            assert np.isfinite(aux["loss"]), (mode, i, aux)
+            losses.append(aux["loss"])
+        curves[mode] = np.array(losses)
+        tr.close()
+    a, b = curves["f32"], curves["f16"]
+    print("loss f32:", a[[0, 1, 19, 39, 59]], " f16:", b[[0, 1, 19, 39, 59]])
+    assert a[-2:].mean() < a[:2].mean() and b[-2:].mean() < b[:2].mean(), "both modes must learn"
+    rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-2)
+    assert rel[:10].max() < 1e-2 and rel.max() < 0.1, (float(rel[:10].max()), float(rel.max()))
