@@ -679,7 +679,7 @@ template <typename T> int backward(arp_dt* c) {
         ProfScope ps(c->prof, st, "dt.policy_bwd");
         hipLaunchKernelGGL(grouped_small_gemm_kernel, dim3(c->gemm_tiles), dim3(256), 0, st, c->gtab.as<SmallGemm>(), c->gprefix.as<int>(), c->n_gemm);
         hipLaunchKernelGGL(grouped_colsum_kernel, dim3(c->cs_tiles), dim3(256), 0, st, c->ctab.as<ColSumJob>(), c->cprefix.as<int>(), c->n_cs);
-        hipLaunchKernelGGL(tokens_bwd_par_kernel, dim3(NA + 1), dim3(256), 0, st, c->dtok.as<float>(), c->rtg.as<float>(), c->action.as<int>(),
+        hipLaunchKernelGGL(tokens_bwd_par_kernel, dim3(NA + 1), dim3(TOKB_THREADS), 0, st, c->dtok.as<float>(), c->rtg.as<float>(), c->action.as<int>(),
                            c->g("rtg_input/kernel"), c->g("action_input/embedding"), R, E, NA);
         ARP_HIP_OK(hipGetLastError());
     } else {
