@@ -709,13 +709,64 @@ static __global__ void loss_finish_kernel(const float* __restrict__ part, int B,
 
 // ---- grouped launches for the deferred parameter gradients ---------------------------------------------------
 // tile_prefix[p] .. tile_prefix[p+1] are the 32x32 output tiles of problem p
+// One 32 x 32 tile of C[M,N] = sum_k A[k,m] B[k,n] (both operands k-major: a weight gradient dY^T X) on the f32 MFMA: each of the four
+// waves owns a 16 x 16 block and feeds v_mfma_f32_16x16x4_f32 STRAIGHT from global memory -- lane l supplies A[k0 + l/16][m0 + l%16] and
+// B[k0 + l/16][n0 + l%16], 64-byte runs per 16 lanes -- with 48 steps of loads in flight.  Exact f32 (the instruction is an fmaf
+// chain).  The VALU tile (LDS-staged, 4 FMAs per 4 LDS reads) took 33 us for the transformer's ~420 gradient tiles, this ~10.
+__device__ __forceinline__ void small_gemm_tile_tn_mfma(const SmallGemm& g, int bx, int by) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = by * 32 + (wave >> 1) * 16, n0 = bx * 32 + (wave & 1) * 16;
+    if (m0 >= g.M || n0 >= g.N) return;  // M, N are multiples of 16 here
+    // explicitly GLOBAL pointers: the job table is read from memory, so the compiler only knows `generic` and emits flat loads, which it
+    // then waits for one MFMA at a time (vmcnt(0) lgkmcnt(0) after every pair: 96 dependent memory round trips per tile)
+    typedef const __attribute__((address_space(1))) float* gptr;
+    gptr a = (gptr)(g.A + (size_t)(lane >> 4) * g.lda + m0 + (lane & 15));
+    gptr b = (gptr)(g.B + (size_t)(lane >> 4) * g.ldb + n0 + (lane & 15));
+    f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t sa = (size_t)4 * g.lda, sb = (size_t)4 * g.ldb;
+    int k = 0;
+    constexpr int UB = 48;  // steps per batch: the whole batch's loads are issued before its first MFMA (K = 384 rows = two batches)
+    for (; k + 4 * UB <= g.K; k += 4 * UB) {
+        float av[UB], bv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            av[u] = a[(size_t)u * sa];
+            bv[u] = b[(size_t)u * sb];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // all loads of the batch go out before its first MFMA (left alone, hipcc keeps two in flight)
+#pragma unroll
+        for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a += UB * sa;
+        b += UB * sb;
+    }
+    for (; k < g.K; k += 4) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(*a, *b, acc, 0, 0, 0);
+        a += sa;
+        b += sb;
+    }
+    // lane holds rows m0 + 4 (l / 16) + j, column n0 + l % 16
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g.C[(size_t)(m0 + 4 * (lane >> 4) + j) * g.ldc + n0 + (lane & 15)] = acc[j];
+}
+
+// which job does this block belong to: the number of job boundaries at or below blockIdx.x, found with ONE load per lane and a ballot
+// (a scan `while (blockIdx.x >= tile_prefix[p + 1]) ++p` is up to n dependent memory round trips in every block; n <= 64)
+__device__ __forceinline__ int grouped_job_index(const int* __restrict__ tile_prefix, int n) {
+    const int lane = threadIdx.x & 63;
+    const int bound = lane + 1 < n ? tile_prefix[lane + 1] : 0x7fffffff;
+    return __builtin_amdgcn_readfirstlane(__popcll(__ballot((int)blockIdx.x >= bound)));
+}
+
 static __global__ __launch_bounds__(256) void grouped_small_gemm_kernel(const SmallGemm* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
-    int p = 0;
-    while (p + 1 < n && (int)blockIdx.x >= tile_prefix[p + 1]) ++p;
+    const int p = grouped_job_index(tile_prefix, n);
     const SmallGemm g = tab[p];
     const int local = blockIdx.x - tile_prefix[p];
     const int nbx = (g.N + 31) / 32;
-    small_gemm_tile(g, local % nbx, local / nbx);
+    if (g.ta && !g.tb && !g.bias && !g.resid && g.act == ACT_NONE && !g.accumulate && !((g.M | g.N) & 15) && !(g.K & 3))
+        small_gemm_tile_tn_mfma(g, local % nbx, local / nbx);
+    else
+        small_gemm_tile(g, local % nbx, local / nbx);
 }
 // embedding / rtg-projection gradients from d tokens: block a < NA sums the action-token rows whose action is a, block NA the
 // rtg-token rows weighted by rtg (same sums as tokens_bwd_kernel, no read-modify-write chain).  The rows are split over 1024 / E thread
@@ -760,8 +811,7 @@ static __global__ __launch_bounds__(TOKB_THREADS) void tokens_bwd_par_kernel(con
 }
 struct ColSumJob { const float* in; float* out; int R, C; };
 static __global__ __launch_bounds__(256) void grouped_colsum_kernel(const ColSumJob* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
-    int p = 0;
-    while (p + 1 < n && (int)blockIdx.x >= tile_prefix[p + 1]) ++p;
+    const int p = grouped_job_index(tile_prefix, n);
     const ColSumJob j = tab[p];
     colsum_tile(j.in, j.R, j.C, j.out, blockIdx.x - tile_prefix[p]);
 }
