@@ -307,14 +307,30 @@ __device__ __forceinline__ void colsum_tile(const float* __restrict__ in, int R,
     const int c = bx * 64 + x;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < C) {
+        // the operand is global memory whoever calls (kernel argument or a pointer read from a job table, which the compiler would
+        // otherwise treat as generic: flat loads, each waited for alone); sixteen rows are requested before the first add -- the
+        // adds keep their order, so the sums are bit for bit those of the four-rows-at-a-time loop
+        const __attribute__((address_space(1))) float* gin = (const __attribute__((address_space(1))) float*)in;
         int r = y;
-        for (; r + 12 < R; r += 16) {
-            s0 += in[(size_t)r * C + c];
-            s1 += in[(size_t)(r + 4) * C + c];
-            s2 += in[(size_t)(r + 8) * C + c];
-            s3 += in[(size_t)(r + 12) * C + c];
+        for (; r + 60 < R; r += 64) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = gin[(size_t)(r + 4 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                s0 += t[u];
+                s1 += t[u + 1];
+                s2 += t[u + 2];
+                s3 += t[u + 3];
+            }
         }
-        for (; r < R; r += 4) s0 += in[(size_t)r * C + c];
+        for (; r + 12 < R; r += 16) {
+            s0 += gin[(size_t)r * C + c];
+            s1 += gin[(size_t)(r + 4) * C + c];
+            s2 += gin[(size_t)(r + 8) * C + c];
+            s3 += gin[(size_t)(r + 12) * C + c];
+        }
+        for (; r < R; r += 4) s0 += gin[(size_t)r * C + c];
     }
     red[y][x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
