@@ -641,16 +641,31 @@ static __global__ __launch_bounds__(256) void norms_partial_kernel(const float* 
     __shared__ float red[2][4];
     float sg = 0.f, sp = 0.f;
     const size_t n4 = n >> 2, d4 = n_decay >> 2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+    auto term = [&](size_t i, const float4 gv, const float4 pv) {
         float g0 = gv.x * gscale, g1 = gv.y * gscale, g2 = gv.z * gscale, g3 = gv.w * gscale;
         if (i < d4) {
-            const float4 pv = reinterpret_cast<const float4*>(p)[i];
             g0 += wd * pv.x; g1 += wd * pv.y; g2 += wd * pv.z; g3 += wd * pv.w;
             sp += (pv.x * pv.x + pv.y * pv.y) + (pv.z * pv.z + pv.w * pv.w);
         }
         sg += (g0 * g0 + g1 * g1) + (g2 * g2 + g3 * g3);
+    };
+    // four grid-stride steps' loads (g and p, p unconditionally: it is n long) in flight before the first add; the adds keep the
+    // one-step-at-a-time order, so the sums are bit for bit the same (two loads in flight per lane ran this pass at 4.9 TB/s)
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 gv[4], pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gv[u] = g4[i + u * stride];
+            pv[u] = p4[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) term(i + u * stride, gv[u], pv[u]);
     }
+    for (; i < n4; i += stride) term(i, g4[i], p4[i]);
     sg = wave_sum(sg);
     sp = wave_sum(sp);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sp; }
