@@ -85,7 +85,11 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
-template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+// STAGES = ring depth of the K loop.  2 (default): two workgroups per CU, a K-tile's loads land under ONE K-tile of MFMAs -- what a grid
+// that fills the chip wants (a four-stage ring was 3-8 % slower on the train steps' split-K streams: two resident workgroups already
+// keep as many bytes in flight).  4: three K-tiles of loads in flight behind counted vmcnt waits, for grids of at most ONE workgroup
+// per CU -- the single-frame (online reward) tower, whose 24-96-tile GEMMs otherwise spend a full memory round trip per K-tile.
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, int STAGES = 2>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPB = GEMM_ROW_BYTES / (int)sizeof(T);  // elements per K-tile: 64 (bf16) / 32 (f32)
@@ -167,13 +171,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    static_assert(STAGES == 2 || STAGES == 4, "ring depths with instantiated wait counts");
+    if constexpr (STAGES == 2) {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        for (int s = 0; s < STAGES - 1 && s < nk; ++s) stage(s, s);
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const int cur = kt & (STAGES - 1);
+        if constexpr (STAGES == 2) {
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        } else {
+            // tile kt has landed once at most the younger tiles (8 LDS-DMA instructions per thread each) are still in flight; the
+            // barrier also says every wave is done with tile kt-1, whose slot tile kt+3 goes to
+            const int ahead = min(nk - 1 - kt, STAGES - 2);
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) & (STAGES - 1), kt + STAGES - 1);
+        }
         const char* base = smem + cur * GEMM_STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -200,9 +220,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     }
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (STAGES == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's fragment reads are behind the wave before the next barrier
+        }
     }
+    if constexpr (STAGES != 2) __syncthreads();  // the staged epilogue overlays the ring
 
     // ---- epilogue: lane holds, per (ni, mi): m = .. + fr, n = .. + 4*fg + {0,1,2,3} ----------------
     OutT* out = static_cast<OutT*>(g.out) + (size_t)blockIdx.y * g.slice_stride;  // may alias g.resid (in-place residual add)
@@ -340,23 +365,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 
 // Host launcher.  Requirements: K % (128/sizeof(T)) == 0, lda/ldw multiples of 16/sizeof(T),
 // 16-byte aligned bases.  M and N are arbitrary (guarded; vector epilogue when N, ldo, ldr % 4 == 0).
-template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, int STAGES = 2>
 inline int launch_gemm_nt(const GemmArgs& g, hipStream_t stream) {
     constexpr int EPB = GEMM_ROW_BYTES / (int)sizeof(T);
     if (g.M <= 0) return 0;
+    if constexpr (STAGES == 2) {
+        // a grid that cannot even give every CU one workgroup, with a contraction long enough to pipeline: the four-stage instance
+        static const bool deep_ok = [] { const char* e = getenv("ARP_GEMM_DEEP"); return !e || atoi(e) != 0; }();
+        const long wgs = (long)((g.M + GEMM_BM - 1) / GEMM_BM) * ((g.N + GEMM_BN - 1) / GEMM_BN) * (g.ksplit > 1 ? g.ksplit : 1);
+        if (deep_ok && wgs <= 128 && g.K / EPB >= 6) return launch_gemm_nt<T, OutT, ACT, RESID, SITE, 4>(g, stream);
+    }
     if (g.N <= 0 || g.K % EPB != 0 || g.K <= 0 || g.lda % (16 / (int)sizeof(T)) != 0 || g.ldw % (16 / (int)sizeof(T)) != 0)
         return fail("gemm_nt: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) +
                     " K=" + std::to_string(g.K));
-    auto kern = gemm_nt_kernel<T, OutT, ACT, RESID, SITE>;
+    auto kern = gemm_nt_kernel<T, OutT, ACT, RESID, SITE, STAGES>;
+    constexpr int lds_bytes = STAGES * GEMM_STAGE_BYTES;
+    static_assert(lds_bytes >= GEMM_LDS_BYTES, "the staged epilogue needs the two-stage ring's 64 KiB");
     static bool attr_set = false;
     if (!attr_set) {
-        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       GEMM_LDS_BYTES));
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
     const int m_tiles = (g.M + GEMM_BM - 1) / GEMM_BM;
     const int n_tiles = (g.N + GEMM_BN - 1) / GEMM_BN;
-    hipLaunchKernelGGL(kern, dim3(m_tiles * n_tiles, g.ksplit > 1 ? g.ksplit : 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, g);
+    hipLaunchKernelGGL(kern, dim3(m_tiles * n_tiles, g.ksplit > 1 ? g.ksplit : 1), dim3(GEMM_THREADS), lds_bytes, stream, g);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
