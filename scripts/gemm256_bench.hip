@@ -55,10 +55,17 @@ template <typename OutT, int ACT, bool RESID> static void run(const char* name, 
     {   // per-tile phase durations in shader cycles, averaged over tiles and waves: K loop | stage | barrier | copy-out issue | drain
         std::vector<long long> h((size_t)ntile * 64);
         hipMemcpy(h.data(), dS, h.size() * 8, hipMemcpyDeviceToHost);
-        double d[5] = {0, 0, 0, 0, 0};
+        double d[5] = {0, 0, 0, 0, 0}, epi = 0;
         for (int t = 0; t < ntile; ++t)
-            for (int w = 0; w < 8; ++w)
+            for (int w = 0; w < 8; ++w) {
                 for (int i = 0; i < 5; ++i) d[i] += (double)(h[((size_t)t * 8 + w) * 8 + i + 1] - h[((size_t)t * 8 + w) * 8 + i]);
+                epi += (double)(h[((size_t)t * 8 + w) * 8 + 4] - h[((size_t)t * 8 + w) * 8 + 1]);
+            }
+        if (sizeof(OutT) == 4) {  // the f32 path takes no mid-epilogue stamps: K loop | whole epilogue | drain
+            printf("  stamps %-10s: kloop %.0f | epilogue (two staged passes) %.0f | drain %.0f cycles\n", name, d[0] / ntile / 8, epi / ntile / 8, d[4] / ntile / 8);
+            hipFree(dS);
+            return;
+        }
         printf("  stamps %-10s: kloop %.0f | stage %.0f | barrier %.0f | copy-out issue %.0f | drain %.0f cycles\n", name, d[0] / ntile / 8, d[1] / ntile / 8,
                d[2] / ntile / 8, d[3] / ntile / 8, d[4] / ntile / 8);
         hipFree(dS);
