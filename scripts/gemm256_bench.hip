@@ -40,6 +40,7 @@ template <typename OutT, int ACT, bool RESID> static void run(const char* name, 
     g.A = dA; g.W = dW; g.bias = dB; g.resid = RESID ? (float*)dR : nullptr; g.out = RESID ? dR : dO;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N;
     if (getenv("G256_LDA0")) g.lda = 0;  // every A row is row 0: the A stream comes from cache (isolates memory latency from loop mechanics)
+    if (const char* e = getenv("G256_STAGGER")) { g.stagger_groups = atoi(e); g.stagger_cycles = getenv("G256_STAGGER_CYCLES") ? atoi(getenv("G256_STAGGER_CYCLES")) : 100000; }
     if (const char* e = getenv("G256_FLAGS")) g.flags = atoi(e);  // 1 = ablate the epilogue stores (K loop only), 2 = unstaged stores
 #ifdef ARP_G2_STAMPS
     const int ntile = ((M + 255) / 256) * ((N + 255) / 256);
