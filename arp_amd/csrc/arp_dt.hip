@@ -68,11 +68,22 @@ struct arp_dt {
     // path -- X, W1, H1, W2, A, Y, Wi -- costs 2.4-6.1e-4 on the logits and they combine to 4.9-8.4e-4 across seeds; with
     // res = sigmoid(4) = 0.98 the adapter branch carries the signal, so carrying Y and Wi as hi + lo pairs, tried, bought
     // nothing for +10 % step time and was removed.)
-    // batch
+    // batch: TWO device-resident slots, so that batch i+1 can be uploaded (arp_dt_upload_batch_async, copy stream) while the step
+    // on batch i runs -- the reference's prefetch_to_device(..., 2) (main_procgen.py:703).  `cur` is the slot the next forward /
+    // step reads; arp_dt_set_batch writes it synchronously as before.
     int B = 0;
-    DevBuf enc32, action, rtg;
+    struct BatchSlot {
+        DevBuf enc32, action, rtg;
+        DevBuf img32;             // raw frames [B*T, res, res, 3] f32 when the encoder is attached
+        int B = 0;
+        bool images = false;
+        hipEvent_t up = nullptr;   // recorded on the copy stream behind the slot's upload
+        hipEvent_t use = nullptr;  // recorded on the compute stream behind the last step that read the slot
+        bool up_pending = false, used = false;
+    } bt[2];
+    int cur = 0;
+    hipStream_t copy_stream = nullptr;
     arp_enc* enc = nullptr;   // optional frozen encoder in front (row N1)
-    DevBuf img32;             // raw frames [B*T, res, res, 3] f32 when the encoder is attached
     bool use_images = false;
     // activations (T = operand type)
     DevBuf Xb, XbT, H1, H1T, A, Y, YT, dY, dApre, dApreT, G, dH1T, dzb, dzT, part, scal;
@@ -88,10 +99,20 @@ struct arp_dt {
     PfArgs pf;
     ncclComm_t comm = nullptr;
     bool has_comm = false;
-    // forward + backward + L2 term captured once per batch geometry and replayed (about 120 short launches)
+    // data-parallel step: gradient all-reduce in two buckets on a communication stream, bucket 1 (image_text_input's kernel, 94 % of
+    // the bytes, + everything the transformer produced) launched while the adapter's backward GEMMs still run (step_impl)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_b1 = nullptr, ev_b2 = nullptr, ev_comm = nullptr;
+    bool overlap_comm = true;   // ARP_DT_OVERLAP=0: the serial form (one all-reduce after the whole backward), for A/B and the bit-identity test
+    bool force_comm = false;    // ARP_DT_FORCE_COMM=1: run the all-reduce path at world = 1 too (what a 1-GPU box can test)
+    bool grads_summed = false;  // the gradient buffer holds the SUM over ranks (set by a data-parallel step)
+    // forward + backward captured once per (batch slot, stage, geometry) and replayed; stage 0 = the whole chain, 1 / 2 = the two
+    // halves either side of the point where bucket 1 is complete
     bool use_graph = true;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_B = 0, graph_images = -1, eager_steps = 0;
+    struct GraphRec {
+        hipGraphExec_t exec = nullptr;
+        int B = 0, images = -1, eager = 0;
+    } graphs[2][3];
     Profiler prof;
 
     size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
@@ -336,7 +357,7 @@ int build_fused_plan(arp_dt* c) {
     PfArgs& a = c->pf;
     memset(&a, 0, sizeof(a));
     a.T = T; a.L = L; a.E = E; a.H = H; a.heads = k.heads; a.NA = NA; a.depth = depth; a.do_bwd = 1; a.R = R; a.lambda = k.lambda_ret;
-    a.img = c->img.as<float>(); a.rtg = c->rtg.as<float>(); a.action = c->action.as<int>();
+    a.img = c->img.as<float>(); a.rtg = c->bt[c->cur].rtg.as<float>(); a.action = c->bt[c->cur].action.as<int>();
     a.Wr = c->p("rtg_input/kernel"); a.emb = c->p("action_input/embedding");
     std::vector<SmallGemm> gj;
     std::vector<ColSumJob> cj;
@@ -406,7 +427,7 @@ int ensure_buffers(arp_dt* c, int B) {
     const int E = k.emb, D = k.enc_dim, H = k.mlp_ratio * E, T = k.window, NA = k.n_actions;
     const size_t R = (size_t)B * T, Mx = R * k.enc_tokens, BL = R * 3, Kin = (size_t)k.enc_tokens * D;
     const size_t Mxp = (Mx + 63) / 64 * 64, Rp = (R + 63) / 64 * 64;
-    ARP_TRY(c->enc32.ensure(Mx * D * 4)); ARP_TRY(c->action.ensure(R * 4)); ARP_TRY(c->rtg.ensure(R * 4));
+    ARP_TRY(c->bt[c->cur].enc32.ensure(Mx * D * 4)); ARP_TRY(c->bt[c->cur].action.ensure(R * 4)); ARP_TRY(c->bt[c->cur].rtg.ensure(R * 4));
     // TN path: these are GEMM operands whose contraction index is the ROW -- rows up to the next multiple of 64 must read as zeros
     const size_t Rp64 = (R + 63) / 64 * 64;
     const size_t rowpad = std::max(Mxp * (size_t)D, Rp64 * Kin);
@@ -477,19 +498,19 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     const int Mxp = (int)((Mx + 63) / 64 * 64);
     ARP_TRY(refresh_shadows<T>(c));
     if (c->use_images) {  // frozen M3AE encoder under stop_gradient (arp_dt/ARPDT.py:418-462): frames -> encodings, on this stream
-        ARP_TRY(enc_forward_on(c->enc, c->stream, c->img32.as<float>(), R, c->enc32.as<float>()));
+        ARP_TRY(enc_forward_on(c->enc, c->stream, c->bt[c->cur].img32.as<float>(), R, c->bt[c->cur].enc32.as<float>()));
     }
     {   // enc f32 -> operand type, both layouts (the transposed one feeds the weight-gradient GEMM)
         ProfScope ps(c->prof, c->stream, "dt.enc_convert");
         if (k.use_adapter && !c->use_tn()) {
-            ARP_TRY((transpose_mask<float, float, T>(c, c->enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D, c->XbT.as<T>(), Mxp, (int)Mx, D)));
+            ARP_TRY((transpose_mask<float, float, T>(c, c->bt[c->cur].enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D, c->XbT.as<T>(), Mxp, (int)Mx, D)));
         } else if constexpr (sizeof(T) == 2) {  // no transposed copy wanted: a flat 16-byte-per-lane conversion
             const size_t n = Mx * D;
-            if (n % 8 == 0) hipLaunchKernelGGL((convert8_kernel<T>), dim3((unsigned)std::min<size_t>(cdiv(n / 8, 256), 4096)), dim3(256), 0, c->stream, c->enc32.as<float>(), c->Xb.as<T>(), n / 8);
-            else hipLaunchKernelGGL((convert_kernel<T>), dim3(cdiv(n, 1024)), dim3(256), 0, c->stream, c->enc32.as<float>(), c->Xb.as<T>(), n);
+            if (n % 8 == 0) hipLaunchKernelGGL((convert8_kernel<T>), dim3((unsigned)std::min<size_t>(cdiv(n / 8, 256), 4096)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<T>(), n / 8);
+            else hipLaunchKernelGGL((convert_kernel<T>), dim3(cdiv(n, 1024)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<T>(), n);
             ARP_HIP_OK(hipGetLastError());
         } else {
-            ARP_TRY((transpose_mask<float, float, T>(c, c->enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D, nullptr, Mxp, (int)Mx, D)));
+            ARP_TRY((transpose_mask<float, float, T>(c, c->bt[c->cur].enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D, nullptr, Mxp, (int)Mx, D)));
         }
     }
     const T* Yp = c->Xb.as<T>();
@@ -500,7 +521,7 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         // (the mix as a second output of fc2's epilogue measured 0.083 ms against 0.050 + 0.035 ms for the two launches: the f32 x rows
         //  arrive behind the tile instead of beside it)
         ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
-        hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->enc32.as<float>(),
+        hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->bt[c->cur].enc32.as<float>(),
                            c->p("residual_weight"), c->Y.as<T>(), Mx * D);
         ARP_HIP_OK(hipGetLastError());
         Yp = c->Y.as<T>();
@@ -512,8 +533,8 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         ARP_TRY(policy_fused(c, with_bwd));
     } else {
         ProfScope ps(c->prof, c->stream, "dt.policy_fwd");
-        hipLaunchKernelGGL(tokens_fwd_kernel, dim3(cdiv((size_t)R * E, 256)), dim3(256), 0, c->stream, c->img.as<float>(), c->rtg.as<float>(),
-                           c->action.as<int>(), c->p("rtg_input/kernel"), c->p("action_input/embedding"), c->xs[0].as<float>(), R, E);
+        hipLaunchKernelGGL(tokens_fwd_kernel, dim3(cdiv((size_t)R * E, 256)), dim3(256), 0, c->stream, c->img.as<float>(), c->bt[c->cur].rtg.as<float>(),
+                           c->bt[c->cur].action.as<int>(), c->p("rtg_input/kernel"), c->p("action_input/embedding"), c->xs[0].as<float>(), R, E);
         ARP_HIP_OK(hipGetLastError());
         for (int i = 0; i < depth; ++i) {
             const std::string p = "policy/Block_" + std::to_string(i) + "/";
@@ -540,8 +561,8 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         ARP_TRY(linear_fwd(c, c->r_in.as<float>(), c->p("return_outputs_0/layers_0/kernel"), c->p("return_outputs_0/layers_0/bias"), nullptr,
                            c->hr.as<float>(), R, E, E, ACT_RELU));
         ARP_TRY(linear_fwd(c, c->hr.as<float>(), c->p("return_outputs_0/layers_2/kernel"), nullptr, nullptr, c->ret.as<float>(), R, 1, E));
-        hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, c->stream, c->logits.as<float>(), c->ret.as<float>(), c->action.as<int>(),
-                           c->rtg.as<float>(), R, NA, k.lambda_ret, c->metrics.as<float>(), c->dlogits.as<float>(), c->dret.as<float>());
+        hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, c->stream, c->logits.as<float>(), c->ret.as<float>(), c->bt[c->cur].action.as<int>(),
+                           c->bt[c->cur].rtg.as<float>(), R, NA, k.lambda_ret, c->metrics.as<float>(), c->dlogits.as<float>(), c->dret.as<float>());
         ARP_HIP_OK(hipGetLastError());
     }
     return 0;
@@ -587,7 +608,9 @@ int tn_gemm(arp_dt* c, const char* site, const T* A, int lda, const T* B, int ld
     return 0;
 }
 
-template <typename T> int backward_adapter_tn(arp_dt* c) {
+// stage: 0 = everything; 1 = up to and including image_text_input's weight gradient (after it every gradient of all-reduce bucket 1
+// exists: step_impl); 2 = the rest (the adapter's own backward)
+template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
     const arp_dt_cfg& k = c->cfg;
     const int E = k.emb, D = k.enc_dim;
     const int R = c->R();
@@ -596,11 +619,13 @@ template <typename T> int backward_adapter_tn(arp_dt* c) {
     const int Mxp = (int)((Mx + 63) / 64 * 64), Rp64 = (R + 63) / 64 * 64;
     const float S = c->act_scale(), invS = 1.0f / S;
     const T* Yp = k.use_adapter ? c->Y.as<T>() : c->Xb.as<T>();
-    // dz (f32) -> operand type, scaled (rows R..Rp64 of dzb stay zero)
-    ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, S, c->dzb.as<T>(), E, nullptr, 0, R, E)));
-    // dWi[E, Kin] = dz^T Y: contraction over the R rows, written straight into the gradient buffer
-    ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS)));
-    if (!k.use_adapter) return 0;
+    if (stage != 2) {
+        // dz (f32) -> operand type, scaled (rows R..Rp64 of dzb stay zero)
+        ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, S, c->dzb.as<T>(), E, nullptr, 0, R, E)));
+        // dWi[E, Kin] = dz^T Y: contraction over the R rows, written straight into the gradient buffer
+        ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS)));
+    }
+    if (!k.use_adapter || stage == 1) return 0;
     const int prow = Mxp / 64, ncb = cdiv(D, 256);
     if (c->use_fused_dy()) {
         // dY = dz Wi, dApre = res * dY * (A > 0), its column sums and sum dY * (A - x) in ONE pass (adapter_bwd.h): no transposed
@@ -610,7 +635,7 @@ template <typename T> int backward_adapter_tn(arp_dt* c) {
         ARP_TRY(c->colpart.ensure((size_t)nrb * k.enc_tokens * D * 4));
         ARP_TRY(c->dres_part.ensure((size_t)nrb * nct * 4));
         AdapterDyArgs a;
-        a.dz = c->dzb.p; a.Wi = c->fwd_w("image_text_input/kernel"); a.A = c->A.p; a.x32 = c->enc32.as<float>(); a.rw = c->p("residual_weight");
+        a.dz = c->dzb.p; a.Wi = c->fwd_w("image_text_input/kernel"); a.A = c->A.p; a.x32 = c->bt[c->cur].enc32.as<float>(); a.rw = c->p("residual_weight");
         a.dApre = c->dApre.p; a.colpart = c->colpart.as<float>(); a.dres_part = c->dres_part.as<float>();
         a.R = R; a.E = E; a.Kin = Kin; a.D = D;
         ARP_TRY(launch_adapter_dy(__is_same(T, bf16_t) ? 1 : 2, a, c->stream));
@@ -626,7 +651,7 @@ template <typename T> int backward_adapter_tn(arp_dt* c) {
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->p("residual_weight"), 1, 1.0f, c->scal.as<float>() + 9, 0);
         hipLaunchKernelGGL(sigmoid_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 9);
         hipLaunchKernelGGL((mask_copy_colsum_kernel<T>), dim3(ncb, prow), dim3(256), 0, c->stream, c->dY.as<T>(), c->A.as<T>(),
-                           c->scal.as<float>() + 9, 1.f, c->dApre.as<T>(), c->colpart.as<float>(), (int)Mx, D, c->enc32.as<float>(), c->scal.as<float>() + 16);
+                           c->scal.as<float>() + 9, 1.f, c->dApre.as<T>(), c->colpart.as<float>(), (int)Mx, D, c->bt[c->cur].enc32.as<float>(), c->scal.as<float>() + 16);
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), prow, D, c->g("AdapterMLP_0/Dense_1/bias"), invS);
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, ncb * prow, invS, c->scal.as<float>() + 8, 0);
         hipLaunchKernelGGL(dres_to_drw_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 8, c->p("residual_weight"), c->g("residual_weight"));
@@ -662,7 +687,7 @@ template <typename T> int backward_adapter_tn(arp_dt* c) {
 }
 
 // ---- backward: fills c->grads (every entry written exactly once; no accumulation across calls) ----------
-template <typename T> int backward(arp_dt* c) {
+template <typename T> int backward(arp_dt* c, int stage = 0) {
     const arp_dt_cfg& k = c->cfg;
     const int E = k.emb, D = k.enc_dim, H = k.mlp_ratio * E, NA = k.n_actions, depth = k.depth;
     const int R = c->R(), L = c->L(), BL = c->B * L;
@@ -670,6 +695,14 @@ template <typename T> int backward(arp_dt* c) {
     const int Kin = k.enc_tokens * D;
     const int Mxp = (int)((Mx + 63) / 64 * 64), Rp = (R + 63) / 64 * 64;
     float* dh = c->dh.as<float>();
+    c->grads_summed = false;  // this rank's own gradient from here on
+    const bool tn = sizeof(T) == 2 && c->use_tn();
+    if (stage == 2) {  // second half of a staged backward: only the TN path has one (the other paths did everything in stage 1)
+        if constexpr (sizeof(T) == 2) {
+            if (tn) return backward_adapter_tn<T>(c, 2);
+        }
+        return 0;
+    }
     if (c->fused) {
         // activation gradients came out of policy_fused_kernel; every parameter gradient of the transformer, the
         // heads, the LayerNorms and the embeddings is produced by three launches
@@ -679,7 +712,7 @@ template <typename T> int backward(arp_dt* c) {
         ProfScope ps(c->prof, st, "dt.policy_bwd");
         hipLaunchKernelGGL(grouped_small_gemm_kernel, dim3(c->gemm_tiles), dim3(256), 0, st, c->gtab.as<SmallGemm>(), c->gprefix.as<int>(), c->n_gemm);
         hipLaunchKernelGGL(grouped_colsum_kernel, dim3(c->cs_tiles), dim3(256), 0, st, c->ctab.as<ColSumJob>(), c->cprefix.as<int>(), c->n_cs);
-        hipLaunchKernelGGL(tokens_bwd_par_kernel, dim3(NA + 1), dim3(TOKB_THREADS), 0, st, c->dtok.as<float>(), c->rtg.as<float>(), c->action.as<int>(),
+        hipLaunchKernelGGL(tokens_bwd_par_kernel, dim3(NA + 1), dim3(TOKB_THREADS), 0, st, c->dtok.as<float>(), c->bt[c->cur].rtg.as<float>(), c->bt[c->cur].action.as<int>(),
                            c->g("rtg_input/kernel"), c->g("action_input/embedding"), R, E, NA);
         ARP_HIP_OK(hipGetLastError());
     } else {
@@ -724,14 +757,14 @@ template <typename T> int backward(arp_dt* c) {
             ARP_TRY(ln_bwd(c, c->xs[i].as<float>(), c->p(p + "LayerNorm_0/scale"), c->t3.as<float>(), dh, 1, c->g(p + "LayerNorm_0/scale"),
                            c->g(p + "LayerNorm_0/bias"), BL, E));
         }
-        hipLaunchKernelGGL(tokens_bwd_kernel, dim3(cdiv(E, 256)), dim3(256), 0, c->stream, dh, c->rtg.as<float>(), c->action.as<int>(),
+        hipLaunchKernelGGL(tokens_bwd_kernel, dim3(cdiv(E, 256)), dim3(256), 0, c->stream, dh, c->bt[c->cur].rtg.as<float>(), c->bt[c->cur].action.as<int>(),
                            c->dimg.as<float>(), c->g("rtg_input/kernel"), c->g("action_input/embedding"), R, E, NA);
         ARP_TRY(ew_bwd(c, c->dimg.as<float>(), c->img.as<float>(), c->dz.as<float>(), (size_t)R * E, EW_TANH_BWD));
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(E, 64)), dim3(256), 0, c->stream, c->dz.as<float>(), R, E, c->g("image_text_input/bias"));
         ARP_HIP_OK(hipGetLastError());
     }
     if constexpr (sizeof(T) == 2) {
-        if (c->use_tn()) return backward_adapter_tn<T>(c);
+        if (tn) return backward_adapter_tn<T>(c, stage);
     }
     // ---- image_text_input: dW[E, Kin] = dz^T Y ;  dY[R, Kin] = dz Wi -------------------------------------
     const T* Yp = k.use_adapter ? c->Y.as<T>() : c->Xb.as<T>();
@@ -748,7 +781,7 @@ template <typename T> int backward(arp_dt* c) {
     {
         ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_elementwise");
         const int nb = 1024;
-        hipLaunchKernelGGL((adapter_dres_kernel<T>), dim3(nb), dim3(256), 0, c->stream, c->dY.as<T>(), c->A.as<T>(), c->enc32.as<float>(),
+        hipLaunchKernelGGL((adapter_dres_kernel<T>), dim3(nb), dim3(256), 0, c->stream, c->dY.as<T>(), c->A.as<T>(), c->bt[c->cur].enc32.as<float>(),
                            c->scal.as<float>() + 16, Mx * D);
         hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, c->scal.as<float>() + 16, nb, invS, c->scal.as<float>() + 8, 0);
         hipLaunchKernelGGL(dres_to_drw_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 8, c->p("residual_weight"), c->g("residual_weight"));
@@ -817,67 +850,128 @@ int apply_update(arp_dt* c, float lr) {
     return 0;
 }
 
-template <typename T> int fwd_bwd(arp_dt* c) {
-    ARP_TRY(forward<T>(c, true));
-    return backward<T>(c);
+template <typename T> int fwd_bwd(arp_dt* c, int stage = 0) {
+    if (stage != 2) ARP_TRY(forward<T>(c, true));
+    return backward<T>(c, stage);
 }
 
 // Replays forward + backward as one hipGraph (a chain of short dependent kernels of a few
 // microseconds).  The first steps of a geometry run eagerly (lazy workspace allocations must not happen under
 // capture); profiling and any capture failure fall back to eager launches.
-template <typename T> int fwd_bwd_graphed(arp_dt* c) {
+template <typename T> int fwd_bwd_graphed(arp_dt* c, int stage = 0) {
     const int images = c->use_images ? 1 : 0;
-    if (!c->use_graph || c->prof.on) return fwd_bwd<T>(c);
-    if (c->graph_exec && (c->graph_B != c->B || c->graph_images != images)) {
-        (void)hipGraphExecDestroy(c->graph_exec);
-        c->graph_exec = nullptr;
-        c->eager_steps = 0;
+    if (!c->use_graph || c->prof.on) return fwd_bwd<T>(c, stage);
+    arp_dt::GraphRec& gr = c->graphs[c->cur][stage];  // the chain holds the batch slot's pointers
+    if (gr.exec && (gr.B != c->B || gr.images != images)) {
+        (void)hipGraphExecDestroy(gr.exec);
+        gr.exec = nullptr;
+        gr.eager = 0;
     }
     if constexpr (sizeof(T) == 2) {
-        if (c->mirror_stale) {  // a host write since the last step: rebuild the operand mirror eagerly, never inside the captured chain
+        if (c->mirror_stale && stage != 2) {  // a host write since the last step: rebuild the operand mirror eagerly, never inside the captured chain
             c->shadows_stale = true;
             ARP_TRY(refresh_shadows<T>(c));
         }
     }
-    if (!c->graph_exec) {
-        if (c->eager_steps < 2) {
-            c->eager_steps++;
-            return fwd_bwd<T>(c);
+    if (!gr.exec) {
+        if (gr.eager < 2) {
+            gr.eager++;
+            return fwd_bwd<T>(c, stage);
         }
-        c->shadows_stale = true;  // the captured chain always refreshes the operand shadows
+        if (stage != 2) c->shadows_stale = true;  // the captured chain always refreshes the operand shadows
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             c->use_graph = false;
-            return fwd_bwd<T>(c);
+            return fwd_bwd<T>(c, stage);
         }
-        const int rc = fwd_bwd<T>(c);
+        const int rc = fwd_bwd<T>(c, stage);
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(c->stream, &g);
-        if (rc != 0 || e != hipSuccess || !g || hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+        if (rc != 0 || e != hipSuccess || !g || hipGraphInstantiate(&gr.exec, g, nullptr, nullptr, 0) != hipSuccess) {
             if (g) (void)hipGraphDestroy(g);
-            c->graph_exec = nullptr;
+            gr.exec = nullptr;
             c->use_graph = false;
             (void)hipGetLastError();
-            c->shadows_stale = true;
-            return fwd_bwd<T>(c);
+            if (stage != 2) c->shadows_stale = true;
+            return fwd_bwd<T>(c, stage);
         }
         (void)hipGraphDestroy(g);
-        c->graph_B = c->B;
-        c->graph_images = images;
+        gr.B = c->B;
+        gr.images = images;
     }
-    ARP_HIP_OK(hipGraphLaunch(c->graph_exec, c->stream));
-    c->shadows_stale = false;
+    ARP_HIP_OK(hipGraphLaunch(gr.exec, c->stream));
+    if (stage != 2) c->shadows_stale = false;
     return 0;
 }
 
+// The flat gradient as two all-reduce buckets of two ranges each (they tile [0, P) exactly once; arp_dt_bucket_plan):
+//   bucket 1 = [off(image_text_input/kernel), n_decay) + [off(image_text_input/bias), P): image_text_input's kernel (25.3 M of the
+//              26.9 M parameters) and every matrix / vector the transformer, the heads and the embeddings own -- all of it exists once
+//              image_text_input_dW has run, BEFORE the adapter's three backward GEMMs;
+//   bucket 2 = [0, off(image_text_input/kernel)) + [n_decay, off(image_text_input/bias)): the adapter's two kernels and its vectors.
+struct BucketPlan { size_t lo[4], hi[4]; };
+BucketPlan bucket_plan(const arp_dt* c) {
+    BucketPlan b;
+    const size_t wi = c->infos[c->index.at("image_text_input/kernel")].off, bi = c->infos[c->index.at("image_text_input/bias")].off;
+    b.lo[0] = wi; b.hi[0] = c->n_decay;   // bucket 1
+    b.lo[1] = bi; b.hi[1] = c->P;
+    b.lo[2] = 0; b.hi[2] = wi;            // bucket 2
+    b.lo[3] = c->n_decay; b.hi[3] = bi;
+    return b;
+}
+int allreduce_ranges(arp_dt* c, const BucketPlan& b, int first, hipStream_t st, bool with_metrics) {
+    RcclApi* r = rccl_api();
+    const bool grp = r->GroupStart && r->GroupEnd;
+    if (grp) r->GroupStart();
+    int rc = 0;
+    for (int i = first; i < first + 2; ++i)
+        if (b.hi[i] > b.lo[i]) {
+            float* p = c->grads.as<float>() + b.lo[i];
+            if (r->AllReduce(p, p, b.hi[i] - b.lo[i], ncclFloat, ncclSum, c->comm, st) != ncclSuccess) rc = -1;
+        }
+    if (with_metrics && r->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, st) != ncclSuccess) rc = -1;
+    if (grp) r->GroupEnd();
+    return rc ? fail("ncclAllReduce(gradient bucket) failed") : 0;
+}
+
 template <typename T> int step_impl(arp_dt* c, float lr, float* aux) {
-    ARP_TRY(fwd_bwd_graphed<T>(c));
-    if (c->has_comm && c->cfg.world > 1) {
-        // pmean of (loss, aux, grads) over devices (main_procgen.py:132): ONE all-reduce(sum) of the flat
-        // gradient plus one of the 8 scalars; the 1/world factor is folded into the update kernel
-        ProfScope ps(c->prof, c->stream, "dt.allreduce");
-        if (rccl_api()->AllReduce(c->grads.p, c->grads.p, c->P, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(grads) failed");
-        if (rccl_api()->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(metrics) failed");
+    arp_dt::BatchSlot& slot = c->bt[c->cur];
+    const bool comm = c->has_comm && (c->cfg.world > 1 || c->force_comm);
+    // pmean of (loss, aux, grads) over devices (main_procgen.py:132); the 1/world factor is folded into the update kernel.  The
+    // reference gets communication / computation overlap from XLA's scheduler under pmap; here it is explicit:
+    if (comm && c->overlap_comm) {
+        // stage 1 (forward, transformer backward, image_text_input_dW) -> bucket 1 goes out on the communication stream while stage
+        // 2 (the adapter's backward: the fused dY pass and three 768 x 768 x 32 896 GEMMs, ~0.25 ms) still runs -> bucket 2 + the
+        // loss scalars -> the update waits for both.
+        const BucketPlan b = bucket_plan(c);
+        ARP_TRY(fwd_bwd_graphed<T>(c, 1));
+        ARP_HIP_OK(hipEventRecord(c->ev_b1, c->stream));
+        ARP_HIP_OK(hipStreamWaitEvent(c->comm_stream, c->ev_b1, 0));
+        {
+            ProfScope ps(c->prof, c->comm_stream, "dt.allreduce_b1");
+            ARP_TRY(allreduce_ranges(c, b, 0, c->comm_stream, false));
+        }
+        ARP_TRY(fwd_bwd_graphed<T>(c, 2));
+        ARP_HIP_OK(hipEventRecord(c->ev_b2, c->stream));
+        ARP_HIP_OK(hipStreamWaitEvent(c->comm_stream, c->ev_b2, 0));
+        {
+            ProfScope ps(c->prof, c->comm_stream, "dt.allreduce_b2");
+            ARP_TRY(allreduce_ranges(c, b, 2, c->comm_stream, true));
+        }
+        ARP_HIP_OK(hipEventRecord(c->ev_comm, c->comm_stream));
+        ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+        c->grads_summed = true;
+    } else {
+        ARP_TRY(fwd_bwd_graphed<T>(c, 0));
+        if (comm) {  // the serial form: ONE all-reduce(sum) of the flat gradient plus one of the 4 loss scalars, behind the whole backward
+            ProfScope ps(c->prof, c->stream, "dt.allreduce");
+            if (rccl_api()->AllReduce(c->grads.p, c->grads.p, c->P, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(grads) failed");
+            if (rccl_api()->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(metrics) failed");
+            c->grads_summed = true;
+        }
     }
+    // the slot's last reader is enqueued: the next upload into it (copy stream) waits for this point
+    ARP_HIP_OK(hipEventRecord(slot.use, c->stream));
+    slot.used = true;
     const long long step_before = c->step;
     ARP_TRY(apply_update(c, lr));
     if (aux) {
@@ -925,9 +1019,15 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (c->cfg.world <= 0) c->cfg.world = 1;
     if (const char* e = getenv("ARP_DT_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FUSE_RELU_BWD")) c->relu_fuse_mode = atoi(e);
+    if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
     build_layout(c);
     auto body = [&]() -> int {
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&c->ev_b1, &c->ev_b2, &c->ev_comm, &c->bt[0].up, &c->bt[0].use, &c->bt[1].up, &c->bt[1].use})
+            ARP_HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
         for (auto* b : fb) {
             ARP_TRY(b->ensure(c->P * 4));
@@ -948,11 +1048,16 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
 int arp_dt_destroy(arp_dt* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    for (hipStream_t st : {c->stream, c->comm_stream, c->copy_stream})
+        if (st) (void)hipStreamSynchronize(st);
+    for (auto& slot : c->graphs)
+        for (auto& gr : slot)
+            if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
+    for (hipEvent_t e : {c->ev_b1, c->ev_b2, c->ev_comm, c->bt[0].up, c->bt[0].use, c->bt[1].up, c->bt[1].use})
+        if (e) (void)hipEventDestroy(e);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->W2t, &c->Wit, &c->colpart, &c->enc32, &c->img32, &c->action, &c->rtg, &c->Xb, &c->XbT,
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->W2t, &c->Wit, &c->colpart, &c->bt[0].enc32, &c->bt[0].img32, &c->bt[0].action, &c->bt[0].rtg, &c->bt[1].enc32, &c->bt[1].img32, &c->bt[1].action, &c->bt[1].rtg, &c->Xb, &c->XbT,
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,
@@ -961,7 +1066,8 @@ int arp_dt_destroy(arp_dt* c) {
     for (auto* v : {&c->xs, &c->ln0, &c->qkv, &c->att, &c->hmid, &c->ln1, &c->u, &c->gl, &c->d_x1, &c->d_u, &c->d_mid, &c->d_qkv, &c->dws0, &c->dbs0,
                     &c->dws1, &c->dbs1})
         for (auto& b : *v) b.release();
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (hipStream_t st : {c->stream, c->comm_stream, c->copy_stream})
+        if (st) (void)hipStreamDestroy(st);
     delete c;
     return 0;
 }
@@ -1039,9 +1145,9 @@ int arp_dt_set_batch(arp_dt* c, const float* enc, const int32_t* action, const f
     ARP_TRY(ensure_buffers(c, B));
     const size_t Mx = (size_t)R * c->cfg.enc_tokens;
     c->use_images = false;
-    ARP_HIP_OK(hipMemcpyAsync(c->enc32.p, enc, Mx * c->cfg.enc_dim * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].enc32.p, enc, Mx * c->cfg.enc_dim * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1067,10 +1173,10 @@ int arp_dt_set_batch_images(arp_dt* c, const float* images, const int32_t* actio
     ARP_TRY(enc_geometry(c->enc, &tokens, &width, &res, &dev));
     ARP_TRY(ensure_buffers(c, B));
     const size_t fb = (size_t)res * res * 3 * 4;
-    ARP_TRY(c->img32.ensure((size_t)R * fb));
-    ARP_HIP_OK(hipMemcpyAsync(c->img32.p, images, (size_t)R * fb, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_TRY(c->bt[c->cur].img32.ensure((size_t)R * fb));
+    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].img32.p, images, (size_t)R * fb, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     c->use_images = true;
     return 0;

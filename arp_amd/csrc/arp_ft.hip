@@ -71,6 +71,7 @@ struct arp_ft {
     ncclComm_t comm = nullptr;
     bool has_comm = false;
     int world = 1, rank = 0;
+    bool grads_summed = false;  // the gradient buffer holds the all-reduced SUM over ranks (set by a data-parallel step)
 
     size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
     // f16 mode: every gradient is seeded with this power-of-two factor (ft_loss_kernel) and carries it to the f32 gradient buffer;
@@ -289,6 +290,7 @@ template <typename T> int forward(arp_ft* c) {
 // ---- backward: every entry of c->grads written exactly once ----------------------------------------------------------
 template <typename T> int backward(arp_ft* c) {
     const arp_ft_cfg& k = c->cfg;
+    c->grads_summed = false;  // this rank's own gradient from here on
     const int B = c->B, F = c->F(), Hd = c->Hd(), Hi = k.hidden, NA = k.n_actions, Dt = c->Dt();
     const int Bp = (B + 63) / 64 * 64;
     {
@@ -384,6 +386,7 @@ template <typename T> int step_impl(arp_ft* c, float lr, float* aux) {
         ProfScope ps(c->prof, c->stream, "ft.allreduce");
         if (rccl_api()->AllReduce(c->grads.p, c->grads.p, c->P, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(grads) failed");
         if (rccl_api()->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(metrics) failed");
+        c->grads_summed = true;
     }
     ARP_TRY(apply_update(c, lr));
     if (aux) {
@@ -491,10 +494,11 @@ static int ft_tensor_io(arp_ft* c, const char* name, int which, float* host, int
         if (which == 0) c->shadows_stale = true;
     } else {
         ARP_HIP_OK(hipMemcpy(host, dev, pi.size * 4, hipMemcpyDeviceToHost));
-        if (which == 1 && c->grad_scale() != 1.f) {  // gradients carry the f16 mode's seed scale on the device
-            const float inv = 1.0f / c->grad_scale();
+        // gradients carry the f16 mode's seed scale on the device and, after a data-parallel step, the SUM over ranks (the mean is
+        // folded into AdamW): the getter returns what the optimizer consumed -- the un-scaled rank MEAN
+        const float inv = 1.0f / (c->grad_scale() * (c->grads_summed ? (float)std::max(c->world, 1) : 1.f));
+        if (which == 1 && inv != 1.f)
             for (size_t i = 0; i < pi.size; ++i) host[i] *= inv;
-        }
     }
     return 0;
 }

@@ -169,11 +169,16 @@ __global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restric
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= s;
                 }
+                if constexpr (__is_same(TO, f16_t)) {  // saturate instead of overflowing to inf (the scaled backward activations); NaN stays NaN
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 65504.f ? 65504.f : (v[e] < -65504.f ? -65504.f : v[e]);
+                }
                 if (outN) store4(outN + (size_t)r * ldn + c, v[0], v[1], v[2], v[3]);
             } else {
                 for (int e = 0; e < 4 && c + e < Ccols; ++e) {
                     float x = Elem<TI>::ld(in + (size_t)r * ldi + c + e) * s;
                     if (mask && !(Elem<TM>::ld(mask + (size_t)r * ldi + c + e) > 0.f)) x = 0.f;
+                    if constexpr (__is_same(TO, f16_t)) x = x > 65504.f ? 65504.f : (x < -65504.f ? -65504.f : x);
                     v[e] = x;
                     if (outN) Elem<TO>::st(outN + (size_t)r * ldn + c + e, x);
                 }
@@ -695,6 +700,11 @@ static __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p,
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 per thread; n, n_decay, n_mirror are multiples of 4
     if (i >= (n >> 2)) return;
     const float gnorm = sqrtf(scal[0]);
+    // A non-finite gradient norm (an f16 backward activation that overflowed its fixed power-of-two scale: a loss spike, huge rtg
+    // targets at tiny B*window) would turn clip / inf * inf into NaN in EVERY parameter and moment, for good.  Such a step is
+    // dropped instead: parameters, moments and the operand mirror keep their values (the step counter still advances, and the
+    // caller sees it in aux: grad_norm is not finite).
+    if (!(gnorm < 3.0e38f)) return;
     const float s = (gnorm < clip) ? 1.0f : clip / gnorm;
     const float4 gv = reinterpret_cast<const float4*>(g)[i];
     float4 pv = reinterpret_cast<float4*>(p)[i];

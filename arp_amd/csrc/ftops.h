@@ -173,7 +173,10 @@ static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict_
     // torch.optim.AdamW skips parameters whose .grad is None -- no decay, no moment update (with use_id_loss off the inverse
     // model and lambda_id never receive a gradient: finetune.py:141 + clip_multiscale_adapter.py:177-250)
     if ((i >= skip0_lo && i < skip0_hi) || (i >= skip1_lo && i < skip1_hi)) return;
-    const float gi = g[i] * gscale;
+    float gi = g[i] * gscale;
+    // f16 mode seeds every gradient x 1024 (arp_ft.hip): an entry that overflowed binary16 on the way arrives as inf / NaN and would
+    // poison this parameter and both moments for good -- it is treated as a missing (zero) gradient for this step
+    if (!(fabsf(gi) < 3.0e38f)) gi = 0.f;
     const float m = b1 * mu[i] + (1.f - b1) * gi;
     const float v = b2 * nu[i] + (1.f - b2) * gi * gi;
     mu[i] = m;

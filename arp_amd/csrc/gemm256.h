@@ -45,6 +45,12 @@ namespace arp {
 // K-loop variants measured in round 2 with the standalone harness scripts/gemm256_bench.hip (10 s per build) and NOT kept: moving
 // U1 / U2 of phase B's six LDS-DMA issues in between that phase's MFMAs (3-7 % slower on every shape, 4096^3 1250 -> 1172 TF),
 // issuing the LDS-DMA ahead of the phase's fragment reads, dropping s_setprio around the MFMA segments (both within +-1.5 % noise).
+// Round 3 (-DARP_G2_FINE stamps, profiles/r3_g256_fine.txt): per K-tile the loop takes ~2550 cycles against 2048 of MFMA time.  A load
+// segment is 16 ds_read_b128 + 2 LDS-DMA (phase A, 410 cycles) or 8 + 6 (phase B, 402): a read costs ~21 issue cycles (all four waves
+// of a group read at once: the LDS array serves 256 B/clk), an LDS-DMA ~40 -- the 2 + 6 split IS the balanced one.  Making it 4 + 4 (W's
+// second unit in a three-slot ring of its own so that it can be issued a phase earlier) was built, bit-identical, and 5-10 % SLOWER on
+// every shape (qkv 212 -> 233 us, 4096^3 1276 -> 1140 TF): phase A grew to 580 cycles.  The 32-MFMA segments themselves run 570-640
+// cycles, not 512, beside the partner group's reads: the two waves of a SIMD share its vector issue port.
 constexpr int G2_BM = 256, G2_BN = 256, G2_THREADS = 512;
 constexpr int G2_BUF_BYTES = (G2_BM + G2_BN) * 128;  // one K-tile: 64 KiB
 static_assert(256 * (256 * 2 + 16) >= 2 * G2_BUF_BYTES && 256 * (256 * 2 + 16) >= 128 * (256 * 4 + 16), "epilogue tile must cover the K-tile ring");
@@ -72,7 +78,7 @@ __device__ __forceinline__ void wait_units(int allow) {
     else wait_vmcnt<0>();
 }
 
-#ifdef ARP_G2_STAMPS
+#if defined(ARP_G2_STAMPS) || defined(ARP_G2_FINE)
 __device__ long long* arp_g2_stamps = nullptr;  // scripts/gemm256_bench.hip: per-tile, per-wave phase time stamps
 #endif
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
@@ -314,6 +320,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+#ifdef ARP_G2_FINE  // scripts/gemm256_bench.hip -DARP_G2_FINE: s_memtime around every segment of the middle K-tile
+    long long f_[12];
+    for (int i = 0; i < 12; ++i) f_[i] = 0;
+#define ARP_FST(i) if (kt == (nk >> 1)) f_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define ARP_FST(i)
+#endif
 #if ARP_G2_TWO_PHASE
     // ---- prologue: steps 0..2 in flight, step 0 landed and visible ---------------------------------------
     if (!pre_issued) {
@@ -335,17 +348,24 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
         const char* buf = smem + (kt & 1) * G2_BUF_BYTES;
         const int p = 2 * kt;
         // phase A: quadrants (0,0) and (0,1)
+        ARP_FST(0);
         load_a(buf, 0);
         load_b(buf, I0{});
         load_b(buf, I1{});
         issue_step(p + 3);
+        ARP_FST(1);
         phase_tail2(p);
+        ARP_FST(2);
         compute2(I0{}, I0{}, I1{});
         // phase B: quadrants (1,1) and (1,0) -- the W sub-tiles are still in registers
+        ARP_FST(4);
         load_a(buf, 1);
         issue_step(p + 4);
+        ARP_FST(5);
         phase_tail2(p + 1);
+        ARP_FST(6);
         compute2(I1{}, I1{}, I0{});
+        ARP_FST(8);
     }
 #else
     // ---- prologue: units 0..4 in flight, units 0 and 1 landed and visible ---------------------------
@@ -397,6 +417,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
         __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef ARP_G2_FINE
+    if (arp_g2_stamps && (threadIdx.x & 63) == 0) {
+        long long* d = arp_g2_stamps + ((size_t)tix * 8 + wave) * 16;
+        for (int i = 0; i < 9; ++i) d[i] = f_[i];
+    }
+#endif
 
     ARP_STAMP(1);
     auto epilogue = [&]() {

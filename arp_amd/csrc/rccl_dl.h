@@ -20,6 +20,8 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;  // optional: several all-reduces of one bucket as one RCCL group
+    ncclResult_t (*GroupEnd)() = nullptr;
     bool ok = false;
 };
 inline RcclApi* rccl_api() {
@@ -36,6 +38,8 @@ inline RcclApi* rccl_api() {
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
     api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(dlsym(h, "ncclBroadcast"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     api.ok = api.GetErrorString && api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.Broadcast;
     return api.ok ? &api : nullptr;
 }

@@ -268,11 +268,18 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
         flush()
         first = bounds[t0] if t0 < len(bounds) else len_data
         for k in target_keys:
-            rows = np.concatenate(parts[k], axis=0) if parts[k] else np.zeros((0, num_frames), np.float32)
             # the reference stores what np.concatenate of the stacks gives: float32 for the CLIP logits, float64 for the
-            # goal-conditioned distances (label_reward.py:163 casts them to float64)
-            out[f"{img_key}_{k}"] = (first, rows if rows.dtype == np.float64 else rows.astype(np.float32))
+            # goal-conditioned distances (label_reward.py:163 casts them to float64).  The dtype follows the MODEL TYPE, not the rows
+            # at hand: a rank with an empty shard must not create (or down-cast into) a float32 dataset ahead of float64 rows
+            dt = reward_dtype(model_type)
+            rows = np.concatenate(parts[k], axis=0).astype(dt, copy=False) if parts[k] else np.zeros((0, num_frames), dt)
+            out[f"{img_key}_{k}"] = (first, rows)
     return out
+
+
+def reward_dtype(model_type):
+    """Stored dtype of the label datasets: float64 for the goal-conditioned distances (label_reward.py:163), float32 otherwise."""
+    return np.float64 if "goal_conditioned" in str(model_type) else np.float32
 
 
 def write_results(store, results, is_hdf5, num_frames):
@@ -325,6 +332,12 @@ def label_reward(
     trajectory of the demonstration file and writes ``{img_key}_{model_type}_reward`` and
     ``..._pos_rtg``.  Returns None.  ``gather(results) -> list of per-rank results`` merges shards
     when ``world > 1`` (rank 0 writes)."""
+    # a misconfigured sharded call fails HERE, not after this rank has labelled its whole shard
+    if not (0 <= int(rank) < int(world)):
+        raise ValueError(f"rank {rank} outside world {world}")
+    if world > 1 and gather is None:
+        raise ValueError("world > 1 needs gather=<callable returning every rank's results>: rank 0 alone would write a file "
+                         "shorter than len_data (the reference always labels the whole file)")
     is_hdf5 = False
     if store is None:
         if data_path is None:
@@ -339,37 +352,39 @@ def label_reward(
 
     compute_reward = make_compute_reward(model_type)
     own_model = clip_model is None
-    if own_model:
-        if weights is None:
-            raise ValueError("no pretrained CLIP checkpoint is reachable offline: pass weights=<openai/CLIP state dict> "
-                             "or clip_model=<ClipLabeller>")
-        if model_type == "clip_ft":  # weights = the fine-tune checkpoint (clip_model.* + head), label_reward.py:166-177
-            from .finetune import FinetunedClip
-            clip_model = FinetunedClip.from_state_dict(weights, mode=mode, device=device, model=model_name)
-        else:
-            clip_model = ClipLabeller(MODELS[model_name], weights, mode=mode, device=device)
-    if model_type in ("clip", "clip_ft"):
-        if tokens is None:
-            if tokenizer is None:
-                raise ValueError("no BPE vocabulary offline: pass tokens=<int32 [1,77]> or tokenizer=<callable>")
-            tokens = tokenizer([text] if not isinstance(text, list) else text)
-        clip_model.set_text(np.asarray(tokens, dtype=np.int32))
+    file_open = is_hdf5
+    try:
+        if own_model:
+            if weights is None:
+                raise ValueError("no pretrained CLIP checkpoint is reachable offline: pass weights=<openai/CLIP state dict> "
+                                 "or clip_model=<ClipLabeller>")
+            if model_type == "clip_ft":  # weights = the fine-tune checkpoint (clip_model.* + head), label_reward.py:166-177
+                from .finetune import FinetunedClip
+                clip_model = FinetunedClip.from_state_dict(weights, mode=mode, device=device, model=model_name)
+            else:
+                clip_model = ClipLabeller(MODELS[model_name], weights, mode=mode, device=device)
+        if model_type in ("clip", "clip_ft"):
+            if tokens is None:
+                if tokenizer is None:
+                    raise ValueError("no BPE vocabulary offline: pass tokens=<int32 [1,77]> or tokenizer=<callable>")
+                tokens = tokenizer([text] if not isinstance(text, list) else text)
+            clip_model.set_text(np.asarray(tokens, dtype=np.int32))
 
-    results = label_store(store, clip_model, compute_reward, image_keys=image_keys, model_type=model_type,
-                          inst_type=inst_type, use_crop=use_crop, rank=rank, world=world, text=text)
-    if is_hdf5 and world > 1:
-        store.close()  # before the gather: it is the barrier after which no rank holds the file
-    if world > 1 and gather is None:
-        raise ValueError("world > 1 needs gather=<callable returning every rank's results>: rank 0 alone would write a file "
-                         "shorter than len_data (the reference always labels the whole file)")
-    per_rank = gather(results) if world > 1 else [results]
-    if rank == 0:
+        results = label_store(store, clip_model, compute_reward, image_keys=image_keys, model_type=model_type,
+                              inst_type=inst_type, use_crop=use_crop, rank=rank, world=world, text=text)
         if is_hdf5 and world > 1:
-            store, _ = _open_store(data_path, "a")
-        for res in per_rank:
-            write_results(store, res, is_hdf5, num_frames)
-    if is_hdf5 and (world == 1 or rank == 0):
-        store.close()
-    if own_model:
-        clip_model.close()
+            store.close()  # before the gather: it is the barrier after which no rank holds the file
+            file_open = False
+        per_rank = gather(results) if world > 1 else [results]
+        if rank == 0:
+            if is_hdf5 and world > 1:
+                store, _ = _open_store(data_path, "a")
+                file_open = True
+            for res in per_rank:
+                write_results(store, res, is_hdf5, num_frames)
+    finally:  # an error on the way (weights, a failed GPU call, the gather) still releases the GPU handle and the file
+        if file_open:
+            store.close()
+        if own_model and clip_model is not None:
+            clip_model.close()
     return None

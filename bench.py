@@ -82,10 +82,15 @@ def spawn_ranks(n):
     WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), BEFORE anything here has
     initialised a GPU -- the parent stays a pure launcher.  Rank 0 prints the JSON line; the exit code is the worst child's."""
     import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = int(os.environ.get("MASTER_PORT", 0))
+    if not port:
+        # bind-and-close leaves a window in which another process may take the port; SO_REUSEADDR on both sides keeps the rendezvous
+        # store able to bind it, and a caller who needs certainty passes MASTER_PORT
+        s = socket.socket()
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
@@ -93,17 +98,29 @@ def spawn_ranks(n):
         # the children get the REAL stdout as their fd 1 (this process's own fd 1 points at stderr since claim_stdout)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
                                       stdout=_JSON_FD if _JSON_FD is not None else None))
+    # poll ALL children under ONE deadline: a rank that dies early (world > device_count, an RCCL init failure) would otherwise leave
+    # its siblings blocked in the rendezvous while this launcher waits on an earlier rank for up to the per-child timeout
+    import time
+    deadline = time.monotonic() + 3600
     rc = 0
-    for p in procs:
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = max(rc, abs(code))
+        if time.monotonic() > deadline:
+            rc = 124
+        if live and rc == 0:
+            time.sleep(0.05)
+    for p in live:  # first failure (or the deadline): the remaining ranks cannot finish
+        p.terminate()
+    for p in live:
         try:
-            rc = max(rc, abs(p.wait(timeout=3600)))
+            p.wait(timeout=10)
         except subprocess.TimeoutExpired:
             p.kill()
-            rc = max(rc, 124)
-    if rc:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
     sys.exit(rc)
 
 

@@ -22,8 +22,10 @@ extern "C" {
 
 #define ARP_MODE_F32 0  /* parity mode: f32 storage, f32-input MFMA (exact f32 FMA chains)        */
 #define ARP_MODE_BF16 1 /* throughput mode: bf16 GEMM operands, f32 accumulate/residual/LN/softmax */
-#define ARP_MODE_F16 2  /* path (1) only: IEEE binary16 GEMM operands (same MFMA rate as bf16, 11 significand bits --
-                           what openai/CLIP itself runs on a GPU), everything else as BF16 */
+#define ARP_MODE_F16 2  /* IEEE binary16 GEMM operands (same MFMA rate as bf16, 11 significand bits -- what openai/CLIP itself runs on a
+                           GPU), everything else as BF16.  The DEFAULT throughput mode of every handle
+                           (arp_clip, arp_dt, arp_ft, arp_enc): the 16-bit mode that meets north_star's 1e-4 / 1e-3; the train steps
+                           carry an exact power-of-two scale on their backward activations (binary16's exponent range) */
 
 #define ARP_ACT_NONE 0
 #define ARP_ACT_QGELU 1
@@ -138,7 +140,7 @@ typedef struct arp_dt_cfg {
     int32_t enc_tokens;  /* 257 (M3AE ViT-B/16 at 256x256) */
     int32_t enc_dim;     /* 768 */
     int32_t use_adapter; /* 1   */
-    int32_t mode;        /* ARP_MODE_F32 | ARP_MODE_BF16: operand type of the adapter / image_text_input GEMMs */
+    int32_t mode;        /* ARP_MODE_F32 | ARP_MODE_F16 (default of arp_amd.train) | ARP_MODE_BF16: operand type of the adapter / image_text_input GEMMs */
     int32_t device;
     int32_t world;       /* data-parallel degree (set again by arp_dt_comm_init) */
     int32_t rank;
@@ -198,7 +200,7 @@ typedef struct arp_ft_cfg {
     int32_t embed;      /* 512 */
     int32_t hidden;     /* hidden_dim 1024: adapters use hidden*(layers+1), the inverse model uses hidden */
     int32_t n_actions;  /* 15 */
-    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_BF16 */
+    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_F16 (default of arp_amd.finetune) | ARP_MODE_BF16 */
     int32_t device;
     int32_t use_vip;    /* use_vip_loss */
     int32_t use_id;     /* use_id_loss */
@@ -267,7 +269,7 @@ typedef struct arp_enc_cfg {
     int32_t heads;      /* 12  */
     int32_t mlp_ratio;  /* 4   */
     int32_t img_res;    /* 256 -> 257 tokens */
-    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_BF16 */
+    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_F16 | ARP_MODE_BF16 (follows the policy handle it is attached to) */
     int32_t device;
     int32_t max_frames; /* frames per internal pass; <= 0 -> 128 */
     int32_t attn_impl;  /* 0 auto, 1 VALU */

@@ -42,6 +42,39 @@ template <typename OutT, int ACT, bool RESID> static void run(const char* name, 
     if (getenv("G256_LDA0")) g.lda = 0;  // every A row is row 0: the A stream comes from cache (isolates memory latency from loop mechanics)
     if (const char* e = getenv("G256_STAGGER")) { g.stagger_groups = atoi(e); g.stagger_cycles = getenv("G256_STAGGER_CYCLES") ? atoi(getenv("G256_STAGGER_CYCLES")) : 100000; }
     if (const char* e = getenv("G256_FLAGS")) g.flags = atoi(e);  // 1 = ablate the epilogue stores (K loop only), 2 = unstaged stores
+#ifdef ARP_G2_FINE
+    {   // -DARP_G2_FINE: s_memtime stamps around every segment of the middle K-tile, per wave group (wr = 0: waves 0-3, wr = 1: waves 4-7)
+        const int ntile = ((M + 255) / 256) * ((N + 255) / 256);
+        long long* dS;
+        hipMalloc(&dS, (size_t)ntile * 128 * 8);
+        hipMemset(dS, 0, (size_t)ntile * 128 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(arp_g2_stamps), &dS, sizeof(dS));
+        launch_gemm256_nt<f16_t, OutT, ACT, RESID, 6>(g, nullptr);
+        hipDeviceSynchronize();
+        std::vector<long long> h((size_t)ntile * 128);
+        hipMemcpy(h.data(), dS, h.size() * 8, hipMemcpyDeviceToHost);
+        const char* nm[8] = {"A:reads+issue", "A:wait+barrier", "A:mfma(+bar)", "A:bar2", "B:reads+issue", "B:wait+barrier", "B:mfma(+bar)", "B:bar2"};
+        for (int grp = 0; grp < 2; ++grp) {
+            double d[8] = {0};
+            for (int t = 0; t < ntile; ++t)
+                for (int w = grp * 4; w < grp * 4 + 4; ++w) {
+                    const long long* f = &h[((size_t)t * 8 + w) * 16];
+                    long long prev = f[0];
+                    for (int i = 1; i < 9; ++i) {
+                        if (f[i] == 0) continue;  // stamp not taken in this build
+                        d[i - 1] += (double)(f[i] - prev);
+                        prev = f[i];
+                    }
+                }
+            printf("  fine %-10s wr=%d:", name, grp);
+            double tot = 0;
+            for (int i = 0; i < 8; ++i) { printf(" %s %.0f |", nm[i], d[i] / ntile / 4); tot += d[i] / ntile / 4; }
+            printf(" K-tile %.0f cycles\n", tot);
+        }
+        hipFree(dS);
+        return;
+    }
+#endif
 #ifdef ARP_G2_STAMPS
     const int ntile = ((M + 255) / 256) * ((N + 255) / 256);
     long long* dS;
