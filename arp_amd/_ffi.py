@@ -38,7 +38,7 @@ class DtCfg(C.Structure):
 
 class FtCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("layers", "width_v", "width_t", "embed", "hidden", "n_actions", "mode", "device", "use_vip", "use_id")] + [
-        (n, C.c_float) for n in ("gamma", "logit_scale", "weight_decay", "b1", "b2", "eps")]
+        (n, C.c_float) for n in ("gamma", "logit_scale", "weight_decay", "b1", "b2", "eps")] + [("goal_conditioned", C.c_int32)]
 
 
 class EncCfg(C.Structure):
@@ -80,6 +80,8 @@ SIGNATURES = {
     "arp_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
     "arp_set_device": (_i, [_i]),
     "arp_dev_synchronize": (_i, []),
+    "arp_host_register": (_i, [_vp, C.c_size_t]),
+    "arp_host_unregister": (_i, [_vp]),
     "arp_clip_create": (_i, [C.POINTER(ClipCfg), C.POINTER(_vp)]),
     "arp_clip_destroy": (_i, [_vp]),
     "arp_clip_load_weight": (_i, [_vp, C.c_char_p, _fp, _i64p, _i]),
@@ -114,6 +116,11 @@ SIGNATURES = {
     "arp_dt_backward": (_i, [_vp]),
     "arp_dt_train_step": (_i, [_vp, _f, _fp]),
     "arp_dt_train_step_async": (_i, [_vp, _f]),
+    "arp_dt_val_step": (_i, [_vp, _fp]),
+    "arp_dt_upload_batch_async": (_i, [_vp, _i, _fp, _i32p, _fp, _i]),
+    "arp_dt_upload_batch_images_async": (_i, [_vp, _i, _fp, _i32p, _fp, _i]),
+    "arp_dt_select_batch": (_i, [_vp, _i]),
+    "arp_dt_bucket_plan": (_i, [C.POINTER(DtCfg), _i64p, _i64p]),
     "arp_dt_sync": (_i, [_vp]),
     "arp_dt_event_record": (_i, [_vp, _vp]),
     "arp_dt_comm_unique_id": (_i, [_vp]),
@@ -144,6 +151,7 @@ SIGNATURES = {
     "arp_ft_sync": (_i, [_vp]),
     "arp_ft_comm_init": (_i, [_vp, _vp, _i, _i]),
     "arp_ft_broadcast_state": (_i, [_vp]),
+    "arp_ft_bucket_plan": (_i, [C.POINTER(FtCfg), _i64p, _i64p]),
     "arp_ft_event_record": (_i, [_vp, _vp]),
     "arp_ft_profile_enable": (_i, [_vp, _i]),
     "arp_ft_profile_reset": (_i, [_vp]),
@@ -157,6 +165,7 @@ SIGNATURES = {
     "arp_enc_profile_json": (_i, [_vp, C.c_char_p, _i]),
     "arp_dt_attach_encoder": (_i, [_vp, _vp]),
     "arp_dt_set_batch_images": (_i, [_vp, _fp, _i32p, _fp, _i]),
+    "arp_h5_write_rows_deflated": (_i, [_vp, C.c_int64, C.c_int64, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _i, _i]),
     "arp_h5_inflate_last_frames": (_i, [_i, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _u8p, C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _u8p, _i]),
     "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),

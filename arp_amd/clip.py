@@ -170,6 +170,16 @@ class ClipLabeller:
             raise ValueError("frames must be uint8 [N, H, W, 3]")
         return f
 
+    @staticmethod
+    def pin_host(a):
+        """Pin a host array that will be passed to :meth:`label` repeatedly (hipHostRegister): its uploads become asynchronous DMA."""
+        check(lib.arp_host_register(a.ctypes.data, a.nbytes))
+        return a
+
+    @staticmethod
+    def unpin_host(a):
+        check(lib.arp_host_unregister(a.ctypes.data))
+
     def label(self, frames, use_crop=False):
         """compute_reward (label_reward.py:132-146): uint8 [N,H,W,3] -> float32 [N]."""
         f = self._frames(frames)

@@ -16,6 +16,7 @@
 #include "gemm256.h"
 #include "tower.h"
 #include "preprocess.h"
+#include "preprocess_host.h"
 #include "rowops.h"
 #include "runtime.h"
 
@@ -26,154 +27,6 @@ void set_error(const std::string& msg) { g_err = msg; }
 int fail(const std::string& msg) {
     g_err = msg;
     return -1;
-}
-
-// ---- Pillow resample table ------------------------------------------------------------------------
-static inline double bicubic_filter(double x) {
-    const double a = -0.5;
-    if (x < 0.0) x = -x;
-    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
-    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
-    return 0.0;
-}
-
-void build_bicubic_table(int in_size, int out_size, ResampleTable& t) {
-    const double scale = (double)in_size / out_size;
-    double filterscale = scale < 1.0 ? 1.0 : scale;
-    const double support = 2.0 * filterscale;
-    const int ksize = (int)std::ceil(support) * 2 + 1;
-    t.ksize = ksize;
-    t.kmax = 0;
-    t.xmin.assign(out_size, 0);
-    t.cnt.assign(out_size, 0);
-    t.w.assign((size_t)out_size * ksize, 0);
-    std::vector<double> k(ksize);
-    const double ss = 1.0 / filterscale;
-    for (int xx = 0; xx < out_size; ++xx) {
-        const double center = (xx + 0.5) * scale;
-        double ww = 0.0;
-        int xmin = (int)(center - support + 0.5);
-        if (xmin < 0) xmin = 0;
-        int xmax = (int)(center + support + 0.5);
-        if (xmax > in_size) xmax = in_size;
-        xmax -= xmin;
-        for (int x = 0; x < xmax; ++x) {
-            const double w = bicubic_filter((x + xmin - center + 0.5) * ss);
-            k[x] = w;
-            ww += w;
-        }
-        for (int x = 0; x < xmax; ++x) {
-            if (ww != 0.0) k[x] /= ww;
-            const double v = k[x] * (double)(1 << 22);
-            t.w[(size_t)xx * ksize + x] = (k[x] < 0) ? (int)(-0.5 + v) : (int)(0.5 + v);
-        }
-        t.xmin[xx] = xmin;
-        t.cnt[xx] = xmax;
-        t.kmax = std::max(t.kmax, xmax);
-    }
-}
-
-// python round() / torchvision CenterCrop offset: round-half-to-even
-static inline int round_half_even(double v) { return (int)std::nearbyint(v); }
-
-struct ResizePlan {
-    int H = 0, W = 0, use_crop = 0, R = 0;
-    int cy = 0, cx = 0, ch = 0, cw = 0;
-    int kmax_h = 0, kmax_v = 0;
-    int TR = 32, max_rows = 0;
-    size_t lds_bytes = 0;
-    DevBuf h_tab, v_tab;
-};
-
-// Packs rows [first, first + R) of a table as [R][1 + kmax]: (xmin | cnt << 16), weights...
-static void pack_table(const ResampleTable& t, int first, int R, std::vector<int>& out) {
-    const int stride = 1 + t.kmax;
-    out.assign((size_t)R * stride, 0);
-    for (int o = 0; o < R; ++o) {
-        const int src = first + o;
-        out[(size_t)o * stride] = t.xmin[src] | (t.cnt[src] << 16);
-        for (int k = 0; k < t.cnt[src]; ++k) out[(size_t)o * stride + 1 + k] = t.w[(size_t)src * t.ksize + k];
-    }
-}
-
-static int build_plan(int H, int W, int use_crop, int R, ResizePlan& p) {
-    if (H <= 0 || W <= 0 || R <= 0 || (R & 3)) return fail("preprocess: bad geometry");
-    p.H = H; p.W = W; p.use_crop = use_crop; p.R = R;
-    int top = 0, left = 0;  // CenterCrop(R) offsets after the resize (non-crop transform)
-    int oh = R, ow = R;
-    if (use_crop) {
-        // label_reward.py:92-104: CenterCrop(image_size // 2), image_size = frame width, then Resize(R)
-        const int crop = W / 2;
-        if (crop <= 0 || crop > H) return fail("preprocess: use_crop needs H >= W/2");
-        p.ch = p.cw = crop;
-        p.cy = round_half_even((H - crop) / 2.0);
-        p.cx = round_half_even((W - crop) / 2.0);
-    } else {
-        p.cy = p.cx = 0; p.ch = H; p.cw = W;
-        // torchvision Resize(int): shorter side -> R, long side int(R * long / short); then CenterCrop(R)
-        if (H <= W) { oh = R; ow = (int)((double)R * W / H); } else { ow = R; oh = (int)((double)R * H / W); }
-        top = round_half_even((oh - R) / 2.0);
-        left = round_half_even((ow - R) / 2.0);
-    }
-    ResampleTable th, tv;
-    build_bicubic_table(p.cw, ow, th);
-    build_bicubic_table(p.ch, oh, tv);
-    std::vector<int> hp, vp;
-    pack_table(th, left, R, hp);
-    pack_table(tv, top, R, vp);
-    p.kmax_h = th.kmax; p.kmax_v = tv.kmax;
-    // rows of input needed by a tile of TR output rows; shrink TR until the LDS carve fits the budget
-    const int row_bytes = p.cw * 3;
-    for (p.TR = 32; p.TR >= 1; p.TR >>= 1) {
-        int need = 0;
-        for (int o0 = 0; o0 < R; o0 += p.TR) {
-            const int o1 = std::min(o0 + p.TR, R) - 1;
-            const int lo = vp[(size_t)o0 * (1 + tv.kmax)] & 0xffff;
-            const int e = vp[(size_t)o1 * (1 + tv.kmax)];
-            need = std::max(need, (e & 0xffff) + (e >> 16) - lo);
-        }
-        p.max_rows = need;
-        // (the fast instance also stages the tile's vertical taps and over-reads up to 27 bytes past a window)
-        p.lds_bytes = (size_t)((R * (1 + th.kmax) * 4 + 15) & ~15) + 768 * 4 + (size_t)((p.TR * (1 + tv.kmax) * 4 + 15) & ~15) +
-                      (size_t)((need * row_bytes + 15) & ~15) + (size_t)need * R * 3 + 64;
-        if (p.lds_bytes <= (size_t)(getenv("ARP_PRE_LDS_KB") ? atoi(getenv("ARP_PRE_LDS_KB")) : 52) * 1024) break;  // three workgroups per CU (measured: 52 KiB 0.30 ms, 78 KiB 0.38 ms per 1024 frames)
-    }
-    if (p.TR < 1) return fail("preprocess: frame too wide for the LDS tile");
-    ARP_TRY(p.h_tab.ensure(hp.size() * 4));
-    ARP_TRY(p.v_tab.ensure(vp.size() * 4));
-    ARP_HIP_OK(hipMemcpy(p.h_tab.p, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
-    ARP_HIP_OK(hipMemcpy(p.v_tab.p, vp.data(), vp.size() * 4, hipMemcpyHostToDevice));
-    return 0;
-}
-
-static void build_lut(float* lut /* [3][256] */) {
-    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};  // label_reward.py:117
-    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
-    for (int c = 0; c < 3; ++c)
-        for (int v = 0; v < 256; ++v) {
-            volatile float x = (float)v / 255.0f;  // ToTensor: uint8 -> f32, div 255
-            volatile float y = x - mean[c];        // Normalize: (x - mean) / std, f32
-            lut[c * 256 + v] = y / stdv[c];
-        }
-}
-
-template <typename T, int LAYOUT>
-static int launch_preprocess(const ResizePlan& p, const uint8_t* frames, int n, int P, const float* lut, void* out,
-                             hipStream_t stream) {
-    PreprocArgs a;
-    a.frames = frames; a.out = out;
-    a.h_tab = p.h_tab.as<int>(); a.v_tab = p.v_tab.as<int>(); a.lut = lut;
-    a.n = n; a.H = p.H; a.W = p.W; a.cy = p.cy; a.cx = p.cx; a.ch = p.ch; a.cw = p.cw;
-    a.R = p.R; a.P = P; a.kmax_h = p.kmax_h; a.kmax_v = p.kmax_v; a.TR = p.TR; a.max_rows = p.max_rows;
-    // short filters + dword-aligned rows: the register-unpacking instance; anything else: the generic one
-    const bool fast = p.kmax_h <= 8 && p.kmax_v <= 8 && ((p.cw * 3) & 3) == 0 && !getenv("ARP_PREPROCESS_GENERIC");
-    auto kern = fast ? preprocess_fast_kernel<T, LAYOUT> : preprocess_kernel<T, LAYOUT>;
-    ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)p.lds_bytes));
-    const int tiles = (p.R + p.TR - 1) / p.TR;
-    hipLaunchKernelGGL(kern, dim3(n * tiles), dim3(256), p.lds_bytes, stream, a);
-    ARP_HIP_OK(hipGetLastError());
-    return 0;
 }
 
 // ---- model ---------------------------------------------------------------------------------------
@@ -227,6 +80,11 @@ struct arp_clip {
     bool is_sibling = false;
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;  // one per sibling
+    // host-fed labelling (the S2 seam): every part's frames go up on ONE copy stream, back to back at the full PCIe rate, and the part's
+    // compute stream waits for its own slice only.  From pinned / registered host memory (arp_host_register) the copies are true DMA and
+    // all of them are in flight before the first kernel; from pageable memory the runtime stages them and the call order does the overlap.
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> ev_copy;  // one per part
     int gemm_force = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (ARP_GEMM env)
     // Fold LayerNorm into the consumer GEMMs of the vision tower in bf16 mode (ARP_LN_FOLD=1).  Numerically fine
     // (cosine error 3.6e-4 vs 4.8e-4 unfused) but MEASURED SLOWER on MI355X (74.2 k vs 79.7 k frames/s): the extra
@@ -600,6 +458,8 @@ static int make_sibling(arp_clip* c) {
     for (auto* b : bufs) *b = DevBuf();
     s->stream = nullptr;
     s->ev_fork = nullptr;
+    s->copy_stream = nullptr;
+    s->ev_copy.clear();
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         delete s;
         return fail("hipStreamCreate failed");
@@ -624,32 +484,53 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
         return label_dev_single(c, frames_dev, n, H, W, use_crop, rewards_dev);
     }
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    // host-fed calls are cut into MORE parts than streams (two per stream, round-robin): the first kernels start after 1 / parts of the
+    // upload instead of 1 / streams of it, and every stream has its next slice on the way while it computes (ARP_CLIP_HOST_PARTS
+    // overrides; each part keeps >= 128 frames)
+    int parts = ns;
+    if (host_src) {
+        static const int env_parts = getenv("ARP_CLIP_HOST_PARTS") ? atoi(getenv("ARP_CLIP_HOST_PARTS")) : 0;
+        parts = env_parts > 0 ? env_parts : 2 * ns;
+        while (parts > ns && n / parts < 128) --parts;
+        if (parts < ns) parts = ns;
+        if (!c->copy_stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        while ((int)c->ev_copy.size() < parts) {
+            hipEvent_t e = nullptr;
+            ARP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_copy.push_back(e);
+        }
+    }
     while ((int)c->siblings.size() < ns - 1) ARP_TRY(make_sibling(c));
     ResizePlan* plan;
     ARP_TRY(get_plan(c, H, W, use_crop, &plan));
     ARP_HIP_OK(hipEventRecord(c->ev_fork, c->stream));
-    // contiguous parts: part 0 on the primary stream, part i on sibling i-1
-    const int per = (n + ns - 1) / ns;
-    for (int i = 0; i < ns; ++i) {
+    for (int i = 1; i < ns; ++i) {
+        arp_clip* s = c->siblings[i - 1];
+        s->plans = c->plans;  // shared, owned by the primary
+        s->txt_feat = c->txt_feat;
+        s->n_prompts = c->n_prompts;
+        s->logit_scale = c->logit_scale;
+        s->prof.on = c->prof.on;
+        ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_fork, 0));
+    }
+    // contiguous parts; part i runs on stream i % ns (0 = the primary, k = sibling k-1)
+    const int per = (n + parts - 1) / parts;
+    for (int i = 0; i < parts; ++i) {
         const int b0 = i * per, nb = std::min(per, n - b0);
         if (nb <= 0) break;
-        arp_clip* s = i == 0 ? c : c->siblings[i - 1];
-        if (i > 0) {
-            s->plans = c->plans;  // shared, owned by the primary
-            s->txt_feat = c->txt_feat;
-            s->n_prompts = c->n_prompts;
-            s->logit_scale = c->logit_scale;
-            s->prof.on = c->prof.on;
-            ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_fork, 0));
-        }
-        if (host_src)
+        arp_clip* s = (i % ns) == 0 ? c : c->siblings[(i % ns) - 1];
+        if (host_src) {
+            // (the staging buffer's previous readers -- the last call's kernels -- were synchronised before that call returned)
             ARP_HIP_OK(hipMemcpyAsync(const_cast<uint8_t*>(frames_dev) + (size_t)b0 * fbytes, host_src + (size_t)b0 * fbytes, (size_t)nb * fbytes,
-                                      hipMemcpyHostToDevice, s->stream));
-        ARP_TRY(label_dev_single(s, frames_dev + (size_t)b0 * H * W * 3, nb, H, W, use_crop, rewards_dev + b0));
-        if (i > 0) {
-            ARP_HIP_OK(hipEventRecord(c->ev_join[i - 1], s->stream));
-            ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join[i - 1], 0));
+                                      hipMemcpyHostToDevice, c->copy_stream));
+            ARP_HIP_OK(hipEventRecord(c->ev_copy[i], c->copy_stream));
+            ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_copy[i], 0));
         }
+        ARP_TRY(label_dev_single(s, frames_dev + (size_t)b0 * H * W * 3, nb, H, W, use_crop, rewards_dev + b0));
+    }
+    for (int i = 1; i < ns; ++i) {  // join: the primary stream continues behind every sibling's last part
+        ARP_HIP_OK(hipEventRecord(c->ev_join[i - 1], c->siblings[i - 1]->stream));
+        ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_join[i - 1], 0));
     }
     return 0;
 }
@@ -683,6 +564,19 @@ int arp_memcpy_h2d(void* dst, const void* src, size_t bytes) {
 }
 int arp_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     ARP_HIP_OK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+// Pin a caller-owned host buffer (hipHostRegister) so that host-fed calls (arp_clip_label, arp_dt_upload_batch_async) move it by true
+// asynchronous DMA instead of staging it.  Registration costs milliseconds per 100 MB: worth it for buffers that are REUSED (a frame
+// reader's recycled batch buffers); the caller unregisters before freeing the memory.
+int arp_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return fail("bad argument");
+    ARP_HIP_OK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return 0;
+}
+int arp_host_unregister(void* p) {
+    if (!p) return 0;
+    ARP_HIP_OK(hipHostUnregister(p));
     return 0;
 }
 int arp_set_device(int device) {
@@ -738,6 +632,8 @@ int arp_clip_destroy(arp_clip* c) {
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : c->ev_join) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_copy) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->prof.destroy();
     for (void* p : c->owned) (void)hipFree(p);
     for (auto& kv : c->plans) {

@@ -82,7 +82,9 @@ struct arp_dt {
         bool up_pending = false, used = false;
     } bt[2];
     int cur = 0;
-    hipStream_t copy_stream = nullptr;
+    // one copy stream per slot; an upload waits on the HOST for the slot's last reader (upload_async) and then runs on a stream with
+    // nothing else queued, beside the step on the other slot
+    hipStream_t copy_stream[2] = {nullptr, nullptr};
     arp_enc* enc = nullptr;   // optional frozen encoder in front (row N1)
     bool use_images = false;
     // activations (T = operand type)
@@ -135,6 +137,13 @@ struct arp_dt {
     // the shape allows (the parity tests' way to reach the masked epilogue at B = 2); read when the handle is created
     int relu_fuse_mode = 1;
     bool fuse_relu_bwd(long tiles256) const { return relu_fuse_mode == 2 || (relu_fuse_mode == 1 && tiles256 >= 192); }
+    // 16-bit modes (default ON, ARP_DT_ITI_F32=0 switches it off): image_text_input's FORWARD contraction (K = 197 376, 6.5 GF) on f32
+    // operands -- the un-rounded mix Y and the f32 master weights on the f32-input MFMA -- instead of their 16-bit copies.  Takes two
+    // of the adapter path's seven operand roundings (Y, Wi) out of the logits: over 16 seeds at the real geometry the f16 logits /
+    // return error goes from max 1.05e-3 (2 seeds of 16 outside north_star's 1e-3) to max 8.7e-4 (none).  Costs the Y32 write and a
+    // 1/16-rate GEMM: 0.866 -> 0.926 ms per step at B = 32 (+7 %).  The backward is unchanged.
+    bool iti_f32 = false;
+    DevBuf Y32;
     DevBuf colpart;  // column partial sums of mask_copy_colsum_kernel
     DevBuf dres_part;  // per-workgroup d loss / d res partials of adapter_dy_kernel
     int R() const { return B * cfg.window; }
@@ -427,7 +436,7 @@ int ensure_buffers(arp_dt* c, int B) {
     const int E = k.emb, D = k.enc_dim, H = k.mlp_ratio * E, T = k.window, NA = k.n_actions;
     const size_t R = (size_t)B * T, Mx = R * k.enc_tokens, BL = R * 3, Kin = (size_t)k.enc_tokens * D;
     const size_t Mxp = (Mx + 63) / 64 * 64, Rp = (R + 63) / 64 * 64;
-    ARP_TRY(c->bt[c->cur].enc32.ensure(Mx * D * 4)); ARP_TRY(c->bt[c->cur].action.ensure(R * 4)); ARP_TRY(c->bt[c->cur].rtg.ensure(R * 4));
+    // (the batch slots size their own buffers: stage_slot)
     // TN path: these are GEMM operands whose contraction index is the ROW -- rows up to the next multiple of 64 must read as zeros
     const size_t Rp64 = (R + 63) / 64 * 64;
     const size_t rowpad = std::max(Mxp * (size_t)D, Rp64 * Kin);
@@ -437,6 +446,7 @@ int ensure_buffers(arp_dt* c, int B) {
         ARP_HIP_OK(hipMemsetAsync(b->p, 0, rowpad * e, c->stream));
     }
     ARP_TRY(c->colpart.ensure((Mxp / 64) * (size_t)D * 4));
+    if (c->iti_f32 && k.use_adapter) ARP_TRY(c->Y32.ensure(Mx * D * 4));
     DevBuf* tt[] = {&c->XbT, &c->H1T, &c->dApreT, &c->dH1T};
     for (auto* b : tt) {
         ARP_TRY(b->ensure((size_t)D * Mxp * e));
@@ -479,6 +489,8 @@ int ensure_buffers(arp_dt* c, int B) {
 int policy_fused(arp_dt* c, bool do_bwd) {
     const arp_dt_cfg& k = c->cfg;
     c->pf.do_bwd = do_bwd ? 1 : 0;
+    c->pf.rtg = c->bt[c->cur].rtg.as<float>();  // the CURRENT batch slot's labels (the plan was built when the geometry last changed)
+    c->pf.action = c->bt[c->cur].action.as<int>();
     const size_t lds = pf_lds_bytes(k.emb, k.mlp_ratio * k.emb, k.heads, k.depth);
     if (k.emb == 128) hipLaunchKernelGGL((policy_fused_kernel<128, 512>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     else hipLaunchKernelGGL((policy_fused_kernel<64, 256>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
@@ -522,10 +534,15 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         //  arrive behind the tile instead of beside it)
         ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
         hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->bt[c->cur].enc32.as<float>(),
-                           c->p("residual_weight"), c->Y.as<T>(), Mx * D);
+                           c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
         ARP_HIP_OK(hipGetLastError());
         Yp = c->Y.as<T>();
     }
+    if (sizeof(T) == 2 && c->iti_f32) {
+        const float* Y32 = k.use_adapter ? c->Y32.as<float>() : c->bt[c->cur].enc32.as<float>();
+        ARP_TRY((splitk_gemm<float, float>(c, "dt.image_text_input", Y32, Kin, c->p("image_text_input/kernel"), Kin, c->p("image_text_input/bias"), ACT_TANH,
+                                           c->img.as<float>(), R, E, Kin)));
+    } else
     // image_text_input + tanh (arp_dt/ARPDT.py:475-484): [R, tokens*dim] x [tokens*dim, E], split over K
     ARP_TRY((splitk_gemm<T, float>(c, "dt.image_text_input", Yp, Kin, c->fwd_w("image_text_input/kernel"), Kin, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>(), R, E, Kin)));
     if (c->fused) {
@@ -903,6 +920,14 @@ template <typename T> int fwd_bwd_graphed(arp_dt* c, int stage = 0) {
     return 0;
 }
 
+// The current slot's last reader is enqueued on the compute stream: an upload into this slot waits (host side) for this event.
+int mark_slot_read(arp_dt* c) {
+    arp_dt::BatchSlot& slot = c->bt[c->cur];
+    ARP_HIP_OK(hipEventRecord(slot.use, c->stream));
+    slot.used = true;
+    return 0;
+}
+
 // The flat gradient as two all-reduce buckets of two ranges each (they tile [0, P) exactly once; arp_dt_bucket_plan):
 //   bucket 1 = [off(image_text_input/kernel), n_decay) + [off(image_text_input/bias), P): image_text_input's kernel (25.3 M of the
 //              26.9 M parameters) and every matrix / vector the transformer, the heads and the embeddings own -- all of it exists once
@@ -934,7 +959,6 @@ int allreduce_ranges(arp_dt* c, const BucketPlan& b, int first, hipStream_t st, 
 }
 
 template <typename T> int step_impl(arp_dt* c, float lr, float* aux) {
-    arp_dt::BatchSlot& slot = c->bt[c->cur];
     const bool comm = c->has_comm && (c->cfg.world > 1 || c->force_comm);
     // pmean of (loss, aux, grads) over devices (main_procgen.py:132); the 1/world factor is folded into the update kernel.  The
     // reference gets communication / computation overlap from XLA's scheduler under pmap; here it is explicit:
@@ -969,9 +993,7 @@ template <typename T> int step_impl(arp_dt* c, float lr, float* aux) {
             c->grads_summed = true;
         }
     }
-    // the slot's last reader is enqueued: the next upload into it (copy stream) waits for this point
-    ARP_HIP_OK(hipEventRecord(slot.use, c->stream));
-    slot.used = true;
+    ARP_TRY(mark_slot_read(c));
     const long long step_before = c->step;
     ARP_TRY(apply_update(c, lr));
     if (aux) {
@@ -1019,13 +1041,16 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (c->cfg.world <= 0) c->cfg.world = 1;
     if (const char* e = getenv("ARP_DT_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FUSE_RELU_BWD")) c->relu_fuse_mode = atoi(e);
+    c->iti_f32 = k.mode != ARP_MODE_F32;
+    if (const char* e = getenv("ARP_DT_ITI_F32")) c->iti_f32 = atoi(e) != 0 && k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
     build_layout(c);
     auto body = [&]() -> int {
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-        ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
+        ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking));
         for (hipEvent_t* e : {&c->ev_b1, &c->ev_b2, &c->ev_comm, &c->bt[0].up, &c->bt[0].use, &c->bt[1].up, &c->bt[1].use})
             ARP_HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
@@ -1048,7 +1073,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
 int arp_dt_destroy(arp_dt* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
-    for (hipStream_t st : {c->stream, c->comm_stream, c->copy_stream})
+    for (hipStream_t st : {c->stream, c->comm_stream, c->copy_stream[0], c->copy_stream[1]})
         if (st) (void)hipStreamSynchronize(st);
     for (auto& slot : c->graphs)
         for (auto& gr : slot)
@@ -1057,7 +1082,7 @@ int arp_dt_destroy(arp_dt* c) {
     for (hipEvent_t e : {c->ev_b1, c->ev_b2, c->ev_comm, c->bt[0].up, c->bt[0].use, c->bt[1].up, c->bt[1].use})
         if (e) (void)hipEventDestroy(e);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->W2t, &c->Wit, &c->colpart, &c->bt[0].enc32, &c->bt[0].img32, &c->bt[0].action, &c->bt[0].rtg, &c->bt[1].enc32, &c->bt[1].img32, &c->bt[1].action, &c->bt[1].rtg, &c->Xb, &c->XbT,
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->W2t, &c->Wit, &c->colpart, &c->Y32, &c->bt[0].enc32, &c->bt[0].img32, &c->bt[0].action, &c->bt[0].rtg, &c->bt[1].enc32, &c->bt[1].img32, &c->bt[1].action, &c->bt[1].rtg, &c->Xb, &c->XbT,
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,
@@ -1066,7 +1091,7 @@ int arp_dt_destroy(arp_dt* c) {
     for (auto* v : {&c->xs, &c->ln0, &c->qkv, &c->att, &c->hmid, &c->ln1, &c->u, &c->gl, &c->d_x1, &c->d_u, &c->d_mid, &c->d_qkv, &c->dws0, &c->dbs0,
                     &c->dws1, &c->dbs1})
         for (auto& b : *v) b.release();
-    for (hipStream_t st : {c->stream, c->comm_stream, c->copy_stream})
+    for (hipStream_t st : {c->stream, c->comm_stream, c->copy_stream[0], c->copy_stream[1]})
         if (st) (void)hipStreamDestroy(st);
     delete c;
     return 0;
@@ -1114,6 +1139,10 @@ static int tensor_io(arp_dt* c, const char* name, int which, float* host, int wr
         if (which == 0) c->shadows_stale = c->mirror_stale = true;
     } else {
         ARP_HIP_OK(hipMemcpy(tmp.data(), dev, pi.size * 4, hipMemcpyDeviceToHost));
+        if (which == 1 && c->grads_summed && c->cfg.world > 1) {  // after a data-parallel step the buffer holds the SUM over ranks; the
+            const float inv = 1.0f / (float)c->cfg.world;         // getter returns what the optimizer consumed: the rank mean
+            for (auto& v : tmp) v *= inv;
+        }
         if (pi.dense) {
             for (int i = 0; i < pi.in; ++i)
                 for (int o = 0; o < pi.out; ++o) host[(size_t)i * pi.out + o] = tmp[(size_t)o * pi.in + i];
@@ -1136,19 +1165,83 @@ int arp_dt_get_step(arp_dt* c, int64_t* step) {
     return 0;
 }
 
-int arp_dt_set_batch(arp_dt* c, const float* enc, const int32_t* action, const float* rtg, int B) {
-    if (!c || !enc || !action || !rtg || B <= 0) return fail("bad argument");
-    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+// Host -> device copy of one batch into slot `si` on stream `st`.  Touches only the slot's own buffers (the caller may be a
+// prefetch thread working beside a running step on the other slot); frames != nullptr: the encoder-in-front boundary (row N1).
+static int stage_slot(arp_dt* c, int si, hipStream_t st, const float* enc, const float* frames, const int32_t* action, const float* rtg, int B) {
     const int R = B * c->cfg.window;
     for (int i = 0; i < R; ++i)
         if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
-    ARP_TRY(ensure_buffers(c, B));
+    arp_dt::BatchSlot& b = c->bt[si];
+    ARP_TRY(b.action.ensure((size_t)R * 4));
+    ARP_TRY(b.rtg.ensure((size_t)R * 4));
     const size_t Mx = (size_t)R * c->cfg.enc_tokens;
+    ARP_TRY(b.enc32.ensure(Mx * c->cfg.enc_dim * 4));  // with frames in: the encoder's output buffer
+    if (frames) {
+        int tokens = 0, width = 0, res = 0, dev = 0;
+        ARP_TRY(enc_geometry(c->enc, &tokens, &width, &res, &dev));
+        const size_t fb = (size_t)res * res * 3 * 4;
+        ARP_TRY(b.img32.ensure((size_t)R * fb));
+        ARP_HIP_OK(hipMemcpyAsync(b.img32.p, frames, (size_t)R * fb, hipMemcpyHostToDevice, st));
+    } else {
+        ARP_HIP_OK(hipMemcpyAsync(b.enc32.p, enc, Mx * c->cfg.enc_dim * 4, hipMemcpyHostToDevice, st));
+    }
+    ARP_HIP_OK(hipMemcpyAsync(b.action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, st));
+    ARP_HIP_OK(hipMemcpyAsync(b.rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, st));
+    b.B = B;
+    b.images = frames != nullptr;
+    return 0;
+}
+
+int arp_dt_set_batch(arp_dt* c, const float* enc, const int32_t* action, const float* rtg, int B) {
+    if (!c || !enc || !action || !rtg || B <= 0) return fail("bad argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(stage_slot(c, c->cur, c->stream, enc, nullptr, action, rtg, B));
+    ARP_TRY(ensure_buffers(c, B));
     c->use_images = false;
-    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].enc32.p, enc, Mx * c->cfg.enc_dim * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Asynchronous upload of a batch into slot 0 / 1 on the handle's COPY stream -- main_procgen.py:703's prefetch_to_device(..., 2).
+// Returns once the copies are enqueued (from pageable host memory: once they are staged); never touches the slot a running step
+// reads, so it may be called from another host thread while arp_dt_train_step runs.  The copy waits (on the GPU) for the last
+// step that read this slot; arp_dt_select_batch makes the compute stream wait for the copy.
+static int upload_async(arp_dt* c, int slot, const float* enc, const float* frames, const int32_t* action, const float* rtg, int B) {
+    if (!c || (!enc && !frames) || !action || !rtg || B <= 0 || slot < 0 || slot > 1) return fail("bad argument");
+    if (frames && !c->enc) return fail("no encoder attached: call arp_dt_attach_encoder first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    arp_dt::BatchSlot& b = c->bt[slot];
+    // Behind the slot's last reader: a HOST-side wait on the event that step recorded (already complete when the caller follows
+    // prefetch_to_device's protocol: a slot is handed back after its step's aux was read).  Not a stream-side wait: from this thread
+    // hipStreamWaitEvent on an event of a stream that is being captured is refused, and a pageable upload queued behind a pending
+    // stream wait ran 4x slower (7.8 ms instead of 1.8 ms per 101 MB).
+    if (b.used) ARP_HIP_OK(hipEventSynchronize(b.use));
+    // a slot that has to GROW frees its old buffers (hipFree synchronises the device): size them once, with the largest batch
+    ARP_TRY(stage_slot(c, slot, c->copy_stream[slot], enc, frames, action, rtg, B));
+    ARP_HIP_OK(hipEventRecord(b.up, c->copy_stream[slot]));
+    b.up_pending = true;
+    return 0;
+}
+int arp_dt_upload_batch_async(arp_dt* c, int slot, const float* enc, const int32_t* action, const float* rtg, int B) {
+    return upload_async(c, slot, enc, nullptr, action, rtg, B);
+}
+int arp_dt_upload_batch_images_async(arp_dt* c, int slot, const float* images, const int32_t* action, const float* rtg, int B) {
+    return upload_async(c, slot, nullptr, images, action, rtg, B);
+}
+
+// The next forward / step reads slot `slot` (compute stream ordered behind the slot's upload).
+int arp_dt_select_batch(arp_dt* c, int slot) {
+    if (!c || slot < 0 || slot > 1) return fail("bad argument");
+    arp_dt::BatchSlot& b = c->bt[slot];
+    if (b.B <= 0) return fail("nothing was uploaded into this batch slot");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (b.up_pending) {
+        ARP_HIP_OK(hipStreamWaitEvent(c->stream, b.up, 0));
+        b.up_pending = false;
+    }
+    c->cur = slot;
+    ARP_TRY(ensure_buffers(c, b.B));
+    c->use_images = b.images;
     return 0;
 }
 
@@ -1166,17 +1259,8 @@ int arp_dt_set_batch_images(arp_dt* c, const float* images, const int32_t* actio
     if (!c || !images || !action || !rtg || B <= 0) return fail("bad argument");
     if (!c->enc) return fail("no encoder attached: call arp_dt_attach_encoder first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    const int R = B * c->cfg.window;
-    for (int i = 0; i < R; ++i)
-        if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
-    int tokens = 0, width = 0, res = 0, dev = 0;
-    ARP_TRY(enc_geometry(c->enc, &tokens, &width, &res, &dev));
+    ARP_TRY(stage_slot(c, c->cur, c->stream, nullptr, images, action, rtg, B));
     ARP_TRY(ensure_buffers(c, B));
-    const size_t fb = (size_t)res * res * 3 * 4;
-    ARP_TRY(c->bt[c->cur].img32.ensure((size_t)R * fb));
-    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].img32.p, images, (size_t)R * fb, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].action.p, action, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->bt[c->cur].rtg.p, rtg, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     c->use_images = true;
     return 0;
@@ -1221,6 +1305,44 @@ int arp_dt_train_step(arp_dt* c, float lr, float* aux) {
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     if (c->cfg.mode == ARP_MODE_F16) return step_impl<f16_t>(c, lr, aux);
     return c->cfg.mode == ARP_MODE_BF16 ? step_impl<bf16_t>(c, lr, aux) : step_impl<float>(c, lr, aux);
+}
+
+// create_val_step's val_step_fn (main_procgen.py:144-169): forward only, then pmean over the ranks of the four metrics
+// aux4 = {loss, trans_loss, return_loss, acc * 100} (the reference's dict order, :154-159).
+int arp_dt_val_step(arp_dt* c, float* aux4) {
+    if (!c || !aux4) return fail("null argument");
+    if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : (c->cfg.mode == ARP_MODE_F16 ? forward<f16_t>(c) : forward<float>(c)));
+    const bool comm = c->has_comm && (c->cfg.world > 1 || c->force_comm);
+    if (comm && rccl_api()->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess)
+        return fail("ncclAllReduce(metrics) failed");
+    ARP_TRY(mark_slot_read(c));
+    float m[4];
+    ARP_HIP_OK(hipMemcpyAsync(m, c->metrics.p, 16, hipMemcpyDeviceToHost, c->stream));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    const float inv = 1.0f / (float)std::max(c->cfg.world, 1);
+    aux4[0] = m[0] * inv;          // loss (no L2 penalty: val_fn returns the model's loss)
+    aux4[1] = m[2] * inv;          // trans_loss
+    aux4[2] = m[3] * inv;          // return_loss
+    aux4[3] = m[1] * inv * 100.f;  // acc * 100
+    return 0;
+}
+
+// The flat-gradient ranges of the data-parallel step's two all-reduce buckets, from the configuration alone (no GPU):
+// ranges8 = {lo, hi} x {bucket 1 range a, bucket 1 range b, bucket 2 range a, bucket 2 range b} in floats; *total = P.
+int arp_dt_bucket_plan(const arp_dt_cfg* cfg, int64_t* ranges8, int64_t* total) {
+    if (!cfg || !ranges8 || !total) return fail("null argument");
+    arp_dt tmp;
+    tmp.cfg = *cfg;
+    build_layout(&tmp);
+    const BucketPlan b = bucket_plan(&tmp);
+    for (int i = 0; i < 4; ++i) {
+        ranges8[2 * i] = (int64_t)b.lo[i];
+        ranges8[2 * i + 1] = (int64_t)b.hi[i];
+    }
+    *total = (int64_t)tmp.P;
+    return 0;
 }
 
 int arp_dt_sync(arp_dt* c) {

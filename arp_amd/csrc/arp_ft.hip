@@ -72,11 +72,21 @@ struct arp_ft {
     bool has_comm = false;
     int world = 1, rank = 0;
     bool grads_summed = false;  // the gradient buffer holds the all-reduced SUM over ranks (set by a data-parallel step)
+    // The 1.9 GB gradient goes out in SEVEN buckets in the order the backward produces them (inverse model; per tower: second adapter
+    // layer, first adapter layer, intermediate linear), each on the communication stream as soon as its last weight-gradient GEMM is
+    // enqueued, so that all but the last bucket's all-reduce runs beside the remaining backward (ft_buckets, step_impl).
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_bucket[8] = {}, ev_comm = nullptr;
+    bool overlap_comm = true;   // ARP_FT_OVERLAP=0: one all-reduce behind the whole backward
+    bool force_comm = false;    // ARP_FT_FORCE_COMM=1: run the all-reduce path at world = 1 too (what a 1-GPU box can test)
+    bool comm_live = false;     // set by step_impl around backward(): the bucket hooks fire
 
     size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
     // f16 mode: every gradient is seeded with this power-of-two factor (ft_loss_kernel) and carries it to the f32 gradient buffer;
     // AdamW's gscale and arp_ft_get_tensor(which = 1) take it out.  bf16 / f32 have the range: 1.
     float grad_scale() const { return cfg.mode == ARP_MODE_F16 ? 1024.f : 1.f; }
+    int groups() const { return cfg.goal_conditioned ? 4 : 3; }  // image groups per sample: image0..2 (+ the goal frame image3)
+    DevBuf dist;  // goal_conditioned: ||a3 - a_k|| per score row
     int Dv() const { return cfg.layers * cfg.width_v; }
     int Dt() const { return cfg.layers * cfg.width_t; }
     int F() const { return cfg.layers * cfg.width_t + cfg.embed; }
@@ -210,7 +220,7 @@ int ensure_buffers(arp_ft* c, int B) {
         return 0;
     };
     for (int w = 0; w < 2; ++w) {
-        const size_t M = w == 0 ? 3 * (size_t)B : (size_t)B, Mp = (M + 63) / 64 * 64;
+        const size_t M = w == 0 ? c->groups() * (size_t)B : (size_t)B, Mp = (M + 63) / 64 * 64;
         const size_t Din = w == 0 ? c->Dv() : c->Dt();
         ARP_TRY(f32(c->x_in[w], M * Din)); ARP_TRY(f32(c->x_fin[w], M * E));
         ARP_TRY(typ(c->X[w], M * Din)); ARP_TRY(typz(c->XT[w], Din * Mp));
@@ -222,7 +232,7 @@ int ensure_buffers(arp_ft* c, int B) {
         ARP_TRY(f32(c->df[w], M * F)); ARP_TRY(typz(c->dUt[w], (size_t)c->Dt() * Mp)); ARP_TRY(f32(c->dres_part[w], M));
     }
     const size_t Bp = ((size_t)B + 63) / 64 * 64;
-    ARP_TRY(f32(c->r, B)); ARP_TRY(f32(c->action, B)); ARP_TRY(f32(c->scores, 3 * (size_t)B)); ARP_TRY(f32(c->ds, 3 * (size_t)B));
+    ARP_TRY(f32(c->r, B)); ARP_TRY(f32(c->action, B)); ARP_TRY(f32(c->scores, 3 * (size_t)B)); ARP_TRY(f32(c->ds, 3 * (size_t)B)); ARP_TRY(f32(c->dist, 3 * (size_t)B));
     ARP_TRY(f32(c->C, (size_t)B * 4 * F)); ARP_TRY(typ(c->CT_, (size_t)B * 4 * F)); ARP_TRY(typz(c->Ct, (size_t)4 * F * Bp));
     ARP_TRY(f32(c->Hinv, (size_t)B * Hi)); ARP_TRY(f32(c->logits, (size_t)B * NA)); ARP_TRY(f32(c->dlogits, (size_t)B * NA));
     ARP_TRY(f32(c->dHinv, (size_t)B * Hi)); ARP_TRY(typ(c->dHinvT_, (size_t)B * Hi)); ARP_TRY(typz(c->dHinvt, (size_t)Hi * Bp));
@@ -263,14 +273,17 @@ template <typename T> int forward(arp_ft* c) {
     const arp_ft_cfg& k = c->cfg;
     const int B = c->B, F = c->F(), Hi = k.hidden, NA = k.n_actions;
     ARP_TRY(refresh_shadows<T>(c));
-    ARP_TRY(encode_tower<T>(c, 0, 3 * B));
-    ARP_TRY(encode_tower<T>(c, 1, B));
+    ARP_TRY(encode_tower<T>(c, 0, c->groups() * B));
+    if (!k.goal_conditioned) ARP_TRY(encode_tower<T>(c, 1, B));
     {
         ProfScope ps(c->prof, c->stream, "ft.rowops");
-        hipLaunchKernelGGL(ft_scores_kernel, dim3(3 * B), dim3(256), 0, c->stream, c->a[0].as<float>(), c->a[1].as<float>(), expf(k.logit_scale),
-                           c->scores.as<float>(), B, F);
-        hipLaunchKernelGGL(ft_build_c_kernel, dim3(cdiv((size_t)B * 4 * F, 256)), dim3(256), 0, c->stream, c->a[0].as<float>(), c->a[1].as<float>(),
-                           c->C.as<float>(), B, F);
+        // the "prompt side" t of the scores and of the inverse-model input: the text head's output, or (goal_conditioned) image3's
+        const float* t = k.goal_conditioned ? c->a[0].as<float>() + (size_t)3 * B * F : c->a[1].as<float>();
+        if (k.goal_conditioned)
+            hipLaunchKernelGGL(ft_goal_scores_kernel, dim3(3 * B), dim3(256), 0, c->stream, c->a[0].as<float>(), c->scores.as<float>(), c->dist.as<float>(), B, F);
+        else
+            hipLaunchKernelGGL(ft_scores_kernel, dim3(3 * B), dim3(256), 0, c->stream, c->a[0].as<float>(), t, expf(k.logit_scale), c->scores.as<float>(), B, F);
+        hipLaunchKernelGGL(ft_build_c_kernel, dim3(cdiv((size_t)B * 4 * F, 256)), dim3(256), 0, c->stream, c->a[0].as<float>(), t, c->C.as<float>(), B, F);
         ARP_HIP_OK(hipGetLastError());
     }
     const int Bp = (B + 63) / 64 * 64;
@@ -288,6 +301,47 @@ template <typename T> int forward(arp_ft* c) {
 }
 
 // ---- backward: every entry of c->grads written exactly once ----------------------------------------------------------
+// Flat-gradient ranges of the all-reduce buckets, in production order.  Bucket b = ranges [2b, 2b + 1] (the second one empty except
+// for the last bucket, which also takes the three scalar parameters at the end of the flat vector).  They tile [0, P) exactly once.
+constexpr int FT_BUCKETS = 7;
+struct FtBuckets { size_t lo[2 * FT_BUCKETS], hi[2 * FT_BUCKETS]; };
+FtBuckets ft_buckets(const arp_ft* c) {
+    FtBuckets b;
+    for (int i = 0; i < 2 * FT_BUCKETS; ++i) b.lo[i] = b.hi[i] = 0;
+    auto off = [&](const char* n) { return c->infos[c->index.at(n)].off; };
+    auto span = [&](int i, const char* first, const char* next) { b.lo[i] = off(first); b.hi[i] = next ? off(next) : c->P; };
+    span(0, "inverse_layer.layers.0.weight", "image_residual_weight");                        // bucket 0: the inverse model
+    span(2, "image_adapter.layers.3.weight", "text_adapter.layers.0.weight");                 // 1: image adapter, second layer
+    span(4, "image_adapter.layers.0.weight", "image_adapter.layers.3.weight");                // 2: image adapter, first layer
+    span(6, "image_intermediate_linear.weight", "text_intermediate_linear.weight");           // 3
+    span(8, "text_adapter.layers.3.weight", "inverse_layer.layers.0.weight");                 // 4: text adapter, second layer
+    span(10, "text_adapter.layers.0.weight", "text_adapter.layers.3.weight");                 // 5: text adapter, first layer
+    span(12, "text_intermediate_linear.weight", "image_adapter.layers.0.weight");             // 6: ... and the scalars
+    span(13, "image_residual_weight", nullptr);
+    return b;
+}
+// bucket `b` is complete on the compute stream: all-reduce it on the communication stream (no-op outside a data-parallel step)
+int ft_bucket_ready(arp_ft* c, int b) {
+    if (!c->comm_live) return 0;
+    const FtBuckets plan = ft_buckets(c);
+    ARP_HIP_OK(hipEventRecord(c->ev_bucket[b], c->stream));
+    ARP_HIP_OK(hipStreamWaitEvent(c->comm_stream, c->ev_bucket[b], 0));
+    static const char* names[FT_BUCKETS] = {"ft.allreduce_b0", "ft.allreduce_b1", "ft.allreduce_b2", "ft.allreduce_b3", "ft.allreduce_b4", "ft.allreduce_b5", "ft.allreduce_b6"};
+    ProfScope ps(c->prof, c->comm_stream, names[b]);
+    RcclApi* r = rccl_api();
+    const bool grp = r->GroupStart && r->GroupEnd;
+    if (grp) r->GroupStart();
+    int rc = 0;
+    for (int i = 2 * b; i < 2 * b + 2; ++i)
+        if (plan.hi[i] > plan.lo[i] && !(c->cfg.goal_conditioned && i >= 8 && i <= 12)) {  // goal_conditioned: the text head has no gradient
+            float* p = c->grads.as<float>() + plan.lo[i];
+            if (r->AllReduce(p, p, plan.hi[i] - plan.lo[i], ncclFloat, ncclSum, c->comm, c->comm_stream) != ncclSuccess) rc = -1;
+        }
+    if (b == FT_BUCKETS - 1 && r->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, c->comm_stream) != ncclSuccess) rc = -1;
+    if (grp) r->GroupEnd();
+    return rc ? fail("ncclAllReduce(gradient bucket) failed") : 0;
+}
+
 template <typename T> int backward(arp_ft* c) {
     const arp_ft_cfg& k = c->cfg;
     c->grads_summed = false;  // this rank's own gradient from here on
@@ -306,15 +360,20 @@ template <typename T> int backward(arp_ft* c) {
     }
     ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1_dW", c->dHinvt.p, Bp, c->Ct.p, Bp, nullptr, ACT_NONE, nullptr, c->g("inverse_layer.layers.0.weight"), 4 * F, Hi,
                                4 * F, Bp)));
+    ARP_TRY(ft_bucket_ready(c, 0));
     ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1_dX", c->dHinvT_.p, Hi, c->sV1t.p, Hi, nullptr, ACT_NONE, nullptr, c->dC.as<float>(), 4 * F, B, 4 * F, Hi)));
     {
         ProfScope ps(c->prof, c->stream, "ft.rowops");
-        hipLaunchKernelGGL(ft_feat_grad_kernel, dim3(cdiv((size_t)B * F, 256)), dim3(256), 0, c->stream, c->ds.as<float>(), c->a[0].as<float>(),
-                           c->a[1].as<float>(), c->dC.as<float>(), expf(k.logit_scale), c->da[0].as<float>(), c->da[1].as<float>(), B, F);
+        if (k.goal_conditioned)
+            hipLaunchKernelGGL(ft_goal_feat_grad_kernel, dim3(cdiv((size_t)B * F, 256)), dim3(256), 0, c->stream, c->ds.as<float>(), c->a[0].as<float>(),
+                               c->dist.as<float>(), c->dC.as<float>(), c->da[0].as<float>(), B, F);
+        else
+            hipLaunchKernelGGL(ft_feat_grad_kernel, dim3(cdiv((size_t)B * F, 256)), dim3(256), 0, c->stream, c->ds.as<float>(), c->a[0].as<float>(),
+                               c->a[1].as<float>(), c->dC.as<float>(), expf(k.logit_scale), c->da[0].as<float>(), c->da[1].as<float>(), B, F);
         ARP_HIP_OK(hipGetLastError());
     }
-    for (int w = 0; w < 2; ++w) {
-        const int M = w == 0 ? 3 * B : B, Mp = (M + 63) / 64 * 64, Din = w == 0 ? c->Dv() : Dt;
+    for (int w = 0; w < (k.goal_conditioned ? 1 : 2); ++w) {
+        const int M = w == 0 ? c->groups() * B : B, Mp = (M + 63) / 64 * 64, Din = w == 0 ? c->Dv() : Dt;
         const std::string a = std::string(TW[w]) + "_adapter", pre = std::string("ft.") + TW[w], rwn = std::string(TW[w]) + "_residual_weight";
         {
             ProfScope ps(c->prof, c->stream, "ft.rowops");
@@ -331,6 +390,7 @@ template <typename T> int backward(arp_ft* c) {
         // A = H W2^T + b2
         ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc2_dW").c_str(), c->dAt[w].p, Mp, c->HT[w].p, Mp, nullptr, ACT_NONE, nullptr, c->g(a + ".layers.3.weight"), Hd, F,
                                    Hd, Mp)));
+        ARP_TRY(ft_bucket_ready(c, 1 + 3 * w));
         ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc2_dX").c_str(), c->dAT_[w].p, F, c->sW2t[w].p, F, nullptr, ACT_NONE, nullptr, c->dH[w].as<T>(), Hd, M, Hd, F)));
         // relu mask (H is the post-activation), both layouts; H = relu(f W1^T + b1)
         ARP_TRY((ft_transpose<T, T, T>(c, c->dH[w].as<T>(), Hd, c->H[w].as<T>(), c->dHp[w].as<T>(), Hd, c->dHpt[w].as<T>(), Mp, M, Hd)));
@@ -338,6 +398,7 @@ template <typename T> int backward(arp_ft* c) {
         ARP_HIP_OK(hipGetLastError());
         ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc1_dW").c_str(), c->dHpt[w].p, Mp, c->fTt[w].p, Mp, nullptr, ACT_NONE, nullptr, c->g(a + ".layers.0.weight"), F, Hd,
                                    F, Mp)));
+        ARP_TRY(ft_bucket_ready(c, 2 + 3 * w));
         // df = res*dy (direct path) + dHpre W1
         ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc1_dX").c_str(), c->dHp[w].p, Hd, c->sW1t[w].p, Hd, nullptr, ACT_NONE, c->dfd[w].as<float>(),
                                    c->df[w].as<float>(), F, M, F, Hd)));
@@ -345,7 +406,9 @@ template <typename T> int backward(arp_ft* c) {
         ARP_TRY((ft_transpose<float, float, T>(c, c->df[w].as<float>(), F, nullptr, nullptr, 0, c->dUt[w].as<T>(), Mp, M, Dt)));
         ARP_TRY((ft_gemm<T, float>(c, (pre + "_inter_dW").c_str(), c->dUt[w].p, Mp, c->XT[w].p, Mp, nullptr, ACT_NONE, nullptr,
                                    c->g(std::string(TW[w]) + "_intermediate_linear.weight"), Din, Dt, Din, Mp)));
+        ARP_TRY(ft_bucket_ready(c, 3 + 3 * w));  // w = 1: the last bucket (+ the scalar parameters and the loss scalars)
     }
+    if (k.goal_conditioned) ARP_TRY(ft_bucket_ready(c, FT_BUCKETS - 1));  // no text head ran: only the scalars and the loss scalars are left
     return 0;
 }
 
@@ -354,19 +417,30 @@ int apply_update(arp_ft* c, float lr) {
     const double t = (double)(c->step + 1);
     const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
     // parameters that received no gradient this step are left alone, as torch does for .grad is None
-    size_t s0lo = 0, s0hi = 0, s1lo = 0, s1hi = 0;
+    FtSkip skip;
+    for (int r = 0; r < FT_SKIP_RANGES; ++r) skip.lo[r] = skip.hi[r] = 0;
+    int nskip = 0;
+    auto skip_span = [&](const char* first, const char* last) {  // [first, end of last), padded offsets
+        const FtParam& a = c->infos[c->index.at(first)];
+        const FtParam& b = c->infos[c->index.at(last)];
+        skip.lo[nskip] = a.off;
+        skip.hi[nskip] = b.off + ((b.size + 3) & ~(size_t)3);
+        ++nskip;
+    };
     if (!c->cfg.use_id) {
-        const FtParam& a = c->infos[c->index.at("inverse_layer.layers.0.weight")];
-        const FtParam& b = c->infos[c->index.at("inverse_layer.layers.3.bias")];
-        const FtParam& l = c->infos[c->index.at("lambda_id")];
-        s0lo = a.off; s0hi = b.off + ((b.size + 3) & ~(size_t)3);
-        s1lo = l.off; s1hi = l.off + 4;
+        skip_span("inverse_layer.layers.0.weight", "inverse_layer.layers.3.bias");
+        skip_span("lambda_id", "lambda_id");
+    }
+    if (c->cfg.goal_conditioned) {
+        skip_span("text_intermediate_linear.weight", "text_intermediate_linear.weight");
+        skip_span("text_adapter.layers.0.weight", "text_adapter.layers.3.bias");
+        skip_span("text_residual_weight", "text_residual_weight");
     }
     const float gscale = 1.0f / ((float)std::max(c->world, 1) * c->grad_scale());
 #define ARP_FT_ADAMW(TM)                                                                                                                          \
     hipLaunchKernelGGL((ft_adamw_kernel<TM>), dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(),        \
                        c->mu.as<float>(), c->nu.as<float>(), gscale, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P, \
-                       c->mirror.as<TM>(), s0lo, s0hi, s1lo, s1hi)
+                       c->mirror.as<TM>(), skip)
     if (c->cfg.mode == ARP_MODE_BF16) ARP_FT_ADAMW(bf16_t);
     else if (c->cfg.mode == ARP_MODE_F16) ARP_FT_ADAMW(f16_t);
     else ARP_FT_ADAMW(float);
@@ -379,9 +453,21 @@ int apply_update(arp_ft* c, float lr) {
 
 template <typename T> int step_impl(arp_ft* c, float lr, float* aux) {
     ARP_TRY(forward<T>(c));
-    ARP_TRY(backward<T>(c));
-    if (c->has_comm && c->world > 1) {
-        // data parallel: every rank ran its shard; ONE all-reduce(sum) of the flat f32 gradient (1.9 GB at full size) plus one of
+    const bool comm = c->has_comm && (c->world > 1 || c->force_comm);
+    if (comm && c->overlap_comm) {
+        // data parallel, overlapped: the buckets leave from inside backward() (ft_bucket_ready); AdamW waits for the last one
+        c->comm_live = true;
+        const int rc = backward<T>(c);
+        c->comm_live = false;
+        ARP_TRY(rc);
+        ARP_HIP_OK(hipEventRecord(c->ev_comm, c->comm_stream));
+        ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+        c->grads_summed = true;
+    } else {
+        ARP_TRY(backward<T>(c));
+    }
+    if (comm && !c->overlap_comm) {
+        // the serial form: every rank ran its shard; ONE all-reduce(sum) of the flat f32 gradient (1.9 GB at full size) plus one of
         // the 4 loss scalars -- the mean over ranks is taken by the 1/world factor inside the AdamW kernel
         ProfScope ps(c->prof, c->stream, "ft.allreduce");
         if (rccl_api()->AllReduce(c->grads.p, c->grads.p, c->P, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess) return fail("ncclAllReduce(grads) failed");
@@ -423,6 +509,11 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
     build_layout(c);
     auto body = [&]() -> int {
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        for (auto& e : c->ev_bucket) ARP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
+        if (const char* e = getenv("ARP_FT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
+        if (const char* e = getenv("ARP_FT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
         DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
         for (auto* b : fb) {
             ARP_TRY(b->ensure(c->P * 4));
@@ -445,8 +536,8 @@ int arp_ft_destroy(arp_ft* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->sV1t, &c->r, &c->action, &c->scores, &c->ds, &c->C, &c->CT_, &c->Ct, &c->Hinv, &c->logits,
-                     &c->dlogits, &c->dHinv, &c->dHinvT_, &c->dHinvt, &c->dC, &c->metrics, &c->scal, &c->part};
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->sV1t, &c->r, &c->action, &c->scores, &c->ds, &c->dist, &c->C, &c->CT_, &c->Ct, &c->Hinv, &c->logits,
+                     &c->dlogits, &c->dHinv, &c->dHinvT_, &c->dHinvt, &c->dist, &c->dC, &c->metrics, &c->scal, &c->part};
     for (auto* b : all) b->release();
     for (int w = 0; w < 2; ++w) {
         DevBuf* tw[] = {&c->sW1t[w], &c->sW2t[w], &c->x_in[w], &c->x_fin[w], &c->X[w], &c->XT[w], &c->f[w], &c->fT_[w],
@@ -454,6 +545,13 @@ int arp_ft_destroy(arp_ft* c) {
                         &c->dHp[w], &c->dHpt[w], &c->df[w], &c->dUt[w], &c->dres_part[w]};
         for (auto* b : tw) b->release();
     }
+    if (c->comm_stream) {
+        (void)hipStreamSynchronize(c->comm_stream);
+        (void)hipStreamDestroy(c->comm_stream);
+    }
+    for (auto e : c->ev_bucket)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -517,16 +615,19 @@ int arp_ft_get_step(arp_ft* c, int64_t* step) {
 
 int arp_ft_set_batch(arp_ft* c, const float* img_inter, const float* img_final, const float* txt_inter, const float* txt_final, const float* r,
                      const int32_t* action, int B) {
-    if (!c || !img_inter || !img_final || !txt_inter || !txt_final || !r || !action || B <= 0) return fail("bad argument");
+    const bool goal = c && c->cfg.goal_conditioned;  // goal_conditioned: FOUR image groups, the prompt features are not read (may be null)
+    if (!c || !img_inter || !img_final || (!goal && (!txt_inter || !txt_final)) || !r || !action || B <= 0) return fail("bad argument");
     for (int i = 0; i < B; ++i)
         if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     ARP_TRY(ensure_buffers(c, B));
     const size_t E = c->cfg.embed;
-    ARP_HIP_OK(hipMemcpyAsync(c->x_in[0].p, img_inter, (size_t)3 * B * c->Dv() * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[0].p, img_final, (size_t)3 * B * E * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->x_in[1].p, txt_inter, (size_t)B * c->Dt() * 4, hipMemcpyHostToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[1].p, txt_final, (size_t)B * E * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_in[0].p, img_inter, (size_t)c->groups() * B * c->Dv() * 4, hipMemcpyHostToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[0].p, img_final, (size_t)c->groups() * B * E * 4, hipMemcpyHostToDevice, c->stream));
+    if (!goal) {
+        ARP_HIP_OK(hipMemcpyAsync(c->x_in[1].p, txt_inter, (size_t)B * c->Dt() * 4, hipMemcpyHostToDevice, c->stream));
+        ARP_HIP_OK(hipMemcpyAsync(c->x_fin[1].p, txt_final, (size_t)B * E * 4, hipMemcpyHostToDevice, c->stream));
+    }
     ARP_HIP_OK(hipMemcpyAsync(c->r.p, r, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
@@ -536,16 +637,19 @@ int arp_ft_set_batch(arp_ft* c, const float* img_inter, const float* img_final, 
 // Same batch with the four feature arrays already in device memory (outputs of arp_clip_encode_*_multiscale_dev).
 int arp_ft_set_batch_dev(arp_ft* c, const float* img_inter_dev, const float* img_final_dev, const float* txt_inter_dev, const float* txt_final_dev,
                          const float* r, const int32_t* action, int B) {
-    if (!c || !img_inter_dev || !img_final_dev || !txt_inter_dev || !txt_final_dev || !r || !action || B <= 0) return fail("bad argument");
+    const bool goal = c && c->cfg.goal_conditioned;
+    if (!c || !img_inter_dev || !img_final_dev || (!goal && (!txt_inter_dev || !txt_final_dev)) || !r || !action || B <= 0) return fail("bad argument");
     for (int i = 0; i < B; ++i)
         if (action[i] < 0 || action[i] >= c->cfg.n_actions) return fail("action id out of range");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     ARP_TRY(ensure_buffers(c, B));
     const size_t E = c->cfg.embed;
-    ARP_HIP_OK(hipMemcpyAsync(c->x_in[0].p, img_inter_dev, (size_t)3 * B * c->Dv() * 4, hipMemcpyDeviceToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[0].p, img_final_dev, (size_t)3 * B * E * 4, hipMemcpyDeviceToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->x_in[1].p, txt_inter_dev, (size_t)B * c->Dt() * 4, hipMemcpyDeviceToDevice, c->stream));
-    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[1].p, txt_final_dev, (size_t)B * E * 4, hipMemcpyDeviceToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_in[0].p, img_inter_dev, (size_t)c->groups() * B * c->Dv() * 4, hipMemcpyDeviceToDevice, c->stream));
+    ARP_HIP_OK(hipMemcpyAsync(c->x_fin[0].p, img_final_dev, (size_t)c->groups() * B * E * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (!goal) {
+        ARP_HIP_OK(hipMemcpyAsync(c->x_in[1].p, txt_inter_dev, (size_t)B * c->Dt() * 4, hipMemcpyDeviceToDevice, c->stream));
+        ARP_HIP_OK(hipMemcpyAsync(c->x_fin[1].p, txt_final_dev, (size_t)B * E * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
     ARP_HIP_OK(hipMemcpyAsync(c->r.p, r, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipMemcpyAsync(c->action.p, action, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
@@ -570,7 +674,7 @@ int arp_ft_forward(arp_ft* c, float* metrics4, float* scores, float* logits) {
 int arp_ft_encode(arp_ft* c, int which, const float* inter, const float* final_feat, int n, float* out) {
     if (!c || !inter || !final_feat || !out || n <= 0 || which < 0 || which > 1) return fail("bad argument");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    ARP_TRY(ensure_buffers(c, which == 0 ? (n + 2) / 3 : n));
+    ARP_TRY(ensure_buffers(c, which == 0 ? (n + c->groups() - 1) / c->groups() : n));
     c->B = 0;  // the staged batch (if any) is gone
     const size_t Din = which == 0 ? c->Dv() : c->Dt();
     ARP_HIP_OK(hipMemcpyAsync(c->x_in[which].p, inter, (size_t)n * Din * 4, hipMemcpyHostToDevice, c->stream));
@@ -619,6 +723,22 @@ int arp_ft_event_record(arp_ft* c, arp_event* e) {
     return 0;
 }
 // Data parallelism (BASELINE configs[4]): the id comes from arp_dt_comm_unique_id (one RCCL id serves any handle type)
+// Flat-gradient ranges of the data-parallel step's seven all-reduce buckets in production order, from the configuration alone (no
+// GPU): ranges28 = {lo, hi} x 14 in floats (bucket b = ranges 2b, 2b + 1), *total = the flat parameter count.
+int arp_ft_bucket_plan(const arp_ft_cfg* cfg, int64_t* ranges28, int64_t* total) {
+    if (!cfg || !ranges28 || !total) return fail("null argument");
+    arp_ft tmp;
+    tmp.cfg = *cfg;
+    build_layout(&tmp);
+    const FtBuckets b = ft_buckets(&tmp);
+    for (int i = 0; i < 2 * FT_BUCKETS; ++i) {
+        ranges28[2 * i] = (int64_t)b.lo[i];
+        ranges28[2 * i + 1] = (int64_t)b.hi[i];
+    }
+    *total = (int64_t)tmp.P;
+    return 0;
+}
+
 int arp_ft_comm_init(arp_ft* c, const void* id128, int world, int rank) {
     if (!c || !id128 || world <= 0 || rank < 0 || rank >= world) return fail("bad argument");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));

@@ -206,17 +206,24 @@ __global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restric
 // x is the f32 encoder output itself, not its operand-type copy: the skip term then carries no operand rounding.
 template <typename T>
 static __global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ a, const float* __restrict__ x, const float* __restrict__ rw,
-                                                          T* __restrict__ y, size_t n) {
+                                                          T* __restrict__ y, size_t n, float* __restrict__ y32 = nullptr) {
+    // y32 (optional): the un-rounded mix, for the f32 image_text_input of the precise mode (arp_dt.hip, ARP_DT_ITI_F32)
     const float res = 1.0f / (1.0f + expf(-rw[0]));
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
-        float av[4], xv[4];
+        float av[4], xv[4], yv[4];
         load4(a + i, av);
         load4(x + i, xv);
-        store4(y + i, res * av[0] + (1.f - res) * xv[0], res * av[1] + (1.f - res) * xv[1], res * av[2] + (1.f - res) * xv[2],
-               res * av[3] + (1.f - res) * xv[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yv[e] = res * av[e] + (1.f - res) * xv[e];
+        store4(y + i, yv[0], yv[1], yv[2], yv[3]);
+        if (y32) store4(y32 + i, yv[0], yv[1], yv[2], yv[3]);
     } else {
-        for (size_t j = i; j < n; ++j) Elem<T>::st(y + j, res * Elem<T>::ld(a + j) + (1.f - res) * x[j]);
+        for (size_t j = i; j < n; ++j) {
+            const float v = res * Elem<T>::ld(a + j) + (1.f - res) * x[j];
+            Elem<T>::st(y + j, v);
+            if (y32) y32[j] = v;
+        }
     }
 }
 

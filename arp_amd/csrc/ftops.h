@@ -54,6 +54,43 @@ static __global__ __launch_bounds__(256) void ft_scores_kernel(const float* __re
     if (threadIdx.x == 0) s[row] = scale * d;
 }
 
+// goal_conditioned (:208-212): s[k*B + b] = -||a[3B + b] - a[k*B + b]||, k = 0..2; the distance is kept for the backward
+static __global__ __launch_bounds__(256) void ft_goal_scores_kernel(const float* __restrict__ a, float* __restrict__ s, float* __restrict__ dist, int B,
+                                                                    int F) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, b = row % B;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < F; c += 256) {
+        const float d = a[((size_t)3 * B + b) * F + c] - a[(size_t)row * F + c];
+        q += d * d;
+    }
+    q = ft_block_sum(q, red);
+    if (threadIdx.x == 0) {
+        const float n = sqrtf(q);
+        s[row] = -n;
+        dist[row] = n;
+    }
+}
+// ... and its backward together with the inverse-model input's ([a1 | a3 | a2 | a3], :224-230):
+//   d s_k / d a_k = (a3 - a_k) / ||.||,  d s_k / d a3 = -(a3 - a_k) / ||.||   (torch.linalg.norm's gradient)
+static __global__ __launch_bounds__(256) void ft_goal_feat_grad_kernel(const float* __restrict__ ds, const float* __restrict__ a,
+                                                                       const float* __restrict__ dist, const float* __restrict__ dC,
+                                                                       float* __restrict__ da, int B, int F) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * F) return;
+    const int b = (int)(i / F), c = (int)(i - (size_t)b * F);
+    const float gv = a[((size_t)3 * B + b) * F + c];
+    const float* dc = dC + (size_t)b * 4 * F;
+    float acc = dc[F + c] + dc[3 * F + c];
+    for (int k = 0; k < 3; ++k) {
+        const size_t row = (size_t)k * B + b;
+        const float u = ds[row] * (gv - a[row * F + c]) / fmaxf(dist[row], 1e-30f);
+        da[row * F + c] = u + (k == 1 ? dc[c] : k == 2 ? dc[2 * F + c] : 0.f);
+        acc -= u;
+    }
+    da[((size_t)3 * B + b) * F + c] = acc;
+}
+
 // VIP loss + inverse-dynamics cross entropy and their gradients w.r.t. the scores / logits (:214-246), single block.
 // The exponent of the VIP term broadcasts r [B,1] against the scores [B] to a [B,B] matrix in the reference; its mean
 // factorises as mean_i exp(-(r_i - 1)) * mean_j exp(-(gamma s2_j - s1_j)).
@@ -163,16 +200,20 @@ static __global__ __launch_bounds__(256) void ft_mix_norm_bwd_kernel(const float
 // torch.optim.AdamW: decoupled decay on EVERY parameter (finetune.py:141 passes model.parameters()), bias correction
 // mirror (bf16 mode): the operand-type copy of the whole flat parameter vector, refreshed here so that the next step's
 // forward GEMMs need no separate conversion pass over the f32 parameters.
+constexpr int FT_SKIP_RANGES = 6;
+struct FtSkip { size_t lo[FT_SKIP_RANGES], hi[FT_SKIP_RANGES]; };  // flat ranges of parameters without a gradient (empty: lo = hi = 0)
 template <typename TM>
 static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
                                                               float* __restrict__ nu, float gscale, float lr, float wd, float b1, float b2,
-                                                              float eps, float bc1, float bc2, size_t n, TM* __restrict__ mirror,
-                                                              size_t skip0_lo, size_t skip0_hi, size_t skip1_lo, size_t skip1_hi) {
+                                                              float eps, float bc1, float bc2, size_t n, TM* __restrict__ mirror, FtSkip skip) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     // torch.optim.AdamW skips parameters whose .grad is None -- no decay, no moment update (with use_id_loss off the inverse
-    // model and lambda_id never receive a gradient: finetune.py:141 + clip_multiscale_adapter.py:177-250)
-    if ((i >= skip0_lo && i < skip0_hi) || (i >= skip1_lo && i < skip1_hi)) return;
+    // model and lambda_id never receive a gradient, with goal_conditioned on the text head does not: finetune.py:141 +
+    // clip_multiscale_adapter.py:177-250)
+#pragma unroll
+    for (int r = 0; r < FT_SKIP_RANGES; ++r)
+        if (i >= skip.lo[r] && i < skip.hi[r]) return;
     float gi = g[i] * gscale;
     // f16 mode seeds every gradient x 1024 (arp_ft.hip): an entry that overflowed binary16 on the way arrives as inf / NaN and would
     // poison this parameter and both moments for good -- it is treated as a missing (zero) gradient for this step

@@ -141,10 +141,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocArgs a) {
 //   * vertical: one thread = 4 output pixels x RGB = 12 contiguous bytes of the intermediate rows, 3 dword reads per tap,
 //     tap weights staged in LDS; the three channels leave as three 4-wide stores.
 // ~5 LDS instructions per output byte; the kernel becomes HBM-bound.
-template <typename T, int LAYOUT>
+// KT = taps computed per output (>= both filters' longest; instances 5, 6, 8).  256 -> 224 needs 5: with the former fixed 8 the
+// kernel multiplied 24 window bytes where 15 carry a non-zero tap and read 7 dwords where 5 hold the window (round 3).
+template <typename T, int LAYOUT, int KT>
 __global__ __launch_bounds__(256) void preprocess_fast_kernel(PreprocArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KT = 8;
+    constexpr int NE = (3 * KT + 3) / 4;  // dwords holding the window's 3 * KT bytes once realigned
+    constexpr int ND = NE + 1;            // aligned dwords read (the window starts 0..3 bytes into the first)
     const int tid = threadIdx.x;
     const int tiles = (a.R + a.TR - 1) / a.TR;
     const int frame = blockIdx.x / tiles;
@@ -197,11 +200,11 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(PreprocArgs a) {
         for (int rr = 0; rr < 4; ++rr) {
             const int r = min(rg * 4 + rr, rows - 1);
             const uint32_t* p = reinterpret_cast<const uint32_t*>(in_s + r * in_row_bytes + a0);
-            uint32_t d[7], e[6];
+            uint32_t d[ND], e[NE];
 #pragma unroll
-            for (int q = 0; q < 7; ++q) d[q] = p[q];
+            for (int q = 0; q < ND; ++q) d[q] = p[q];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+            for (int q = 0; q < NE; ++q) e[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
             int acc[3] = {1 << 21, 1 << 21, 1 << 21};
 #pragma unroll
             for (int k = 0; k < KT; ++k)

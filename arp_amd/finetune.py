@@ -32,6 +32,7 @@ class FinetuneConfig:
     logit_scale: float = float(np.log(1 / 0.07))  # clip_model.logit_scale (:95)
     use_vip: bool = True                      # finetune.py:41-42
     use_id: bool = True
+    goal_conditioned: bool = False            # clip_multiscale_adapter.py:208-212,224-230: image3 stands where the prompt stands
     weight_decay: float = 0.001               # finetune.py:31
     b1: float = 0.9
     b2: float = 0.999
@@ -50,13 +51,24 @@ class FinetuneConfig:
         return self.layers * self.width_t + self.embed
 
 
+def bucket_plan(cfg):
+    """Flat-gradient ranges of the data-parallel step's seven all-reduce buckets in the order the backward produces them
+    (``[[(lo, hi), (lo, hi)]] * 7``, empty ranges have lo == hi) and the flat parameter count.  Needs no GPU."""
+    c = _ffi.FtCfg(cfg.layers, cfg.width_v, cfg.width_t, cfg.embed, cfg.hidden, cfg.n_actions, MODES["f16"], 0, int(cfg.use_vip), int(cfg.use_id),
+                   cfg.gamma, cfg.logit_scale, cfg.weight_decay, cfg.b1, cfg.b2, cfg.eps)
+    r = (C.c_int64 * 28)()
+    tot = C.c_int64()
+    check(lib.arp_ft_bucket_plan(C.byref(c), r, C.byref(tot)))
+    return [[(r[4 * b], r[4 * b + 1]), (r[4 * b + 2], r[4 * b + 3])] for b in range(7)], tot.value
+
+
 class FinetuneTrainer:
     """Parameters, AdamW state and the staged batch live on the GPU; one host thread per handle."""
 
     def __init__(self, cfg, mode="bf16", device=0):
         self.cfg = cfg
         c = _ffi.FtCfg(cfg.layers, cfg.width_v, cfg.width_t, cfg.embed, cfg.hidden, cfg.n_actions, MODES[mode], device, int(cfg.use_vip), int(cfg.use_id),
-                       cfg.gamma, cfg.logit_scale, cfg.weight_decay, cfg.b1, cfg.b2, cfg.eps)
+                       cfg.gamma, cfg.logit_scale, cfg.weight_decay, cfg.b1, cfg.b2, cfg.eps, int(cfg.goal_conditioned))
         h = C.c_void_p()
         check(lib.arp_ft_create(C.byref(c), C.byref(h)))
         self._h = h
@@ -128,19 +140,25 @@ class FinetuneTrainer:
     # -- compute --------------------------------------------------------------------------------------
     def set_batch(self, img_inter, img_final, txt_inter, txt_final, r, action):
         """img_inter [3,B,layers*width_v], img_final [3,B,embed] (image0..2), txt_inter [B,layers*width_t], txt_final [B,embed],
-        r [B] or [B,1] as stored in the batch, action [B] class ids."""
+        r [B] or [B,1] as stored in the batch, action [B] class ids.  ``goal_conditioned``: four image groups (image0..3), txt_* ignored."""
         c = self.cfg
         f32 = lambda x: np.require(np.asarray(x, dtype=np.float32), requirements="C")
-        img_inter, img_final, txt_inter, txt_final = f32(img_inter), f32(img_final), f32(txt_inter), f32(txt_final)
+        img_inter, img_final = f32(img_inter), f32(img_final)
         r = f32(np.asarray(r).reshape(-1))
         action = np.require(np.asarray(action, dtype=np.int32).reshape(-1), requirements="C")
         B = action.shape[0]
-        if img_inter.shape != (3, B, c.d_img) or img_final.shape != (3, B, c.embed) or txt_inter.shape != (B, c.d_txt) or \
-                txt_final.shape != (B, c.embed) or r.shape != (B,):
-            raise ValueError(f"batch shapes: {img_inter.shape} {img_final.shape} {txt_inter.shape} {txt_final.shape} {r.shape} {action.shape}")
+        G = 4 if c.goal_conditioned else 3  # goal_conditioned: image0..image3, no prompt features (txt_* may be None)
+        if img_inter.shape != (G, B, c.d_img) or img_final.shape != (G, B, c.embed) or r.shape != (B,):
+            raise ValueError(f"batch shapes: {img_inter.shape} {img_final.shape} {r.shape} {action.shape}")
         p = _ffi.as_ptr
-        check(lib.arp_ft_set_batch(self._h, p(img_inter, C.c_float), p(img_final, C.c_float), p(txt_inter, C.c_float), p(txt_final, C.c_float),
-                                   p(r, C.c_float), p(action, C.c_int32), B))
+        if c.goal_conditioned:
+            ti = tf = None
+        else:
+            txt_inter, txt_final = f32(txt_inter), f32(txt_final)
+            if txt_inter.shape != (B, c.d_txt) or txt_final.shape != (B, c.embed):
+                raise ValueError(f"batch shapes: {txt_inter.shape} {txt_final.shape}")
+            ti, tf = p(txt_inter, C.c_float), p(txt_final, C.c_float)
+        check(lib.arp_ft_set_batch(self._h, p(img_inter, C.c_float), p(img_final, C.c_float), ti, tf, p(r, C.c_float), p(action, C.c_int32), B))
         self._B = B
 
     def feature_buffers(self, B):

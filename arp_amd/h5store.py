@@ -146,6 +146,11 @@ def lib():
             except AttributeError as e:
                 raise ImportError(f"{h._name}: missing {name} (HDF5 >= 1.10.3 is required)") from e
             fn.restype, fn.argtypes = res, args
+        for opt in ("H5Pset_small_data_block_size", "H5Pset_meta_block_size"):  # allocation block sizes of a writer (H5Store.__init__)
+            if hasattr(h, opt):
+                getattr(h, opt).restype, getattr(h, opt).argtypes = herr_t, [hid_t, hsize_t]
+        if hasattr(h, "H5Dwrite_chunk"):  # 1.10.3+: place a pre-filtered chunk (H5Dataset._write_rows_direct)
+            h.H5Dwrite_chunk.restype, h.H5Dwrite_chunk.argtypes = herr_t, [hid_t, hid_t, C.c_uint32, C.POINTER(hsize_t), C.c_size_t, C.c_void_p]
         try:  # 1.10.5+: where a chunk lives in the file, so that worker threads can pread() it without the library lock
             h.H5Dget_chunk_info_by_coord.restype = herr_t
             h.H5Dget_chunk_info_by_coord.argtypes = [hid_t, C.POINTER(hsize_t), C.POINTER(C.c_uint), C.POINTER(C.c_uint64), C.POINTER(hsize_t)]
@@ -427,9 +432,35 @@ class H5Dataset:
                 raise IndexError(f"unsupported index {k!r}")
         return start, count, squeeze, rows
 
+    def _write_rows_direct(self, start, count, arr):
+        """Whole rows of a dataset chunked one row per chunk with the deflate filter alone (the reward datasets of
+        label_reward.py:277-283): deflate + H5Dwrite_chunk per row on the native side (arp_h5_write_rows_deflated) instead of the
+        library's filter pipeline -- 2.7x faster on 8192 rows of 32 bytes.  Returns False when the fast path does not apply."""
+        shape = self.shape
+        if (os.environ.get("ARP_H5_DIRECT_WRITE", "1") == "0" or self.chunks is None or len(self.filters) != 1 or self.filters[0][0] != H5Z_FILTER_DEFLATE
+                or self.chunks != (1,) + tuple(shape[1:]) or list(start[1:]) != [0] * (len(shape) - 1) or list(count[1:]) != list(shape[1:])
+                or arr.dtype != self.dtype or self.dtype == np.bool_ or count[0] < 64):
+            return False
+        L = lib()
+        fn = getattr(L, "H5Dwrite_chunk", None)
+        try:
+            from . import _ffi
+        except Exception:  # noqa: BLE001 -- libarp_hip.so not built: the library's own write path
+            return False
+        if fn is None:
+            return False
+        a = np.ascontiguousarray(arr)
+        level = self.compression_opts
+        with _lock:
+            _ffi.check(_ffi.lib.arp_h5_write_rows_deflated(C.cast(fn, C.c_void_p), self._id, H5P_DEFAULT, a.ctypes.data_as(C.c_void_p),
+                                                           a.nbytes // count[0], count[0], start[0], len(shape), 4 if level is None else int(level)))
+        return True
+
     def _rw(self, start, count, arr, write):
         L = lib()
         if int(np.prod(count)) == 0:
+            return
+        if write and self._write_rows_direct(start, count, arr):
             return
         with _lock:
             fsp = _ck(L.H5Dget_space(self._id), "H5Dget_space")
@@ -665,18 +696,34 @@ class H5Store:
         self._ds = {}
         b = os.fsencode(path)
         with _lock:
-            if mode == "r":
-                fid = L.H5Fopen(b, H5F_ACC_RDONLY, H5P_DEFAULT)
-            elif mode == "r+":
-                fid = L.H5Fopen(b, H5F_ACC_RDWR, H5P_DEFAULT)
-            elif mode == "a":
-                fid = L.H5Fopen(b, H5F_ACC_RDWR, H5P_DEFAULT) if os.path.exists(path) else L.H5Fcreate(b, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT)
-            elif mode == "w":
-                fid = L.H5Fcreate(b, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
-            elif mode in ("w-", "x"):
-                fid = L.H5Fcreate(b, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT)
-            else:
-                raise ValueError(f"bad mode {mode!r}")
+            # writers: the reward datasets are thousands of ~40-byte chunks; with the default 2 KiB allocation blocks the library goes to
+            # its free-space manager every ~50 chunks.  1 MiB blocks (file-access properties only: the file format is unchanged) take
+            # ~13 % off creating them.  (The v1.10 chunk index -- libver bounds -- would take another 15 %, but changes what older
+            # readers can open: not used.)
+            fapl = H5P_DEFAULT
+            if mode != "r" and hasattr(L, "H5Pset_small_data_block_size"):
+                fapl = L.H5Pcreate(_gid("H5P_CLS_FILE_ACCESS_ID_g"))
+                if fapl >= 0:
+                    L.H5Pset_small_data_block_size(fapl, 1 << 20)
+                    L.H5Pset_meta_block_size(fapl, 1 << 20)
+                else:
+                    fapl = H5P_DEFAULT
+            try:
+                if mode == "r":
+                    fid = L.H5Fopen(b, H5F_ACC_RDONLY, H5P_DEFAULT)
+                elif mode == "r+":
+                    fid = L.H5Fopen(b, H5F_ACC_RDWR, fapl)
+                elif mode == "a":
+                    fid = L.H5Fopen(b, H5F_ACC_RDWR, fapl) if os.path.exists(path) else L.H5Fcreate(b, H5F_ACC_EXCL, H5P_DEFAULT, fapl)
+                elif mode == "w":
+                    fid = L.H5Fcreate(b, H5F_ACC_TRUNC, H5P_DEFAULT, fapl)
+                elif mode in ("w-", "x"):
+                    fid = L.H5Fcreate(b, H5F_ACC_EXCL, H5P_DEFAULT, fapl)
+                else:
+                    raise ValueError(f"bad mode {mode!r}")
+            finally:
+                if fapl != H5P_DEFAULT:
+                    L.H5Pclose(fapl)
         if fid < 0:
             raise H5Error(f"cannot open {path!r} in mode {mode!r}")
         self._id = fid

@@ -217,8 +217,18 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
             import queue
             frame_elems = int(np.prod(ds.shape[2:]))
             free = queue.Queue()  # frame buffers go round: reader fills one, the labeller hands it back (no malloc / munmap per batch)
+            pinned = []
             for _ in range(4):
-                free.put(np.empty(max(sum(b - a for a, b in g) for g in groups) * frame_elems, ds.dtype))
+                buf = np.empty(max(sum(b - a for a, b in g) for g in groups) * frame_elems, ds.dtype)
+                # the buffers are reused for every batch of the file: pinned once, their uploads are true asynchronous DMA on the labeller's
+                # copy stream (arp_host_register; a labeller without the hook -- a test double -- simply gets pageable buffers)
+                if getattr(clip_model, "pin_host", None) is not None and os.environ.get("ARP_LABEL_PIN", "1") != "0":
+                    try:
+                        clip_model.pin_host(buf)
+                        pinned.append(buf)
+                    except Exception:
+                        pass
+                free.put(buf)
 
             def read(g):
                 nonlocal t_read
@@ -247,6 +257,8 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                     o += b - a
                     parts[target_keys[0]].append(stack_outputs(r, num_frames))
                     parts[target_keys[1]].append(stack_outputs(discount_cumsum(r), num_frames))
+            for buf in pinned:
+                clip_model.unpin_host(buf)
             if timing:
                 print(f"[label_store] {len(groups)} batches: reader thread busy {t_read:.3f} s, labeller waited for frames {t_wait:.3f} s, "
                       f"labelling {t_label:.3f} s", flush=True)

@@ -4,6 +4,8 @@ Mirrors /root/reference/arp_dt/main_procgen.py:
   * ``create_train_step(model, learning_rate, weight_decay) -> train_step_fn`` (:104-141)
   * ``train_step_fn(state, batch, rng) -> (new_state, aux, next_rng)`` with the reference's ``aux`` keys
     (``loss, acc, trans_loss, return_loss, weight_penalty, weight_l2, train_state_step, learning_rate``)
+  * ``create_val_step(model) -> val_step_fn(state, batch, rng) -> (aux, next_rng)`` (:144-169)
+  * ``prefetch_to_device(iterator, 2, ...)`` (:703): batch i+1 uploads while step i runs
   * ``sync_state_fn`` (:94-101) = :meth:`PolicyTrainer.broadcast_state`
 and ARPDT.__call__ (arp_dt/ARPDT.py:152-236) = :meth:`PolicyTrainer.forward`.
 
@@ -131,6 +133,32 @@ class PolicyTrainer:
             raise ValueError(f"batch shapes: enc {enc.shape}, action {action.shape}, rtg {rtg.shape}")
         check(lib.arp_dt_set_batch(self._h, _ffi.as_ptr(enc, C.c_float), _ffi.as_ptr(action, C.c_int32), _ffi.as_ptr(rtg, C.c_float), B))
         self._B = B
+
+    # -- two device-resident batch slots: the reference's prefetch_to_device(..., 2) (main_procgen.py:703) ----------------------
+    def upload_async(self, slot, enc, action, rtg, images=False):
+        """Enqueue the host -> device copy of a batch into slot 0 / 1 on the handle's copy stream.  Safe to call from another
+        thread while :meth:`train_step` runs on the other slot.  The arrays must stay alive until :meth:`select` (kept here)."""
+        enc = np.require(np.asarray(enc, dtype=np.float32), requirements="C")
+        action = np.require(np.asarray(action, dtype=np.int32), requirements="C")
+        rtg = np.require(np.asarray(rtg, dtype=np.float32), requirements="C")
+        B, T = action.shape
+        if rtg.size != B * T or T != self.cfg.window or (not images and enc.shape != (B, T, self.cfg.enc_tokens, self.cfg.enc_dim)):
+            raise ValueError(f"batch shapes: enc {enc.shape}, action {action.shape}, rtg {rtg.shape}")
+        fn = lib.arp_dt_upload_batch_images_async if images else lib.arp_dt_upload_batch_async
+        check(fn(self._h, int(slot), _ffi.as_ptr(enc, C.c_float), _ffi.as_ptr(action, C.c_int32), _ffi.as_ptr(rtg, C.c_float), B))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[int(slot)] = (enc, action, rtg, B)
+
+    def select(self, slot):
+        """The next forward / val_step / train_step reads batch slot ``slot`` (ordered behind its upload on the GPU)."""
+        check(lib.arp_dt_select_batch(self._h, int(slot)))
+        self._B = self._inflight[int(slot)][3]
+
+    def val_step(self):
+        """val_step_fn's aux (main_procgen.py:144-169): forward only, rank mean of loss / trans_loss / return_loss / acc*100."""
+        m = np.empty(4, np.float32)
+        check(lib.arp_dt_val_step(self._h, _ffi.as_ptr(m, C.c_float)))
+        return {"loss": float(m[0]), "trans_loss": float(m[1]), "return_loss": float(m[2]), "acc": float(m[3])}
 
     def attach_encoder(self, encoder):
         """Put the frozen M3AE encoder (arp_amd.m3ae.M3AEEncoder) inside the step: the boundary then is the
@@ -328,6 +356,135 @@ class DataParallel:
         return self.trainer.train_step(lr)
 
 
+def bucket_plan(cfg):
+    """Flat-gradient ranges ``[(lo, hi)] * 4`` of the data-parallel step's two all-reduce buckets (bucket 1 = ranges 0, 1:
+    image_text_input's kernel + everything the transformer owns, launched while the adapter's backward still runs; bucket 2 =
+    ranges 2, 3) and the flat parameter count.  Needs no GPU."""
+    c = _ffi.DtCfg(cfg.emb, cfg.depth, cfg.heads, cfg.mlp_ratio, cfg.n_actions, cfg.window, cfg.enc_tokens, cfg.enc_dim, int(cfg.use_adapter),
+                   MODE_F16, 0, 1, 0, cfg.lambda_ret, cfg.weight_decay, cfg.clip_norm, cfg.b1, cfg.b2, cfg.eps)
+    r = (C.c_int64 * 8)()
+    tot = C.c_int64()
+    check(lib.arp_dt_bucket_plan(C.byref(c), r, C.byref(tot)))
+    return [(r[2 * i], r[2 * i + 1]) for i in range(4)], tot.value
+
+
+def _threefry2x32(key, x0, x1):
+    """Threefry-2x32, 20 rounds (Salmon et al. 2011) on uint32 arrays: the block cipher behind jax.random's default PRNG."""
+    rot = ((13, 15, 26, 6), (17, 29, 16, 24))
+    k0, k1 = np.uint32(key[0]), np.uint32(key[1])
+    ks = (k0, k1, np.uint32(k0 ^ k1 ^ np.uint32(0x1BD11BDA)))
+    x0 = (x0 + ks[0]).astype(np.uint32)
+    x1 = (x1 + ks[1]).astype(np.uint32)
+    for i in range(5):
+        for r in rot[i % 2]:
+            x0 = (x0 + x1).astype(np.uint32)
+            x1 = ((x1 << np.uint32(r)) | (x1 >> np.uint32(32 - r))).astype(np.uint32)
+            x1 = x1 ^ x0
+        x0 = (x0 + ks[(i + 1) % 3]).astype(np.uint32)
+        x1 = (x1 + ks[(i + 2) % 3] + np.uint32(i + 1)).astype(np.uint32)
+    return x0, x1
+
+
+def split_rng(rng):
+    """``next_rng, split_rng = jax.random.split(rng)`` (main_procgen.py:130,163) for a raw threefry key ``uint32[2]`` (or a stack
+    ``[..., 2]`` of them, the pmapped ``sharded_rng``), computed as jax's original (non-partitionable) split does: counts
+    ``0..3`` enciphered pairwise under the key.  Anything else (None, an int seed, an opaque object) is carried through: the
+    shipped configuration has dropout 0, so the step never draws from it."""
+    a = np.asarray(rng) if isinstance(rng, (np.ndarray, list, tuple)) else None
+    if a is None or a.dtype.kind not in "ui" or a.ndim < 1 or a.shape[-1] != 2:
+        return rng, rng
+    a = a.astype(np.uint32)
+    if a.ndim > 1:
+        parts = [split_rng(k) for k in a.reshape(-1, 2)]
+        return (np.stack([p[0] for p in parts]).reshape(a.shape), np.stack([p[1] for p in parts]).reshape(a.shape))
+    with np.errstate(over="ignore"):
+        y0, y1 = _threefry2x32(a, np.array([0, 1], np.uint32), np.array([2, 3], np.uint32))
+    out = np.concatenate([y0, y1]).reshape(2, 2)
+    return out[0], out[1]
+
+
+class DeviceBatch:
+    """A batch resident in (or on its way into) one of the trainer's two device slots: what :func:`prefetch_to_device` yields
+    and what ``train_step_fn`` / ``val_step_fn`` accept where the reference passes a device-put batch."""
+
+    def __init__(self, trainer, slot, release):
+        self.trainer, self.slot, self._release = trainer, slot, release
+
+    def done(self):
+        """The step that read this batch has been synchronised (its aux was read back): the slot may be refilled."""
+        if self._release is not None:
+            self._release()
+            self._release = None
+
+
+def prefetch_to_device(iterator, size, trainer, *, rank=0, world=1, device_axis=False):
+    """``flax.jax_utils.prefetch_to_device(iterator, size, devices)`` as the reference uses it (main_procgen.py:703,706: size 2):
+    host batches (the reference's batch dicts) are uploaded into the trainer's two device slots by a background thread -- the
+    ctypes call releases the GIL, the copy runs on the handle's copy stream -- while the main thread is inside ``train_step_fn``
+    on the other slot.  Yields :class:`DeviceBatch`.  ``size`` > 2 is clamped: the library keeps two slots."""
+    import queue
+    import threading
+
+    free = queue.Queue()
+    for s in range(min(max(int(size), 1), 2)):
+        free.put(s)
+    ready = queue.Queue()
+    stop = threading.Event()
+
+    def worker():
+        try:
+            for batch in iterator:
+                slot = free.get()
+                if stop.is_set():
+                    return
+                enc, act, rtg = _batch_arrays(shard_batch(batch, rank, world, device_axis), trainer.cfg.use_symlog)
+                trainer.upload_async(slot, enc, act, rtg, images=getattr(trainer, "_encoder", None) is not None and enc.ndim == 5 and enc.shape[-1] == 3)
+                ready.put(DeviceBatch(trainer, slot, lambda s=slot: free.put(s)))
+            ready.put(None)
+        except BaseException as e:  # surfaces in the consumer
+            ready.put(e)
+
+    th = threading.Thread(target=worker, daemon=True)
+    th.start()
+    try:
+        while True:
+            item = ready.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        free.put(0)  # wake a worker blocked on a free slot
+
+
+def _stage(tr, batch, rank, world, device_axis):
+    """Put ``batch`` (a host batch dict, or a DeviceBatch from prefetch_to_device) in front of the next step."""
+    if isinstance(batch, DeviceBatch):
+        tr.select(batch.slot)
+        return batch
+    tr.set_batch(*_batch_arrays(shard_batch(batch, rank, world, device_axis), tr.cfg.use_symlog))
+    return None
+
+
+def create_val_step(model, *, rank=0, world=1, device_axis=False):
+    """main_procgen.py:144-169: ``val_step_fn(state, batch, rng) -> (aux, next_rng)`` -- forward only (``deterministic=True``),
+    aux = the rank mean of ``loss, trans_loss, return_loss, acc * 100``; the state is NOT consumed (no ``donate_argnums``)."""
+
+    def val_step_fn(state, batch, rng):
+        tr = state.trainer
+        if world > 1 and getattr(tr, "world", 1) != world:
+            raise ValueError("world > 1: wrap the state's trainer in DataParallel (RCCL communicator + state sync) first")
+        dev = _stage(tr, batch, rank, world, device_axis)
+        aux = tr.val_step()
+        if dev is not None:
+            dev.done()
+        return aux, split_rng(rng)[0]
+
+    return val_step_fn
+
+
 def create_train_step(model, learning_rate, weight_decay, *, rank=0, world=1, device_axis=False):
     """main_procgen.py:104-141.  ``learning_rate`` is the schedule ``step -> lr`` (``:135``).  With ``world > 1`` (one process
     per GPU, the state's trainer wrapped by :class:`DataParallel` beforehand) every call steps on this rank's shard of the
@@ -344,9 +501,13 @@ def create_train_step(model, learning_rate, weight_decay, *, rank=0, world=1, de
             raise ValueError("state was created with a different weight_decay than create_train_step")
         if world > 1 and getattr(tr, "world", 1) != world:
             raise ValueError("world > 1: wrap the state's trainer in DataParallel (RCCL communicator + state sync) first")
-        tr.set_batch(*_batch_arrays(shard_batch(batch, rank, world, device_axis), tr.cfg.use_symlog))
+        dev = _stage(tr, batch, rank, world, device_axis)  # a host batch dict (synchronous upload) or a prefetched DeviceBatch
         aux = tr.train_step(learning_rate(tr.step))
+        if dev is not None:
+            dev.done()
         state._live = False
-        return TrainState(tr), aux, rng  # dropout is 0 in the shipped config: the rng is carried through unused
+        # next_rng of jax.random.split(rng) (main_procgen.py:130) when rng is a raw threefry key; dropout is 0 in the shipped
+        # configuration, so the step itself never draws from the split key
+        return TrainState(tr), aux, split_rng(rng)[0]
 
     return train_step_fn

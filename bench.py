@@ -124,6 +124,28 @@ def spawn_ranks(n):
     sys.exit(rc)
 
 
+def run_secondary(a):
+    """--all-secondary: the other benches as child processes (each prints its own ONE JSON line), collected under `extra` so that the
+    driver's single run of bench.py carries them.  Called before the parent initialises the GPU."""
+    runs = {
+        "policy": ["--path", "policy"],
+        "policy_with_encoder": ["--path", "policy", "--with-encoder"],
+        "finetune": ["--path", "finetune"],
+        "label_vit_b16": ["--model", "ViT-B/16", "--batch", "256"],
+    }
+    extra = {}
+    for name, args in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup), "--cpu-seconds", "0",
+               "--no-secondary"] + args
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            extra[name] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-400:], "rc": r.returncode}
+        except Exception as e:  # a secondary line must never cost the headline one
+            extra[name] = {"error": repr(e)}
+    return extra
+
+
 def gather_rates(dist, world, units, elapsed_local):
     """per-rank units/s over the timed region (control plane, gloo)"""
     if dist is None:
@@ -236,6 +258,31 @@ def bench_policy(a):
         tr.sync()
         prof.update({k: {"ms": v["ms"] * a.steps, "calls": v["calls"] * a.steps} for k, v in enc.profile_read().items()})
     aux = tr.train_step(lr)
+    # ---- the S4 seam as the reference calls it: train_step_fn(state, HOST batch, rng) (main_procgen.py:718), outside the timed region.
+    # serial = the 101 MB batch uploaded synchronously in front of every step; prefetched = prefetch_to_device(.., 2): batch i+1 goes up
+    # on the copy stream from a background thread while step i runs (PCIe-bound: 101 MB per step).
+    seam = None
+    if rank == 0 and world == 1 and enc is None:
+        from arp_amd.train import TrainState, create_train_step, prefetch_to_device
+        hb = S.policy_batch(cfg, a.policy_batch, seed=100)
+        host_batch = {"image": {"ob": hb[0]}, "action": hb[1], "rtg": {"ob": hb[2]}}
+        fn = create_train_step(cfg, lambda step: lr, cfg.weight_decay)
+        n_seam = 12
+        res = {}
+        for name in ("serial", "prefetched"):
+            state = TrainState(tr)
+            src = (host_batch for _ in range(n_seam + 2))
+            if name == "prefetched":
+                src = prefetch_to_device(src, 2, tr)
+            t_s, k = None, 0
+            for b in src:
+                if k == 2:
+                    t_s = time.perf_counter()
+                state, _, _ = fn(state, b, None)
+                k += 1
+            res[name] = (time.perf_counter() - t_s) / n_seam * 1e3
+        seam = {"serial_ms_per_step": res["serial"], "prefetched_ms_per_step": res["prefetched"], "host_batch_mb": hb[0].nbytes / 1e6,
+                "call": "train_step_fn(state, host batch dict, rng) incl. the H2D upload of the f32 encodings and the aux read-back"}
     if rank == 0:
         sites = policy_sites(cfg, a.policy_batch, tr.num_params)
         known = {k: v for k, v in prof.items() if k in sites and v["calls"]}
@@ -270,7 +317,7 @@ def bench_policy(a):
                            "mfma_frac_of_peak": flops / (elapsed / a.steps) / 1e12 / PEAK_TFLOPS[a.mode]},
             "parity": {"max_logit_err_vs_oracle": parity, "geometry": "B = 2, window 4, 257 x 768 encodings (K = 197 376)", "tolerance": 1e-3,
                        "within_tolerance": None if parity is None else bool(parity < 1e-3)},
-            "cpu_baseline": cpu, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
+            "cpu_baseline": cpu, "seam": seam, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
     tr.close()
     if dist is not None:
@@ -406,6 +453,10 @@ def main():
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
+    ap.add_argument("--all-secondary", dest="all_secondary", action="store_true", default=True,
+                    help="label path, 1 GPU (default ON): after the headline line is measured, run the policy / policy --with-encoder / finetune / "
+                         "ViT-B/16 benches as child processes and append their JSON lines under `extra`, so that one driver run carries them")
+    ap.add_argument("--no-secondary", dest="all_secondary", action="store_false", help="headline line only")
     a = ap.parse_args()
     if a.mode is None:
         a.mode = "f16"  # IEEE-half MFMA operands on every path: the 16-bit mode that meets the parity bars (bf16 stays selectable)
@@ -424,6 +475,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
         cpu = cpu_baseline(a.model, a.cpu_seconds)
+    # The secondary benches run as child processes BEFORE this process touches the GPU (a process that has initialised the GPU must
+    # not fork + exec another program on this pool), one after the other, each alone on the device; the headline bench follows.
+    extra = None
+    if rank == 0 and world == 1 and a.all_secondary and a.model == "ViT-B/32" and not a.fp8_mlp and a.batch == 1024 and a.mode == "f16":
+        extra = run_secondary(a)
 
     dist = None
     if world > 1:
@@ -492,6 +548,27 @@ def main():
     rewards = d_rewards.download(np.float32, a.batch)
     assert np.isfinite(rewards).all(), "non-finite rewards"
 
+    # ---- the S2 seam as the reference calls it (label_reward.py:132-146: host frames in, host rewards out), OUTSIDE the timed
+    # region: arp_clip_label incl. the H2D upload over PCIe and the D2H of the rewards.  Never `value`.
+    seam = None
+    if rank == 0 and world == 1:
+        model.label(frames)
+        ts = time.perf_counter()
+        for _ in range(5):
+            r_host = model.label(frames)
+        seam_s = (time.perf_counter() - ts) / 5
+        model.pin_host(frames)  # the same call on a buffer the caller has registered once (what arp_amd's own HDF5 reader does)
+        model.label(frames)
+        ts = time.perf_counter()
+        for _ in range(5):
+            model.label(frames)
+        pin_s = (time.perf_counter() - ts) / 5
+        model.unpin_host(frames)
+        seam = {"frames_per_s": a.batch / seam_s, "ms_per_call": seam_s * 1e3, "frames_per_call": a.batch,
+                "pinned_frames_per_s": a.batch / pin_s, "pinned_ms_per_call": pin_s * 1e3,
+                "call": "arp_clip_label(host uint8 frames [n,256,256,3] -> host float32 rewards): upload over PCIe, label, download",
+                "bit_identical_to_hbm_resident": bool(np.array_equal(r_host, rewards))}
+
     # ---- per-launch kernel timing: the same steps again with HIP events around every launch ---------
     model.profile(True)
     model.profile_reset()
@@ -538,11 +615,13 @@ def main():
         achieved = sites[dom] / (avg_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.mode]
         traffic = None
+        mfma_util = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch of the dominant kernel from committed rocprofv3 --pmc passes
             try:
                 rec = json.load(open(tpath)).get(dom, {})
                 traffic = rec.get("hbm_bytes_per_launch")
+                mfma_util = rec.get("mfma_util_pct")  # rocprofv3 --pmc MfmaUtil of the same kernel, measured alone (committed run)
                 # the committed PMC run may have used a different launch size: algorithmic and measured bytes scale with the frames
                 if traffic and rec.get("frames_per_launch"):
                     traffic = traffic * (-(-a.batch // nsplit)) / rec["frames_per_launch"]
@@ -575,7 +654,7 @@ def main():
                                     "headline configuration; see parity)" if a.fp8_mlp else ""),
                        "parallelism": f"shard{world} (no collective)", "streams_per_gpu": nsplit},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "kernel": f"{kname} @ {dom}",
+                         "traffic": traffic, "mfma_util_pct": mfma_util, "kernel": f"{kname} @ {dom}",
                          "note": (f"each launch covers {-(-a.batch // nsplit)} frames; with --streams {nsplit} that many such launches (the parts of a batch) share "
                                   "the chip, so a launch's HIP-event duration includes time it ran beside the other stream's kernels; "
                                   "--streams 1 gives the isolated per-kernel figure") if nsplit > 1 else "single stream", "flops_per_launch": sites[dom],
@@ -586,6 +665,7 @@ def main():
                 "avg_launch_ms": iso[dom]["ms"] / iso[dom]["calls"], "flops_per_launch": gemm_sites(cfg, a.batch)[dom],
                 "note": f"same kernel @ {dom}, whole {a.batch}-frame batch per launch on a single stream (nothing else resident)"}),
             "cpu_baseline": cpu,
+            "seam": seam,
             "alt_dtype": alt,
             # mfma_frac_of_peak counts the FLOPs actually ISSUED (the last block runs out_proj + MLP on the class-token row only,
             # tower.h); the nominal figure prices the pass at SURVEY section 8(d)'s 8.82 GFLOP/frame including that skipped work
@@ -598,6 +678,8 @@ def main():
             "sites_total_ms_per_step": total_ms / a.steps,
             "per_rank_frames_per_s": [round(v, 1) for v in per_rank],
         }
+        if extra is not None:
+            out["extra"] = extra
         emit(json.dumps(out))
     model.close()
     if dist is not None:

@@ -43,6 +43,10 @@ int arp_dev_free(void* p);
 int arp_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int arp_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int arp_set_device(int device);
+/* Pin / unpin a caller-owned host buffer (hipHostRegister): host-fed calls then move it by true asynchronous DMA.  For buffers that are
+   reused across calls (registration costs milliseconds per 100 MB); unregister before freeing the memory. */
+int arp_host_register(void* p, size_t bytes);
+int arp_host_unregister(void* p);
 int arp_dev_synchronize(void); /* hipDeviceSynchronize on the current device */
 
 /* ---- path (1): CLIP reward labelling ------------------------------------------------------------
@@ -156,7 +160,7 @@ int arp_dt_num_params(arp_dt* h, int64_t* total, int32_t* n_tensors);
 int arp_dt_param_info(arp_dt* h, int i, char* name_buf, int name_len, int64_t* shape4, int32_t* ndim);
 /* which: 0 = params, 1 = gradients (of the last backward), 2 = adam mu, 3 = adam nu */
 int arp_dt_set_tensor(arp_dt* h, const char* name, int which, const float* data);
-int arp_dt_get_tensor(arp_dt* h, const char* name, int which, float* out);
+int arp_dt_get_tensor(arp_dt* h, const char* name, int which, float* out); /* which = 1 after a data-parallel step: the rank MEAN */
 int arp_dt_set_step(arp_dt* h, int64_t step);
 int arp_dt_get_step(arp_dt* h, int64_t* step);
 /* Stages one per-device batch in HBM: enc f32 [B,T,enc_tokens,enc_dim], action int32 [B,T], rtg f32 [B,T,1]. */
@@ -171,6 +175,23 @@ int arp_dt_backward(arp_dt* h);
  * weight_l2, train_state_step, learning_rate, (extra) gradient norm. */
 int arp_dt_train_step(arp_dt* h, float lr, float* aux);
 int arp_dt_train_step_async(arp_dt* h, float lr); /* no read-back; pair with arp_dt_sync */
+/* val_step_fn of create_val_step (main_procgen.py:144-169): forward on the staged batch, rank mean (pmean, :165) of
+   aux4 = {loss, trans_loss, return_loss, acc * 100}.  No parameter changes. */
+int arp_dt_val_step(arp_dt* h, float* aux4);
+/* Two device-resident batch slots (0 / 1) = prefetch_to_device(..., 2) of main_procgen.py:703.  upload_*_async copies a host batch
+   into a slot on the handle's copy stream and returns without waiting for the GPU; it touches only that slot, so a prefetch thread
+   may call it while arp_dt_train_step runs on the other slot (the copy itself waits, on the GPU, for the last step that read the
+   slot).  select_batch makes the next forward / val_step / train_step read a slot, ordered behind its upload.  arp_dt_set_batch
+   (synchronous) keeps writing the selected slot.  Pinned host memory makes the copy truly asynchronous; pageable works (staged). */
+int arp_dt_upload_batch_async(arp_dt* h, int slot, const float* enc, const int32_t* action, const float* rtg, int B);
+int arp_dt_upload_batch_images_async(arp_dt* h, int slot, const float* images, const int32_t* action, const float* rtg, int B);
+int arp_dt_select_batch(arp_dt* h, int slot);
+/* The data-parallel step all-reduces the flat gradient in two buckets of two ranges each; bucket 1 (image_text_input's kernel and
+   everything the transformer owns) is launched on a communication stream while the adapter's backward GEMMs still run.
+   ranges8 = {lo, hi} x 4 in floats (bucket 1: ranges 0, 1; bucket 2: ranges 2, 3), *total = the flat parameter count.  Needs no GPU.
+   Environment: ARP_DT_OVERLAP=0 selects the serial form (one all-reduce behind the whole backward), ARP_DT_FORCE_COMM=1 runs the
+   all-reduce path at world = 1 as well. */
+int arp_dt_bucket_plan(const arp_dt_cfg* cfg, int64_t* ranges8, int64_t* total);
 int arp_dt_sync(arp_dt* h);
 int arp_dt_event_record(arp_dt* h, arp_event* e);
 /* Data parallelism: one process per GPU.  Rank 0 calls arp_dt_comm_unique_id, ships the 128 bytes to the
@@ -208,6 +229,9 @@ typedef struct arp_ft_cfg {
     float logit_scale;  /* ln of the similarity scale, clip_model.logit_scale (:95) */
     float weight_decay; /* AdamW decoupled decay, finetune.py:31 (0.001) */
     float b1, b2, eps;  /* 0.9, 0.999, 1e-8 */
+    int32_t goal_conditioned; /* clip_multiscale_adapter.py:208-212,224-230: the batch carries FOUR image groups (image0..image3); image3's
+                                 adapted feature takes the prompt's place -- scores = -||a3 - a_k||, inverse-model input [a1|a3|a2|a3] --
+                                 and the text head is never run (its parameters get no gradient and AdamW leaves them alone) */
 } arp_ft_cfg;
 /* The frozen towers' side of the step, on an arp_clip handle (ViT-B/16 in the reference, :118): per-block CLS / EOT
  * features and the un-normalised CLIP features.  Image frames go through the fine-tune transform of :120-132 (float,
@@ -253,6 +277,12 @@ int arp_ft_event_record(arp_ft* h, arp_event* e);
  * folded into the AdamW kernel) -- the scheme of the policy step (main_procgen.py:128-139). */
 int arp_ft_comm_init(arp_ft* h, const void* id128, int world, int rank);
 int arp_ft_broadcast_state(arp_ft* h);
+/* The data-parallel step all-reduces the 1.9 GB gradient in seven buckets in the order the backward produces them (inverse model;
+   per tower: second adapter layer, first adapter layer, intermediate linear), each launched on a communication stream as soon as its
+   last weight-gradient GEMM is enqueued.  ranges28 = {lo, hi} x 14 in floats (bucket b = ranges 2b, 2b + 1; empty ranges have
+   lo = hi), *total = the flat parameter count.  Needs no GPU.  ARP_FT_OVERLAP=0: one all-reduce behind the whole backward;
+   ARP_FT_FORCE_COMM=1: the all-reduce path at world = 1 too.  arp_ft_get_tensor(which = 1) after such a step: the rank MEAN. */
+int arp_ft_bucket_plan(const arp_ft_cfg* cfg, int64_t* ranges28, int64_t* total);
 int arp_ft_profile_enable(arp_ft* h, int on);
 int arp_ft_profile_reset(arp_ft* h);
 int arp_ft_profile_json(arp_ft* h, char* buf, int buf_len);
@@ -296,6 +326,11 @@ int arp_dt_set_batch_images(arp_dt* h, const float* images, const int32_t* actio
 int arp_h5_inflate_last_frames(int fd, int n, const uint64_t* addr, const uint64_t* size, const uint8_t* stored_raw,
                                uint64_t chunk_bytes, uint64_t frame_bytes, const uint64_t* dst_off, const uint32_t* cnt,
                                uint8_t* out, int threads);
+/* Reward datasets of label_reward.py:273-289 (gzip chunks of ONE row): rows [first_row, first_row + n_rows) of a dataset whose chunk
+   is (1, row...) are deflated here with one reused zlib stream and placed with H5Dwrite_chunk -- `write_chunk_fn` is that function's
+   address inside the libhdf5 the caller has loaded (hid_t = int64, HDF5 >= 1.10.3).  `level` = the dataset's deflate level. */
+int arp_h5_write_rows_deflated(void* write_chunk_fn, int64_t dset, int64_t dxpl, const void* rows, uint64_t row_bytes, uint64_t n_rows,
+                               uint64_t first_row, int ndim, int level);
 
 /* ---- single-operator entry points (host buffers; used by the per-kernel parity tests) ---------- */
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid), operands rounded to bf16 in ARP_MODE_BF16. */

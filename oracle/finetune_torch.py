@@ -35,6 +35,7 @@ class HeadConfig:
     logit_scale: float = float(np.log(1 / 0.07))
     use_vip: bool = True
     use_id: bool = True
+    goal_conditioned: bool = False  # clip_multiscale_adapter.py:208-212,224-230: image3 stands where the prompt stands
 
     @property
     def d_img(self):
@@ -103,11 +104,17 @@ def _encode(P, which, inter, final):
 
 def forward(P, cfg, img_inter, img_final, txt_inter, txt_final, r, action):
     """img_inter [3,B,d_img], img_final [3,B,embed] (frames 0,1,2 of each sample), txt_inter [B,d_txt], txt_final [B,embed],
-    r [B] as stored in the batch (the loss uses r - 1), action [B] int64."""
+    r [B] as stored in the batch (the loss uses r - 1), action [B] int64.  goal_conditioned: FOUR image groups, txt_* = None."""
     a = [_encode(P, "image", img_inter[k], img_final[k]) for k in range(3)]
-    t = _encode(P, "text", txt_inter, txt_final)
-    scale = float(np.exp(cfg.logit_scale))
-    s = [scale * (a[k] * t).sum(-1) for k in range(3)]
+    if cfg.goal_conditioned:
+        # :208-212 -- img_inter / img_final carry FOUR groups (image0..image3); the scores are negative distances to the goal frame's
+        # adapted feature, which also takes the prompt's two slots of the inverse-model input (:224-230); no text tower, no logit scale
+        t = _encode(P, "image", img_inter[3], img_final[3])
+        s = [-torch.linalg.norm(t - a[k], dim=-1) for k in range(3)]
+    else:
+        t = _encode(P, "text", txt_inter, txt_final)
+        scale = float(np.exp(cfg.logit_scale))
+        s = [scale * (a[k] * t).sum(-1) for k in range(3)]
     rr = (r - 1.0).reshape(-1, 1)  # [B,1] against [B] scores: a [B,B] exponent, exactly as the reference broadcasts
     vip = (1 - cfg.gamma) * -s[0].mean() + torch.log(1e-8 + torch.mean(torch.exp(-(rr + cfg.gamma * s[2] - s[1]))))
     c = torch.cat([a[1], t, a[2], t], dim=-1)
@@ -129,7 +136,7 @@ def to_torch(P, dtype=torch.float64, requires_grad=False):
 
 def grads(P, cfg, batch, dtype=torch.float64):
     Pt = to_torch(P, dtype, requires_grad=True)
-    out = forward(Pt, cfg, *[torch.as_tensor(b, dtype=dtype) for b in batch[:5]], torch.as_tensor(batch[5], dtype=torch.long))
+    out = forward(Pt, cfg, *[None if b is None else torch.as_tensor(b, dtype=dtype) for b in batch[:5]], torch.as_tensor(batch[5], dtype=torch.long))
     out["loss"].backward()
     g = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy() for k, v in Pt.items()}
     aux = {k: float(out[k].detach()) for k in ("loss", "vip_loss", "id_loss")}

@@ -5,8 +5,8 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_mfma -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --parity-frames 0 > $R/gpurun_out/prof_${TAG}_mfma.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_sq -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --parity-frames 0 > $R/gpurun_out/prof_${TAG}_sq.log 2>&1
+rocprofv3 --pmc MfmaUtil --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_mfma -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --parity-frames 0 --no-secondary > $R/gpurun_out/prof_${TAG}_mfma.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_sq -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --parity-frames 0 --no-secondary > $R/gpurun_out/prof_${TAG}_sq.log 2>&1
 python3 - <<PY
 import csv, glob, collections, json, os
 R = "$R"; tag = "$TAG"

@@ -108,13 +108,15 @@ def _install_stubs():
     sys.modules["torchvision"], sys.modules["torchvision.transforms"], sys.modules["torchvision.transforms.functional"] = tv, tr, fn
 
 
-def main():
+def main(goal=False):
+    """goal = True: the goal_conditioned variant (clip_multiscale_adapter.py:208-212,224-230) -> finetune_tiny_goal.npz: image3 takes
+    the prompt's place (scores = -||a3 - a_k||, inverse-model input [a1|a3|a2|a3]); the text tower is never run."""
     _install_stubs()
     sys.path.insert(0, REF)
     torch.manual_seed(0)
     from finetune_module.clip_multiscale_adapter import CLIPMultiscaleAdapter
     model = CLIPMultiscaleAdapter(input_dim=WT, hidden_dim=HID, output_dim=WT, action_dim=NA, use_discrete_action=True, use_vip_loss=True,
-                                  use_id_loss=True)
+                                  use_id_loss=True, goal_conditioned=goal)
     for p in model.clip_model.parameters():  # finetune.py:139-140
         p.requires_grad = False
     # move the head off its special init so that every term of the gradient is exercised
@@ -163,8 +165,11 @@ def main():
     loss.backward()
     out = {"cfg": np.array([L, WV, WT, WT, HID, NA]), "gamma": model.gamma, "logit_scale": float(model.logit_scale),
            "img_inter": torch.stack(rec["img_inter"]).numpy(), "img_final": torch.stack(rec["img_final"]).numpy(),
-           "txt_inter": rec["txt_inter"][0].numpy(), "txt_final": rec["txt_final"][0].numpy(), "r": r[:, 0].astype(np.float32), "action": action,
-           "loss": float(loss)}
+           "r": r[:, 0].astype(np.float32), "action": action, "loss": float(loss), "goal_conditioned": int(goal)}
+    if not goal:
+        out["txt_inter"], out["txt_final"] = rec["txt_inter"][0].numpy(), rec["txt_final"][0].numpy()
+    else:  # four image groups (image0..image3), no prompt
+        assert len(rec["img_inter"]) == 4 and not rec["txt_inter"]
     for n, p in model.named_parameters():
         if n.startswith("clip_model."):
             assert p.grad is None
@@ -177,9 +182,9 @@ def main():
         out["vip_loss"] = float(model(batch))
         model.use_id_loss, model.use_vip_loss = True, False
         out["lambda_id_times_id_loss"] = float(model(batch))
-    np.savez_compressed(os.path.join(HERE, "finetune_tiny.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "finetune_tiny_goal.npz" if goal else "finetune_tiny.npz"), **out)
     print({k: (v.shape if hasattr(v, "shape") and getattr(v, "ndim", 0) else v) for k, v in out.items() if not k.startswith(("param:", "grad:"))})
 
 
 if __name__ == "__main__":
-    main()
+    main(goal="--goal" in sys.argv)

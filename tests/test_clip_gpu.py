@@ -298,7 +298,8 @@ def test_heavy_tailed_weights_f16_stays_finite_and_in_tolerance(gpu_lib):
     print(f"heavy-tailed: |residual stream| up to {np.abs(inter).max():.1f}; cosine err f32 {np.abs(r32 - ref).max() / 100:.2e}, f16 {np.abs(r16 - ref).max() / 100:.2e}")
     assert np.abs(inter).max() > 100.0, "the stress case must actually stress the range"
     assert np.abs(r32 - ref).max() / 100.0 < COS_TOL_F32
-    assert np.abs(r16 - ref).max() / 100.0 < 2 * COS_TOL_F16  # outlier channels concentrate the rounding error: measured value in DESIGN.md
+    # north_star's 1e-4 itself (VERDICT r2 next #2c): pretrained CLIP IS the heavy-tailed case, so this is where "f16 meets 1e-4" counts
+    assert np.abs(r16 - ref).max() / 100.0 < COS_TOL_F16
     m32.close(); m16.close()
 
 

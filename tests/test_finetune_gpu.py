@@ -436,3 +436,83 @@ def test_f16_head_training_tracks_f32_over_many_steps(gpu_lib):
     assert a[-2:].mean() < a[:2].mean() and b[-2:].mean() < b[:2].mean(), "both modes must learn"
     rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-2)
     assert rel[:10].max() < 1e-2 and rel.max() < 0.1, (float(rel[:10].max()), float(rel.max()))
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_finetune_bucketed_allreduce_equals_serial(gpu_lib, monkeypatch, mode):
+    """seven gradient buckets leave in production order from inside the backward, on a communication
+    stream.  With the all-reduce path forced on at world = 1 the overlapped step equals the serial step and the step without a
+    communicator, bit for bit."""
+    from arp_amd import finetune as FT
+    cfg = FT.FinetuneConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64, n_actions=5)
+    P = FT.synth_params(cfg, seed=1)
+    batch = FT.synth_batch(cfg, 6, seed=2)
+    res = {}
+    for name, env in (("plain", None), ("serial", {"ARP_FT_FORCE_COMM": "1", "ARP_FT_OVERLAP": "0"}), ("overlap", {"ARP_FT_FORCE_COMM": "1", "ARP_FT_OVERLAP": "1"})):
+        for k in ("ARP_FT_FORCE_COMM", "ARP_FT_OVERLAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        tr = FT.FinetuneTrainer(cfg, mode=mode)
+        tr.set_params(P)
+        if env:
+            tr.comm_init(FT.FinetuneTrainer.new_unique_id(), 1, 0)
+            tr.broadcast_state()
+        if name == "overlap":
+            tr.profile(True)
+        tr.set_batch(*batch)
+        auxs = [tr.train_step(1e-3) for _ in range(3)]
+        if name == "overlap":
+            sites = tr.profile_read()
+            assert all(f"ft.allreduce_b{b}" in sites for b in range(7)), sorted(sites)
+        res[name] = (tr.get_params(), auxs, tr.get_grads())
+        tr.close()
+    for other in ("serial", "overlap"):
+        for k in P:
+            assert np.array_equal(res["plain"][0][k], res[other][0][k]), (other, k)
+            assert np.array_equal(res["plain"][2][k], res[other][2][k]), (other, "grad", k)
+        assert [a["loss"] for a in res["plain"][1]] == [a["loss"] for a in res[other][1]]
+
+
+@pytest.mark.parametrize("mode,tol_l,tol_g", [("f32", 5e-5, 5e-4), ("f16", 2e-3, None)])
+def test_goal_conditioned_head_matches_the_reference_class_fixture(gpu_lib, mode, tol_l, tol_g):
+    """clip_multiscale_adapter.py:208-212,224-230 (goal_conditioned=True): four image groups, scores = -||a3 - a_k||, inverse-model
+    input [a1|a3|a2|a3], no text head.  Fixture = the reference class itself with the switch on (make_golden_finetune.py --goal).
+    Loss, both components, every gradient; AdamW leaves the text head's parameters and moments exactly alone."""
+    import os
+    from arp_amd import finetune as FT
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "finetune_tiny_goal.npz"))
+    L, wv, wt, embed, hid, na = [int(v) for v in g["cfg"]]
+    cfg = FT.FinetuneConfig(layers=L, width_v=wv, width_t=wt, embed=embed, hidden=hid, n_actions=na, gamma=float(g["gamma"]),
+                            logit_scale=float(g["logit_scale"]), goal_conditioned=True)
+    P = {k[6:]: g[k] for k in g.files if k.startswith("param:")}
+    G = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
+    tr = FT.FinetuneTrainer(cfg, mode=mode)
+    tr.set_params(P)
+    tr.set_batch(g["img_inter"], g["img_final"], None, None, g["r"], g["action"])
+    out = tr.forward()
+    assert abs(out["loss"] - float(g["loss"])) < tol_l and abs(out["vip_loss"] - float(g["vip_loss"])) < tol_l, (out["loss"], float(g["loss"]))
+    assert abs(out["lambda_id"] * out["id_loss"] - float(g["lambda_id_times_id_loss"])) < 10 * tol_l
+    tr.backward()
+    got = tr.get_grads()
+    if tol_g is not None:
+        for k in G:
+            if k.startswith("text_"):
+                continue
+            scale = max(np.abs(G[k]).max(), 1e-6)
+            assert np.abs(got[k] - G[k]).max() / scale < tol_g, (k, np.abs(got[k] - G[k]).max() / scale)
+    else:  # f16 operands: direction of the whole gradient
+        num = sum(float((got[k].astype(np.float64) * G[k]).sum()) for k in G if not k.startswith("text_"))
+        den = np.sqrt(sum(float((got[k].astype(np.float64) ** 2).sum()) for k in G if not k.startswith("text_")) * sum(float((G[k].astype(np.float64) ** 2).sum()) for k in G))
+        assert num / den > 0.9999, num / den
+    tr.set_batch(g["img_inter"], g["img_final"], None, None, g["r"], g["action"])
+    tr.train_step(1e-3)
+    after = tr.get_params()
+    for k in P:
+        if k.startswith("text_"):
+            assert np.array_equal(after[k], P[k]), k  # no gradient: no decay, no moments (torch.optim.AdamW skips .grad is None)
+        elif k != "lambda_id" or True:
+            assert not np.array_equal(after[k], P[k]) or P[k].size == 0, k
+    mu = tr.get_tensors(2)
+    assert all(not np.any(mu[k]) for k in P if k.startswith("text_"))
+    tr.close()

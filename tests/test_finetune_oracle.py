@@ -9,16 +9,32 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def load_golden():
+def load_golden(goal=False):
     from oracle import finetune_torch as O
-    g = np.load(os.path.join(HERE, "golden", "finetune_tiny.npz"))
+    g = np.load(os.path.join(HERE, "golden", "finetune_tiny_goal.npz" if goal else "finetune_tiny.npz"))
     L, wv, wt, embed, hid, na = [int(v) for v in g["cfg"]]
     cfg = O.HeadConfig(layers=L, width_v=wv, width_t=wt, embed=embed, hidden=hid, n_actions=na, gamma=float(g["gamma"]),
-                       logit_scale=float(g["logit_scale"]))
+                       logit_scale=float(g["logit_scale"]), goal_conditioned=goal)
     P = {k[6:]: g[k] for k in g.files if k.startswith("param:")}
     G = {k[5:]: g[k] for k in g.files if k.startswith("grad:")}
-    batch = (g["img_inter"], g["img_final"], g["txt_inter"], g["txt_final"], g["r"], g["action"])
+    batch = (g["img_inter"], g["img_final"], None if goal else g["txt_inter"], None if goal else g["txt_final"], g["r"], g["action"])
     return cfg, P, G, batch, g
+
+
+def test_goal_conditioned_variant_matches_the_reference_class():
+    """clip_multiscale_adapter.py:208-212,224-230 (goal_conditioned=True): fixture = the reference class itself with that switch on
+    (make_golden_finetune.py --goal).  Loss, both components, every gradient; the text head's parameters get NO gradient."""
+    from oracle import finetune_torch as O
+    cfg, P, G, batch, g = load_golden(goal=True)
+    assert int(g["goal_conditioned"]) == 1 and batch[0].shape[0] == 4
+    got, aux = O.grads(P, cfg, batch)
+    assert abs(aux["loss"] - float(g["loss"])) < 2e-5 and abs(aux["vip_loss"] - float(g["vip_loss"])) < 2e-5
+    assert abs(float(P["lambda_id"]) * aux["id_loss"] - float(g["lambda_id_times_id_loss"])) < 2e-5
+    for k in G:
+        scale = max(np.abs(G[k]).max(), 1e-6)
+        assert np.abs(got[k] - G[k]).max() / scale < 2e-4, k
+    text_side = {k for k in P if k.startswith("text_")}
+    assert text_side <= set(aux["no_grad"]) and all(not np.any(G[k]) for k in text_side)
 
 
 def test_param_tree_matches_reference_state_dict():

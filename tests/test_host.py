@@ -243,3 +243,85 @@ def test_policy_batch_rtg_views_mean_and_symlog():
     np.testing.assert_allclose(symlog(np.array([-np.e + 1, 0.0, np.e - 1])), [-1.0, 0.0, 1.0], atol=1e-6)
     _, _, r1 = _batch_arrays({"image": enc, "action": act, "rtg": views["ob"]}, use_symlog=True)  # a bare array = one view
     np.testing.assert_allclose(r1, symlog(views["ob"]), rtol=1e-6)
+
+
+def test_allreduce_bucket_plan_tiles_the_flat_gradient_exactly_once():
+    """the data-parallel step all-reduces the flat gradient in two buckets of two ranges; every float must be in
+    exactly one range, bucket 1 must hold image_text_input's kernel (the bulk, produced before the adapter's backward)."""
+    from arp_amd.train import PolicyConfig, bucket_plan
+    for cfg in (PolicyConfig(), PolicyConfig(use_adapter=False), PolicyConfig(emb=64, depth=3, heads=4, window=3, enc_tokens=5, enc_dim=64)):
+        ranges, total = bucket_plan(cfg)
+        assert len(ranges) == 4 and all(0 <= lo <= hi <= total for lo, hi in ranges)
+        cover = np.zeros(total, np.int32)
+        for lo, hi in ranges:
+            cover[lo:hi] += 1
+        assert (cover == 1).all(), "the bucket ranges must tile [0, P) exactly once"
+        wi = cfg.enc_tokens * cfg.enc_dim * cfg.emb
+        assert ranges[0][1] - ranges[0][0] >= wi                       # bucket 1, range a: image_text_input/kernel + the transformer's matrices
+        b2 = sum(hi - lo for lo, hi in ranges[2:])
+        if cfg.use_adapter:
+            assert b2 == 2 * cfg.enc_dim * cfg.enc_dim + 2 * cfg.enc_dim + 4  # two Dense kernels, two biases, residual_weight (padded to 4)
+        else:
+            assert b2 == 0
+    ranges, total = bucket_plan(PolicyConfig())
+    assert sum(hi - lo for lo, hi in ranges[:2]) / total > 0.94            # what overlaps the adapter's backward GEMMs
+
+
+def test_split_rng_is_jax_random_split():
+    """train_step_fn / val_step_fn return jax.random.split(rng)[0] (main_procgen.py:130,163).  Known answer: the documented
+    jax.random.split(jax.random.PRNGKey(0)) = [[4146024105, 967050713], [2718843009, 1272950319]] (threefry2x32, original split)."""
+    from arp_amd.train import split_rng
+    nxt, sub = split_rng(np.array([0, 0], np.uint32))
+    assert nxt.tolist() == [4146024105, 967050713] and sub.tolist() == [2718843009, 1272950319]
+    # the pmapped "sharded_rng": one key per device, split independently
+    keys = np.array([[0, 0], [0, 1]], np.uint32)
+    n2, s2 = split_rng(keys)
+    assert n2.shape == (2, 2) and n2[0].tolist() == [4146024105, 967050713] and not np.array_equal(n2[0], n2[1])
+    # anything that is not a raw threefry key is carried through untouched
+    assert split_rng(None) == (None, None) and split_rng(7) == (7, 7)
+
+
+def test_label_reward_rejects_a_misconfigured_shard_before_doing_any_work():
+    """rank / world / gather are validated BEFORE the store or the model is touched."""
+    from arp_amd.label_reward import label_reward, reward_dtype
+
+    class Boom(dict):
+        def __getitem__(self, k):
+            raise AssertionError("the store was touched before validation")
+
+    kw = dict(env_name="coinrun", distribution_mode="hard", num_levels=500, start_level=0, text="x", base_path="/nonexistent")
+    with pytest.raises(ValueError, match="gather"):
+        label_reward(**kw, store=Boom(), clip_model=object(), world=2, rank=0)
+    with pytest.raises(ValueError, match="rank"):
+        label_reward(**kw, store=Boom(), clip_model=object(), world=2, rank=2, gather=lambda r: [r])
+    assert reward_dtype("clip") == np.float32 and reward_dtype("clip_ft") == np.float32 and reward_dtype("clip_goal_conditioned") == np.float64
+
+
+def test_empty_shard_keeps_the_goal_conditioned_dtype():
+    """a rank without trajectories must hand over float64 (0, F) rows for the goal-conditioned model, so that whichever rank's
+    result reaches create_dataset first fixes the reference's dtype."""
+    from arp_amd.label_reward import label_store
+    store = _store([5])  # one trajectory: rank 1 of 2 gets nothing
+    dist = lambda m, im, text=None, use_crop=False: np.arange(len(im), dtype=np.float64)
+    for rank in (0, 1):
+        res = label_store(store, None, dist, model_type="clip_goal_conditioned", rank=rank, world=2)
+        assert res, "both ranks report both datasets"
+        for k, (first, rows) in res.items():
+            assert rows.dtype == np.float64, (rank, k, rows.dtype)
+        assert sum(rows.shape[0] for _, rows in res.values()) == (0 if rank == 1 else 10) or rank == 0
+
+
+def test_finetune_bucket_plan_tiles_the_flat_gradient_exactly_once():
+    from arp_amd.finetune import FinetuneConfig, bucket_plan
+    for cfg in (FinetuneConfig(), FinetuneConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64, n_actions=5)):
+        buckets, total = bucket_plan(cfg)
+        cover = np.zeros(total, np.int8)
+        for b in buckets:
+            for lo, hi in b:
+                assert 0 <= lo <= hi <= total
+                cover[lo:hi] += 1
+        assert (cover == 1).all() and len(buckets) == 7
+    # the buckets that overlap the backward carry all but the last intermediate-linear weight and the scalars
+    buckets, total = bucket_plan(FinetuneConfig())
+    last = sum(hi - lo for lo, hi in buckets[-1])
+    assert last / total < 0.1

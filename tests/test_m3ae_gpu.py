@@ -10,7 +10,7 @@ SMALL_ENC = dict(patch=16, width=128, layers=2, heads=2, img_res=64)    # head_d
 
 
 @pytest.mark.parametrize("kw", [TINY_ENC, SMALL_ENC])
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("f16", 8e-3), ("bf16", 6e-2)])
 def test_encoder_parity(gpu_lib, kw, mode, tol):
     from arp_amd import m3ae, synth_policy as S
     from oracle import m3ae_np as M
@@ -34,7 +34,7 @@ def test_full_size_encoder_parity(gpu_lib):
     P = S.m3ae_params(ocfg, seed=0)
     x = S.normalized_frames(2, 256, seed=1)
     ref = M.forward_representation(P, ocfg, x)
-    for mode, tol in (("f32", 1e-4), ("bf16", 8e-2)):
+    for mode, tol in (("f32", 1e-4), ("f16", 1e-2), ("bf16", 8e-2)):  # f16: the mode bench.py --path policy --with-encoder times
         enc = m3ae.M3AEEncoder(cfg, P, mode=mode)
         got = enc.forward_representation(x)
         err = np.abs(got - ref).max()
@@ -68,3 +68,42 @@ def test_train_step_with_encoder_inside(gpu_lib):
     pa, pb = a.get_params(), b.get_params()
     assert max(np.abs(pa[k] - pb[k]).max() for k in pa) < 1e-6
     a.close(); b.close(); enc.close()
+
+
+def test_policy_logits_with_the_f16_encoder_inside_full_geometry(gpu_lib):
+    """VERDICT r2 next #2a: the configuration `bench.py --path policy --with-encoder` times -- frames in, f16 encoder (ViT-B/16 at
+    256 x 256, 257 tokens) in front of the f16 policy -- against oracle/m3ae_np -> oracle/arpdt_torch in fp64, at the real geometry.
+    Measured (round 3): 1.0-1.3e-3 on the logits -- the twelve f16 encoder layers alone leave 3e-3 max / 5.5e-4 rms on the LayerNorm'ed
+    encodings, about as much on the logits as the policy's own operand roundings -- so this row (N1) sits marginally OUTSIDE
+    north_star's 1e-3 in f16 and inside it only in the f32 mode (2e-6).  The test pins the measured level; README / DESIGN say so."""
+    import torch
+    from arp_amd import m3ae, synth_policy as S
+    from arp_amd.train import PolicyConfig, PolicyTrainer
+    from oracle import arpdt_torch as O, m3ae_np as M
+    ecfg, eocfg = m3ae.EncoderConfig(), M.EncConfig()
+    pcfg, pocfg = PolicyConfig(lambda_ret=0.01), O.PolicyConfig(lambda_ret=0.01)
+    B, T = 2, pcfg.window
+    errs = {}
+    for seed in (0, 1):
+        EP = S.m3ae_params(eocfg, seed=50 + seed)
+        P = S.policy_params(pcfg, seed=60 + seed)
+        rng = np.random.default_rng(70 + seed)
+        frames = S.normalized_frames(B * T, 256, seed=80 + seed).reshape(B, T, 256, 256, 3)
+        act = rng.integers(0, pcfg.n_actions, (B, T)).astype(np.int32)
+        rtg = rng.random((B, T, 1)).astype(np.float32)
+        codes = M.forward_representation(EP, eocfg, frames.reshape(-1, 256, 256, 3)).reshape(B, T, ecfg.tokens, ecfg.width)
+        Pt = {k: torch.from_numpy(v).double() for k, v in P.items()}
+        ref = O.forward(Pt, pocfg, torch.from_numpy(np.asarray(codes, np.float64)), torch.from_numpy(act).long(), torch.from_numpy(rtg).double())
+        for mode in ("f16", "f32"):
+            enc = m3ae.M3AEEncoder(ecfg, EP, mode=mode)
+            tr = PolicyTrainer(pcfg, mode=mode)
+            tr.set_params(P)
+            tr.attach_encoder(enc)
+            tr.set_batch_images(frames, act, rtg)
+            out = tr.forward()
+            e = max(float(np.abs(out["action_pred"] - ref["action_pred"].numpy()).max()), float(np.abs(out["return_pred"] - ref["return_pred"].numpy()).max()))
+            errs[(mode, seed)] = e
+            tr.close(); enc.close()
+    print("policy logits / return with the encoder inside, full geometry: " + ", ".join(f"{m} seed {s}: {e:.2e}" for (m, s), e in errs.items()))
+    assert max(e for (m, s), e in errs.items() if m == "f32") < 5e-5
+    assert max(e for (m, s), e in errs.items() if m == "f16") < 1.6e-3  # NOT north_star's 1e-3: see the docstring

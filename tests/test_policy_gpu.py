@@ -340,3 +340,146 @@ def test_f16_training_tracks_f32_over_many_steps(gpu_lib):
     assert a[-1] < 0.5 * a[0] and b[-1] < 0.5 * b[0], "both modes must learn the fixed batch"
     rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-3)
     assert rel[:20].max() < 5e-3 and rel.max() < 5e-2, (float(rel[:20].max()), float(rel.max()))
+
+
+def test_f16_full_geometry_logits_over_sixteen_seeds(gpu_lib, monkeypatch):
+    """VERDICT r2 next #2b: north_star's 1e-3 on the f16 logits AND return prediction at the REAL geometry (257 x 768 encodings,
+    K = 197 376) across 16 seeds, not on two or three.  Prints max / p99 over all seeds (the committed log is the evidence).
+    Measured (round 3): with every adapter-path operand in f16 (ARP_DT_ITI_F32=0, round 2's default) p99 is 7e-4 / 9.7e-4 and TWO seeds
+    in sixteen reach 1.05e-3 -- the path rounds seven operands (X, W1, H1, W2, A, Y, Wi) at 2.4-6.1e-4 each.  The default now
+    takes two of them out (image_text_input's forward contraction on the un-rounded mix and the f32 master weights, +7 % step
+    time): max 8.7e-4, no seed outside.  Asserted: the default inside 1e-3 on every seed; the all-f16 switch inside 1.2e-3 (max)
+    and 1e-3 (p99)."""
+    from arp_amd.train import PolicyTrainer
+    from oracle import arpdt_torch as O
+    cases = []
+    for seed in range(16):
+        cfg, ocfg, P, batch, Pt, tb = _setup(FULL, 2, 100 + 7 * seed)
+        ref = O.forward(Pt, ocfg, *tb)
+        cases.append((cfg, P, batch, ref["action_pred"].numpy(), ref["return_pred"].numpy()))
+    stats = {}
+    for name, flag in (("all_f16", "0"), ("default", None)):
+        monkeypatch.delenv("ARP_DT_ITI_F32", raising=False)
+        if flag is not None:
+            monkeypatch.setenv("ARP_DT_ITI_F32", flag)
+        tr = PolicyTrainer(cases[0][0], mode="f16")
+        e_log, e_ret = [], []
+        for cfg, P, (enc, act, rtg), r_log, r_ret in cases:
+            tr.set_params(P)
+            tr.set_batch(enc, act, rtg)
+            out = tr.forward()
+            e_log.append(np.abs(out["action_pred"] - r_log).ravel())
+            e_ret.append(np.abs(out["return_pred"] - r_ret).ravel())
+        tr.close()
+        el, er = np.concatenate(e_log), np.concatenate(e_ret)
+        per_seed = [float(max(a.max(), b.max())) for a, b in zip(e_log, e_ret)]
+        stats[name] = (el.max(), np.quantile(el, 0.99), er.max(), np.quantile(er, 0.99), sum(v >= LOGIT_TOL_16BIT for v in per_seed))
+        print(f"f16 FULL geometry, 16 seeds [{name}]: logits max {el.max():.2e} p99 {np.quantile(el, 0.99):.2e}; return max {er.max():.2e} p99 "
+              f"{np.quantile(er, 0.99):.2e}; per-seed max {min(per_seed):.2e} .. {max(per_seed):.2e}; seeds outside 1e-3: {stats[name][4]} of 16")
+    for name in stats:
+        assert stats[name][1] < LOGIT_TOL_16BIT and stats[name][3] < LOGIT_TOL_16BIT, (name, stats[name])
+    assert max(stats["all_f16"][0], stats["all_f16"][2]) < 1.2e-3, stats["all_f16"]
+    assert max(stats["default"][0], stats["default"][2]) < LOGIT_TOL_16BIT, stats["default"]
+
+
+def test_f16_step_survives_an_overflowing_backward(gpu_lib):
+    """f16 mode scales the adapter path's backward activations by a fixed 2^14; a loss spike (huge rtg targets at
+    B = 1) pushes them past binary16's range.  The scaled dz saturates instead of becoming inf, and a step whose gradient norm is
+    still not finite is dropped -- either way parameters and moments stay finite and training can go on."""
+    from arp_amd.train import PolicyTrainer
+    cfg, ocfg, P, (enc, act, rtg), Pt, tb = _setup(SMALL, 1, 11)
+    tr = PolicyTrainer(cfg, mode="f16")
+    tr.set_params(P)
+    big = np.full_like(rtg, 3.0e4)
+    big[0, 0, 0] = -3.0e4
+    tr.set_batch(enc, act, big)
+    aux = tr.train_step(1e-3)
+    got = tr.get_params()
+    assert all(np.isfinite(v).all() for v in got.values()), "a parameter went non-finite"
+    assert all(np.isfinite(v).all() for v in tr.get_tensors(2).values()) and all(np.isfinite(v).all() for v in tr.get_tensors(3).values())
+    print(f"overflow guard: loss {aux['loss']:.3e}, grad_norm {aux['grad_norm']:.3e}, "
+          f"params moved: {any((got[k] != P[k]).any() for k in P)}")
+    # ... and an ordinary batch afterwards trains normally
+    tr.set_batch(enc, act, rtg)
+    aux2 = tr.train_step(1e-3)
+    assert np.isfinite(aux2["loss"]) and np.isfinite(aux2["grad_norm"]) and all(np.isfinite(v).all() for v in tr.get_params().values())
+    tr.close()
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_bucketed_overlapped_allreduce_equals_serial(gpu_lib, monkeypatch, mode):
+    """VERDICT r2 next #3.  The data-parallel step all-reduces the gradient in two buckets on a communication stream, bucket 1 while
+    the adapter's backward still runs.  What one GPU can check: with the all-reduce path forced on at world = 1 (an identity
+    reduction through RCCL, same streams / events / staged graphs) the overlapped step equals the serial step -- and the step
+    without any communicator -- bit for bit, over several steps, at a geometry that takes the fused + TN path."""
+    from arp_amd.train import PolicyTrainer
+    cfg, ocfg, P, (enc, act, rtg), Pt, tb = _setup(SMALL, 6, 21)
+    res = {}
+    for name, env in (("plain", None), ("serial", {"ARP_DT_FORCE_COMM": "1", "ARP_DT_OVERLAP": "0"}), ("overlap", {"ARP_DT_FORCE_COMM": "1", "ARP_DT_OVERLAP": "1"})):
+        for k in ("ARP_DT_FORCE_COMM", "ARP_DT_OVERLAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        tr = PolicyTrainer(cfg, mode=mode)
+        tr.set_params(P)
+        if env:
+            tr.comm_init(PolicyTrainer.new_unique_id(), 1, 0)
+            tr.broadcast_state()
+        if name == "overlap":
+            tr.profile(True)
+        auxs = []
+        for i in range(5):  # eager, eager, capture, replay, replay of every staged graph
+            tr.set_batch(enc, act, rtg)
+            auxs.append(tr.train_step(1e-3))
+        if name == "overlap":
+            sites = tr.profile_read()
+            assert "dt.allreduce_b1" in sites and "dt.allreduce_b2" in sites, sorted(sites)
+        res[name] = (tr.get_params(), auxs, tr.get_grads())
+        tr.close()
+    for other in ("serial", "overlap"):
+        for k in P:
+            assert np.array_equal(res["plain"][0][k], res[other][0][k]), (other, k)
+            assert np.array_equal(res["plain"][2][k], res[other][2][k]), (other, "grad", k)
+        assert [a["loss"] for a in res["plain"][1]] == [a["loss"] for a in res[other][1]]
+
+
+def test_prefetched_slots_equal_synchronous_upload(gpu_lib):
+    """prefetch_to_device (main_procgen.py:703): batches uploaded into the two device slots by a background thread while the step on
+    the other slot runs give the same trajectory as the synchronous set_batch path; val_step_fn leaves the state alone."""
+    from arp_amd import synth_policy as S
+    from arp_amd.train import PolicyTrainer, TrainState, create_train_step, create_val_step, prefetch_to_device
+    cfg, ocfg, P, _, Pt, tb = _setup(SMALL, 4, 31)
+    batches = []
+    for i in range(6):
+        enc, act, rtg = S.policy_batch(cfg, 4, seed=40 + i)
+        batches.append({"image": {"ob": enc}, "action": act, "rtg": {"ob": rtg}})
+    lr = lambda step: 1e-3
+    key = np.array([0, 42], np.uint32)
+
+    def run(prefetch):
+        state = TrainState.create(cfg, P, mode="f32")
+        fn, vfn = create_train_step(cfg, lr, cfg.weight_decay), create_val_step(cfg)
+        rng, out = key, []
+        src = prefetch_to_device(iter(batches), 2, state.trainer) if prefetch else iter(batches)
+        for b in src:
+            state, aux, rng = fn(state, b, rng)
+            out.append(aux)
+        vaux, vrng = vfn(state, batches[0], rng)
+        p = state.params
+        state.trainer.close()
+        return out, p, vaux, rng, vrng
+
+    a, pa, va, ra, vra = run(False)
+    b, pb, vb, rb, vrb = run(True)
+    assert [x["loss"] for x in a] == [x["loss"] for x in b] and [x["train_state_step"] for x in b] == list(range(6))
+    assert all(np.array_equal(pa[k], pb[k]) for k in pa)
+    assert va == vb and set(va) == {"loss", "trans_loss", "return_loss", "acc"}
+    # the rng is jax.random.split's first output at every call (threefry, known-answer-tested on the CPU side)
+    assert np.array_equal(ra, rb) and not np.array_equal(ra, key) and not np.array_equal(vra, ra)
+    # val_step = the forward's metrics, rank mean at world 1
+    tr = PolicyTrainer(cfg, mode="f32")
+    tr.set_params(pa)
+    tr.set_batch(batches[0]["image"]["ob"], batches[0]["action"], batches[0]["rtg"]["ob"])
+    f = tr.forward()
+    tr.close()
+    assert abs(f["loss"] - va["loss"]) < 1e-6 and abs(f["acc"] * 100 - va["acc"]) < 1e-4 and abs(f["return_loss"] - va["return_loss"]) < 1e-6
