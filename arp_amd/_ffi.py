@@ -90,6 +90,8 @@ SIGNATURES = {
     "arp_clip_set_text": (_i, [_vp, _i32p, _i]),
     "arp_clip_get_text_features": (_i, [_vp, _fp]),
     "arp_clip_label": (_i, [_vp, _u8p, _i, _i, _i, _i, _fp]),
+    "arp_clip_label_submit": (_i, [_vp, _i, _u8p, _i, _i, _i, _i]),
+    "arp_clip_label_collect": (_i, [_vp, _i, _fp]),
     "arp_clip_label_dev_async": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "arp_clip_sync": (_i, [_vp]),
     "arp_clip_set_streams": (_i, [_vp, _i]),

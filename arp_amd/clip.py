@@ -117,6 +117,7 @@ class ClipLabeller:
         the f32 towers), never the labelling default (1e-4 needs the 11 significand bits of f16)."""
         _ffi.require_gpu()
         self.cfg = cfg
+        self.max_batch = int(max_batch)
         self.mode = {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32}[mode]
         c = _ffi.ClipCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.embed, cfg.img_res, cfg.txt_width,
                          cfg.txt_layers, cfg.txt_heads, cfg.ctx, cfg.vocab, self.mode, device, max_batch, attn_impl, n_streams)
@@ -186,6 +187,20 @@ class ClipLabeller:
         out = np.empty(f.shape[0], np.float32)
         check(lib.arp_clip_label(self._h, _ffi.as_ptr(f, C.c_uint8), f.shape[0], f.shape[1], f.shape[2],
                                  int(bool(use_crop)), _ffi.as_ptr(out, C.c_float)))
+        return out
+
+    def label_submit(self, slot, frames, use_crop=False):
+        """Asynchronous :meth:`label` on slot 0 / 1 (at most ``max_batch`` frames): returns once upload, pass and download are enqueued.
+        Submit call i+1 before collecting call i and the GPU never drains between calls.  ``frames`` is kept alive here."""
+        f = self._frames(frames)
+        check(lib.arp_clip_label_submit(self._h, int(slot), _ffi.as_ptr(f, C.c_uint8), f.shape[0], f.shape[1], f.shape[2], int(bool(use_crop))))
+        self._pending = getattr(self, "_pending", {})
+        self._pending[int(slot)] = f
+
+    def label_collect(self, slot):
+        f = getattr(self, "_pending", {}).pop(int(slot), None)
+        out = np.empty(f.shape[0] if f is not None else 1, np.float32)  # (an empty slot: the library reports the misuse)
+        check(lib.arp_clip_label_collect(self._h, int(slot), _ffi.as_ptr(out, C.c_float)))
         return out
 
     def encode_image(self, frames, use_crop=False, normalize=False):

@@ -85,6 +85,17 @@ struct arp_clip {
     // all of them are in flight before the first kernel; from pageable memory the runtime stages them and the call order does the overlap.
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> ev_copy;  // one per part
+    // arp_clip_label_submit / _collect: two host-fed calls in flight.  A synchronous arp_clip_label pays the pipeline's fill and drain on
+    // every call (13.3 ms per 1024 frames where back-to-back passes take 10.5 ms and the 3.5 ms upload overlaps them completely:
+    // scripts/seam_probe.py); with the next call's upload and kernels queued behind the running one the streams never drain.
+    struct LabelSlot {
+        DevBuf frames, rewards;
+        float* host = nullptr;  // pinned staging of the rewards (a D2H into pageable memory would block the submitting thread)
+        size_t host_n = 0;
+        hipEvent_t done = nullptr;
+        int n = 0;
+        bool busy = false;
+    } lslot[2];
     int gemm_force = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel (ARP_GEMM env)
     // Fold LayerNorm into the consumer GEMMs of the vision tower in bf16 mode (ARP_LN_FOLD=1).  Numerically fine
     // (cosine error 3.6e-4 vs 4.8e-4 unfused) but MEASURED SLOWER on MI355X (74.2 k vs 79.7 k frames/s): the extra
@@ -460,6 +471,7 @@ static int make_sibling(arp_clip* c) {
     s->ev_fork = nullptr;
     s->copy_stream = nullptr;
     s->ev_copy.clear();
+    for (auto& ls : s->lslot) ls = arp_clip::LabelSlot();
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         delete s;
         return fail("hipStreamCreate failed");
@@ -484,13 +496,14 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
         return label_dev_single(c, frames_dev, n, H, W, use_crop, rewards_dev);
     }
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    // host-fed calls are cut into MORE parts than streams (two per stream, round-robin): the first kernels start after 1 / parts of the
-    // upload instead of 1 / streams of it, and every stream has its next slice on the way while it computes (ARP_CLIP_HOST_PARTS
-    // overrides; each part keeps >= 128 frames)
+    // host-fed calls may be cut into MORE parts than streams (ARP_CLIP_HOST_PARTS, round-robin over the streams): the first kernels then
+    // start after 1 / parts of the upload.  Measured (profiles/r3_seam_sweep.txt): 2, 4, 6 or 8 parts on two streams all give 77-80 k
+    // frames/s -- what a synchronous call loses is the pipeline's fill and drain, not the exposed first slice, and smaller parts cost
+    // GEMM tile quantisation (c_proj at 256 frames: 150 tiles on 256 CUs) -- so the default stays one part per stream.
     int parts = ns;
     if (host_src) {
         static const int env_parts = getenv("ARP_CLIP_HOST_PARTS") ? atoi(getenv("ARP_CLIP_HOST_PARTS")) : 0;
-        parts = env_parts > 0 ? env_parts : 2 * ns;
+        parts = env_parts > 0 ? env_parts : ns;
         while (parts > ns && n / parts < 128) --parts;
         if (parts < ns) parts = ns;
         if (!c->copy_stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -634,6 +647,12 @@ int arp_clip_destroy(arp_clip* c) {
     for (hipEvent_t e : c->ev_join) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_copy) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto& ls : c->lslot) {
+        ls.frames.release();
+        ls.rewards.release();
+        if (ls.host) (void)hipHostFree(ls.host);
+        if (ls.done) (void)hipEventDestroy(ls.done);
+    }
     c->prof.destroy();
     for (void* p : c->owned) (void)hipFree(p);
     for (auto& kv : c->plans) {
@@ -747,6 +766,44 @@ int arp_clip_label(arp_clip* c, const uint8_t* frames, int n, int H, int W, int 
         ARP_HIP_OK(hipMemcpyAsync(rewards + off, c->rewards.p, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+// Asynchronous form of arp_clip_label: submit() enqueues the upload, the labelling pass and the download of n <= max_batch frames on
+// slot 0 / 1 and returns; collect() waits for that slot and hands the rewards over.  Two slots: the next call is submitted before the
+// previous one is collected, so its upload overlaps the running pass and the compute streams never drain between calls.  The caller
+// keeps `frames` alive and unchanged until collect() of the same slot has returned.
+int arp_clip_label_submit(arp_clip* c, int slot, const uint8_t* frames, int n, int H, int W, int use_crop) {
+    ARP_TRY(check_ready(c, true));
+    if (slot < 0 || slot > 1 || !frames || n <= 0) return fail("bad argument");
+    if (n > c->cfg.max_batch) return fail("arp_clip_label_submit: at most max_batch frames per call");
+    arp_clip::LabelSlot& ls = c->lslot[slot];
+    if (ls.busy) return fail("arp_clip_label_submit: the slot still holds an uncollected call");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    const size_t fb = (size_t)H * W * 3;
+    ARP_TRY(ls.frames.ensure((size_t)c->cfg.max_batch * fb));
+    ARP_TRY(ls.rewards.ensure((size_t)c->cfg.max_batch * 4));
+    if (ls.host_n < (size_t)c->cfg.max_batch) {
+        if (ls.host) ARP_HIP_OK(hipHostFree(ls.host));
+        ls.host = nullptr;
+        ARP_HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&ls.host), (size_t)c->cfg.max_batch * 4, hipHostMallocDefault));
+        ls.host_n = (size_t)c->cfg.max_batch;
+    }
+    if (!ls.done) ARP_HIP_OK(hipEventCreateWithFlags(&ls.done, hipEventDisableTiming));
+    ARP_TRY(label_dev(c, ls.frames.as<uint8_t>(), n, H, W, use_crop, ls.rewards.as<float>(), frames));
+    ARP_HIP_OK(hipMemcpyAsync(ls.host, ls.rewards.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    ARP_HIP_OK(hipEventRecord(ls.done, c->stream));
+    ls.n = n;
+    ls.busy = true;
+    return 0;
+}
+int arp_clip_label_collect(arp_clip* c, int slot, float* rewards) {
+    if (!c || slot < 0 || slot > 1 || !rewards) return fail("bad argument");
+    arp_clip::LabelSlot& ls = c->lslot[slot];
+    if (!ls.busy) return fail("arp_clip_label_collect: nothing was submitted on this slot");
+    ARP_HIP_OK(hipEventSynchronize(ls.done));
+    memcpy(rewards, ls.host, (size_t)ls.n * 4);
+    ls.busy = false;
     return 0;
 }
 

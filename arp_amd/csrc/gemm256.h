@@ -81,8 +81,18 @@ __device__ __forceinline__ void wait_units(int allow) {
 #if defined(ARP_G2_STAMPS) || defined(ARP_G2_FINE)
 __device__ long long* arp_g2_stamps = nullptr;  // scripts/gemm256_bench.hip: per-tile, per-wave phase time stamps
 #endif
+// Register cap (round 3 experiment, OFF): at 2 x 240 registers a SIMD has 32 left, exactly one wave of the row-wise kernels
+// (layernorm_kernel allocates 32), so the OTHER stream's HBM-bound LayerNorm could be resident on a CU beside a GEMM workgroup instead
+// of waiting for the CU to come free.  amdgpu_num_vgpr counts per register FILE on gfx90a+ (the backend doubles it for the unified
+// file): 120 = 240 registers in all, which the K loop fits without a spill (eight dwords of prologue / epilogue state spill in the
+// 16-bit-output instances).  Measured with gemm256 and gemm2w both capped: 96.8 k frames/s against 98-101 k uncapped -- every GEMM site a
+// few per cent slower (c_fc 5.50 vs 5.25 ms, c_proj 4.70 vs 4.45 ms of site time per step), LayerNorm's site time unchanged (0.92 ms): no
+// co-residency gain to pay for it.  128 = uncapped.
+#ifndef ARP_G2_MAX_VGPR
+#define ARP_G2_MAX_VGPR 128
+#endif
 template <typename T, typename OutT, int ACT, bool RESID, int SITE>
-__global__ __launch_bounds__(G2_THREADS, 2) void gemm256_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G2_MAX_VGPR))) void gemm256_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPB = 128 / (int)sizeof(T);
     constexpr int EPC = 16 / (int)sizeof(T);

@@ -10,7 +10,11 @@
 namespace arp {
 
 template <typename T, typename OutT, int ACT, bool RESID>
-__global__ __launch_bounds__(W2_THREADS, 2) void gemm2w_kernel(GemmArgs g) {
+// (register cap experiment of gemm256.h, OFF: 120 = 240 registers in all, 128 = uncapped)
+#ifndef W2_MAX_VGPR
+#define W2_MAX_VGPR 128
+#endif
+__global__ __launch_bounds__(W2_THREADS, 2) __attribute__((amdgpu_num_vgpr(W2_MAX_VGPR))) void gemm2w_kernel(GemmArgs g) {
     static_assert(sizeof(T) == 2, "16-bit operand types only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPB = 64, EPC = 8;

@@ -217,12 +217,17 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
             import queue
             frame_elems = int(np.prod(ds.shape[2:]))
             free = queue.Queue()  # frame buffers go round: reader fills one, the labeller hands it back (no malloc / munmap per batch)
+            # plain CLIP rewards of a labeller with the asynchronous pair (arp_clip_label_submit / _collect): ONE call stays in flight while
+            # the next is submitted, so the GPU does not drain between batches (a synchronous call pays the pipeline's fill and drain)
+            pipelined = (model_type == "clip" and getattr(clip_model, "label_submit", None) is not None and os.environ.get("ARP_LABEL_PIPELINE", "1") != "0"
+                         and max(sum(b - a for a, b in g) for g in groups) <= getattr(clip_model, "max_batch", 0))
             pinned = []
-            for _ in range(4):
+            for _ in range(6 if pipelined else 4):
                 buf = np.empty(max(sum(b - a for a, b in g) for g in groups) * frame_elems, ds.dtype)
-                # the buffers are reused for every batch of the file: pinned once, their uploads are true asynchronous DMA on the labeller's
-                # copy stream (arp_host_register; a labeller without the hook -- a test double -- simply gets pageable buffers)
-                if getattr(clip_model, "pin_host", None) is not None and os.environ.get("ARP_LABEL_PIN", "1") != "0":
+                # (ARP_LABEL_PIN=1 pins the buffers -- arp_host_register.  Measured, and therefore OFF by default: registering 200 MB costs
+                # ~15 ms per buffer while the staged pageable upload already runs at the link rate, 56.5 against 57.4 GB/s, and overlaps the
+                # pass equally well: profiles/r3_seam_probe.txt)
+                if getattr(clip_model, "pin_host", None) is not None and os.environ.get("ARP_LABEL_PIN", "0") == "1":
                     try:
                         clip_model.pin_host(buf)
                         pinned.append(buf)
@@ -238,7 +243,16 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                 t_read += time.perf_counter() - t
                 return g, (fr, buf)
 
+            def emit(grp, r_all):
+                o = 0
+                for a, b in grp:
+                    r = r_all[o : o + b - a]
+                    o += b - a
+                    parts[target_keys[0]].append(stack_outputs(r, num_frames))
+                    parts[target_keys[1]].append(stack_outputs(discount_cumsum(r), num_frames))
+
             it = _prefetch((read(g) for g in groups), depth=2)
+            inflight, k = None, 0  # (slot, trajectories, buffer) of the submitted, not yet collected call
             while True:
                 t = time.perf_counter()
                 nxt = next(it, None)
@@ -247,16 +261,21 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                     break
                 grp, (frames_all, buf) = nxt
                 t = time.perf_counter()
-                r_all = np.array(compute_reward(clip_model, frames_all, text=text, use_crop=use_crop))
+                if pipelined:
+                    clip_model.label_submit(k & 1, frames_all, use_crop=use_crop)
+                    prev, inflight = inflight, (k & 1, grp, buf)
+                    k += 1
+                    if prev is not None:
+                        emit(prev[1], clip_model.label_collect(prev[0]))
+                        free.put(prev[2])
+                else:
+                    emit(grp, np.array(compute_reward(clip_model, frames_all, text=text, use_crop=use_crop)))
+                    free.put(buf)
                 t_label += time.perf_counter() - t
                 del frames_all
-                free.put(buf)
-                o = 0
-                for a, b in grp:
-                    r = r_all[o : o + b - a]
-                    o += b - a
-                    parts[target_keys[0]].append(stack_outputs(r, num_frames))
-                    parts[target_keys[1]].append(stack_outputs(discount_cumsum(r), num_frames))
+            if inflight is not None:
+                emit(inflight[1], clip_model.label_collect(inflight[0]))
+                free.put(inflight[2])
             for buf in pinned:
                 clip_model.unpin_host(buf)
             if timing:

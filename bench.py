@@ -457,6 +457,9 @@ def main():
                     help="label path, 1 GPU (default ON): after the headline line is measured, run the policy / policy --with-encoder / finetune / "
                          "ViT-B/16 benches as child processes and append their JSON lines under `extra`, so that one driver run carries them")
     ap.add_argument("--no-secondary", dest="all_secondary", action="store_false", help="headline line only")
+    ap.add_argument("--timed-only", action="store_true", help="label path: only the warm-up, the timed steps and the per-launch profiled repeat of the "
+                    "same steps -- no seam calls, no isolated single-stream pass, no bf16 parity handle -- so that a rocprofv3 --stats run of this "
+                    "command averages exactly the launches `roofline.avg_launch_ms` averages (scripts/prof_label.sh)")
     a = ap.parse_args()
     if a.mode is None:
         a.mode = "f16"  # IEEE-half MFMA operands on every path: the 16-bit mode that meets the parity bars (bf16 stays selectable)
@@ -551,7 +554,7 @@ def main():
     # ---- the S2 seam as the reference calls it (label_reward.py:132-146: host frames in, host rewards out), OUTSIDE the timed
     # region: arp_clip_label incl. the H2D upload over PCIe and the D2H of the rewards.  Never `value`.
     seam = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.timed_only:
         model.label(frames)
         ts = time.perf_counter()
         for _ in range(5):
@@ -564,8 +567,18 @@ def main():
             model.label(frames)
         pin_s = (time.perf_counter() - ts) / 5
         model.unpin_host(frames)
+        # a STREAM of such calls through the asynchronous pair (one call in flight while the next is submitted: what label_store does)
+        model.label_submit(0, frames)
+        ts = time.perf_counter()
+        for k in range(1, 9):
+            model.label_submit(k & 1, frames)
+            r_pipe = model.label_collect((k - 1) & 1)
+        r_pipe = model.label_collect(0)
+        pipe_s = (time.perf_counter() - ts) / 8
         seam = {"frames_per_s": a.batch / seam_s, "ms_per_call": seam_s * 1e3, "frames_per_call": a.batch,
                 "pinned_frames_per_s": a.batch / pin_s, "pinned_ms_per_call": pin_s * 1e3,
+                "pipelined_frames_per_s": a.batch / pipe_s, "pipelined_ms_per_call": pipe_s * 1e3,
+                "pipelined_call": "arp_clip_label_submit / arp_clip_label_collect, two calls in flight; bit-identical: " + str(bool(np.array_equal(r_pipe, rewards))),
                 "call": "arp_clip_label(host uint8 frames [n,256,256,3] -> host float32 rewards): upload over PCIe, label, download",
                 "bit_identical_to_hbm_resident": bool(np.array_equal(r_host, rewards))}
 
@@ -583,7 +596,7 @@ def main():
     # isolated per-kernel figures: the same steps on ONE stream (no other kernel shares the chip with a launch)
     iso = None
     nsplit = max(1, min(a.streams, a.batch // 128))  # parts a batch is labelled in, one HIP stream each (label_dev in arp_clip.hip)
-    if nsplit > 1:
+    if nsplit > 1 and not a.timed_only:
         model.set_streams(1)
         step()
         model.sync()
@@ -600,7 +613,7 @@ def main():
     # it is not re-timed here (a second handle's streams shared hardware queues with the first's under the runtime's default of 4
     # queues and ran at the single-stream rate, whichever mode came second; arp_amd._ffi now asks for 8).
     alt = None
-    if rank == 0 and world == 1 and a.mode == "f16" and a.alt_bf16 and parity is not None:
+    if rank == 0 and world == 1 and a.mode == "f16" and a.alt_bf16 and parity is not None and not a.timed_only:
         m2 = clip.ClipLabeller(cfg, weights, mode="bf16", device=local_rank, max_batch=a.batch, n_streams=1).set_text(tokens)
         err2 = float(np.abs(m2.label(fr) - ref).max() / np.exp(float(weights["logit_scale"])))
         m2.close()

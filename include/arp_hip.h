@@ -96,6 +96,11 @@ int arp_clip_get_text_features(arp_clip* h, float* out /* [n_prompts, embed], L2
  * = exp(logit_scale) * cos(image, prompt 0).  use_crop selects the transform of label_reward.py:92-102. */
 int arp_clip_label(arp_clip* h, const uint8_t* frames_host, int n, int H, int W, int use_crop, float* rewards_host);
 /* Same, frames and rewards already in device memory; enqueued on the handle's stream. */
+/* Asynchronous form of arp_clip_label for a STREAM of calls (n <= max_batch each): submit() enqueues upload + pass + download on slot
+ * 0 / 1 and returns, collect() waits for that slot.  Submitting call i+1 before collecting call i keeps the compute streams full across
+ * calls (a synchronous call pays the pipeline's fill and drain every time).  `frames` must stay valid until collect() of the slot. */
+int arp_clip_label_submit(arp_clip* h, int slot, const uint8_t* frames_host, int n, int H, int W, int use_crop);
+int arp_clip_label_collect(arp_clip* h, int slot, float* rewards_host);
 int arp_clip_label_dev_async(arp_clip* h, const uint8_t* frames_dev, int n, int H, int W, int use_crop,
                              float* rewards_dev);
 int arp_clip_sync(arp_clip* h);

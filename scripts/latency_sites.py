@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Row N4: where a single-frame reward's latency goes -- per call-site device time (HIP events) beside the wall time of the call."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from arp_amd import clip, synth
+
+for name in ("ViT-B/16", "ViT-B/32"):
+    cfg = clip.MODELS[name]
+    m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), mode="f16", max_batch=64, n_streams=1).set_text(synth.prompt_tokens(1, 8, seed=2))
+    fr = synth.procgen_like_frames(8, seed=3)
+    for n in (1, 8):
+        for _ in range(5):
+            m.label(fr[:n])
+        t0 = time.perf_counter()
+        for _ in range(50):
+            m.label(fr[:n])
+        wall = (time.perf_counter() - t0) / 50 * 1e3
+        m.profile(True); m.profile_reset()
+        for _ in range(20):
+            m.label(fr[:n])
+        s = m.profile_read(); m.profile(False)
+        tot = sum(v["ms"] for v in s.values()) / 20
+        calls = sum(v["calls"] for v in s.values()) / 20
+        top = sorted(((k, v["ms"] / 20, v["calls"] / 20) for k, v in s.items()), key=lambda t: -t[1])[:10]
+        print(f"{name} n={n}: wall {wall:.3f} ms per call; device {tot:.3f} ms in {calls:.0f} launches; " + ", ".join(f"{k} {ms*1e3:.0f}us/{c:.0f}" for k, ms, c in top), flush=True)
+    m.close()

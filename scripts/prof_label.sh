@@ -4,7 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 --cpu-seconds 0 --parity-frames 0 --no-secondary"
+ARGS="--steps 20 --warmup 5 --cpu-seconds 0 --parity-frames 0 --no-secondary --timed-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --parity-frames 0 --no-secondary > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --parity-frames 0 --no-secondary > $R/gpurun_out/prof_${TAG}_write.log 2>&1

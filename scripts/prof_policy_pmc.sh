@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 export ARP_DT_GRAPH=0
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/prof_r2_policy_$C -- python3 $R/bench.py --path policy --steps 3 --warmup 2 --cpu-seconds 0 > $R/gpurun_out/prof_r2_policy_$C.log 2>&1
-  find $R/gpurun_out/prof_r2_policy_$C -name "*kernel_trace.csv" -delete
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/prof_r3_policy_$C -- python3 $R/bench.py --path policy --steps 3 --warmup 2 --cpu-seconds 0 > $R/gpurun_out/prof_r3_policy_$C.log 2>&1
+  find $R/gpurun_out/prof_r3_policy_$C -name "*kernel_trace.csv" -delete
 done
-ls -la $R/gpurun_out/prof_r2_policy_*/*/ | head
+ls -la $R/gpurun_out/prof_r3_policy_*/*/ | head

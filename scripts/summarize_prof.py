@@ -75,5 +75,16 @@ for site, subs in SITES.items():
                          "write_KiB": e["WRITE_SIZE_KiB_avg"], "kernel": e["kernel"], "grid_threads": e["grid_threads"],
                          "frames_per_launch": FRAMES_PER_LAUNCH, "round": tag,
                          "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), profiles/{tag}_pmc_summary.json"}
+# MFMA-pipe utilisation of the same kernels, measured alone (scripts/prof_mfma.sh -> gpurun_out/<tag>_mfma_util.json): bench.py prints it
+# next to the roofline fraction of the dominant kernel
+mf = os.path.join(ROOT, "gpurun_out", f"{tag}_mfma_util.json")
+if os.path.exists(mf):
+    shutil.copy(mf, os.path.join(out_dir, f"{tag}_mfma_util.json"))
+    util = json.load(open(mf))
+    for site, rec in traffic.items():
+        e = util.get(f"{rec['kernel']} | grid={rec['grid_threads']}")
+        if e and "MfmaUtil_avg" in e:
+            rec["mfma_util_pct"] = round(e["MfmaUtil_avg"], 2)
+            rec["sq_wait_any_frac"] = round(e.get("SQ_WAIT_ANY_frac_of_wave_cycles", float("nan")), 3)
 json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic, indent=1))

@@ -371,3 +371,35 @@ def test_label_reward_from_hdf5_file(gpu_lib, tmp_path):
         got = np.concatenate([f["ob_clip_reward"][0:3, -1], f["ob_clip_reward"][3:4, -1]])
     assert np.abs(got - orc).max() / float(np.exp(Wt["logit_scale"])) < COS_TOL_F32
     m.close()
+
+
+def test_pipelined_submit_collect_equals_synchronous_label(gpu_lib):
+    """arp_clip_label_submit / _collect (two host-fed calls in flight): rewards bit-identical to arp_clip_label, any interleaving of the
+    two slots, ragged sizes, pinned and pageable sources; misuse (busy slot, empty slot, oversize) is an error, not a hang."""
+    from arp_amd import clip, synth
+    from arp_amd._ffi import ArpError
+    from oracle import clip_np as C
+    kw = dict(MID)
+    W = synth.clip_weights(C.ClipConfig(**kw), seed=5)
+    m = clip.ClipLabeller(clip.ClipConfig(**kw), W, mode="f16", max_batch=300, n_streams=2).set_text(synth.prompt_tokens(1, 6, vocab=kw["vocab"], seed=6))
+    sets = [synth.procgen_like_frames(n, seed=10 + i) for i, n in enumerate((300, 17, 256, 129, 300))]
+    ref = [m.label(f) for f in sets]
+    m.pin_host(sets[2])
+    got = [None] * len(sets)
+    m.label_submit(0, sets[0])
+    for i in range(1, len(sets)):
+        m.label_submit(i & 1, sets[i])
+        got[i - 1] = m.label_collect((i - 1) & 1)
+    got[-1] = m.label_collect((len(sets) - 1) & 1)
+    m.unpin_host(sets[2])
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    m.label_submit(0, sets[1])
+    with pytest.raises(ArpError):
+        m.label_submit(0, sets[1])          # the slot is busy
+    m.label_collect(0)
+    with pytest.raises(ArpError):
+        m.label_collect(1)                  # nothing submitted
+    with pytest.raises(ArpError):
+        m.label_submit(1, synth.procgen_like_frames(301, seed=3))  # more than max_batch
+    m.close()

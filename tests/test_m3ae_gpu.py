@@ -107,3 +107,40 @@ def test_policy_logits_with_the_f16_encoder_inside_full_geometry(gpu_lib):
     print("policy logits / return with the encoder inside, full geometry: " + ", ".join(f"{m} seed {s}: {e:.2e}" for (m, s), e in errs.items()))
     assert max(e for (m, s), e in errs.items() if m == "f32") < 5e-5
     assert max(e for (m, s), e in errs.items() if m == "f16") < 1.6e-3  # NOT north_star's 1e-3: see the docstring
+
+
+def test_prefetched_frames_with_the_encoder_inside_equal_the_synchronous_path(gpu_lib):
+    """prefetch_to_device with the frozen encoder attached: FRAMES go up into the device slots (arp_dt_upload_batch_images_async) while the
+    step on the other slot runs; the trajectory equals set_batch_images' synchronous one."""
+    from arp_amd import m3ae, synth_policy as S
+    from arp_amd.train import PolicyConfig, TrainState, create_train_step, prefetch_to_device
+    from oracle import m3ae_np as M
+    ecfg = m3ae.EncoderConfig(**TINY_ENC)
+    pcfg = PolicyConfig(emb=64, depth=2, heads=4, window=3, enc_tokens=ecfg.tokens, enc_dim=ecfg.width, lambda_ret=0.5)
+    EP = S.m3ae_params(M.EncConfig(**TINY_ENC), seed=5)
+    P = S.policy_params(pcfg, seed=6)
+    rng = np.random.default_rng(9)
+    batches = []
+    for i in range(5):
+        frames = S.normalized_frames(4 * pcfg.window, ecfg.img_res, seed=20 + i).reshape(4, pcfg.window, ecfg.img_res, ecfg.img_res, 3)
+        batches.append({"image": {"ob": frames}, "action": rng.integers(0, pcfg.n_actions, (4, pcfg.window)).astype(np.int32),
+                        "rtg": {"ob": rng.random((4, pcfg.window, 1)).astype(np.float32)}})
+    out = {}
+    for name in ("sync", "prefetch"):
+        enc = m3ae.M3AEEncoder(ecfg, EP, mode="f32")
+        state = TrainState.create(pcfg, P, mode="f32")
+        state.trainer.attach_encoder(enc)
+        fn = create_train_step(pcfg, lambda step: 1e-3, pcfg.weight_decay)
+        losses = []
+        if name == "sync":
+            for b in batches:
+                state.trainer.set_batch_images(b["image"]["ob"], b["action"], b["rtg"]["ob"])
+                losses.append(state.trainer.train_step(1e-3)["loss"])
+        else:
+            for b in prefetch_to_device(iter(batches), 2, state.trainer):
+                state, aux, _ = fn(state, b, None)
+                losses.append(aux["loss"])
+        out[name] = (losses, state.trainer.get_params())
+        state.trainer.close(); enc.close()
+    assert out["sync"][0] == out["prefetch"][0]
+    assert all(np.array_equal(out["sync"][1][k], out["prefetch"][1][k]) for k in out["sync"][1])
