@@ -171,6 +171,7 @@ SIGNATURES = {
     "arp_h5_inflate_last_frames": (_i, [_i, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _u8p, C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _u8p, _i]),
     "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
+    "arp_op_skinny_gemm": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _f, _fp]),
     "arp_op_gemm_fp8": (_i, [_i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _f]),
     "arp_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "arp_op_gemm_tn": (_i, [_i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _f]),

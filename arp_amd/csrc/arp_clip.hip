@@ -106,6 +106,28 @@ struct arp_clip {
     bool qkv_fused = true;      // QKV projection + attention in one kernel (qkvattn.h) where the geometry allows; ARP_QKV_FUSED=0 disables
     bool cls_only_last = true;  // vision tower: the last block computes only what ln_post reads (tower.h); ARP_CLS_ONLY=0 disables
     DevBuf stats;
+    // latency path (get_torch_clip_reward): split-K slabs of the skinny GEMMs (tower.h), and the whole pass over
+    // <= SKINNY_MAX_M token rows -- preprocess .. reward, ~80 launches -- replayed as ONE hipGraph per (buffers, geometry): the host then
+    // pays one graph launch instead of 80 kernel launches that each cost more host time than the kernel runs
+    DevBuf part;
+    bool skinny = true;     // ARP_SKINNY=0: the output-tiled GEMMs at every size
+    bool lat_now = false;   // the pass being enqueued has at most SKINNY_MAX_M token rows (set by forward_chunk)
+    bool lat_graph = true;  // ARP_CLIP_GRAPH=0: launch by launch
+    struct LatGraph {
+        const uint8_t* frames;
+        float* rewards;
+        int n, H, W, crop;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    };
+    std::vector<LatGraph> lat_graphs;
+    // host-fed single-frame calls: the frame is copied into pinned memory by the CPU and the preprocess kernel reads it over PCIe;
+    // the reward kernel writes into pinned memory -- no copy operations on the stream at all (ARP_CLIP_PINNED=0: hipMemcpyAsync both ways)
+    uint8_t* pin_frames = nullptr;
+    size_t pin_frames_bytes = 0;
+    float* pin_rewards = nullptr;
+    size_t pin_rewards_n = 0;
+    bool lat_pinned = true;
 
     int ntok() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
     size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
@@ -122,6 +144,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.qkv_fused = c->qkv_fused;
     t.fp8_mlp = c->fp8_mlp;
     t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
+    t.skinny = c->lat_now; t.part = c->part.as<float>(); t.part_floats = c->part.bytes / 4;
     return t;
 }
 
@@ -287,8 +310,21 @@ static int run_blocks(arp_clip* c, const TowerW& tw, const char* tag, float* x, 
 }
 
 
+// every captured pass holds raw pointers into the workspace, the prompt features and the kernel arguments of its day
+static void drop_lat_graphs(arp_clip* c) {
+    for (auto& g : c->lat_graphs) {
+        (void)hipGraphExecDestroy(g.exec);
+        (void)hipGraphDestroy(g.graph);
+    }
+    c->lat_graphs.clear();
+}
+
 static int ensure_workspace(arp_clip* c, int frames) {
     if (frames <= c->ws_frames) return 0;
+    if (!c->lat_graphs.empty()) {
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+        drop_lat_graphs(c);
+    }
     const arp_clip_cfg& k = c->cfg;
     const size_t e = c->esz();
     const int G = k.img_res / k.patch, N = c->ntok(), D = k.width;
@@ -307,15 +343,15 @@ static int ensure_workspace(arp_clip* c, int frames) {
     return 0;
 }
 
-static int get_plan(arp_clip* c, int H, int W, int use_crop, ResizePlan** out) {
-    const long long key = ((long long)H << 32) | ((long long)W << 1) | (use_crop ? 1 : 0);
+static int get_plan(arp_clip* c, int H, int W, int use_crop, ResizePlan** out, bool small = false) {
+    const long long key = ((long long)H << 32) | ((long long)W << 2) | (small ? 2 : 0) | (use_crop ? 1 : 0);
     auto it = c->plans.find(key);
     if (it != c->plans.end()) {
         *out = it->second;
         return 0;
     }
     ResizePlan* p = new ResizePlan();
-    const int r = build_plan(H, W, use_crop, c->cfg.img_res, *p);
+    const int r = build_plan(H, W, use_crop, c->cfg.img_res, *p, small ? 8 : 32);
     if (r != 0) {
         delete p;
         return r;
@@ -330,6 +366,11 @@ template <typename T>
 static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizePlan* plan) {
     const arp_clip_cfg& k = c->cfg;
     const int G = k.img_res / k.patch, N = c->ntok(), D = k.width, KP = 3 * k.patch * k.patch;
+    c->lat_now = c->skinny && sizeof(T) == 2 && (long)nb * N <= SKINNY_MAX_M;
+    struct LatGuard {
+        arp_clip* c;
+        ~LatGuard() { c->lat_now = false; }
+    } lat_guard{c};
     if (c->pre_bilinear) {
         ProfScope ps(c->prof, c->stream, "preprocess_bilinear");
         const int H = c->pre_bilinear >> 16, W = c->pre_bilinear & 0xffff, R = k.img_res;
@@ -440,17 +481,48 @@ static int label_dev_single(arp_clip* c, const uint8_t* frames_dev, int n, int H
     if (n == 0) return 0;
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     ResizePlan* plan;
-    ARP_TRY(get_plan(c, H, W, use_crop, &plan));
     const int mb = c->cfg.max_batch;
+    const bool small = !c->is_sibling && n <= mb && (long)n * c->ntok() <= SKINNY_MAX_M;  // the rollout loop's call (one frame, or a few)
+    ARP_TRY(get_plan(c, H, W, use_crop, &plan, small));
     ARP_TRY(ensure_workspace(c, std::min(n, mb)));
     const float scale = expf(c->logit_scale);
-    for (int off = 0; off < n; off += mb) {
-        const int nb = std::min(mb, n - off);
-        ARP_TRY(forward_chunk_dispatch(c, frames_dev + (size_t)off * H * W * 3, nb, plan));
+    auto pass = [&](const uint8_t* fr, int nb, float* rw) -> int {
+        ARP_TRY(forward_chunk_dispatch(c, fr, nb, plan));
         ProfScope ps(c->prof, c->stream, "reward");
         hipLaunchKernelGGL(reward_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, c->feat.as<float>(), c->txt_feat.as<float>(),
-                           scale, rewards_dev + off, nb, c->cfg.embed);
+                           scale, rw, nb, c->cfg.embed);
         ARP_HIP_OK(hipGetLastError());
+        return 0;
+    };
+    // replay the captured pass
+    if (c->lat_graph && small && !c->prof.on && !c->ms_out && !c->pre_bilinear) {
+        for (auto& g : c->lat_graphs)
+            if (g.frames == frames_dev && g.rewards == rewards_dev && g.n == n && g.H == H && g.W == W && g.crop == use_crop) {
+                ARP_HIP_OK(hipGraphLaunch(g.exec, c->stream));
+                return 0;
+            }
+        arp_clip::LatGraph g{frames_dev, rewards_dev, n, H, W, use_crop, nullptr, nullptr};
+        ARP_HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = pass(frames_dev, n, rewards_dev);
+        const hipError_t ec = hipStreamEndCapture(c->stream, &g.graph);
+        if (rc != 0) {
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+            return rc;
+        }
+        ARP_HIP_OK(ec);
+        ARP_HIP_OK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        if (c->lat_graphs.size() >= 8) {  // a caller that keeps changing buffers: forget the oldest
+            (void)hipGraphExecDestroy(c->lat_graphs.front().exec);
+            (void)hipGraphDestroy(c->lat_graphs.front().graph);
+            c->lat_graphs.erase(c->lat_graphs.begin());
+        }
+        c->lat_graphs.push_back(g);
+        ARP_HIP_OK(hipGraphLaunch(g.exec, c->stream));
+        return 0;
+    }
+    for (int off = 0; off < n; off += mb) {
+        const int nb = std::min(mb, n - off);
+        ARP_TRY(pass(frames_dev + (size_t)off * H * W * 3, nb, rewards_dev + off));
     }
     return 0;
 }
@@ -467,6 +539,9 @@ static int make_sibling(arp_clip* c) {
     s->ws_frames = 0;
     DevBuf* bufs[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards, &s->stats};
     for (auto* b : bufs) *b = DevBuf();
+    s->part = DevBuf();  // the latency path never runs on a sibling (parts of >= 128 frames)
+    s->lat_graphs.clear();
+    s->pin_frames = nullptr; s->pin_frames_bytes = 0; s->pin_rewards = nullptr; s->pin_rewards_n = 0;
     s->stream = nullptr;
     s->ev_fork = nullptr;
     s->copy_stream = nullptr;
@@ -622,6 +697,9 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     if (const char* e = getenv("ARP_LN_FOLD")) c->ln_fold = atoi(e) != 0;
     if (const char* e = getenv("ARP_CLS_ONLY")) c->cls_only_last = atoi(e) != 0;
     if (const char* e = getenv("ARP_QKV_FUSED")) c->qkv_fused = atoi(e) != 0;
+    if (const char* e = getenv("ARP_SKINNY")) c->skinny = atoi(e) != 0;
+    if (const char* e = getenv("ARP_CLIP_GRAPH")) c->lat_graph = atoi(e) != 0;
+    if (const char* e = getenv("ARP_CLIP_PINNED")) c->lat_pinned = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail("hipStreamCreate failed");
@@ -654,6 +732,10 @@ int arp_clip_destroy(arp_clip* c) {
         if (ls.done) (void)hipEventDestroy(ls.done);
     }
     c->prof.destroy();
+    drop_lat_graphs(c);
+    c->part.release();
+    if (c->pin_frames) (void)hipHostFree(c->pin_frames);
+    if (c->pin_rewards) (void)hipHostFree(c->pin_rewards);
     for (void* p : c->owned) (void)hipFree(p);
     for (auto& kv : c->plans) {
         kv.second->h_tab.release();
@@ -714,6 +796,7 @@ int arp_clip_finalize_weights(arp_clip* c) {
     std::vector<float> lut(768);
     build_lut(lut.data());
     ARP_TRY(upload_f32(c, lut, &c->lut));
+    ARP_TRY(c->part.ensure((size_t)4 * SKINNY_MAX_M * std::max(D, Tw) * 4));
     c->staged.clear();
     c->finalized = true;
     return 0;
@@ -723,6 +806,10 @@ int arp_clip_set_text(arp_clip* c, const int32_t* tokens, int n_prompts) {
     ARP_TRY(check_ready(c, false));
     if (!tokens || n_prompts <= 0) return fail("set_text: need at least one prompt");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    if (!c->lat_graphs.empty()) {  // the captured passes read the old prompt features
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+        drop_lat_graphs(c);
+    }
     // 16-bit handles: the cached prompt features come from the f32 copy of the text tower (arp_clip::txt32); ARP_TEXT_F32=0 keeps
     // the handle's own operand type (A/B measurements)
     static const bool text32 = [] { const char* e = getenv("ARP_TEXT_F32"); return !e || atoi(e) != 0; }();
@@ -758,6 +845,27 @@ int arp_clip_label(arp_clip* c, const uint8_t* frames, int n, int H, int W, int 
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     const size_t fb = (size_t)H * W * 3;
     const int mb = c->cfg.max_batch;
+    if (c->lat_pinned && n <= mb && (long)n * c->ntok() <= SKINNY_MAX_M) {
+        if (c->pin_frames_bytes < (size_t)n * fb) {
+            ARP_HIP_OK(hipStreamSynchronize(c->stream));
+            if (c->pin_frames) ARP_HIP_OK(hipHostFree(c->pin_frames));
+            c->pin_frames = nullptr; c->pin_frames_bytes = 0;
+            ARP_HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c->pin_frames), (size_t)n * fb, hipHostMallocDefault));
+            c->pin_frames_bytes = (size_t)n * fb;
+        }
+        if (c->pin_rewards_n < (size_t)n) {
+            ARP_HIP_OK(hipStreamSynchronize(c->stream));
+            if (c->pin_rewards) ARP_HIP_OK(hipHostFree(c->pin_rewards));
+            c->pin_rewards = nullptr; c->pin_rewards_n = 0;
+            ARP_HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c->pin_rewards), (size_t)std::max(n, 16) * 4, hipHostMallocDefault));
+            c->pin_rewards_n = (size_t)std::max(n, 16);
+        }
+        memcpy(c->pin_frames, frames, (size_t)n * fb);
+        ARP_TRY(label_dev_single(c, c->pin_frames, n, H, W, use_crop, c->pin_rewards));
+        ARP_HIP_OK(hipStreamSynchronize(c->stream));
+        memcpy(rewards, c->pin_rewards, (size_t)n * 4);
+        return 0;
+    }
     ARP_TRY(c->frames_in.ensure((size_t)std::min(n, mb) * fb));
     ARP_TRY(c->rewards.ensure((size_t)std::min(n, mb) * 4));
     for (int off = 0; off < n; off += mb) {
@@ -1082,7 +1190,55 @@ template <typename T> static int op_gemm(int act, const float* A, const float* W
     return rc;
 }
 
+// The latency path's GEMM (skinny.h) on host arrays.  ksplit = 0: one launch with the bias / activation / residual epilogue;
+// ksplit >= 1: raw split-K slabs + the row kernel: out = resid + bias + A.W^T (resid required), h_out = LayerNorm(out) when ln_w is given.
+template <typename T> static int op_skinny(int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N, int K,
+                                           int ksplit, const float* ln_w, const float* ln_b, float eps, float* h_out) {
+    DevBuf dA, dW, dB, dR, dO, dP, dH, dLw, dLb;
+    const int tcode = __is_same(T, bf16_t) ? 1 : 2;
+    auto body = [&]() -> int {
+        ARP_TRY(to_dev<T>(A, (size_t)M * K, dA)); ARP_TRY(to_dev<T>(W, (size_t)N * K, dW));
+        if (bias) ARP_TRY(to_dev<float>(bias, N, dB));
+        SkinnyArgs k;
+        k.A = dA.p; k.W = dW.p; k.M = M; k.N = N; k.K = K; k.lda = K; k.ldw = K; k.ldr = N; k.ldo = N; k.out_f32 = 1;
+        if (ksplit == 0) {
+            ARP_TRY(dO.ensure((size_t)M * N * 4));
+            if (resid) ARP_TRY(to_dev<float>(resid, (size_t)M * N, dR));
+            k.bias = bias ? dB.as<float>() : nullptr; k.resid = resid ? dR.as<float>() : nullptr; k.out = dO.p; k.act = act;
+            ARP_TRY(launch_skinny_gemm(tcode, k, nullptr));
+            ARP_HIP_OK(hipDeviceSynchronize());
+            return from_dev<float>(out, (size_t)M * N, dO);
+        }
+        if (!resid || act != ACT_NONE) return fail("skinny split: needs the residual, takes no activation");
+        ARP_TRY(to_dev<float>(resid, (size_t)M * N, dR));
+        ARP_TRY(dP.ensure((size_t)ksplit * M * N * 4));
+        if (ln_w) {
+            if (!ln_b || !h_out) return fail("skinny split: ln_w needs ln_b and h_out");
+            ARP_TRY(to_dev<float>(ln_w, N, dLw)); ARP_TRY(to_dev<float>(ln_b, N, dLb)); ARP_TRY(dH.ensure((size_t)M * N * sizeof(T)));
+        }
+        k.out = dP.p; k.ksplit = ksplit; k.slice_stride = (size_t)M * N;
+        ARP_TRY(launch_skinny_gemm(tcode, k, nullptr));
+        ARP_TRY(launch_skinny_reduce_ln(tcode, dP.as<float>(), ksplit, (size_t)M * N, bias ? dB.as<float>() : nullptr, dR.as<float>(), N, dH.p, N,
+                                        ln_w ? dLw.as<float>() : nullptr, ln_w ? dLb.as<float>() : nullptr, M, N, eps, nullptr));
+        ARP_HIP_OK(hipDeviceSynchronize());
+        ARP_TRY(from_dev<float>(out, (size_t)M * N, dR));
+        if (ln_w) ARP_TRY(from_dev<T>(h_out, (size_t)M * N, dH));
+        return 0;
+    };
+    const int rc = body();
+    dA.release(); dW.release(); dB.release(); dR.release(); dO.release(); dP.release(); dH.release(); dLw.release(); dLb.release();
+    return rc;
+}
+
 extern "C" {
+
+int arp_op_skinny_gemm(int mode, int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N, int K, int ksplit,
+                       const float* ln_w, const float* ln_b, float eps, float* h_out) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K <= 0 || ksplit < 0) return fail("bad argument");
+    if (mode == ARP_MODE_BF16) return op_skinny<bf16_t>(act, A, W, bias, resid, out, M, N, K, ksplit, ln_w, ln_b, eps, h_out);
+    if (mode == ARP_MODE_F16) return op_skinny<f16_t>(act, A, W, bias, resid, out, M, N, K, ksplit, ln_w, ln_b, eps, h_out);
+    return fail("skinny gemm: 16-bit modes only");
+}
 
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N,
                    int K) {

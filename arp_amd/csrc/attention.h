@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
     // (Two query blocks per wave at a time, so that each K / V^T fragment read feeds two MFMAs: 245-256 VGPRs plus accumulation
     //  registers -- one workgroup per CU instead of two, 100 us against 51 us at N = 197.  The full score row of a block, NT x 4
     //  registers, is what makes this kernel register-bound.)
-    for (int qb = wave; qb < nqb; qb += 4) {
+    // gridDim.y > 1 (the single-frame tower: 12 workgroups would otherwise walk 13 query blocks on 4 waves each): the query blocks are
+    // dealt over gridDim.y workgroups, each of which stages the whole K / V image of its head
+    for (int qb = wave + 4 * (int)blockIdx.y; qb < nqb; qb += 4 * (int)gridDim.y) {
         int qrow = qb * 16 + fr;
         const int qvalid = qrow < N;
         qrow = qvalid ? qrow : N - 1;

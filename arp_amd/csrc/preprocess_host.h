@@ -79,7 +79,9 @@ static void pack_table(const ResampleTable& t, int first, int R, std::vector<int
     }
 }
 
-static int build_plan(int H, int W, int use_crop, int R, ResizePlan& p) {
+// tr_start: the largest tile (output rows per workgroup) tried.  32 for batches (R / 32 = 7 workgroups per frame, thousands per launch);
+// the single-frame pass asks for 4 (56 workgroups for its one frame: 17 -> ~5 us)
+static int build_plan(int H, int W, int use_crop, int R, ResizePlan& p, int tr_start = 32) {
     if (H <= 0 || W <= 0 || R <= 0 || (R & 3)) return fail("preprocess: bad geometry");
     p.H = H; p.W = W; p.use_crop = use_crop; p.R = R;
     int top = 0, left = 0;  // CenterCrop(R) offsets after the resize (non-crop transform)
@@ -107,7 +109,7 @@ static int build_plan(int H, int W, int use_crop, int R, ResizePlan& p) {
     p.kmax_h = th.kmax; p.kmax_v = tv.kmax;
     // rows of input needed by a tile of TR output rows; shrink TR until the LDS carve fits the budget
     const int row_bytes = p.cw * 3;
-    for (p.TR = 32; p.TR >= 1; p.TR >>= 1) {
+    for (p.TR = tr_start; p.TR >= 1; p.TR >>= 1) {
         int need = 0;
         for (int o0 = 0; o0 < R; o0 += p.TR) {
             const int o1 = std::min(o0 + p.TR, R) - 1;

@@ -1,0 +1,52 @@
+// Skinny NT GEMM for the LATENCY path: M <= 256 rows (one frame's 50 / 197 tokens, a handful of class rows).
+//
+// The throughput kernels (gemm.h, gemm256.h) tile the OUTPUT: at M = 50 a [50, 768] x [768, 3072]^T product is 24 tiles of
+// 128 x 128 on a 256-CU chip, and a K = 3072 one is 6 workgroups that each walk 48 K-tiles one memory round trip at a time
+// (37 us per c_proj launch at one frame: profiles/r3_latency_sites_before.txt).  At this size the product is neither MFMA- nor
+// HBM-bound but LATENCY-bound: what matters is that every byte of W is requested at once, from as many CUs as there are.
+//
+// So this kernel tiles W instead:  one workgroup = 16 output columns (16 rows of W), NW waves, wave w owns the K range
+// [w, w+1) * K / NW of those rows.  A wave issues ALL its loads up front -- its W fragments (16 rows x 64 B per MFMA k-step,
+// straight into the MFMA operand layout: no LDS staging, no barrier) and the activation fragments of every 16-row m-tile
+// (L2-resident: the activations are a few hundred KB) -- then MT x KS MFMAs, then the NW partial tiles are summed through LDS
+// in a fixed order (deterministic) and the epilogue (bias, activation, f32 residual, f32 / 16-bit store) runs on the sum.
+// grid.x = N / 16 (48 - 192 workgroups for the tower's GEMMs), grid.y = cross-workgroup K split (c_proj, K = 3072: raw f32
+// partial slabs, summed by skinny_reduce_ln_kernel together with bias + residual + the NEXT LayerNorm, which is a launch the
+// tower needs anyway).
+#pragma once
+#include "common.h"
+
+namespace arp {
+
+struct SkinnyArgs {
+    const void* A = nullptr;       // [M, lda] T (f16 / bf16)
+    const void* W = nullptr;       // [N, ldw] T
+    const float* bias = nullptr;   // [N] or null
+    const float* resid = nullptr;  // [M, ldr] f32 or null (out_f32 only; may alias out)
+    void* out = nullptr;           // [M, ldo] T or f32;  ksplit > 1: f32 slabs out + s * slice_stride, raw products
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldw = 0, ldr = 0, ldo = 0;
+    int act = 0;       // enum Act
+    int out_f32 = 0;
+    int ksplit = 1;
+    size_t slice_stride = 0;
+    int rotate = 1;    // 0: every workgroup walks the m-tiles in the same order (A/B switch of the harness)
+};
+
+constexpr int SKINNY_MAX_M = 256;
+
+// true when launch_skinny_gemm accepts the geometry
+inline bool skinny_supported(int M, int N, int K, int lda, int ldw, int ksplit = 1) {
+    return M >= 1 && M <= SKINNY_MAX_M && N >= 16 && (N & 15) == 0 && K >= 32 && ksplit >= 1 && (K % (32 * ksplit)) == 0 && (lda & 7) == 0 &&
+           (ldw & 7) == 0;
+}
+
+// tcode: 1 = bf16, 2 = f16
+int launch_skinny_gemm(int tcode, const SkinnyArgs& g, hipStream_t stream);
+
+// x[r] (f32, row stride x_stride) = x[r] + bias + sum_s part[s][r][:] ;  h[r] = LayerNorm(x[r]) as T when ln_w != null.
+// One wave per row; `part` slabs are [rows, D] f32 with stride slice_stride between slabs.
+int launch_skinny_reduce_ln(int tcode, const float* part, int S, size_t slice_stride, const float* bias, float* x, size_t x_stride, void* h,
+                            int h_stride, const float* ln_w, const float* ln_b, int rows, int D, float eps, hipStream_t stream);
+
+}  // namespace arp

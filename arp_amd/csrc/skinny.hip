@@ -1,0 +1,206 @@
+// Latency-path kernels: the W-tiled skinny GEMM and the slab-reduce + residual + LayerNorm row kernel (skinny.h).
+#include "skinny.h"
+
+#include "rowops.h"
+
+namespace arp {
+
+namespace {
+
+__device__ __forceinline__ float act_rt(int act, float x) {
+    switch (act) {
+        case ACT_QGELU: return apply_act<ACT_QGELU>(x);
+        case ACT_RELU: return apply_act<ACT_RELU>(x);
+        case ACT_TANH: return apply_act<ACT_TANH>(x);
+        case ACT_GELU_TANH: return apply_act<ACT_GELU_TANH>(x);
+        default: return x;
+    }
+}
+
+// MT = 16-row m-tiles, KS = MFMA k-steps (32 elements) per chunk; a wave walks chunks of 32 * KS elements of its K range.
+template <typename T, int MT, int KS>
+__global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4_v* red = reinterpret_cast<f32x4_v*>(smem);  // [NW][MT][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int slice = blockIdx.y;
+    const int kslice = g.K / (int)gridDim.y;
+    const int kw = kslice / NW;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int kbase = slice * kslice + wave * kw + fg * 8;
+    const T* __restrict__ wp = static_cast<const T*>(g.W) + (size_t)(n0 + fr) * g.ldw + kbase;
+    const T* __restrict__ ap[MT];
+    // slot t works on m-tile mrow[t]: rotated by the workgroup index, so that the workgroups of one XCD -- which all read the same
+    // activations -- are not all asking the same L2 channel for the same line at the same moment
+    const int mtd = (g.M + 15) >> 4;
+    const int rot = g.rotate ? (int)(blockIdx.x % (unsigned)mtd) : 0;
+    int mrow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        mrow[t] = t < mtd ? (t + rot >= mtd ? t + rot - mtd : t + rot) : t;
+        int m = mrow[t] * 16 + fr;
+        m = m < g.M ? m : g.M - 1;  // rows past M: computed on valid memory, never stored
+        ap[t] = static_cast<const T*>(g.A) + (size_t)m * g.lda + kbase;
+    }
+    f32x4_v acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < kw; c += 32 * KS) {
+        // every load of the chunk is issued before the first MFMA (left to itself the compiler keeps ~7 in flight and interleaves the
+        // rest behind waits: two or three memory round trips instead of one)
+        u32x4_v wf[KS], af[MT][KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) wf[j] = *reinterpret_cast<const u32x4_v*>(wp + c + 32 * j);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < KS; ++j) af[t][j] = *reinterpret_cast<const u32x4_v*>(ap[t] + c + 32 * j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = mfma16<T>(wf[j], af[t][j], acc[t]);  // swapped: D[n = 4 fg + i][m = fr]
+    }
+    // lane holds, per m-tile, 4 consecutive output columns n0 + 4 fg .. + 3 of row 16 t + fr
+    auto epilogue = [&](int t, f32x4_v v) {
+        const int mt_ = t < mtd ? (t + rot >= mtd ? t + rot - mtd : t + rot) : t;
+        const int m = mt_ * 16 + fr, n = n0 + fg * 4;
+        if (m >= g.M) return;
+        if (gridDim.y > 1) {
+            *reinterpret_cast<f32x4_v*>(static_cast<float*>(g.out) + (size_t)slice * g.slice_stride + (size_t)m * g.ldo + n) = v;
+            return;
+        }
+        float r[4] = {v[0], v[1], v[2], v[3]};
+        if (g.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+            r[0] += b.x; r[1] += b.y; r[2] += b.z; r[3] += b.w;
+        }
+        if (g.act != ACT_NONE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = act_rt(g.act, r[i]);
+        }
+        if (g.out_f32) {
+            if (g.resid) {
+                const float4 q = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+                r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
+            }
+            store4(static_cast<float*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
+        } else {
+            store4(static_cast<T*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
+        }
+    };
+    if (NW == 1) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) epilogue(t, acc[t]);
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) red[(wave * MT + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    for (int t = wave; t < MT; t += NW) {
+        f32x4_v s = red[t * 64 + lane];
+        for (int v = 1; v < NW; ++v) s += red[(v * MT + t) * 64 + lane];  // fixed order: waves 0 .. NW-1
+        epilogue(t, s);
+    }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(64) void skinny_reduce_ln_kernel(const float* __restrict__ part, int S, size_t slice_stride, const float* __restrict__ bias,
+                                                              float* __restrict__ x, size_t x_stride, T* __restrict__ h, int h_stride,
+                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, int D, float eps) {
+    const int lane = threadIdx.x, row = blockIdx.x;
+    float* xr = x + (size_t)row * x_stride;
+    const float* pr = part + (size_t)row * D;
+    float v[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            load4(xr + c, v[i]);
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + c);
+                v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
+            }
+            for (int s = 0; s < S; ++s) {  // fixed order: slabs 0 .. S-1
+                const float4 p = *reinterpret_cast<const float4*>(pr + (size_t)s * slice_stride + c);
+                v[i][0] += p.x; v[i][1] += p.y; v[i][2] += p.z; v[i][3] += p.w;
+            }
+            store4(xr + c, v[i][0], v[i][1], v[i][2], v[i][3]);
+        }
+    }
+    if (ln_w) ln_row_store<T, NV>(v, D, lane, ln_w, ln_b, eps, h + (size_t)row * h_stride);
+}
+
+template <typename T, int MT, int KS>
+int launch_one(const SkinnyArgs& g, int nw, hipStream_t stream) {
+    auto kern = skinny_gemm_kernel<T, MT, KS>;
+    const int lds = nw > 1 ? nw * MT * 1024 : 0;
+    if (lds > 48 * 1024) ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3(g.N / 16, g.ksplit), dim3(nw * 64), lds, stream, g);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+template <typename T, int MT>
+int launch_ks(const SkinnyArgs& g, hipStream_t stream) {
+    const int kslice = g.K / g.ksplit;
+    int nw = 1;
+    for (int c = 8; c >= 2; c >>= 1)
+        if (kslice % (c * 32) == 0 && kslice / c >= 96) {
+            nw = c;
+            break;
+        }
+    const int kw = kslice / nw;
+    if constexpr (MT <= 13) {  // MT = 16: 48 fragments + 64 accumulators do not fit 256 registers at three k-steps
+        if (kw % 96 == 0) return launch_one<T, MT, 3>(g, nw, stream);
+    }
+    if (kw % 64 == 0) return launch_one<T, MT, 2>(g, nw, stream);
+    return launch_one<T, MT, 1>(g, nw, stream);
+}
+
+template <typename T>
+int launch_mt(const SkinnyArgs& g, hipStream_t stream) {
+    const int mt = (g.M + 15) / 16;
+    if (mt <= 1) return launch_ks<T, 1>(g, stream);
+    if (mt <= 2) return launch_ks<T, 2>(g, stream);
+    if (mt <= 4) return launch_ks<T, 4>(g, stream);
+    if (mt <= 8) return launch_ks<T, 8>(g, stream);
+    if (mt <= 13) return launch_ks<T, 13>(g, stream);
+    return launch_ks<T, 16>(g, stream);
+}
+
+}  // namespace
+
+int launch_skinny_gemm(int tcode, const SkinnyArgs& g, hipStream_t stream) {
+    if (!skinny_supported(g.M, g.N, g.K, g.lda, g.ldw, g.ksplit)) return fail("skinny gemm: unsupported geometry");
+    if (g.ksplit > 1 && (!g.slice_stride || (g.ldo & 3))) return fail("skinny gemm: split-K needs f32 slabs");
+    if (g.resid && !g.out_f32) return fail("skinny gemm: the residual epilogue writes f32");
+    if ((g.ldo & 3) || (g.resid && (g.ldr & 3))) return fail("skinny gemm: unaligned output");
+    if (tcode == 2) return launch_mt<f16_t>(g, stream);
+    if (tcode == 1) return launch_mt<bf16_t>(g, stream);
+    return fail("skinny gemm: 16-bit operands only");
+}
+
+int launch_skinny_reduce_ln(int tcode, const float* part, int S, size_t slice_stride, const float* bias, float* x, size_t x_stride, void* h,
+                            int h_stride, const float* ln_w, const float* ln_b, int rows, int D, float eps, hipStream_t stream) {
+    if (D % 4 || D > ROW_MAX_V4 * 256 || rows < 1 || S < 1) return fail("skinny reduce: unsupported geometry");
+#define ARP_SR_CALL(NV)                                                                                                                          \
+    do {                                                                                                                                         \
+        if (tcode == 2)                                                                                                                          \
+            hipLaunchKernelGGL((skinny_reduce_ln_kernel<f16_t, NV>), dim3(rows), dim3(64), 0, stream, part, S, slice_stride, bias, x, x_stride,   \
+                               static_cast<f16_t*>(h), h_stride, ln_w, ln_b, D, eps);                                                            \
+        else                                                                                                                                     \
+            hipLaunchKernelGGL((skinny_reduce_ln_kernel<bf16_t, NV>), dim3(rows), dim3(64), 0, stream, part, S, slice_stride, bias, x, x_stride,  \
+                               static_cast<bf16_t*>(h), h_stride, ln_w, ln_b, D, eps);                                                           \
+    } while (0)
+    if (tcode != 1 && tcode != 2) return fail("skinny reduce: 16-bit operands only");
+    ARP_NV_DISPATCH(D, ARP_SR_CALL);
+#undef ARP_SR_CALL
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace arp

@@ -10,6 +10,7 @@
 #include "gemm256.h"
 #include "qkvattn.h"
 #include "rowops.h"
+#include "skinny.h"
 #include "runtime.h"
 
 namespace arp {
@@ -120,6 +121,13 @@ struct TowerCtx {
     // significand bits: a lower-precision THROUGHPUT mode for the frozen towers of the fine-tune step, not the labelling default.
     bool fp8_mlp = false;
     bool qkv_fused = true;  // QKV projection + attention in one kernel where qkvattn.h supports the geometry (ARP_QKV_FUSED=0 disables)
+    // Latency path (the rollout loop's single-frame reward): with at most SKINNY_MAX_M rows in the residual stream the
+    // GEMMs run on the W-tiled skinny kernel (skinny.h), out_proj / c_proj as split-K slabs whose reduction kernel also adds bias +
+    // residual and applies the NEXT LayerNorm -- six launches per block, each near the 3 us a dependent launch costs.
+    bool skinny = false;       // set by the owner for a pass of at most SKINNY_MAX_M rows IN TOTAL (never per GEMM: a batch cut into
+                               // parts must give the same bits whatever the part size, tests/test_clip_gpu.py two-stream test)
+    float* part = nullptr;     // split-K slabs, f32 [<= 4][rows][width]; null: out_proj / c_proj stay single launches
+    size_t part_floats = 0;
     // multi-scale export: after every block, one row per sample of the residual stream -- what the forward
     // hooks of finetune_module/utils.py:6-18 capture on each resblock output -- is copied to ms_out[b, layer*D ..]
     float* ms_out = nullptr;
@@ -156,6 +164,17 @@ static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* 
     g.M = M; g.N = N; g.K = K; g.lda = lda ? lda : K; g.ldw = K; g.ldr = ldr ? ldr : N; g.ldo = ldo ? ldo : N;
     ProfScope ps(*c.prof, c.stream, site);
     int force = c.gemm_force;
+    if constexpr (sizeof(T) == 2 && (sizeof(OutT) == 4 || sizeof(OutT) == 2)) {
+        // a handful of rows: the W-tiled kernel (5.4 against 11.5 us at 50 rows, K = 768; equal at 197 rows, where a K = 3072 product
+        // is better off on the output-tiled kernel unless it is split: scripts/skinny_bench.hip)
+        if (c.skinny && force == 0 && !f && (M <= 64 || K <= 1024) && skinny_supported(M, N, K, g.lda, g.ldw) && !(g.ldo & 3) && !(RESID && (g.ldr & 3))) {
+            SkinnyArgs k;
+            k.A = A; k.W = W; k.bias = bias; k.resid = RESID ? resid : nullptr; k.out = out;
+            k.M = M; k.N = N; k.K = K; k.lda = g.lda; k.ldw = g.ldw; k.ldr = g.ldr; k.ldo = g.ldo;
+            k.act = ACT; k.out_f32 = sizeof(OutT) == 4;
+            return launch_skinny_gemm(__is_same(T, bf16_t) ? 1 : 2, k, c.stream);
+        }
+    }
     // out_proj (K = N = width, f32 residual epilogue) is the one big GEMM where the two-workgroups-per-CU kernel wins: its tiles
     // are short (12 K-tiles) and epilogue-heavy, so a second resident workgroup pays (measured 57.7 vs 66.8 us at M = 25 600)
     if (force == 0 && (SITE & 7) == SITE_OUT && M >= 4096) force = 3;
@@ -191,7 +210,9 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
         auto kern = attn_mfma_kernel<T, nt>;                                                                                  \
         const int lds = nt * 16 * 256;                                                                 \
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal, nq);          \
+        const int nqb_ = (nq + 15) / 16;                                                                                    \
+        const int qsplit_ = (B * heads < 128 && nqb_ > 4) ? std::min((nqb_ + 3) / 4, 4) : 1;                                   \
+        hipLaunchKernelGGL(kern, dim3(B* heads, qsplit_), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal, nq);  \
         ARP_HIP_OK(hipGetLastError());                                                                                      \
         return 0;                                                                                                           \
     }
@@ -235,7 +256,8 @@ static int tower_qkv_attention(TowerCtx& c, const TowerW& tw, const LayerW& L, c
                                T* qkv, T* ao, int B, int N, int causal, int nq) {
     const int D = tw.width, M = B * N;
     if constexpr (sizeof(T) == 2) {
-        if (c.qkv_fused && L.w_in_hm && c.attn_impl == 0 && qkv_attn_supported(N, D, tw.heads, (int)sizeof(T))) {
+        // (with <= SKINNY_MAX_M rows the fused kernel is 12-60 workgroups walking K one round trip at a time: 18 us per block at one frame)
+        if (c.qkv_fused && L.w_in_hm && c.attn_impl == 0 && qkv_attn_supported(N, D, tw.heads, (int)sizeof(T)) && !(c.skinny && M <= SKINNY_MAX_M)) {
             QkvAttnArgs q;
             q.A = h; q.W = L.w_in_hm; q.bias = L.b_in_hm; q.out = ao;
             q.B = B; q.N = N; q.K = D; q.heads = tw.heads; q.lda = D; q.ldw = D; q.ldo = D; q.fpt = 0; q.nq = nq; q.causal = causal; q.scale = 0.f;
@@ -270,6 +292,31 @@ static int tower_mlp_fp8(TowerCtx& c, const LayerW& L, const char* s_ln2, const 
     q.alpha = L.a_proj;
     ProfScope ps(*c.prof, c.stream, s_fc2);
     return launch_gemm256_nt<fp8_t, float, ACT_NONE, true, SB + SITE_FC2>(q, c.stream);
+}
+
+// Latency path: x += A.W^T + bias, then h = LayerNorm(x) with (ln_w, ln_b) when given -- the product as `S` split-K slabs of the
+// skinny kernel, summed in slab order by the row kernel that also applies the residual and the LayerNorm.
+template <typename T>
+static int tower_gemm_split_ln(TowerCtx& c, const char* s_gemm, const char* s_red, const void* A, const void* W, const float* bias, float* x, int M, int D,
+                               int K, int S, T* h, const float* ln_w, const float* ln_b, float eps) {
+    const int tcode = __is_same(T, bf16_t) ? 1 : 2;
+    const size_t slab = (size_t)M * D;
+    if ((size_t)S * slab > c.part_floats) return fail("tower: split-K slab buffer too small");
+    SkinnyArgs k;
+    k.A = A; k.W = W; k.out = c.part; k.M = M; k.N = D; k.K = K; k.lda = K; k.ldw = K; k.ldo = D; k.out_f32 = 1;
+    k.ksplit = S; k.slice_stride = slab;
+    {
+        ProfScope ps(*c.prof, c.stream, s_gemm);
+        ARP_TRY(launch_skinny_gemm(tcode, k, c.stream));
+    }
+    ProfScope ps(*c.prof, c.stream, s_red);
+    return launch_skinny_reduce_ln(tcode, c.part, S, slab, bias, x, D, h, D, ln_w, ln_b, M, D, eps, c.stream);
+}
+// slabs for a [M, D] x [D, K]^T product on the latency path (0: geometry not supported)
+static inline int tower_split_of(int M, int D, int K) {
+    for (int S = K >= 2048 ? 4 : (K >= 512 ? 2 : 1); S >= 1; S >>= 1)
+        if (skinny_supported(M, D, K, K, K, S) && K / S >= 32) return S;
+    return 0;
 }
 
 // 12 x ResidualAttentionBlock (arp_dt/models/openai/layers.py:235-271) on the f32 residual stream x.
@@ -309,13 +356,33 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
         }
         return 0;
     }
+    // latency path: see TowerCtx::skinny
+    const int S_out = tower_split_of(M, D, D), S_proj = tower_split_of(M, D, 4 * D);
+    const bool lat = sizeof(T) == 2 && c.skinny && c.gemm_force == 0 && !c.fp8_mlp && c.part && M <= SKINNY_MAX_M && S_out && S_proj &&
+                     (size_t)std::max(S_out, S_proj) * M * D <= c.part_floats && skinny_supported(M, 3 * D, D, D, D) && skinny_supported(M, 4 * D, D, D, D);
+    const std::string s_red2 = t + ".out_reduce_ln_2", s_red1 = t + ".proj_reduce_ln_1";
+    bool h_ready = false;  // h already holds ln_1 of this block (written by the previous block's reduction)
     for (int i = 0; i < tw.layers; ++i) {
         const LayerW& L = tw.L[i];
+        if constexpr (sizeof(T) == 2) {
+            if (lat && !(c.cls_only_last && i == tw.layers - 1 && N > 1)) {
+                if (!h_ready) ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));
+                ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn.c_str(), s_qa.c_str(), h, qkv, ao, B, N, causal, 0)));
+                ARP_TRY(tower_gemm_split_ln<T>(c, s_out.c_str(), s_red2.c_str(), ao, L.w_out, L.b_out, x, M, D, D, S_out, h, L.ln2_w, L.ln2_b, eps));
+                ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc1.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, M, 4 * D, D)));
+                const LayerW* nx = i + 1 < tw.layers ? &tw.L[i + 1] : nullptr;
+                ARP_TRY(tower_gemm_split_ln<T>(c, s_fc2.c_str(), s_red1.c_str(), fc, L.w_proj, L.b_proj, x, M, D, 4 * D, S_proj, h, nx ? nx->ln1_w : nullptr,
+                                               nx ? nx->ln1_b : nullptr, eps));
+                h_ready = nx != nullptr;
+                ARP_TRY(tower_export_rows(c, x, D, i, B, N));
+                continue;
+            }
+        }
         if (c.cls_only_last && i == tw.layers - 1 && N > 1) {
             const std::string s_attn1 = t + ".attn_cls", s_out1 = t + ".out_proj_cls", s_ln21 = t + ".ln_2_cls", s_fc11 = t + ".c_fc_cls",
                               s_fc21 = t + ".c_proj_cls";
             const int ND = N * D;  // row stride of the class-token rows inside the [B*N, D] buffers
-            ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));  // K and V need every token
+            if (!h_ready) ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));  // K and V need every token
             ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn1.c_str(), s_qa1.c_str(), h, qkv, ao, B, N, causal, 1)));
             ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out1.c_str(), ao, L.w_out, L.b_out, x, x, B, D, D, nullptr, ND, ND, ND)));
             ARP_TRY(tower_layernorm<T>(c, s_ln21.c_str(), x, ND, h, D, L.ln2_w, L.ln2_b, B, D, eps));

@@ -132,6 +132,7 @@ def run_secondary(a):
         "policy_with_encoder": ["--path", "policy", "--with-encoder"],
         "finetune": ["--path", "finetune"],
         "label_vit_b16": ["--model", "ViT-B/16", "--batch", "256"],
+        "online": ["--path", "online"],
     }
     extra = {}
     for name, args in runs.items():
@@ -324,6 +325,64 @@ def bench_policy(a):
         dist.destroy_process_group()
 
 
+def bench_online(a):
+    """Secondary benchmark (the rollout loop): latency of ONE call -- `get_torch_clip_reward` on one 256 x 256 x 3 host frame
+    (envs/vl_reward.py:11-23) for both CLIP models, and `greedy_action` on one window of encodings (rollout_procgen.py:123-155)."""
+    import time
+    from arp_amd import _ffi, clip, synth, label_reward as L, synth_policy as S
+    from arp_amd.train import PolicyConfig, PolicyTrainer
+    _ffi.require_gpu()
+    _ffi.check(_ffi.lib.arp_set_device(0))
+    reps = max(50, 10 * a.steps)
+    lat = {}
+    for name in ("ViT-B/32", "ViT-B/16"):
+        cfg = clip.MODELS[name]
+        m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), mode=a.mode, max_batch=64, n_streams=1).set_text(synth.prompt_tokens(1, 8, seed=2))
+        fr = synth.procgen_like_frames(8, seed=3)
+        for i in range(8):
+            L.get_torch_clip_reward(m, fr[i])
+        ts = []
+        for i in range(reps):
+            t0 = time.perf_counter()
+            L.get_torch_clip_reward(m, fr[i % 8])
+            ts.append(time.perf_counter() - t0)
+        d_fr = clip.DeviceBuffer(fr[:1].nbytes); d_fr.upload(fr[:1])
+        d_rw = clip.DeviceBuffer(4)
+        e0, e1 = clip.Event(), clip.Event()
+        for _ in range(3):
+            m.label_device_async(d_fr, 1, 256, 256, d_rw)
+        m.sync(); m.record(e0)
+        for _ in range(reps):
+            m.label_device_async(d_fr, 1, 256, 256, d_rw)
+        m.record(e1); m.sync()
+        dev = clip.elapsed_ms(e0, e1) / reps
+        m.profile(True); m.profile_reset()
+        m.label(fr[:1])
+        launches = int(sum(v["calls"] for v in m.profile_read().values())); m.profile(False)
+        lat[name] = {"latency_ms": round(float(np.median(ts)) * 1e3, 4), "mean_ms": round(float(np.mean(ts)) * 1e3, 4),
+                     "p99_ms": round(float(np.quantile(ts, 0.99)) * 1e3, 4), "device_ms": round(dev, 4), "launches": launches, "calls": reps}
+        m.close()
+    pcfg = PolicyConfig(lambda_ret=0.01)
+    tr = PolicyTrainer(pcfg, mode=a.mode)
+    tr.set_params(S.policy_params(pcfg, seed=0))
+    enc, act, rtg = S.policy_batch(pcfg, 1, seed=5)
+    for _ in range(5):
+        tr.greedy_action(enc, act, rtg)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        tr.greedy_action(enc, act, rtg)
+        ts.append(time.perf_counter() - t0)
+    tr.close()
+    ga = {"latency_ms": round(float(np.median(ts)) * 1e3, 4), "mean_ms": round(float(np.mean(ts)) * 1e3, 4), "enc_bytes": int(enc.nbytes), "calls": reps}
+    v = lat["ViT-B/32"]["latency_ms"]
+    emit(json.dumps({"metric": "single_frame_reward_latency", "value": v, "unit": "ms", "latency_ms": v, "n_gpus": 1, "steps": reps, "warmup": 8,
+                     "ms_per_step": v, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
+                     "config": {"workload": "get_torch_clip_reward: one 256x256x3 uint8 host frame in, one f32 reward out per call (ViT-B/32; the same for "
+                                            "ViT-B/16 under reward); greedy_action: one [1,4,257,768] f32 window of encodings in, one action out"},
+                     "reward": lat, "greedy_action": ga}))
+
+
 def bench_finetune(a):
     """Secondary benchmark: the CLIP multi-scale adapter fine-tune head step (BASELINE.json configs[4]):
     B = 64 samples x 3 frames, frozen-tower features resident in HBM, forward + backward + AdamW over 476 M parameters.
@@ -442,9 +501,10 @@ def main():
     ap.add_argument("--parity-frames", type=int, default=8, help="frames checked against the oracle before timing (rank 0)")
     ap.add_argument("--streams", type=int, default=2, help="label path: N = each batch is labelled in N contiguous parts on N HIP streams of "
                     "the same GPU (one half's LayerNorm/attention/GEMM tails overlap the other half's GEMMs); 1 = single stream")
-    ap.add_argument("--path", default="label", choices=["label", "policy", "finetune"],
+    ap.add_argument("--path", default="label", choices=["label", "policy", "finetune", "online"],
                     help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary); "
-                         "finetune = CLIP multi-scale adapter head step (configs[4], secondary)")
+                         "finetune = CLIP multi-scale adapter head step (configs[4], secondary); online = latency of one single-frame reward / one "
+                         "greedy action (the rollout loop, SURVEY row N4; secondary)")
     ap.add_argument("--finetune-batch", type=int, default=64, help="samples per step (finetune.py:25)")
     ap.add_argument("--fp8-mlp", action="store_true", help="label path / finetune --with-towers: the vision tower's c_fc / c_proj GEMMs on e4m3 "
                     "operands (scaled fp8 MFMA; BASELINE configs[4] 'fp8 MFMA GEMMs'): a lower-precision throughput mode, its parity is printed")
@@ -469,6 +529,8 @@ def main():
         return bench_policy(a)
     if a.path == "finetune":
         return bench_finetune(a)
+    if a.path == "online":
+        return bench_online(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -345,6 +345,12 @@ int arp_op_gemm_fp8(int act, const float* A, const float* W, const float* bias, 
                     int out_fp8, float out_scale);
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,
                    float* out, int M, int N, int K);
+/* The latency path's GEMM (csrc/skinny.h: W-tiled, M <= 256 rows, N % 16, K % 32, 16-bit modes), the kernel behind the single-frame
+ * reward (reference call site: arp_dt/envs/vl_reward.py:11-23).  ksplit = 0: one launch, out = act(A.W^T + bias) + resid;
+ * ksplit >= 1 (K % (32 ksplit) == 0): split-K slabs + row kernel, out = resid + bias + A.W^T, and h_out = LayerNorm(out; ln_w, ln_b, eps)
+ * rounded to the operand type when ln_w != NULL. */
+int arp_op_skinny_gemm(int mode, int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N, int K,
+                       int ksplit, const float* ln_w, const float* ln_b, float eps, float* h_out);
 /* Kernels of the policy train step (16-bit modes; reference math: arp_dt/ARPDT.py:462-484 and its autodiff).
  * arp_op_gemm_tn: C[M,N] = alpha * sum_k A[k,m] B[k,n], A [K,M] and B [K,N] row-major (weight gradients dW = dY^T X);
  *   tile256 = 0: 128x128 tiles (M, N % 128), 1: 256x256 tiles (M, N % 256); K % 64; ksplit >= 1 K-slices.

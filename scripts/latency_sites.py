@@ -8,8 +8,12 @@ from arp_amd import clip, synth
 for name in ("ViT-B/16", "ViT-B/32"):
     cfg = clip.MODELS[name]
     m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), mode="f16", max_batch=64, n_streams=1).set_text(synth.prompt_tokens(1, 8, seed=2))
-    fr = synth.procgen_like_frames(8, seed=3)
-    for n in (1, 8):
+    fr = synth.procgen_like_frames(64, seed=3)
+    big = m.label(fr)  # 64 frames: the throughput kernels
+    scale = float(np.exp(synth.clip_weights(cfg, seed=0)["logit_scale"]))
+    for n in (1, 4, 8):
+        small = np.concatenate([m.label(fr[i:i + n]) for i in range(0, 16, n)])
+        print(f"{name} n={n}: latency path vs the 64-frame pass, cosine difference max {np.abs(small - big[:16]).max() / scale:.2e}", flush=True)
         for _ in range(5):
             m.label(fr[:n])
         t0 = time.perf_counter()

@@ -122,6 +122,56 @@ def test_online_single_frame_reward(gpu_lib):
     m.close()
 
 
+@pytest.mark.parametrize("name", ["ViT-B/32", "ViT-B/16"])
+def test_latency_path_full_size(gpu_lib, name, monkeypatch):
+    """Row N4 at the real geometry: single-frame calls (skinny GEMMs, split-K + reduce + LayerNorm kernels, small preprocess tiles, the
+    pass replayed as a hipGraph, pinned staging) within north_star's 1e-4 cosine of the fp32 oracle in f16 mode; the graph replays the
+    same bits as launch-by-launch; a call of more frames than SKINNY_MAX_M token rows allows leaves the path; a new prompt drops the
+    captured passes."""
+    from arp_amd import clip, synth, label_reward as L
+    from oracle import clip_np as C
+    cfg = clip.MODELS[name]
+    ocfg = C.ClipConfig(patch=cfg.patch)
+    Wt = synth.clip_weights(ocfg, seed=0)
+    fr = synth.procgen_like_frames(6, seed=1)
+    tok = synth.prompt_tokens(1, 8, seed=2)
+    tok2 = synth.prompt_tokens(1, 6, seed=9)
+    ref, ref2 = C.compute_reward(Wt, ocfg, fr, tok), C.compute_reward(Wt, ocfg, fr[:2], tok2)
+    m = clip.ClipLabeller(cfg, Wt, mode="f16", n_streams=1).set_text(tok)
+    one = np.concatenate([L.get_torch_clip_reward(m, fr[i]) for i in range(6)])
+    again = np.concatenate([L.get_torch_clip_reward(m, fr[i]) for i in range(6)])  # replays
+    assert (one == again).all()
+    err = np.abs(one - ref).max() / 100.0
+    print(f"{name} single-frame latency path: cosine err {err:.2e}")
+    assert err < COS_TOL_F16
+    m.profile(True)  # profiling: launch by launch, one event pair per site
+    prof = np.concatenate([m.label(fr[i:i + 1]) for i in range(6)])
+    sites = m.profile_read(); m.profile(False)
+    assert (prof == one).all() and "vit.proj_reduce_ln_1" in sites and "vit.qkv_attn" not in sites
+    assert np.abs(m.label(fr) - ref).max() / 100.0 < COS_TOL_F16  # 6 frames: 300 / 1182 rows, the throughput kernels
+    m.set_text(tok2)
+    assert np.abs(np.concatenate([m.label(fr[i:i + 1]) for i in range(2)]) - ref2).max() / 100.0 < COS_TOL_F16
+    m.close()
+    monkeypatch.setenv("ARP_SKINNY", "0"); monkeypatch.setenv("ARP_CLIP_GRAPH", "0"); monkeypatch.setenv("ARP_CLIP_PINNED", "0")
+    m = clip.ClipLabeller(cfg, Wt, mode="f16", n_streams=1).set_text(tok)
+    old = np.concatenate([m.label(fr[i:i + 1]) for i in range(6)])
+    m.close()
+    assert np.abs(old - ref).max() / 100.0 < COS_TOL_F16 and np.abs(old - one).max() / 100.0 < COS_TOL_F16
+
+
+def test_latency_path_tiny_bf16_and_crop(gpu_lib):
+    """The same path on the tiny geometry (K = 64: one wave per workgroup, split 1 and 2), bf16, with the use_crop transform and a few
+    frames per call."""
+    from arp_amd import clip
+    ocfg, Wt, fr, tok, ref = _setup(TINY, 6, seed=41, use_crop=True)
+    scale = float(np.exp(Wt["logit_scale"]))
+    for mode, tol in (("bf16", COS_TOL_BF16), ("f16", 2 * COS_TOL_F16)):
+        m = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode=mode, n_streams=1).set_text(tok)
+        got = np.concatenate([m.label(fr[i:i + 2], use_crop=True) for i in (0, 2, 4)])
+        assert np.abs(got - ref).max() / scale < tol
+        m.close()
+
+
 def test_two_stream_split_matches_single_stream(gpu_lib):
     """n_streams = 2 labels the two halves of a batch on two HIP streams; results are bit-identical to one stream."""
     from arp_amd import clip, synth
@@ -237,9 +287,11 @@ def test_fused_qkv_attention_is_exact(gpu_lib, monkeypatch, mode):
     workgroup owns 5 whole frames x one head, q|k|v never leave the CU).  Every q/k/v value is the same MFMA chain rounded at
     the same point and the attention arithmetic is attn_mfma_kernel's, so rewards, features and the multi-scale export must be
     bit-identical to the two-kernel path (ARP_QKV_FUSED=0) -- on full tiles, a ragged last tile (37 = 7 x 5 + 2 frames), fewer
-    frames than one tile, and with the class-token-only last block on and off."""
+    frames than one tile, and with the class-token-only last block on and off.  (ARP_SKINNY=0: a 3-frame call would otherwise take the
+    latency path, which never uses the fused kernel -- tests/test_clip_gpu.py::test_latency_path_*.)"""
     from arp_amd import clip, synth
     from oracle import clip_np as C
+    monkeypatch.setenv("ARP_SKINNY", "0")
     ocfg = C.ClipConfig(**MID)
     Wt = synth.clip_weights(ocfg, seed=29)
     tok = synth.prompt_tokens(1, 5, ctx=ocfg.ctx, vocab=ocfg.vocab, seed=4)

@@ -65,6 +65,58 @@ def test_gemm_nt(gpu_lib, mode, shape, kernel, monkeypatch):
         assert err < tol, f"gemm mode={mode} shape={shape} act={act} bias={use_b} resid={use_r}: max err {err} (tol {tol})"
 
 
+SKINNY_SHAPES = [  # M, N, K: the single-frame tower's products (50 / 197 token rows, class rows) and the edges of the kernel's domain
+    (50, 2304, 768), (197, 768, 768), (50, 768, 3072), (197, 3072, 768), (1, 512, 768), (8, 768, 3072), (256, 64, 64), (17, 16, 32),
+    (49, 768, 3072), (100, 192, 160), (208, 128, 256),
+]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("shape", SKINNY_SHAPES)
+def test_skinny_gemm(gpu_lib, mode, shape):
+    """csrc/skinny.hip: direct epilogues, and split-K slabs + the reduce / residual / LayerNorm row kernel,
+    against float64 on the rounded operands."""
+    M, N, K = shape
+    rng = np.random.default_rng(M * 5 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    resid = rng.standard_normal((M, N)).astype(np.float32)
+    rnd = {1: bf16_round, 2: lambda x: x.astype(np.float16).astype(np.float32)}[mode]
+    prod = rnd(A).astype(np.float64) @ rnd(W).astype(np.float64).T
+    for act, use_b, use_r in ((0, True, True), (1, True, False), (0, False, False), (4, True, True)):
+        out = np.empty((M, N), np.float32)
+        gpu_lib.check(gpu_lib.lib.arp_op_skinny_gemm(mode, act, _fp(A), _fp(W), _fp(bias) if use_b else None, _fp(resid) if use_r else None, _fp(out),
+                                                     M, N, K, 0, None, None, 0.0, None))
+        ref = _act(prod + (bias if use_b else 0.0), act) + (resid if use_r else 0.0)
+        err = np.abs(out - ref).max()
+        assert err < 3e-4 * max(1.0, np.abs(ref).max()), f"skinny mode={mode} shape={shape} act={act}: max err {err}"
+    lw = (1 + 0.2 * rng.standard_normal(N)).astype(np.float32)
+    lb = rng.standard_normal(N).astype(np.float32)
+    for S in (1, 2, 4, 8):
+        if K % (32 * S) or N > 2048:  # the row kernel holds a row in registers: widths up to 2048 (the tower reduces [rows, width] only)
+            continue
+        out, h = np.empty((M, N), np.float32), np.empty((M, N), np.float32)
+        gpu_lib.check(gpu_lib.lib.arp_op_skinny_gemm(mode, 0, _fp(A), _fp(W), _fp(bias), _fp(resid), _fp(out), M, N, K, S, _fp(lw), _fp(lb), 1e-5, _fp(h)))
+        ref = prod + bias + resid
+        assert np.abs(out - ref).max() < 3e-4 * max(1.0, np.abs(ref).max()), f"skinny split {S} mode={mode} shape={shape}"
+        x = out.astype(np.float64)  # the LayerNorm is judged on the kernel's own x (its f32 rounding is not the subject)
+        ln = (x - x.mean(1, keepdims=True)) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * lw + lb
+        assert np.abs(h - ln).max() < (1.6e-2 if mode == 1 else 2e-3) * max(1.0, np.abs(ln).max()), f"skinny split {S} LayerNorm mode={mode} shape={shape}"
+        # the slab order is fixed: a second launch gives the same bits
+        out2 = np.empty((M, N), np.float32)
+        gpu_lib.check(gpu_lib.lib.arp_op_skinny_gemm(mode, 0, _fp(A), _fp(W), _fp(bias), _fp(resid), _fp(out2), M, N, K, S, None, None, 0.0, None))
+        assert (out2 == out).all()
+
+
+def test_skinny_gemm_rejects(gpu_lib):
+    A = np.zeros((300, 64), np.float32); W = np.zeros((16, 64), np.float32); out = np.zeros((300, 16), np.float32)
+    assert gpu_lib.lib.arp_op_skinny_gemm(2, 0, _fp(A), _fp(W), None, None, _fp(out), 300, 16, 64, 0, None, None, 0.0, None) != 0   # M > 256
+    assert gpu_lib.lib.arp_op_skinny_gemm(2, 0, _fp(A), _fp(W), None, None, _fp(out), 8, 15, 64, 0, None, None, 0.0, None) != 0     # N % 16
+    assert gpu_lib.lib.arp_op_skinny_gemm(2, 0, _fp(A), _fp(W), None, None, _fp(out), 8, 16, 48, 0, None, None, 0.0, None) != 0     # K % 32
+    assert gpu_lib.lib.arp_op_skinny_gemm(0, 0, _fp(A), _fp(W), None, None, _fp(out), 8, 16, 64, 0, None, None, 0.0, None) != 0     # f32 mode
+
+
 @pytest.mark.parametrize("kernel", ["2", "3"])
 def test_gemm256_race_screen(gpu_lib, monkeypatch, kernel):
     """The pipelined kernel's LDS hand-offs are ordered by counted vmcnt + barriers: repeated launches on
