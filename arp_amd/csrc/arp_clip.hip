@@ -111,6 +111,7 @@ struct arp_clip {
     // pays one graph launch instead of 80 kernel launches that each cost more host time than the kernel runs
     DevBuf part;
     bool skinny = true;     // ARP_SKINNY=0: the output-tiled GEMMs at every size
+    bool lat_h0 = false;    // ... and its token-assembly kernel already wrote ln_1 of the first block into h
     bool lat_now = false;   // the pass being enqueued has at most SKINNY_MAX_M token rows (set by forward_chunk)
     bool lat_graph = true;  // ARP_CLIP_GRAPH=0: launch by launch
     struct LatGraph {
@@ -144,7 +145,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.qkv_fused = c->qkv_fused;
     t.fp8_mlp = c->fp8_mlp;
     t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
-    t.skinny = c->lat_now; t.part = c->part.as<float>(); t.part_floats = c->part.bytes / 4;
+    t.skinny = c->lat_now; t.h_ready0 = c->lat_now && c->lat_h0; t.part = c->part.as<float>(); t.part_floats = c->part.bytes / 4;
     return t;
 }
 
@@ -351,7 +352,7 @@ static int get_plan(arp_clip* c, int H, int W, int use_crop, ResizePlan** out, b
         return 0;
     }
     ResizePlan* p = new ResizePlan();
-    const int r = build_plan(H, W, use_crop, c->cfg.img_res, *p, small ? 8 : 32);
+    const int r = build_plan(H, W, use_crop, c->cfg.img_res, *p, small ? (getenv("ARP_PRE_TR_SMALL") ? atoi(getenv("ARP_PRE_TR_SMALL")) : 8) : 32);
     if (r != 0) {
         delete p;
         return r;
@@ -369,7 +370,7 @@ static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizeP
     c->lat_now = c->skinny && sizeof(T) == 2 && (long)nb * N <= SKINNY_MAX_M;
     struct LatGuard {
         arp_clip* c;
-        ~LatGuard() { c->lat_now = false; }
+        ~LatGuard() { c->lat_now = false; c->lat_h0 = false; }
     } lat_guard{c};
     if (c->pre_bilinear) {
         ProfScope ps(c->prof, c->stream, "preprocess_bilinear");
@@ -382,6 +383,32 @@ static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizeP
         ProfScope ps(c->prof, c->stream, "preprocess");
         ARP_TRY((launch_preprocess<T, PRE_PATCH>(*plan, frames_dev, nb, k.patch, c->lut, c->patches.p, c->stream)));
     }
+    c->lat_h0 = false;
+    bool assembled = false;
+    if constexpr (sizeof(T) == 2) {
+        // latency path: the patch embedding as split-K slabs, summed by the token-assembly kernel, which also applies the first ln_1
+        const int Mp = nb * G * G, S = c->lat_now ? tower_split_of(Mp, D, KP) : 0;
+        if (S && (size_t)S * Mp * D * 4 <= c->part.bytes && c->vis.layers > 0 && D % 4 == 0 && D <= ROW_MAX_V4 * 256) {
+            const int tcode = __is_same(T, bf16_t) ? 1 : 2;
+            SkinnyArgs q;
+            q.A = c->patches.p; q.W = c->conv_w; q.out = c->part.p; q.M = Mp; q.N = D; q.K = KP; q.lda = KP; q.ldw = KP; q.ldo = D; q.out_f32 = 1;
+            q.ksplit = S; q.slice_stride = (size_t)Mp * D;
+            {
+                ProfScope ps(c->prof, c->stream, "vit.patch_embed");
+                ARP_TRY(launch_skinny_gemm(tcode, q, c->stream));
+            }
+            ProfScope ps(c->prof, c->stream, "vit.assemble_ln_pre_ln_1");
+#define ARP_ASML_CALL(NV)                                                                                                                \
+    hipLaunchKernelGGL((vit_assemble_lat_kernel<T, NV>), dim3(nb * N), dim3(64), 0, c->stream, c->part.as<float>(), S, (size_t)Mp * D, c->cls, c->pos, \
+                       c->lnpre_w, c->lnpre_b, c->x.as<float>(), c->h.as<T>(), c->vis.L[0].ln1_w, c->vis.L[0].ln1_b, N, D, 1e-5f)
+            ARP_NV_DISPATCH(D, ARP_ASML_CALL);
+#undef ARP_ASML_CALL
+            ARP_HIP_OK(hipGetLastError());
+            assembled = true;
+            c->lat_h0 = true;
+        }
+    }
+    if (!assembled) {
     ARP_TRY((gemm<T, float, ACT_NONE, false, SITE_PATCH>(c, "vit.patch_embed", c->patches.p, c->conv_w, nullptr, nullptr, c->pe.p,
                                                          nb * G * G, D, KP)));
     {
@@ -392,6 +419,7 @@ static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizeP
         ARP_NV_DISPATCH(D, ARP_ASM_CALL);
 #undef ARP_ASM_CALL
         ARP_HIP_OK(hipGetLastError());
+    }
     }
     ARP_TRY(run_blocks<T>(c, c->vis, "vit", c->x.as<float>(), c->h.as<T>(), c->qkv.as<T>(), c->ao.as<T>(), c->fc.as<T>(), nb, N, 0, c->stats.as<float>()));
     // ln_post on the CLS rows only, then proj (arp_dt/models/openai/layers.py:330-332)

@@ -124,6 +124,70 @@ __global__ __launch_bounds__(256) void vit_assemble_lnpre_kernel(const float* __
     ln_row_store<float, NV>(v, D, lane, w, b, eps, x + (size_t)row * D);
 }
 
+// Latency-path variant (one frame, or a few): the patch embedding arrives as S split-K slabs of the skinny GEMM, and the row that
+// ln_pre produces is normalised once more with the first block's ln_1 into h -- one launch instead of three.
+template <typename T, int NV>
+__global__ __launch_bounds__(64) void vit_assemble_lat_kernel(const float* __restrict__ patch, int S, size_t slice_stride, const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, const float* __restrict__ w, const float* __restrict__ b,
+                                                              float* __restrict__ x, T* __restrict__ h, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1, int ntok, int D, float eps) {
+    const int lane = threadIdx.x, row = blockIdx.x;
+    const int bi = row / ntok, t = row - bi * ntok;
+    const float* src = (t == 0) ? cls : patch + ((size_t)bi * (ntok - 1) + (t - 1)) * D;
+    const float* prow = pos + (size_t)t * D;
+    float v[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            float p4[4], sl[3][4];
+            load4(src + c, v[i]);
+            load4(prow + c, p4);
+            const int nsl = t != 0 ? S - 1 : 0;  // slabs 1 .. S-1 on top of slab 0, all loads issued before the first add
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < nsl) load4(src + (size_t)(k + 1) * slice_stride + c, sl[k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] += p4[j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < nsl) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[i][j] += sl[k][j];
+                }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    // ln_pre in registers (the arithmetic of ln_row_store), then ln_1 of the first block on the rounded-to-f32 result
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float4 ww = *reinterpret_cast<const float4*>(w + c);
+            const float4 bb = *reinterpret_cast<const float4*>(b + c);
+            v[i][0] = (v[i][0] - mean) * rstd * ww.x + bb.x; v[i][1] = (v[i][1] - mean) * rstd * ww.y + bb.y;
+            v[i][2] = (v[i][2] - mean) * rstd * ww.z + bb.z; v[i][3] = (v[i][3] - mean) * rstd * ww.w + bb.w;
+            store4(x + (size_t)row * D + c, v[i][0], v[i][1], v[i][2], v[i][3]);
+        }
+    }
+    ln_row_store<T, NV>(v, D, lane, w1, b1, eps, h + (size_t)row * D);
+}
+
 // Text token embedding (arp_dt/models/openai/layers.py:364-365): x[p*ctx + t] = tok_emb[tokens] + pos[t]
 static __global__ __launch_bounds__(256) void text_embed_kernel(const int* __restrict__ tokens, const float* __restrict__ emb,
                                                          const float* __restrict__ pos, float* __restrict__ x, int rows, int ctx,

@@ -30,7 +30,7 @@ struct SkinnyArgs {
     int out_f32 = 0;
     int ksplit = 1;
     size_t slice_stride = 0;
-    int rotate = 1;    // 0: every workgroup walks the m-tiles in the same order (A/B switch of the harness)
+    int strips = 0;    // 1: 16-column strips even above 64 rows (A/B switch of the harness)
 };
 
 constexpr int SKINNY_MAX_M = 256;

@@ -17,43 +17,50 @@ __device__ __forceinline__ float act_rt(int act, float x) {
     }
 }
 
-// MT = 16-row m-tiles, KS = MFMA k-steps (32 elements) per chunk; a wave walks chunks of 32 * KS elements of its K range.
-template <typename T, int MT, int KS>
+// MT = 16-row m-tiles and NT = 16-column n-tiles per workgroup (every wave computes all MT x NT of them over its own K range),
+// KS = MFMA k-steps (32 elements) per chunk; a wave walks chunks of 32 * KS elements of its K range.
+// blockIdx.x: n-group (16 NT columns), blockIdx.y: cross-workgroup K slice, blockIdx.z: m-group (16 MT rows).
+//   NT = 1: the one-frame shapes (<= 64 rows): (64 + 16) x K operand bytes per workgroup, N / 16 workgroups.
+//   NT = 4, MT = 4: 65 .. 256 rows (ViT-B/16's 197): 64 x 64 tiles, (64 + 64) x K bytes per workgroup instead of the (208 + 16) x K
+//     of one 16-column strip over all rows -- a CU fills its L1 at ~45 KB/us whatever the access pattern (scripts/skinny_bench.hip),
+//     so operand bytes per workgroup ARE the kernel's time above the launch floor.
+template <typename T, int MT, int NT, int KS>
 __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4_v* red = reinterpret_cast<f32x4_v*>(smem);  // [NW][MT][64]
+    f32x4_v* red = reinterpret_cast<f32x4_v*>(smem);  // [NW][MT * NT][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16 * NT;
+    const int mt0 = blockIdx.z * MT;
     const int slice = blockIdx.y;
     const int kslice = g.K / (int)gridDim.y;
     const int kw = kslice / NW;
     const int fr = lane & 15, fg = lane >> 4;
     const int kbase = slice * kslice + wave * kw + fg * 8;
-    const T* __restrict__ wp = static_cast<const T*>(g.W) + (size_t)(n0 + fr) * g.ldw + kbase;
+    const T* __restrict__ wp[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) wp[u] = static_cast<const T*>(g.W) + (size_t)(n0 + u * 16 + fr) * g.ldw + kbase;
     const T* __restrict__ ap[MT];
-    // slot t works on m-tile mrow[t]: rotated by the workgroup index, so that the workgroups of one XCD -- which all read the same
-    // activations -- are not all asking the same L2 channel for the same line at the same moment
-    const int mtd = (g.M + 15) >> 4;
-    const int rot = g.rotate ? (int)(blockIdx.x % (unsigned)mtd) : 0;
-    int mrow[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        mrow[t] = t < mtd ? (t + rot >= mtd ? t + rot - mtd : t + rot) : t;
-        int m = mrow[t] * 16 + fr;
+        int m = (mt0 + t) * 16 + fr;
         m = m < g.M ? m : g.M - 1;  // rows past M: computed on valid memory, never stored
         ap[t] = static_cast<const T*>(g.A) + (size_t)m * g.lda + kbase;
     }
-    f32x4_v acc[MT];
+    f32x4_v acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4_v{0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < kw; c += 32 * KS) {
         // every load of the chunk is issued before the first MFMA (left to itself the compiler keeps ~7 in flight and interleaves the
         // rest behind waits: two or three memory round trips instead of one)
-        u32x4_v wf[KS], af[MT][KS];
+        u32x4_v wf[NT][KS], af[MT][KS];
 #pragma unroll
-        for (int j = 0; j < KS; ++j) wf[j] = *reinterpret_cast<const u32x4_v*>(wp + c + 32 * j);
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int j = 0; j < KS; ++j) wf[u][j] = *reinterpret_cast<const u32x4_v*>(wp[u] + c + 32 * j);
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -62,12 +69,14 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs g) {
 #pragma unroll
         for (int j = 0; j < KS; ++j)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = mfma16<T>(wf[j], af[t][j], acc[t]);  // swapped: D[n = 4 fg + i][m = fr]
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = mfma16<T>(wf[u][j], af[t][j], acc[t][u]);  // swapped: D[n = 4 fg + i][m = fr]
     }
-    // lane holds, per m-tile, 4 consecutive output columns n0 + 4 fg .. + 3 of row 16 t + fr
-    auto epilogue = [&](int t, f32x4_v v) {
-        const int mt_ = t < mtd ? (t + rot >= mtd ? t + rot - mtd : t + rot) : t;
-        const int m = mt_ * 16 + fr, n = n0 + fg * 4;
+    // per (m-tile t, n-tile u) a lane holds 4 consecutive output columns n0 + 16 u + 4 fg .. + 3 of row 16 (mt0 + t) + fr
+    auto epilogue = [&](int f, f32x4_v v) {
+        const int t = f / NT, u = f - t * NT;
+        const int m = (mt0 + t) * 16 + fr, n = n0 + u * 16 + fg * 4;
         if (m >= g.M) return;
         if (gridDim.y > 1) {
             *reinterpret_cast<f32x4_v*>(static_cast<float*>(g.out) + (size_t)slice * g.slice_stride + (size_t)m * g.ldo + n) = v;
@@ -94,16 +103,20 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs g) {
     };
     if (NW == 1) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) epilogue(t, acc[t]);
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) epilogue(t * NT + u, acc[t][u]);
         return;
     }
 #pragma unroll
-    for (int t = 0; t < MT; ++t) red[(wave * MT + t) * 64 + lane] = acc[t];
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) red[(wave * (MT * NT) + t * NT + u) * 64 + lane] = acc[t][u];
     __syncthreads();
-    for (int t = wave; t < MT; t += NW) {
-        f32x4_v s = red[t * 64 + lane];
-        for (int v = 1; v < NW; ++v) s += red[(v * MT + t) * 64 + lane];  // fixed order: waves 0 .. NW-1
-        epilogue(t, s);
+    for (int f = wave; f < MT * NT; f += NW) {
+        f32x4_v s = red[f * 64 + lane];
+        for (int v = 1; v < NW; ++v) s += red[(v * (MT * NT) + f) * 64 + lane];  // fixed order: waves 0 .. NW-1
+        epilogue(f, s);
     }
 }
 
@@ -115,16 +128,30 @@ __global__ __launch_bounds__(64) void skinny_reduce_ln_kernel(const float* __res
     float* xr = x + (size_t)row * x_stride;
     const float* pr = part + (size_t)row * D;
     float v[NV][4];
+    // every load of the row is issued before the first add (a runtime slab loop would walk the slabs one L2 round trip at a time:
+    // 6.0 us per launch against the 4.5 us of a plain LayerNorm kernel, profiles/r3_latency_trace_vitb32.txt); the adds keep slab order
+    constexpr int SU = 4;  // slabs held in registers at once
+    float4 pb[NV], ps[SU][NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < D) {
             load4(xr + c, v[i]);
-            if (bias) {
-                const float4 b = *reinterpret_cast<const float4*>(bias + c);
-                v[i][0] += b.x; v[i][1] += b.y; v[i][2] += b.z; v[i][3] += b.w;
-            }
-            for (int s = 0; s < S; ++s) {  // fixed order: slabs 0 .. S-1
+            pb[i] = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < SU; ++s)
+                ps[s][i] = s < S ? *reinterpret_cast<const float4*>(pr + (size_t)s * slice_stride + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            v[i][0] += pb[i].x; v[i][1] += pb[i].y; v[i][2] += pb[i].z; v[i][3] += pb[i].w;
+#pragma unroll
+            for (int s = 0; s < SU; ++s)
+                if (s < S) { v[i][0] += ps[s][i].x; v[i][1] += ps[s][i].y; v[i][2] += ps[s][i].z; v[i][3] += ps[s][i].w; }
+            for (int s = SU; s < S; ++s) {  // more than SU slabs (not used by the tower): the rest one by one
                 const float4 p = *reinterpret_cast<const float4*>(pr + (size_t)s * slice_stride + c);
                 v[i][0] += p.x; v[i][1] += p.y; v[i][2] += p.z; v[i][3] += p.w;
             }
@@ -134,17 +161,18 @@ __global__ __launch_bounds__(64) void skinny_reduce_ln_kernel(const float* __res
     if (ln_w) ln_row_store<T, NV>(v, D, lane, ln_w, ln_b, eps, h + (size_t)row * h_stride);
 }
 
-template <typename T, int MT, int KS>
+template <typename T, int MT, int NT, int KS>
 int launch_one(const SkinnyArgs& g, int nw, hipStream_t stream) {
-    auto kern = skinny_gemm_kernel<T, MT, KS>;
-    const int lds = nw > 1 ? nw * MT * 1024 : 0;
+    auto kern = skinny_gemm_kernel<T, MT, NT, KS>;
+    const int lds = nw > 1 ? nw * MT * NT * 1024 : 0;
     if (lds > 48 * 1024) ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3(g.N / 16, g.ksplit), dim3(nw * 64), lds, stream, g);
+    const int mtd = (g.M + 15) / 16;
+    hipLaunchKernelGGL(kern, dim3(g.N / (16 * NT), g.ksplit, (mtd + MT - 1) / MT), dim3(nw * 64), lds, stream, g);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
 
-template <typename T, int MT>
+template <typename T, int MT, int NT>
 int launch_ks(const SkinnyArgs& g, hipStream_t stream) {
     const int kslice = g.K / g.ksplit;
     int nw = 1;
@@ -154,22 +182,23 @@ int launch_ks(const SkinnyArgs& g, hipStream_t stream) {
             break;
         }
     const int kw = kslice / nw;
-    if constexpr (MT <= 13) {  // MT = 16: 48 fragments + 64 accumulators do not fit 256 registers at three k-steps
-        if (kw % 96 == 0) return launch_one<T, MT, 3>(g, nw, stream);
-    }
-    if (kw % 64 == 0) return launch_one<T, MT, 2>(g, nw, stream);
-    return launch_one<T, MT, 1>(g, nw, stream);
+    if (kw % 96 == 0) return launch_one<T, MT, NT, 3>(g, nw, stream);
+    if (kw % 64 == 0) return launch_one<T, MT, NT, 2>(g, nw, stream);
+    return launch_one<T, MT, NT, 1>(g, nw, stream);
 }
 
 template <typename T>
 int launch_mt(const SkinnyArgs& g, hipStream_t stream) {
     const int mt = (g.M + 15) / 16;
-    if (mt <= 1) return launch_ks<T, 1>(g, stream);
-    if (mt <= 2) return launch_ks<T, 2>(g, stream);
-    if (mt <= 4) return launch_ks<T, 4>(g, stream);
-    if (mt <= 8) return launch_ks<T, 8>(g, stream);
-    if (mt <= 13) return launch_ks<T, 13>(g, stream);
-    return launch_ks<T, 16>(g, stream);
+    if (mt <= 1) return launch_ks<T, 1, 1>(g, stream);
+    if (mt <= 2) return launch_ks<T, 2, 1>(g, stream);
+    if (mt <= 4) return launch_ks<T, 4, 1>(g, stream);
+    // 65 .. 256 rows, ceil(mt / 4) m-groups of 64 rows.  Wide outputs (qkv, c_fc) and 4-way split products (c_proj): 64 x 64 tiles,
+    // 144-192 workgroups of (64 + 64) x K bytes (8.8 / 9.8 / 9.4 us at 197 rows against 9.7 / 15.0 / 13 us on strips -- 576-768
+    // workgroups, several per CU); width-wide outputs (out_proj, the ViT-B/16 patch embedding): 64 x 16 strips, 192 workgroups of
+    // (64 + 16) x K bytes (6.4 against 9.0 us on 48 tiles).  scripts/skinny_bench.hip, profiles/r3_skinny_bench.txt
+    if ((g.N & 63) == 0 && !g.strips && (g.N >= 1536 || g.ksplit >= 4)) return launch_ks<T, 4, 4>(g, stream);
+    return launch_ks<T, 4, 1>(g, stream);
 }
 
 }  // namespace

@@ -126,6 +126,7 @@ struct TowerCtx {
     // residual and applies the NEXT LayerNorm -- six launches per block, each near the 3 us a dependent launch costs.
     bool skinny = false;       // set by the owner for a pass of at most SKINNY_MAX_M rows IN TOTAL (never per GEMM: a batch cut into
                                // parts must give the same bits whatever the part size, tests/test_clip_gpu.py two-stream test)
+    bool h_ready0 = false;     // the caller already wrote ln_1 of the first block into h (the latency path's token-assembly kernel)
     float* part = nullptr;     // split-K slabs, f32 [<= 4][rows][width]; null: out_proj / c_proj stay single launches
     size_t part_floats = 0;
     // multi-scale export: after every block, one row per sample of the residual stream -- what the forward
@@ -361,7 +362,7 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
     const bool lat = sizeof(T) == 2 && c.skinny && c.gemm_force == 0 && !c.fp8_mlp && c.part && M <= SKINNY_MAX_M && S_out && S_proj &&
                      (size_t)std::max(S_out, S_proj) * M * D <= c.part_floats && skinny_supported(M, 3 * D, D, D, D) && skinny_supported(M, 4 * D, D, D, D);
     const std::string s_red2 = t + ".out_reduce_ln_2", s_red1 = t + ".proj_reduce_ln_1";
-    bool h_ready = false;  // h already holds ln_1 of this block (written by the previous block's reduction)
+    bool h_ready = lat && c.h_ready0;  // h already holds ln_1 of this block (written by the previous block's reduction)
     for (int i = 0; i < tw.layers; ++i) {
         const LayerW& L = tw.L[i];
         if constexpr (sizeof(T) == 2) {

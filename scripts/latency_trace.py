@@ -30,7 +30,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--analyze":
         for r, nx in zip(ks, ks[1:]):
             gaps.append((int(nx["Start_Timestamp"]) - int(r["End_Timestamp"])) / 1e3)
         for r in ks:
-            name = r["Kernel_Name"].split("(")[0].replace("void arp::", "").replace("(anonymous namespace)::", "")[:70]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("arp::", "").split("(")[0][:70]
+            if "skinny_gemm" in name:
+                name += f" grid {r.get('Grid_Size_X', '?')}x{r.get('Grid_Size_Y', '?')} wg {r.get('Workgroup_Size_X', '?')}"
             per[name][0] += 1
             per[name][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     n = len(spans)
