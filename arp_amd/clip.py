@@ -133,7 +133,7 @@ class ClipLabeller:
             shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
             check(lib.arp_clip_load_weight(h, name.encode(), _ffi.as_ptr(a, C.c_float), shape, a.ndim))
         if fp8_mlp:
-            check(lib.arp_clip_set_fp8_mlp(h, 1))
+            check(lib.arp_clip_set_fp8_mlp(h, 2 if fp8_mlp in (2, "all") else 1))  # 2 / "all": in_proj and out_proj on fp8 operands too
         check(lib.arp_clip_finalize_weights(h))
 
     def close(self):

@@ -103,6 +103,7 @@ struct arp_clip {
     // while the LayerNorm kernels they replace overlap with the other stream's GEMMs.  Off by default.
     bool ln_fold = false;
     bool fp8_mlp = false;       // vision tower MLP GEMMs on the scaled fp8 MFMA (arp_clip_set_fp8_mlp before finalize; tower.h)
+    bool fp8_attn = false;      // ... and in_proj / out_proj as well (arp_clip_set_fp8_mlp(c, 2))
     bool qkv_fused = true;      // QKV projection + attention in one kernel (qkvattn.h) where the geometry allows; ARP_QKV_FUSED=0 disables
     bool cls_only_last = true;  // vision tower: the last block computes only what ln_post reads (tower.h); ARP_CLS_ONLY=0 disables
     DevBuf stats;
@@ -143,7 +144,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.attn_impl = c->cfg.attn_impl;
     t.gemm_force = c->gemm_force;
     t.qkv_fused = c->qkv_fused;
-    t.fp8_mlp = c->fp8_mlp;
+    t.fp8_mlp = c->fp8_mlp; t.fp8_attn = c->fp8_attn;
     t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
     t.skinny = c->lat_now; t.h_ready0 = c->lat_now && c->lat_h0; t.part = c->part.as<float>(); t.part_floats = c->part.bytes / 4;
     return t;
@@ -262,6 +263,19 @@ static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers,
             for (auto& v : g8) v *= FP8_S_H;
             for (auto& v : b8) v *= FP8_S_H;
             ARP_TRY(upload_f32(c, g8, &L.ln2_w8)); ARP_TRY(upload_f32(c, b8, &L.ln2_b8));
+            if (c->fp8_attn) {  // the attention's projections too (tower.h::tower_attn_fp8)
+                const HostTensor *wi, *wo;
+                float si = 1.f, so = 1.f;
+                ARP_TRY(get_staged(c, p + "attn.in_proj_weight", {3 * d, d}, &wi)); ARP_TRY(put8(wi->data, &L.w_in8, &si));
+                ARP_TRY(get_staged(c, p + "attn.out_proj.weight", {d, d}, &wo)); ARP_TRY(put8(wo->data, &L.w_out8, &so));
+                L.a_in = 1.0f / (FP8_S_H * si);
+                L.a_out = 1.0f / (FP8_S_A * so);
+                ARP_TRY(get_staged(c, p + "ln_1.weight", {d}, &lw)); ARP_TRY(get_staged(c, p + "ln_1.bias", {d}, &lb));
+                std::vector<float> g1(lw->data), b1(lb->data);
+                for (auto& v : g1) v *= FP8_S_H;
+                for (auto& v : b1) v *= FP8_S_H;
+                ARP_TRY(upload_f32(c, g1, &L.ln1_w8)); ARP_TRY(upload_f32(c, b1, &L.ln1_b8));
+            }
         }
         if (fold) {  // LayerNorm folded into in_proj (ln_1) and c_fc (ln_2): tower.h fold_layernorm
             const HostTensor *w, *b, *lw, *lb;
@@ -1080,6 +1094,7 @@ int arp_clip_set_fp8_mlp(arp_clip* c, int on) {
     if (on && c->cfg.mode == ARP_MODE_F32) return fail("fp8 MLP needs a 16-bit mode for the rest of the tower");
     if (on && c->cfg.width % 128) return fail("fp8 MLP needs width % 128 == 0");
     c->fp8_mlp = on != 0;
+    c->fp8_attn = on >= 2;
     return 0;
 }
 
@@ -1311,6 +1326,13 @@ int arp_op_gemm_fp8(int act, const float* A, const float* W, const float* bias, 
         g.A = dA.p; g.W = dW.p; g.bias = bias ? dB.as<float>() : nullptr; g.resid = resid ? dR.as<float>() : nullptr; g.out = dO.p;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldr = N; g.ldo = N; g.alpha = alpha; g.out_scale = out_scale;
         int rc;
+        if (out_fp8 == 2) {  // f16 output (the in_proj of the fp8 attention projections)
+            if (act != ACT_NONE || resid) return fail("f16 output: no activation, no residual");
+            rc = launch_gemm256_nt<fp8_t, f16_t, ACT_NONE, false, SITE_OP>(g, nullptr);
+            ARP_TRY(rc);
+            ARP_HIP_OK(hipDeviceSynchronize());
+            return from_dev<f16_t>(out, (size_t)M * N, dO);
+        }
         if (out_fp8) rc = act == ACT_QGELU ? launch_gemm256_nt<fp8_t, fp8_t, ACT_QGELU, false, SITE_OP>(g, nullptr) : launch_gemm256_nt<fp8_t, fp8_t, ACT_NONE, false, SITE_OP>(g, nullptr);
         else if (act != ACT_NONE) return fail("f32 output: act must be ACT_NONE");
         else rc = resid ? launch_gemm256_nt<fp8_t, float, ACT_NONE, true, SITE_OP>(g, nullptr) : launch_gemm256_nt<fp8_t, float, ACT_NONE, false, SITE_OP>(g, nullptr);

@@ -84,7 +84,8 @@ __device__ long long* arp_attn_stamps = nullptr;  // scripts/attn_bench.hip: per
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int D,
-                                                        int heads, float scale, int causal, int nq) {
+                                                        int heads, float scale, int causal, int nq, float out8 = 0.f) {
+    // out8 != 0: `out` is an e4m3 buffer [B*N, D] bytes and receives out8 * value (operand of an fp8 out_proj, tower.h)
     constexpr int NP = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -206,10 +207,17 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
         }
         AT_ACC(3);
         if (qvalid && qidx < nq) {
-            T* orow = out + ((size_t)b * N + qidx) * D + h * 64;
+            if (out8 != 0.f) {
+                fp8_t* orow = reinterpret_cast<fp8_t*>(out) + ((size_t)b * N + qidx) * D + h * 64;
+                const float sc = inv * out8;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                store4(orow + dt * 16 + fg * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+                for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16 + fg * 4, o[dt][0] * sc, o[dt][1] * sc, o[dt][2] * sc, o[dt][3] * sc);
+            } else {
+                T* orow = out + ((size_t)b * N + qidx) * D + h * 64;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    store4(orow + dt * 16 + fg * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            }
         }
         AT_ACC(4);
     }

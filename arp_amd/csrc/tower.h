@@ -26,6 +26,10 @@ struct LayerW {
     void *w_fc8 = nullptr, *w_proj8 = nullptr;
     float *ln2_w8 = nullptr, *ln2_b8 = nullptr;
     float a_fc = 1.f, a_proj = 1.f;
+    // fp8 projections of the attention (TowerCtx::fp8_attn): e4m3 in_proj / out_proj, ln_1 pre-multiplied by the activation scale
+    void *w_in8 = nullptr, *w_out8 = nullptr;
+    float *ln1_w8 = nullptr, *ln1_b8 = nullptr;
+    float a_in = 1.f, a_out = 1.f;
     // head-major in-proj operands of the fused QKV + attention kernel (qkvattn.h): rows h*192 + {q | k | v of head h}
     void* w_in_hm = nullptr;
     float* b_in_hm = nullptr;
@@ -120,6 +124,10 @@ struct TowerCtx {
     // reads it and writes QuickGELU x 16 as e4m3, c_proj reads that; accumulation, bias, residual stream stay f32.  Three
     // significand bits: a lower-precision THROUGHPUT mode for the frozen towers of the fine-tune step, not the labelling default.
     bool fp8_mlp = false;
+    // ... and the attention's two projections as well (blocks whose QKV + attention do not run on the fused kernel, i.e. ViT-B/16's
+    // 197 tokens): ln_1 writes e4m3 (x 32), in_proj is an fp8 GEMM with a 16-bit output (the attention kernel's operand type), the
+    // attention writes its output as e4m3 (x 16), out_proj is an fp8 GEMM into the f32 residual stream.
+    bool fp8_attn = false;
     bool qkv_fused = true;  // QKV projection + attention in one kernel where qkvattn.h supports the geometry (ARP_QKV_FUSED=0 disables)
     // Latency path (the rollout loop's single-frame reward): with at most SKINNY_MAX_M rows in the residual stream the
     // GEMMs run on the W-tiled skinny kernel (skinny.h), out_proj / c_proj as split-K slabs whose reduction kernel also adds bias +
@@ -199,7 +207,7 @@ static int tower_layernorm(TowerCtx& c, const char* site, const float* in, size_
 }
 
 template <typename T>
-static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, int B, int N, int D, int heads, int causal, int nq = 0) {
+static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, int B, int N, int D, int heads, int causal, int nq = 0, float out8 = 0.f) {
     const int hd = D / heads;
     if (nq <= 0 || nq > N) nq = N;  // query rows produced per sample
     const float scale = 1.0f / sqrtf((float)hd);
@@ -213,7 +221,7 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         const int nqb_ = (nq + 15) / 16;                                                                                    \
         const int qsplit_ = (B * heads < 128 && nqb_ > 4) ? std::min((nqb_ + 3) / 4, 4) : 1;                                   \
-        hipLaunchKernelGGL(kern, dim3(B* heads, qsplit_), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal, nq);  \
+        hipLaunchKernelGGL(kern, dim3(B* heads, qsplit_), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal, nq, out8);  \
         ARP_HIP_OK(hipGetLastError());                                                                                      \
         return 0;                                                                                                           \
     }
@@ -229,6 +237,7 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
 #undef ARP_ATTN_CASE
         }
     }
+    if (out8 != 0.f) return fail("attention: the e4m3 output exists on the MFMA kernel only");
     const size_t lds = (size_t)2 * N * hd * 4;
     if (lds > 160 * 1024) return fail("attention: sequence too long for the LDS-resident kernel");
     const int threads = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
@@ -249,6 +258,40 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
     }
     ARP_HIP_OK(hipGetLastError());
     return 0;
+}
+
+// the MFMA attention kernel is instantiated for this sequence length (launch_attention's switch)
+static inline bool attn_mfma_has(int N, int hd) {
+    const int NT = ((N + 31) / 32) * 2;
+    return hd == 64 && (NT == 2 || NT == 4 || NT == 6 || NT == 8 || NT == 14 || NT == 18);
+}
+constexpr float FP8_S_A = 16.f;  // activation scale of the attention output as an fp8 operand
+
+// ln_1 -> in_proj -> attention -> out_proj (+ residual) with both projections on fp8 operands (TowerCtx::fp8_attn)
+template <typename T, int SB>
+static int tower_attn_fp8(TowerCtx& c, const TowerW& tw, const LayerW& L, const char* s_ln1, const char* s_qkv, const char* s_attn, const char* s_out, float* x,
+                          T* h, T* qkv, T* ao, int B, int N, int causal, float eps) {
+    const int D = tw.width, M = B * N;
+    fp8_t* h8 = reinterpret_cast<fp8_t*>(h);
+    ARP_TRY(tower_layernorm<fp8_t>(c, s_ln1, x, D, h8, D, L.ln1_w8, L.ln1_b8, M, D, eps));
+    GemmArgs g;
+    g.A = h8; g.W = L.w_in8; g.bias = L.b_in; g.out = qkv;
+    g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D; g.ldr = 3 * D; g.ldo = 3 * D;
+    g.alpha = L.a_in;
+    {
+        ProfScope ps(*c.prof, c.stream, s_qkv);
+        ARP_TRY((launch_gemm256_nt<fp8_t, T, ACT_NONE, false, SB + SITE_QKV>(g, c.stream)));
+    }
+    {
+        ProfScope ps(*c.prof, c.stream, s_attn);
+        ARP_TRY(launch_attention<T>(c.stream, 0, qkv, ao, B, N, D, tw.heads, causal, 0, FP8_S_A));
+    }
+    GemmArgs q;
+    q.A = ao; q.W = L.w_out8; q.bias = L.b_out; q.resid = x; q.out = x;
+    q.M = M; q.N = D; q.K = D; q.lda = D; q.ldw = D; q.ldr = D; q.ldo = D;
+    q.alpha = L.a_out;
+    ProfScope ps(*c.prof, c.stream, s_out);
+    return launch_gemm256_nt<fp8_t, float, ACT_NONE, true, SB + SITE_OUT>(q, c.stream);
 }
 
 // ln_1 output -> attention output: the fused kernel where the geometry allows it, else projection + attention kernel
@@ -392,9 +435,20 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
             ARP_TRY(tower_export_rows(c, x, D, i, B, N));
             break;
         }
-        ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));
-        ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn.c_str(), s_qa.c_str(), h, qkv, ao, B, N, causal, 0)));
-        ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out.c_str(), ao, L.w_out, L.b_out, x, x, M, D, D)));
+        bool attn_done = false;
+        if constexpr (sizeof(T) == 2) {
+            if (c.fp8_attn && L.w_in8 && c.attn_impl == 0 && (D % 128) == 0 && attn_mfma_has(N, D / tw.heads) &&
+                !(c.qkv_fused && L.w_in_hm && qkv_attn_supported(N, D, tw.heads, (int)sizeof(T)))) {
+                const std::string s_ln18 = t + ".ln_1_fp8", s_qkv8 = t + ".qkv_fp8", s_attn8 = t + ".attn_out8", s_out8 = t + ".out_proj_fp8";
+                ARP_TRY((tower_attn_fp8<T, SB>(c, tw, L, s_ln18.c_str(), s_qkv8.c_str(), s_attn8.c_str(), s_out8.c_str(), x, h, qkv, ao, B, N, causal, eps)));
+                attn_done = true;
+            }
+        }
+        if (!attn_done) {
+            ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));
+            ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn.c_str(), s_qa.c_str(), h, qkv, ao, B, N, causal, 0)));
+            ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out.c_str(), ao, L.w_out, L.b_out, x, x, M, D, D)));
+        }
         if (sizeof(T) == 2 && c.fp8_mlp && L.w_fc8 && (D % 128) == 0) {
             const std::string s_fc18 = t + ".c_fc_fp8", s_fc28 = t + ".c_proj_fp8";
             ARP_TRY((tower_mlp_fp8<T, ACT, SB>(c, L, s_ln2.c_str(), s_fc18.c_str(), s_fc28.c_str(), x, h, fc, M, D, eps)));

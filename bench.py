@@ -413,7 +413,7 @@ def bench_finetune(a):
         # frames in: the frozen CLIP ViT-B/16 towers (random init) produce the per-block CLS / EOT features every step;
         from arp_amd import clip, synth
         ccfg = clip.MODELS["ViT-B/16"]
-        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=local_rank, max_batch=3 * B, fp8_mlp=a.fp8_mlp)
+        towers = clip.ClipLabeller(ccfg, synth.clip_weights(ccfg, seed=0), mode=a.mode, device=local_rank, max_batch=3 * B, fp8_mlp=(2 if a.fp8_attn else 1) if a.fp8_mlp else False)
         frames = np.concatenate([synth.procgen_like_frames(B, seed=200 + k) for k in range(3)])  # image0 | image1 | image2
         tokens = synth.prompt_tokens(B, [8] * B, seed=203)
         rb = FT.synth_batch(cfg, B, seed=100 + rank)
@@ -468,7 +468,7 @@ def bench_finetune(a):
                   "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": world * a.finetune_batch * a.steps / elapsed,
         "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
-        "config": {"towers": None if towers is None else ("ViT-B/16, " + a.mode + (" + fp8 (e4m3) c_fc / c_proj" if a.fp8_mlp else "")),
+        "config": {"towers": None if towers is None else ("ViT-B/16, " + a.mode + ((" + fp8 (e4m3) c_fc / c_proj" + (" / in_proj / out_proj" if a.fp8_attn else "")) if a.fp8_mlp else "")),
                    "workload": f"CLIPMultiscaleAdapter head train step, {a.finetune_batch} samples x 3 frames, ViT-B/16-shaped tower features "
                                f"[3,B,9216]+[3,B,512] / [B,6144]+[B,512] resident in HBM, {tr.n_params / 1e6:.0f} M trainable params "
                                f"(BASELINE.json configs[4])", "parallelism": "single GPU (as the reference)" if world == 1 else f"dp{world}: one RCCL all-reduce(sum) of the "
@@ -508,6 +508,7 @@ def main():
     ap.add_argument("--finetune-batch", type=int, default=64, help="samples per step (finetune.py:25)")
     ap.add_argument("--fp8-mlp", action="store_true", help="label path / finetune --with-towers: the vision tower's c_fc / c_proj GEMMs on e4m3 "
                     "operands (scaled fp8 MFMA; BASELINE configs[4] 'fp8 MFMA GEMMs'): a lower-precision throughput mode, its parity is printed")
+    ap.add_argument("--fp8-attn", action="store_true", help="with --fp8-mlp: the attention's in_proj / out_proj on e4m3 operands too (ViT-B/16 towers)")
     ap.add_argument("--with-towers", action="store_true", help="finetune path: run the frozen CLIP ViT-B/16 towers inside the timed step "
                     "(uint8 frames + tokens in) instead of feeding pre-computed tower features")
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
@@ -561,7 +562,7 @@ def main():
     cfg = clip.MODELS[a.model]
     weights = synth.clip_weights(cfg, seed=0)
     tokens = synth.prompt_tokens(1, 8, seed=2)
-    model = clip.ClipLabeller(cfg, weights, mode=a.mode, device=local_rank, max_batch=a.batch, n_streams=a.streams, fp8_mlp=a.fp8_mlp).set_text(tokens)
+    model = clip.ClipLabeller(cfg, weights, mode=a.mode, device=local_rank, max_batch=a.batch, n_streams=a.streams, fp8_mlp=(2 if a.fp8_attn else 1) if a.fp8_mlp else False).set_text(tokens)
 
     # parity gate on a few frames (rank 0): the thing timed below is the thing checked here
     parity = None

@@ -83,7 +83,8 @@ int arp_clip_load_weight(arp_clip* h, const char* name, const float* data, const
 /* Before arp_clip_finalize_weights: run the vision tower's c_fc / c_proj GEMMs on the scaled fp8 MFMA (e4m3 operands, f32 accumulate;
  * BASELINE.json configs[4] "bf16 with fp8 MFMA GEMMs").  A THROUGHPUT mode for the frozen towers of the fine-tune step
  * (finetune_module/clip_multiscale_adapter.py:134-175): 3 significand bits, features ~1e-2 off the f32 towers -- not for labelling
- * to 1e-4.  16-bit modes only, width % 128 == 0. */
+ * to 1e-4.  16-bit modes only, width % 128 == 0.  on = 2: the attention's in_proj / out_proj on fp8 operands as well, in blocks whose QKV +
+ * attention do not run on the fused kernel (ViT-B/16's 197 tokens): ln_1 and the attention output are written as e4m3. */
 int arp_clip_set_fp8_mlp(arp_clip* h, int on);
 int arp_clip_finalize_weights(arp_clip* h);
 
@@ -340,7 +341,8 @@ int arp_h5_write_rows_deflated(void* write_chunk_fn, int64_t dset, int64_t dxpl,
 /* ---- single-operator entry points (host buffers; used by the per-kernel parity tests) ---------- */
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid), operands rounded to bf16 in ARP_MODE_BF16. */
 /* fp8 (e4m3) instances of the 256x256 GEMM: operands rounded to e4m3 on the host; f32 output (+ residual) or e4m3 output
- * (out_scale * act(...), returned decoded).  K % 128 == 0, N % 16 == 0. */
+ * (out_scale * act(...), returned decoded); out_fp8 = 2: IEEE-half output (the in_proj of the fp8 attention projections, returned
+ * decoded).  K % 128 == 0, N % 16 == 0. */
 int arp_op_gemm_fp8(int act, const float* A, const float* W, const float* bias, const float* resid, float* out, int M, int N, int K, float alpha,
                     int out_fp8, float out_scale);
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,

@@ -70,11 +70,17 @@ def _softmax(s):
     return e / e.sum(-1, keepdims=True)
 
 
-def mha(x, w_in, b_in, w_out, b_out, heads, causal):
-    """torch ``nn.MultiheadAttention`` self-attention: fused in-proj [3D, D], rows ordered q,k,v."""
+def mha(x, w_in, b_in, w_out, b_out, heads, causal, fp8=False):
+    """torch ``nn.MultiheadAttention`` self-attention: fused in-proj [3D, D], rows ordered q,k,v.
+    fp8: the product's optional e4m3 projections (csrc/tower.h::tower_attn_fp8): ln_1 output x 32 and the attention output x 16 as
+    e4m3, both weight matrices x a per-tensor power of two as e4m3; the attention itself stays on the 16-bit path."""
     n, t, d = x.shape
     hd = d // heads
-    qkv = x @ w_in.T + b_in
+    if fp8:
+        si = _pow2_scale(w_in)
+        qkv = (quant_e4m3(x * 32.0) @ quant_e4m3(w_in * si).T) / (32.0 * si) + b_in
+    else:
+        qkv = x @ w_in.T + b_in
     q, k, v = np.split(qkv, 3, axis=-1)
     sh = lambda a: a.reshape(n, t, heads, hd).transpose(0, 2, 1, 3)
     q, k, v = sh(q), sh(k), sh(v)
@@ -83,6 +89,9 @@ def mha(x, w_in, b_in, w_out, b_out, heads, causal):
         s = np.where(np.triu(np.ones((t, t), bool), 1), -np.inf, s)
     p = _softmax(s)
     o = (p @ v).transpose(0, 2, 1, 3).reshape(n, t, d)
+    if fp8:
+        so = _pow2_scale(w_out)
+        return (quant_e4m3(o * 16.0) @ quant_e4m3(w_out * so).T) / (16.0 * so) + b_out
     return o @ w_out.T + b_out
 
 
@@ -102,11 +111,11 @@ def _pow2_scale(w):
     return 2.0 ** np.floor(np.log2(240.0 / np.abs(w).max()))
 
 
-def resblock(x, W, pre, heads, causal, mlp_fp8=False):
+def resblock(x, W, pre, heads, causal, mlp_fp8=False, attn_fp8=False):
     g = lambda k: W[pre + k]
     h = layer_norm(x, g("ln_1.weight"), g("ln_1.bias"))
     x = x + mha(h, g("attn.in_proj_weight"), g("attn.in_proj_bias"), g("attn.out_proj.weight"),
-                g("attn.out_proj.bias"), heads, causal)
+                g("attn.out_proj.bias"), heads, causal, fp8=attn_fp8)
     h = layer_norm(x, g("ln_2.weight"), g("ln_2.bias"))
     if mlp_fp8:
         # the product's fp8 MLP (csrc/tower.h::tower_mlp_fp8): e4m3 activations x 32 / x 16, e4m3 weights x a per-tensor power of two
@@ -119,7 +128,7 @@ def resblock(x, W, pre, heads, causal, mlp_fp8=False):
     return x + h @ g("mlp.c_proj.weight").T + g("mlp.c_proj.bias")
 
 
-def encode_image(W, cfg, x_nchw, return_tokens=False, mlp_fp8=False):
+def encode_image(W, cfg, x_nchw, return_tokens=False, mlp_fp8=False, attn_fp8=False):
     """x_nchw: float [n,3,R,R] already normalised.  Returns un-normalised features [n, embed]."""
     n = x_nchw.shape[0]
     P, G, D = cfg.patch, cfg.grid, cfg.width
@@ -131,7 +140,8 @@ def encode_image(W, cfg, x_nchw, return_tokens=False, mlp_fp8=False):
     x = layer_norm(x, W["visual.ln_pre.weight"], W["visual.ln_pre.bias"])
     for i in range(cfg.layers):
         # (the product keeps the class-token-only last block on 16-bit operands: its row count is below the fp8 kernel's tile)
-        x = resblock(x, W, f"visual.transformer.resblocks.{i}.", cfg.heads, causal=False, mlp_fp8=mlp_fp8 and i < cfg.layers - 1)
+        x = resblock(x, W, f"visual.transformer.resblocks.{i}.", cfg.heads, causal=False, mlp_fp8=mlp_fp8 and i < cfg.layers - 1,
+                     attn_fp8=attn_fp8 and i < cfg.layers - 1)
     if return_tokens:
         return x
     c = layer_norm(x[:, 0], W["visual.ln_post.weight"], W["visual.ln_post.bias"])

@@ -387,6 +387,36 @@ def test_fp8_mlp_mode(gpu_lib):
     m16.close(); m8.close()
 
 
+def test_fp8_attention_projections(gpu_lib):
+    """fp8 level 2 (arp_clip_set_fp8_mlp(h, 2)): in_proj and out_proj on e4m3 operands as well, in a geometry whose attention is NOT the
+    fused kernel (patch 16: 197 tokens, the fine-tune step's ViT-B/16 towers).  Checked like the MLP mode: close to the oracle with the
+    same e4m3 roundings inserted, and the price against the plain oracle reported and bounded."""
+    from arp_amd import clip, synth
+    from oracle import clip_np as C, preprocess as P
+    kw = dict(MID, patch=16, width=256, heads=4, layers=3)
+    ocfg = C.ClipConfig(**kw)
+    Wt = synth.clip_weights(ocfg, seed=43)
+    fr = synth.procgen_like_frames(10, seed=44)   # 1970 rows
+    Wd = C.cast_weights(Wt, np.float64)
+    x = P.preprocess(fr).astype(np.float64)
+    f_ref = C.encode_image(Wd, ocfg, x)
+    f_emul = C.encode_image(Wd, ocfg, x, mlp_fp8=True, attn_fp8=True)
+    m8 = clip.ClipLabeller(clip.ClipConfig(**kw), Wt, mode="f16", n_streams=1, fp8_mlp=2)
+    m8.profile(True)
+    f8 = m8.encode_image(fr)
+    sites = m8.profile_read()
+    assert "vit.qkv_fp8" in sites and "vit.out_proj_fp8" in sites and "vit.c_fc_fp8" in sites and np.isfinite(f8).all()
+    cos = lambda a, b: float(np.min(np.sum(a * b, 1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))))
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    print(f"fp8 MLP + attention projections: vs e4m3-emulating oracle rel {rel(f8, f_emul):.2e}; vs plain oracle rel {rel(f8, f_ref):.2e}, "
+          f"min cosine {cos(f8, f_ref):.5f} (emulation vs plain: rel {rel(f_emul, f_ref):.2e})")
+    # (five e4m3 roundings per block instead of two: more values sit on a rounding boundary that 16-bit noise can cross, so the product
+    #  and the emulation agree a little less closely than in the MLP-only mode; the kernels themselves are checked exactly in test_ops_gpu.py)
+    assert rel(f8, f_emul) < 0.8 * rel(f_emul, f_ref) and rel(f8, f_emul) < 3e-2
+    assert cos(f8, f_ref) > 0.99 and cos(f8, f_emul) > 0.999
+    m8.close()
+
+
 def test_label_reward_from_hdf5_file(gpu_lib, tmp_path):
     """SURVEY row N3 end to end on the GPU: recorder-style HDF5 file in, reward / rtg datasets out (gzip, chunks (1, num_frames)),
     equal to labelling the same frames from memory."""

@@ -233,6 +233,10 @@ def test_gemm_fp8_exact_on_representable_operands(gpu_lib, shape):
     assert (np.abs(out - r) <= tol).all(), float((np.abs(out - r) / tol).max())
     gpu_lib.check(gpu_lib.lib.arp_op_gemm_fp8(0, _fp(A), _fp(W), None, None, _fp(out), M, N, K, alpha, 0, 1.0))
     assert (np.abs(out - ref) <= tol).all(), float((np.abs(out - ref) / tol).max())
+    # IEEE-half output (in_proj of the fp8 attention projections): alpha * acc + bias rounded to f16
+    gpu_lib.check(gpu_lib.lib.arp_op_gemm_fp8(0, _fp(A), _fp(W), _fp(bias), None, _fp(out), M, N, K, alpha, 2, 1.0))
+    want16 = (ref + bias).astype(np.float16).astype(np.float32)
+    assert (np.abs(out - want16) <= tol + np.abs(want16) * 2.0 ** -10).all()
     # e4m3 output: 0.25 * quickgelu(alpha * acc + bias), saturating; allow one rounding step where f32 noise crosses a boundary
     gpu_lib.check(gpu_lib.lib.arp_op_gemm_fp8(1, _fp(A), _fp(W), _fp(bias), None, _fp(out), M, N, K, alpha, 1, 0.25))
     want = O.quant_e4m3(0.25 * _act(ref + bias, 1))
