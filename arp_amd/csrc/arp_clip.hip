@@ -113,6 +113,8 @@ struct arp_clip {
     DevBuf part;
     bool skinny = true;     // ARP_SKINNY=0: the output-tiled GEMMs at every size
     bool lat_h0 = false;    // ... and its token-assembly kernel already wrote ln_1 of the first block into h
+    int lat_rows = 640;     // a pass of at most this many token rows takes the latency path (ARP_SKINNY_ROWS).  Measured crossover against the
+                            // throughput kernels: ~800 rows (profiles/r3_latency_rows.txt: +57 % at 50 rows, +43 % at 300, +16 % at 600, 0 at 800)
     bool lat_now = false;   // the pass being enqueued has at most SKINNY_MAX_M token rows (set by forward_chunk)
     bool lat_graph = true;  // ARP_CLIP_GRAPH=0: launch by launch
     struct LatGraph {
@@ -381,7 +383,7 @@ template <typename T>
 static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizePlan* plan) {
     const arp_clip_cfg& k = c->cfg;
     const int G = k.img_res / k.patch, N = c->ntok(), D = k.width, KP = 3 * k.patch * k.patch;
-    c->lat_now = c->skinny && sizeof(T) == 2 && (long)nb * N <= SKINNY_MAX_M;
+    c->lat_now = c->skinny && sizeof(T) == 2 && (long)nb * N <= c->lat_rows;
     struct LatGuard {
         arp_clip* c;
         ~LatGuard() { c->lat_now = false; c->lat_h0 = false; }
@@ -524,7 +526,7 @@ static int label_dev_single(arp_clip* c, const uint8_t* frames_dev, int n, int H
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     ResizePlan* plan;
     const int mb = c->cfg.max_batch;
-    const bool small = !c->is_sibling && n <= mb && (long)n * c->ntok() <= SKINNY_MAX_M;  // the rollout loop's call (one frame, or a few)
+    const bool small = !c->is_sibling && n <= mb && (long)n * c->ntok() <= c->lat_rows;  // the rollout loop's call (one frame, or a few)
     ARP_TRY(get_plan(c, H, W, use_crop, &plan, small));
     ARP_TRY(ensure_workspace(c, std::min(n, mb)));
     const float scale = expf(c->logit_scale);
@@ -544,15 +546,17 @@ static int label_dev_single(arp_clip* c, const uint8_t* frames_dev, int n, int H
                 return 0;
             }
         arp_clip::LatGraph g{frames_dev, rewards_dev, n, H, W, use_crop, nullptr, nullptr};
-        ARP_HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        // (Relaxed: another thread's HIP calls -- a reader thread pinning a buffer, a second handle -- must not invalidate the capture)
+        ARP_HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
         const int rc = pass(frames_dev, n, rewards_dev);
         const hipError_t ec = hipStreamEndCapture(c->stream, &g.graph);
-        if (rc != 0) {
+        if (rc != 0 || ec != hipSuccess || !g.graph || hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+            // a capture that did not take: this handle goes on launch by launch (same kernels, same results)
             if (g.graph) (void)hipGraphDestroy(g.graph);
-            return rc;
+            for (int k = 0; k < 4 && hipGetLastError() != hipSuccess; ++k) {}
+            c->lat_graph = false;
+            return pass(frames_dev, n, rewards_dev);
         }
-        ARP_HIP_OK(ec);
-        ARP_HIP_OK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
         if (c->lat_graphs.size() >= 8) {  // a caller that keeps changing buffers: forget the oldest
             (void)hipGraphExecDestroy(c->lat_graphs.front().exec);
             (void)hipGraphDestroy(c->lat_graphs.front().graph);
@@ -741,6 +745,7 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     if (const char* e = getenv("ARP_QKV_FUSED")) c->qkv_fused = atoi(e) != 0;
     if (const char* e = getenv("ARP_SKINNY")) c->skinny = atoi(e) != 0;
     if (const char* e = getenv("ARP_CLIP_GRAPH")) c->lat_graph = atoi(e) != 0;
+    if (const char* e = getenv("ARP_SKINNY_ROWS")) c->lat_rows = std::min(std::max(atoi(e), 1), SKINNY_MAX_M);
     if (const char* e = getenv("ARP_CLIP_PINNED")) c->lat_pinned = atoi(e) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -887,7 +892,7 @@ int arp_clip_label(arp_clip* c, const uint8_t* frames, int n, int H, int W, int 
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     const size_t fb = (size_t)H * W * 3;
     const int mb = c->cfg.max_batch;
-    if (c->lat_pinned && n <= mb && (long)n * c->ntok() <= SKINNY_MAX_M) {
+    if (c->lat_pinned && n <= mb && (long)n * c->ntok() <= c->lat_rows) {
         if (c->pin_frames_bytes < (size_t)n * fb) {
             ARP_HIP_OK(hipStreamSynchronize(c->stream));
             if (c->pin_frames) ARP_HIP_OK(hipHostFree(c->pin_frames));

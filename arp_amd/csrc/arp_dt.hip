@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -47,6 +48,7 @@ inline int cdiv(size_t a, size_t b) { return (int)((a + b - 1) / b); }
 struct arp_dt {
     arp_dt_cfg cfg;
     hipStream_t stream = nullptr;
+    std::mutex capture_mu;  // graph capture on the compute thread vs the uploader thread's HIP calls (fwd_bwd_graphed / upload_async)
     std::vector<ParamInfo> infos;
     std::map<std::string, int> index;
     size_t P = 0, n_decay = 0;  // total parameters; the first n_decay are the ndim > 1 ones (L2 penalty applies)
@@ -896,6 +898,12 @@ template <typename T> int fwd_bwd_graphed(arp_dt* c, int stage = 0) {
             return fwd_bwd<T>(c, stage);
         }
         if (stage != 2) c->shadows_stale = true;  // the captured chain always refreshes the operand shadows
+        // The uploader thread of prefetch_to_device must not issue HIP calls while this thread captures: its hipEventSynchronize on the
+        // slot's `use` event (last recorded on THIS stream, before the capture) is refused while the stream captures ("operation not
+        // permitted on an event last recorded in a capturing stream") and the refusal invalidates the capture ("operation failed due to
+        // a previous error during capture": one run in ~300 before this lock, every second run when provoked).  capture_mu is held for
+        // the few hundred microseconds of a capture -- three per trainer and batch slot -- and by arp_dt_upload_batch*_async.
+        std::lock_guard<std::mutex> capture_lock(c->capture_mu);
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             c->use_graph = false;
             return fwd_bwd<T>(c, stage);
@@ -907,7 +915,7 @@ template <typename T> int fwd_bwd_graphed(arp_dt* c, int stage = 0) {
             if (g) (void)hipGraphDestroy(g);
             gr.exec = nullptr;
             c->use_graph = false;
-            (void)hipGetLastError();
+            for (int k = 0; k < 4 && hipGetLastError() != hipSuccess; ++k) {}  // the invalidated capture's error is sticky until read
             if (stage != 2) c->shadows_stale = true;
             return fwd_bwd<T>(c, stage);
         }
@@ -1215,6 +1223,9 @@ static int upload_async(arp_dt* c, int slot, const float* enc, const float* fram
     // prefetch_to_device's protocol: a slot is handed back after its step's aux was read).  Not a stream-side wait: from this thread
     // hipStreamWaitEvent on an event of a stream that is being captured is refused, and a pageable upload queued behind a pending
     // stream wait ran 4x slower (7.8 ms instead of 1.8 ms per 101 MB).
+    // Never beside a graph capture on the compute thread (fwd_bwd_graphed): HIP refuses hipEventSynchronize on an event whose stream is
+    // capturing at that moment -- even one recorded long before the capture began -- and that refusal also invalidates the capture.
+    std::lock_guard<std::mutex> capture_lock(c->capture_mu);
     if (b.used) ARP_HIP_OK(hipEventSynchronize(b.use));
     // a slot that has to GROW frees its old buffers (hipFree synchronises the device): size them once, with the largest batch
     ARP_TRY(stage_slot(c, slot, c->copy_stream[slot], enc, frames, action, rtg, B));

@@ -1,4 +1,4 @@
-// Skinny NT GEMM for the LATENCY path: M <= 256 rows (one frame's 50 / 197 tokens, a handful of class rows).
+// Skinny NT GEMM for the LATENCY path: a few hundred rows at most (one frame's 50 / 197 tokens, a handful of frames, class rows).
 //
 // The throughput kernels (gemm.h, gemm256.h) tile the OUTPUT: at M = 50 a [50, 768] x [768, 3072]^T product is 24 tiles of
 // 128 x 128 on a 256-CU chip, and a K = 3072 one is 6 workgroups that each walk 48 K-tiles one memory round trip at a time
@@ -33,7 +33,7 @@ struct SkinnyArgs {
     int strips = 0;    // 1: 16-column strips even above 64 rows (A/B switch of the harness)
 };
 
-constexpr int SKINNY_MAX_M = 256;
+constexpr int SKINNY_MAX_M = 1024;  // hard cap of the kernel's domain (slab buffers are sized for it); the owner's row limit is lower
 
 // true when launch_skinny_gemm accepts the geometry
 inline bool skinny_supported(int M, int N, int K, int lda, int ldw, int ksplit = 1) {

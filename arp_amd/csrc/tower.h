@@ -301,7 +301,7 @@ static int tower_qkv_attention(TowerCtx& c, const TowerW& tw, const LayerW& L, c
     const int D = tw.width, M = B * N;
     if constexpr (sizeof(T) == 2) {
         // (with <= SKINNY_MAX_M rows the fused kernel is 12-60 workgroups walking K one round trip at a time: 18 us per block at one frame)
-        if (c.qkv_fused && L.w_in_hm && c.attn_impl == 0 && qkv_attn_supported(N, D, tw.heads, (int)sizeof(T)) && !(c.skinny && M <= SKINNY_MAX_M)) {
+        if (c.qkv_fused && L.w_in_hm && c.attn_impl == 0 && qkv_attn_supported(N, D, tw.heads, (int)sizeof(T)) && !c.skinny) {
             QkvAttnArgs q;
             q.A = h; q.W = L.w_in_hm; q.bias = L.b_in_hm; q.out = ao;
             q.B = B; q.N = N; q.K = D; q.heads = tw.heads; q.lda = D; q.ldw = D; q.ldo = D; q.fpt = 0; q.nq = nq; q.causal = causal; q.scale = 0.f;

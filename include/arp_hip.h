@@ -347,7 +347,7 @@ int arp_op_gemm_fp8(int act, const float* A, const float* W, const float* bias, 
                     int out_fp8, float out_scale);
 int arp_op_gemm_nt(int mode, int act, const float* A, const float* W, const float* bias, const float* resid,
                    float* out, int M, int N, int K);
-/* The latency path's GEMM (csrc/skinny.h: W-tiled, M <= 256 rows, N % 16, K % 32, 16-bit modes), the kernel behind the single-frame
+/* The latency path's GEMM (csrc/skinny.h: W-tiled, M <= 1024 rows, N % 16, K % 32, 16-bit modes), the kernel behind the single-frame
  * reward (reference call site: arp_dt/envs/vl_reward.py:11-23).  ksplit = 0: one launch, out = act(A.W^T + bias) + resid;
  * ksplit >= 1 (K % (32 ksplit) == 0): split-K slabs + row kernel, out = resid + bias + A.W^T, and h_out = LayerNorm(out; ln_w, ln_b, eps)
  * rounded to the operand type when ln_w != NULL. */

@@ -126,7 +126,7 @@ def test_online_single_frame_reward(gpu_lib):
 def test_latency_path_full_size(gpu_lib, name, monkeypatch):
     """Row N4 at the real geometry: single-frame calls (skinny GEMMs, split-K + reduce + LayerNorm kernels, small preprocess tiles, the
     pass replayed as a hipGraph, pinned staging) within north_star's 1e-4 cosine of the fp32 oracle in f16 mode; the graph replays the
-    same bits as launch-by-launch; a call of more frames than SKINNY_MAX_M token rows allows leaves the path; a new prompt drops the
+    same bits as launch-by-launch; a call of more token rows than the path's limit (640) leaves it; a new prompt drops the
     captured passes."""
     from arp_amd import clip, synth, label_reward as L
     from oracle import clip_np as C
@@ -148,7 +148,9 @@ def test_latency_path_full_size(gpu_lib, name, monkeypatch):
     prof = np.concatenate([m.label(fr[i:i + 1]) for i in range(6)])
     sites = m.profile_read(); m.profile(False)
     assert (prof == one).all() and "vit.proj_reduce_ln_1" in sites and "vit.qkv_attn" not in sites
-    assert np.abs(m.label(fr) - ref).max() / 100.0 < COS_TOL_F16  # 6 frames: 300 / 1182 rows, the throughput kernels
+    big = m.label(np.concatenate([fr, fr, fr]))  # 18 frames: 900 / 3546 token rows, past the path's row limit: the throughput kernels
+    assert np.abs(big - np.concatenate([ref, ref, ref])).max() / 100.0 < COS_TOL_F16
+    assert np.abs(m.label(fr[:3]) - ref[:3]).max() / 100.0 < COS_TOL_F16  # 150 / 591 rows: several frames per call on the latency path
     m.set_text(tok2)
     assert np.abs(np.concatenate([m.label(fr[i:i + 1]) for i in range(2)]) - ref2).max() / 100.0 < COS_TOL_F16
     m.close()
@@ -198,9 +200,11 @@ MID = dict(patch=32, width=128, layers=3, heads=2, embed=64, img_res=224, txt_wi
 def test_layernorm_fold_matches_unfused(gpu_lib, monkeypatch):
     """bf16 mode folds LayerNorm into the consumer GEMMs (gamma into W, mean/rstd from the residual GEMM's epilogue
     partial sums).  Folded and unfused paths must agree with each other and with the oracle; LN scale/bias are far
-    from identity and the rows have a large mean so the mean-subtraction term is exercised."""
+    from identity and the rows have a large mean so the mean-subtraction term is exercised.  (ARP_SKINNY=0: the 9-frame call would
+    otherwise take the latency path, which has no separate ln_1 launches to look for.)"""
     from arp_amd import clip, synth
     from oracle import clip_np as C
+    monkeypatch.setenv("ARP_SKINNY", "0")
     ocfg = C.ClipConfig(**MID)
     Wt = synth.clip_weights(ocfg, seed=17)
     rng = np.random.default_rng(3)

@@ -67,7 +67,7 @@ def test_gemm_nt(gpu_lib, mode, shape, kernel, monkeypatch):
 
 SKINNY_SHAPES = [  # M, N, K: the single-frame tower's products (50 / 197 token rows, class rows) and the edges of the kernel's domain
     (50, 2304, 768), (197, 768, 768), (50, 768, 3072), (197, 3072, 768), (1, 512, 768), (8, 768, 3072), (256, 64, 64), (17, 16, 32),
-    (49, 768, 3072), (100, 192, 160), (208, 128, 256),
+    (49, 768, 3072), (100, 192, 160), (208, 128, 256), (600, 2304, 768), (1000, 768, 768), (394, 768, 3072),
 ]
 
 
@@ -110,8 +110,8 @@ def test_skinny_gemm(gpu_lib, mode, shape):
 
 
 def test_skinny_gemm_rejects(gpu_lib):
-    A = np.zeros((300, 64), np.float32); W = np.zeros((16, 64), np.float32); out = np.zeros((300, 16), np.float32)
-    assert gpu_lib.lib.arp_op_skinny_gemm(2, 0, _fp(A), _fp(W), None, None, _fp(out), 300, 16, 64, 0, None, None, 0.0, None) != 0   # M > 256
+    A = np.zeros((1100, 64), np.float32); W = np.zeros((16, 64), np.float32); out = np.zeros((1100, 16), np.float32)
+    assert gpu_lib.lib.arp_op_skinny_gemm(2, 0, _fp(A), _fp(W), None, None, _fp(out), 1100, 16, 64, 0, None, None, 0.0, None) != 0   # M > 1024
     assert gpu_lib.lib.arp_op_skinny_gemm(2, 0, _fp(A), _fp(W), None, None, _fp(out), 8, 15, 64, 0, None, None, 0.0, None) != 0     # N % 16
     assert gpu_lib.lib.arp_op_skinny_gemm(2, 0, _fp(A), _fp(W), None, None, _fp(out), 8, 16, 48, 0, None, None, 0.0, None) != 0     # K % 32
     assert gpu_lib.lib.arp_op_skinny_gemm(0, 0, _fp(A), _fp(W), None, None, _fp(out), 8, 16, 64, 0, None, None, 0.0, None) != 0     # f32 mode
