@@ -607,7 +607,8 @@ static int make_sibling(arp_clip* c) {
 
 // host_src != null: the frames still live in host memory; every part uploads its own slice on its own stream right before its
 // compute, so the upload of part i+1 overlaps the kernels of part i (the S2 seam hands over host buffers).
-static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev, const uint8_t* host_src = nullptr) {
+static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W, int use_crop, float* rewards_dev, const uint8_t* host_src = nullptr,
+                     int lead = 0) {
     ARP_TRY(check_ready(c, true));
     int ns = c->cfg.n_streams;
     while (ns > 1 && n / ns < 128) --ns;  // keep every part big enough to fill the chip's GEMM grid
@@ -628,7 +629,7 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
         while (parts > ns && n / parts < 128) --parts;
         if (parts < ns) parts = ns;
         if (!c->copy_stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        while ((int)c->ev_copy.size() < parts) {
+        while ((int)c->ev_copy.size() < parts + 1) {
             hipEvent_t e = nullptr;
             ARP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             c->ev_copy.push_back(e);
@@ -647,18 +648,22 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
         s->prof.on = c->prof.on;
         ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_fork, 0));
     }
-    // contiguous parts; part i runs on stream i % ns (0 = the primary, k = sibling k-1)
-    const int per = (n + parts - 1) / parts;
-    for (int i = 0; i < parts; ++i) {
-        const int b0 = i * per, nb = std::min(per, n - b0);
+    // contiguous parts; part i runs on stream i % ns (0 = the primary, k = sibling k-1).
+    // lead > 0 (a SYNCHRONOUS host-fed call): a short first part on the primary stream, so that kernels start after lead / n of the upload
+    // instead of 1 / parts of it; the remaining frames are cut into `parts` equal parts, the first of them on the first sibling.
+    if (!host_src || lead <= 0 || n < 8 * lead) lead = 0;
+    const int per = (n - lead + parts - 1) / parts;
+    for (int i = lead ? -1 : 0; i < parts; ++i) {
+        const int b0 = i < 0 ? 0 : lead + i * per, nb = i < 0 ? lead : std::min(per, n - b0);
         if (nb <= 0) break;
-        arp_clip* s = (i % ns) == 0 ? c : c->siblings[(i % ns) - 1];
+        const int si = i < 0 ? 0 : (lead ? (i + 1) % ns : i % ns);
+        arp_clip* s = si == 0 ? c : c->siblings[si - 1];
         if (host_src) {
             // (the staging buffer's previous readers -- the last call's kernels -- were synchronised before that call returned)
             ARP_HIP_OK(hipMemcpyAsync(const_cast<uint8_t*>(frames_dev) + (size_t)b0 * fbytes, host_src + (size_t)b0 * fbytes, (size_t)nb * fbytes,
                                       hipMemcpyHostToDevice, c->copy_stream));
-            ARP_HIP_OK(hipEventRecord(c->ev_copy[i], c->copy_stream));
-            ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_copy[i], 0));
+            ARP_HIP_OK(hipEventRecord(c->ev_copy[i + 1], c->copy_stream));
+            ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_copy[i + 1], 0));
         }
         ARP_TRY(label_dev_single(s, frames_dev + (size_t)b0 * H * W * 3, nb, H, W, use_crop, rewards_dev + b0));
     }
@@ -917,7 +922,9 @@ int arp_clip_label(arp_clip* c, const uint8_t* frames, int n, int H, int W, int 
     ARP_TRY(c->rewards.ensure((size_t)std::min(n, mb) * 4));
     for (int off = 0; off < n; off += mb) {
         const int nb = std::min(mb, n - off);
-        ARP_TRY(label_dev(c, c->frames_in.as<uint8_t>(), nb, H, W, use_crop, c->rewards.as<float>(), frames + (size_t)off * fb));
+        // measured at 1 024 frames (scripts/lead_probe.py): lead 0: 13.24 ms per call, 64: 12.83, 96: 12.60, 128: 12.50, 192: 13.40; same bits
+        static const int lead_frames = getenv("ARP_CLIP_LEAD") ? atoi(getenv("ARP_CLIP_LEAD")) : 128;
+        ARP_TRY(label_dev(c, c->frames_in.as<uint8_t>(), nb, H, W, use_crop, c->rewards.as<float>(), frames + (size_t)off * fb, lead_frames));
         ARP_HIP_OK(hipMemcpyAsync(rewards + off, c->rewards.p, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
     }
