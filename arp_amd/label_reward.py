@@ -160,8 +160,61 @@ def _open_store(data_path, mode="a"):
     raise ValueError(f"unsupported data file {data_path!r}: pass store=<mapping of arrays> instead")
 
 
+class RowSink:
+    """Writes label rows into the demonstration file WHILE the GPU labels the next batch (one process, HDF5; ARP_LABEL_STREAM_WRITE=0
+    keeps the reference's order: everything labelled, then everything written).  The datasets are created -- gzip, chunks
+    (1, num_frames), maxshape (None, num_frames): label_reward.py:277-283 -- or grown to the file's row count on first use; a writer
+    thread places the row blocks (h5store's lock serialises it against the reader's chunk-address queries; the inflate threads never
+    enter the library).  The file's final content is the reference's: same datasets, same rows, same filters."""
+
+    def __init__(self, store, num_frames, total_rows, dtype):
+        import queue
+        import threading
+        self.store, self.num_frames, self.total_rows, self.dtype = store, num_frames, int(total_rows), dtype
+        self.q = queue.Queue()
+        self.err = None
+        self.rows = 0
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _dataset(self, key):
+        ds = self.store.get(key) if hasattr(self.store, "get") else None
+        if ds is None:
+            return self.store.create_dataset(key, shape=(self.total_rows, self.num_frames), dtype=self.dtype, compression="gzip",
+                                             chunks=(1, self.num_frames), maxshape=(None, self.num_frames))
+        if ds.shape[0] < self.total_rows:
+            ds.resize(self.total_rows, axis=0)
+        return ds
+
+    def _run(self):
+        cache = {}
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if self.err is not None:
+                continue  # drain: the error surfaces in close()
+            try:
+                key, first, rows = item
+                if key not in cache:
+                    cache[key] = self._dataset(key)
+                cache[key][first : first + rows.shape[0]] = rows.astype(self.dtype, copy=False)
+            except BaseException as e:  # noqa: BLE001 -- re-raised by close()
+                self.err = e
+
+    def __call__(self, key, first, rows):
+        self.rows += rows.shape[0]
+        self.q.put((key, int(first), rows))
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()
+        if self.err is not None:
+            raise self.err
+
+
 def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="clip", inst_type="none", use_crop=False,
-                rank=0, world=1, text=None, batch_frames=1024):
+                rank=0, world=1, text=None, batch_frames=1024, sink=None):
     """The per-trajectory loop (label_reward.py:256-289) over any mapping of arrays.
 
     For the per-frame rewards (``clip``, ``clip_ft``: frame i's reward depends on frame i and the prompt only) consecutive
@@ -169,7 +222,9 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
     same values, but a 64-frame call is launch-bound (30 k frames/s host-to-host) where a 1024-frame call runs at 70 k.
     ``clip_goal_conditioned`` compares against the trajectory's own last frame and stays one call per trajectory.
 
-    Returns ``{dataset_key: (first_row, float32 [rows, num_frames])}`` for this rank's shard."""
+    Returns ``{dataset_key: (first_row, float32 [rows, num_frames])}`` for this rank's shard.  ``sink(dataset_key, first_row, rows)``
+    (a ``RowSink``): the batched HDF5 path hands every batch's rows over as soon as they exist instead of collecting them; the
+    returned row arrays are then empty."""
     len_data, num_frames, bounds = trajectory_bounds(store)
     target_keys = [f"{model_type}_reward", f"{model_type}_pos_rtg"]
     if inst_type != "none":
@@ -211,6 +266,8 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
             if cur:
                 groups.append(cur)
         if hasattr(ds, "read_last_frames_spans") and per_frame and groups:
+            if sink is not None:
+                sink.total_rows = spans[-1][1]  # the reference's datasets end with the last LABELLED row (rows after the last `done` are not labelled)
             timing = os.environ.get("ARP_LABEL_TIMING") == "1"
             t_read = t_wait = t_label = 0.0
 
@@ -245,11 +302,18 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
 
             def emit(grp, r_all):
                 o = 0
+                rs, gs = [], []
                 for a, b in grp:
                     r = r_all[o : o + b - a]
                     o += b - a
-                    parts[target_keys[0]].append(stack_outputs(r, num_frames))
-                    parts[target_keys[1]].append(stack_outputs(discount_cumsum(r), num_frames))
+                    rs.append(stack_outputs(r, num_frames))
+                    gs.append(stack_outputs(discount_cumsum(r), num_frames))
+                if sink is not None:  # a group is whole consecutive trajectories: one contiguous block of rows from grp[0][0]
+                    sink(f"{img_key}_{target_keys[0]}", grp[0][0], np.concatenate(rs, axis=0))
+                    sink(f"{img_key}_{target_keys[1]}", grp[0][0], np.concatenate(gs, axis=0))
+                else:
+                    parts[target_keys[0]].extend(rs)
+                    parts[target_keys[1]].extend(gs)
 
             it = _prefetch((read(g) for g in groups), depth=2)
             inflight, k = None, 0  # (slot, trajectories, buffer) of the submitted, not yet collected call
@@ -401,8 +465,16 @@ def label_reward(
                 tokens = tokenizer([text] if not isinstance(text, list) else text)
             clip_model.set_text(np.asarray(tokens, dtype=np.int32))
 
-        results = label_store(store, clip_model, compute_reward, image_keys=image_keys, model_type=model_type,
-                              inst_type=inst_type, use_crop=use_crop, rank=rank, world=world, text=text)
+        # one process on a real file: rows are written while the next batch is labelled (RowSink)
+        sink = None
+        if is_hdf5 and world == 1 and model_type in ("clip", "clip_ft") and os.environ.get("ARP_LABEL_STREAM_WRITE", "1") != "0":
+            sink = RowSink(store, num_frames, 0, reward_dtype(model_type))  # label_store sets the row count once it knows its spans
+        try:
+            results = label_store(store, clip_model, compute_reward, image_keys=image_keys, model_type=model_type,
+                                  inst_type=inst_type, use_crop=use_crop, rank=rank, world=world, text=text, sink=sink)
+        finally:
+            if sink is not None:
+                sink.close()
         if is_hdf5 and world > 1:
             store.close()  # before the gather: it is the barrier after which no rank holds the file
             file_open = False

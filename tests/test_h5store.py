@@ -175,6 +175,31 @@ def test_label_reward_on_an_hdf5_file_matches_the_mapping_path(tmp_path, bool_do
             assert np.array_equal(f[k][...], v), k
 
 
+def test_streamed_and_collected_writes_give_the_same_file_content(tmp_path, monkeypatch):
+    """RowSink (rows written by a writer thread while the next batch is labelled) against ARP_LABEL_STREAM_WRITE=0 (the reference's
+    order: label everything, then write): same datasets, shapes, filters and values -- also when the file has rows after the last
+    `done` (not labelled, not part of the datasets) and when the datasets already exist and are longer or shorter."""
+    from arp_amd import label_reward as L
+    tok = np.zeros((1, 77), np.int32)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ARP_LABEL_STREAM_WRITE", mode)
+        p = str(tmp_path / f"data{mode}.hdf5")
+        _recorder_file(p, [5, 40, 2, 130, 9], hw=8, seed=11, trailing=4)
+        L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=p, clip_model=_FakeClip(), tokens=tok)
+        with h5store.H5Store(p, "a") as f:  # a too-short and a too-long existing dataset, then a second run
+            f["ob_clip_reward"].resize(100, axis=0)
+            f["ob_clip_pos_rtg"].resize(400, axis=0)
+        L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=p, clip_model=_FakeClip(), tokens=tok)
+        with h5store.H5Store(p, "r") as f:
+            out[mode] = {k: (f[k][...], f[k].chunks, f[k].compression, f[k].maxshape, f[k].dtype) for k in sorted(f.keys()) if k.startswith("ob_clip")}
+    assert set(out["0"]) == set(out["1"]) == {"ob_clip_reward", "ob_clip_pos_rtg"}
+    for k in out["0"]:
+        a, b = out["0"][k], out["1"][k]
+        assert a[1:] == b[1:] and a[0].shape == b[0].shape and np.array_equal(a[0], b[0]), k
+    assert out["1"]["ob_clip_reward"][0].shape == (186, F) and out["1"]["ob_clip_pos_rtg"][0].shape == (400, F)
+
+
 def test_default_path_layout(tmp_path):
     """data_path=None builds <base>/<env>_<mode>_level<start>to<num>_num<demos>_frame<frames>[_<env_type>]/data.hdf5 (label_reward.py:62-68)."""
     from arp_amd import label_reward as L
