@@ -54,6 +54,12 @@ def stack_outputs(pos_outputs, num_frames):
 def trajectory_bounds(store, done_key=None):
     """label_reward.py:71-87, including the ``time`` fallback of :84-87 when the done-key path raises.
     Returns (len_data, num_frames, [traj start indices..., end])."""
+    # label_reward and label_store both ask; on a recorder file the scan is one library read per row of `done` (31 ms for 8192 rows),
+    # so the answer is kept on the store object for the lifetime of the handle (nothing here writes `done` / `time`)
+    cached = getattr(store, "_arp_bounds", None) if done_key is None else None
+    if cached is not None:
+        return cached[0], cached[1], list(cached[2])
+    auto_key = done_key is None
     if done_key is None:
         for k in ("done", "rewards", "is_terminal"):
             if k in store and store[k] is not None:
@@ -71,6 +77,11 @@ def trajectory_bounds(store, done_key=None):
         len_data, num_frames = t.shape[:2]
         idx = list(np.where(np.asarray(t[:, -1, 0]) == 1.0)[0])
         idx.append(len(t))
+    if auto_key:
+        try:
+            store._arp_bounds = (len_data, num_frames, list(idx))
+        except (AttributeError, TypeError):  # a plain dict: nothing to hang the cache on
+            pass
     return len_data, num_frames, idx
 
 
@@ -158,6 +169,26 @@ def _open_store(data_path, mode="a"):
         from .h5store import H5Store  # ctypes over libhdf5 -- the library h5py wraps; ImportError if absent
         return H5Store(data_path, mode), True
     raise ValueError(f"unsupported data file {data_path!r}: pass store=<mapping of arrays> instead")
+
+
+def _big_buffer(n_elems, dtype):
+    """A frame buffer of ~200 MB that is filled once per batch and dropped at the end of the pass.  ARP_LABEL_HUGEPAGES=1 asks for
+    transparent huge pages (anonymous memory + MADV_HUGEPAGE): 49 k page faults going in and an munmap of as many pages coming out cost
+    ~9 ms each per buffer with 4 KiB pages (six buffers: 50 ms of a 220 ms file pass).  OFF by default -- measured on the MI355X host
+    it is a loss: 0.81 s instead of 0.21 s for the 8192-row pass (2 MiB pages zeroed inside the faults of 32 inflate threads, with
+    the host's `defrag = madvise` compaction in the way); on an idle 8-core box the same switch took first touch from 885 to 130 ms."""
+    nbytes = int(n_elems) * np.dtype(dtype).itemsize
+    try:
+        import mmap
+        if nbytes >= (8 << 20) and hasattr(mmap, "MADV_HUGEPAGE") and os.environ.get("ARP_LABEL_HUGEPAGES", "0") == "1":
+            mm = mmap.mmap(-1, nbytes + (2 << 20))
+            mm.madvise(mmap.MADV_HUGEPAGE)
+            base = np.frombuffer(mm, np.uint8)
+            off = (-base.ctypes.data) % (2 << 20)  # start on a 2 MiB boundary: every huge page of the range is whole
+            return base[off : off + nbytes].view(dtype)
+    except (OSError, ValueError, ImportError):
+        pass
+    return np.empty(int(n_elems), dtype)
 
 
 class RowSink:
@@ -280,7 +311,7 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                          and max(sum(b - a for a, b in g) for g in groups) <= getattr(clip_model, "max_batch", 0))
             pinned = []
             for _ in range(6 if pipelined else 4):
-                buf = np.empty(max(sum(b - a for a, b in g) for g in groups) * frame_elems, ds.dtype)
+                buf = _big_buffer(max(sum(b - a for a, b in g) for g in groups) * frame_elems, ds.dtype)
                 # (ARP_LABEL_PIN=1 pins the buffers -- arp_host_register.  Measured, and therefore OFF by default: registering 200 MB costs
                 # ~15 ms per buffer while the staged pageable upload already runs at the link rate, 56.5 against 57.4 GB/s, and overlaps the
                 # pass equally well: profiles/r3_seam_probe.txt)
@@ -315,6 +346,7 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                     parts[target_keys[0]].extend(rs)
                     parts[target_keys[1]].extend(gs)
 
+            t_setup = time.perf_counter()
             it = _prefetch((read(g) for g in groups), depth=2)
             inflight, k = None, 0  # (slot, trajectories, buffer) of the submitted, not yet collected call
             while True:
@@ -337,6 +369,7 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                     free.put(buf)
                 t_label += time.perf_counter() - t
                 del frames_all
+            t_tail = time.perf_counter()
             if inflight is not None:
                 emit(inflight[1], clip_model.label_collect(inflight[0]))
                 free.put(inflight[2])
@@ -344,7 +377,7 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                 clip_model.unpin_host(buf)
             if timing:
                 print(f"[label_store] {len(groups)} batches: reader thread busy {t_read:.3f} s, labeller waited for frames {t_wait:.3f} s, "
-                      f"labelling {t_label:.3f} s", flush=True)
+                      f"labelling {t_label:.3f} s, last collect {time.perf_counter() - t_tail:.3f} s, loop {t_tail - t_setup:.3f} s", flush=True)
             source = ()
         elif hasattr(ds, "read_last_frames"):
             source = _prefetch((ds.read_last_frames(a, b) for a, b in spans), depth=4)
