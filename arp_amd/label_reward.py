@@ -191,6 +191,21 @@ def _big_buffer(n_elems, dtype):
     return np.empty(int(n_elems), dtype)
 
 
+_FRAME_POOL = []  # frame buffers of earlier label_store passes in this process (dropping one costs ~9 ms of munmap; a later pass --
+                  # the next image key, the next demonstration file -- takes them back).  release_frame_buffers() empties it.
+
+
+def release_frame_buffers():
+    _FRAME_POOL.clear()
+
+
+def _take_frame_buffer(n_elems, dtype):
+    for i, b in enumerate(_FRAME_POOL):
+        if b.dtype == np.dtype(dtype) and b.size >= n_elems:
+            return _FRAME_POOL.pop(i)
+    return _big_buffer(n_elems, dtype)
+
+
 class RowSink:
     """Writes label rows into the demonstration file WHILE the GPU labels the next batch (one process, HDF5; ARP_LABEL_STREAM_WRITE=0
     keeps the reference's order: everything labelled, then everything written).  The datasets are created -- gzip, chunks
@@ -310,8 +325,10 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
             pipelined = (model_type == "clip" and getattr(clip_model, "label_submit", None) is not None and os.environ.get("ARP_LABEL_PIPELINE", "1") != "0"
                          and max(sum(b - a for a, b in g) for g in groups) <= getattr(clip_model, "max_batch", 0))
             pinned = []
-            for _ in range(6 if pipelined else 4):
-                buf = _big_buffer(max(sum(b - a for a, b in g) for g in groups) * frame_elems, ds.dtype)
+            bufs = []
+            for _ in range(min(len(groups) + 1, 5 if pipelined else 4)):  # filling + two read ahead + one in flight + the one being submitted
+                buf = _take_frame_buffer(max(sum(b - a for a, b in g) for g in groups) * frame_elems, ds.dtype)
+                bufs.append(buf)
                 # (ARP_LABEL_PIN=1 pins the buffers -- arp_host_register.  Measured, and therefore OFF by default: registering 200 MB costs
                 # ~15 ms per buffer while the staged pageable upload already runs at the link rate, 56.5 against 57.4 GB/s, and overlaps the
                 # pass equally well: profiles/r3_seam_probe.txt)
@@ -375,6 +392,8 @@ def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="
                 free.put(inflight[2])
             for buf in pinned:
                 clip_model.unpin_host(buf)
+            del _FRAME_POOL[: max(0, len(_FRAME_POOL) + len(bufs) - 6)]
+            _FRAME_POOL.extend(bufs)
             if timing:
                 print(f"[label_store] {len(groups)} batches: reader thread busy {t_read:.3f} s, labeller waited for frames {t_wait:.3f} s, "
                       f"labelling {t_label:.3f} s, last collect {time.perf_counter() - t_tail:.3f} s, loop {t_tail - t_setup:.3f} s", flush=True)
