@@ -31,6 +31,7 @@ struct SkinnyArgs {
     int ksplit = 1;
     size_t slice_stride = 0;
     int strips = 0;    // 1: 16-column strips even above 64 rows (A/B switch of the harness)
+    int gather = 0;    // 1: the fragment-gather kernel even where the coalesced LDS-DMA kernel applies (A/B switch of the harness)
 };
 
 constexpr int SKINNY_MAX_M = 1024;  // hard cap of the kernel's domain (slab buffers are sized for it); the owner's row limit is lower

@@ -120,6 +120,147 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs g) {
     }
 }
 
+// ---- the same product with COALESCED operand loads --------------------------------------------------------------------------------
+// scripts/fill_bench.hip: one CU fills from L2 at 18 B/clk with the fragment gather above (16 rows x 64 B per wave instruction) and at
+// 69 B/clk with 1 KiB-contiguous wave instructions -- so above the launch floor the gather IS the kernel's time.  Here every wave
+// brings its K range in as 64-element blocks by LDS-DMA (8 rows x 128 B per instruction, the 16-byte chunk index XOR-swizzled on the
+// source side like gemm.h) into its OWN double-buffered LDS image -- no workgroup barrier in the loop, only the wave's counted vmcnt --
+// and reads the MFMA fragments back with ds_read_b128.  K % (64 x waves) == 0; other shapes keep the gather kernel.
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = (MT + NT) * 16, GROUPS = ROWS / 8, REGION = ROWS * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    const int n0 = blockIdx.x * 16 * NT;
+    const int mt0 = blockIdx.z * MT;
+    const int slice = blockIdx.y;
+    const int kslice = g.K / (int)gridDim.y;
+    const int kw = kslice / NW, nblk = kw >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int kbase = slice * kslice + wave * kw;
+    char* my = smem + (size_t)wave * 2 * REGION;
+    // LDS-DMA sources: lane -> (row-in-group = lane / 8, PHYSICAL chunk lane % 8 holding logical chunk (lane % 8) ^ (row & 7))
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const T* __restrict__ src[GROUPS];
+#pragma unroll
+    for (int q = 0; q < GROUPS; ++q) {
+        const int r = q * 8 + srow;
+        if (r < MT * 16) {
+            int m = mt0 * 16 + r;
+            m = m < g.M ? m : g.M - 1;  // rows past M: computed on valid memory, never stored
+            src[q] = static_cast<const T*>(g.A) + (size_t)m * g.lda + kbase + schunk * 8;
+        } else {
+            src[q] = static_cast<const T*>(g.W) + (size_t)(n0 + r - MT * 16) * g.ldw + kbase + schunk * 8;
+        }
+    }
+    auto stage = [&](int buf, int b) {
+#pragma unroll
+        for (int q = 0; q < GROUPS; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[q] + b * 64),
+                                             (__attribute__((address_space(3))) void*)(my + buf * REGION + q * 1024), 16, 0, 0);
+    };
+    f32x4_v acc[MT][NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    stage(0, 0);
+    if (nblk > 1) stage(1, 1);
+    const int sw = fr & 7;
+    for (int b = 0; b < nblk; ++b) {
+        // block b has landed once at most block b+1's GROUPS instructions are still in flight (loads return in issue order)
+        if (b + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GROUPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* base = my + (b & 1) * REGION;
+        u32x4_v af[2][MT], wf[2][NT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fg) ^ sw) << 4;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[ks][t] = *reinterpret_cast<const u32x4_v*>(base + (t * 16 + fr) * 128 + coff);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) wf[ks][u] = *reinterpret_cast<const u32x4_v*>(base + (MT * 16 + u * 16 + fr) * 128 + coff);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is in registers: its slot may take block b+2
+        if (b + 2 < nblk) stage(b & 1, b + 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[t][u] = mfma16<T>(wf[ks][u], af[ks][t], acc[t][u]);  // swapped: D[n = 4 fg + i][m = fr]
+    }
+    auto epilogue = [&](int f, f32x4_v v) {
+        const int t = f / NT, u = f - t * NT;
+        const int m = (mt0 + t) * 16 + fr, n = n0 + u * 16 + fg * 4;
+        if (m >= g.M) return;
+        if (gridDim.y > 1) {
+            *reinterpret_cast<f32x4_v*>(static_cast<float*>(g.out) + (size_t)slice * g.slice_stride + (size_t)m * g.ldo + n) = v;
+            return;
+        }
+        float r[4] = {v[0], v[1], v[2], v[3]};
+        if (g.bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+            r[0] += bb.x; r[1] += bb.y; r[2] += bb.z; r[3] += bb.w;
+        }
+        if (g.act != ACT_NONE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = act_rt(g.act, r[i]);
+        }
+        if (g.out_f32) {
+            if (g.resid) {
+                const float4 q = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+                r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
+            }
+            store4(static_cast<float*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
+        } else {
+            store4(static_cast<T*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
+        }
+    };
+    if (NW == 1) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) epilogue(t * NT + u, acc[t][u]);
+        return;
+    }
+    __syncthreads();  // every wave is done with its operand image: the partial tiles overlay them
+    f32x4_v* red = reinterpret_cast<f32x4_v*>(smem);  // [NW][MT * NT][64]
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) red[(wave * (MT * NT) + t * NT + u) * 64 + lane] = acc[t][u];
+    __syncthreads();
+    for (int f = wave; f < MT * NT; f += NW) {
+        f32x4_v sum = red[f * 64 + lane];
+        for (int v = 1; v < NW; ++v) sum += red[(v * (MT * NT) + f) * 64 + lane];  // fixed order: waves 0 .. NW-1
+        epilogue(f, sum);
+    }
+}
+
+// waves for the coalesced kernel (0: the geometry needs the gather kernel)
+template <int MT, int NT>
+static int lds_waves(int kslice) {
+    constexpr int REGION = (MT + NT) * 16 * 128;
+    if (kslice % 64) return 0;
+    for (int nw : {8, 6, 4, 3, 2, 1})
+        if (kslice % (64 * nw) == 0 && (size_t)nw * 2 * REGION <= 150 * 1024 && (kslice / nw >= 128 || nw == 1)) return nw;
+    return 0;
+}
+template <typename T, int MT, int NT>
+int launch_lds(const SkinnyArgs& g, int nw, hipStream_t stream) {
+    constexpr int REGION = (MT + NT) * 16 * 128;
+    auto kern = skinny_lds_kernel<T, MT, NT>;
+    const int lds = std::max(nw * 2 * REGION, nw > 1 ? nw * MT * NT * 1024 : 0);
+    if (lds > 48 * 1024) ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int mtd = (g.M + 15) / 16;
+    hipLaunchKernelGGL(kern, dim3(g.N / (16 * NT), g.ksplit, (mtd + MT - 1) / MT), dim3(nw * 64), lds, stream, g);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
 template <typename T, int NV>
 __global__ __launch_bounds__(64) void skinny_reduce_ln_kernel(const float* __restrict__ part, int S, size_t slice_stride, const float* __restrict__ bias,
                                                               float* __restrict__ x, size_t x_stride, T* __restrict__ h, int h_stride,
@@ -175,6 +316,10 @@ int launch_one(const SkinnyArgs& g, int nw, hipStream_t stream) {
 template <typename T, int MT, int NT>
 int launch_ks(const SkinnyArgs& g, hipStream_t stream) {
     const int kslice = g.K / g.ksplit;
+    if (!g.gather) {
+        const int nwl = lds_waves<MT, NT>(kslice);
+        if (nwl) return launch_lds<T, MT, NT>(g, nwl, stream);
+    }
     int nw = 1;
     for (int c = 8; c >= 2; c >>= 1)
         if (kslice % (c * 32) == 0 && kslice / c >= 96) {

@@ -174,9 +174,9 @@ static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* 
     ProfScope ps(*c.prof, c.stream, site);
     int force = c.gemm_force;
     if constexpr (sizeof(T) == 2 && (sizeof(OutT) == 4 || sizeof(OutT) == 2)) {
-        // a handful of rows: the W-tiled kernel (5.4 against 11.5 us at 50 rows, K = 768; equal at 197 rows, where a K = 3072 product
-        // is better off on the output-tiled kernel unless it is split: scripts/skinny_bench.hip)
-        if (c.skinny && force == 0 && !f && (M <= 64 || K <= 1024) && skinny_supported(M, N, K, g.lda, g.ldw) && !(g.ldo & 3) && !(RESID && (g.ldr & 3))) {
+        // a handful of rows: the W-tiled kernel (3.9 against 11.5 us at 50 rows, K = 768; 6.2 against 11.6 at 197 rows; K = 3072: 7 against
+        // 33 us: scripts/skinny_bench.hip)
+        if (c.skinny && force == 0 && !f && skinny_supported(M, N, K, g.lda, g.ldw) && !(g.ldo & 3) && !(RESID && (g.ldr & 3))) {
             SkinnyArgs k;
             k.A = A; k.W = W; k.bias = bias; k.resid = RESID ? resid : nullptr; k.out = out;
             k.M = M; k.N = N; k.K = K; k.lda = g.lda; k.ldw = g.ldw; k.ldr = g.ldr; k.ldo = g.ldo;

@@ -44,6 +44,7 @@ static void run(const char* name, int M, int N, int K, int act, int resid, int o
     k.A = dA; k.W = dW; k.bias = dB; k.resid = resid ? (float*)dR : nullptr; k.out = resid ? dR : dO;
     k.M = M; k.N = N; k.K = K; k.lda = K; k.ldw = K; k.ldr = N; k.ldo = N; k.act = act; k.out_f32 = !out16;
     if (getenv("SK_STRIPS")) k.strips = 1;
+    if (getenv("SK_GATHER")) k.gather = 1;
     if (ksplit > 1) { k.ksplit = ksplit; k.slice_stride = (size_t)M * N; k.out = dP; k.out_f32 = 1; k.bias = nullptr; k.resid = nullptr; k.act = 0; }
     auto go_ref = [&]() -> int {
         if (resid) return launch_gemm_nt<f16_t, float, ACT_NONE, true, 0>(g, nullptr);
