@@ -113,8 +113,8 @@ struct arp_clip {
     DevBuf part;
     bool skinny = true;     // ARP_SKINNY=0: the output-tiled GEMMs at every size
     bool lat_h0 = false;    // ... and its token-assembly kernel already wrote ln_1 of the first block into h
-    int lat_rows = 640;     // a pass of at most this many token rows takes the latency path (ARP_SKINNY_ROWS).  Measured crossover against the
-                            // throughput kernels: ~800 rows (profiles/r3_latency_rows.txt: +57 % at 50 rows, +43 % at 300, +16 % at 600, 0 at 800)
+    int lat_rows = 1024;    // a pass of at most this many token rows takes the latency path (ARP_SKINNY_ROWS; = the kernel's cap).  Against the
+                            // throughput kernels (profiles/r3_latency_rows.txt): +63 % at 50 rows, +51 % at 300, +29 % at 600, +5..12 % at 1000
     bool lat_now = false;   // the pass being enqueued has at most SKINNY_MAX_M token rows (set by forward_chunk)
     bool lat_graph = true;  // ARP_CLIP_GRAPH=0: launch by launch
     struct LatGraph {

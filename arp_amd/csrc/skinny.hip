@@ -338,10 +338,23 @@ int launch_mt(const SkinnyArgs& g, hipStream_t stream) {
     if (mt <= 1) return launch_ks<T, 1, 1>(g, stream);
     if (mt <= 2) return launch_ks<T, 2, 1>(g, stream);
     if (mt <= 4) return launch_ks<T, 4, 1>(g, stream);
-    // 65 .. 256 rows, ceil(mt / 4) m-groups of 64 rows.  Wide outputs (qkv, c_fc) and 4-way split products (c_proj): 64 x 64 tiles,
-    // 144-192 workgroups of (64 + 64) x K bytes (8.8 / 9.8 / 9.4 us at 197 rows against 9.7 / 15.0 / 13 us on strips -- 576-768
-    // workgroups, several per CU); width-wide outputs (out_proj, the ViT-B/16 patch embedding): 64 x 16 strips, 192 workgroups of
-    // (64 + 16) x K bytes (6.4 against 9.0 us on 48 tiles).  scripts/skinny_bench.hip, profiles/r3_skinny_bench.txt
+    // More than 64 rows: m-groups of 64 rows (blockIdx.z), n-groups of 16 NT columns.  With the coalesced kernel a launch costs
+    // ~1.7 us + its workgroups' operand bytes at ~40 KB/us as long as every workgroup has a CU of its own (profiles/r3_skinny_variants.txt:
+    // 120 KB 3.9 us, 144 KB 4.5, 168 KB 5.5, 192 KB 6.1 at 197 rows; 288-768 workgroups: 7.4-9.5 us), so: the NARROWEST n-group that
+    // keeps the grid within 256 workgroups.
+    const int mg = (mt + 3) / 4;
+    const int kslice = g.K / g.ksplit;
+    if (!g.strips && !g.gather && lds_waves<4, 1>(kslice)) {
+        for (int nt = 1; nt <= 4; ++nt) {
+            if (g.N % (16 * nt)) continue;
+            if ((long)(g.N / (16 * nt)) * mg * g.ksplit > 256 && nt < 4) continue;
+            if (nt == 1) return launch_ks<T, 4, 1>(g, stream);
+            if (nt == 2) return launch_ks<T, 4, 2>(g, stream);
+            if (nt == 3) return launch_ks<T, 4, 3>(g, stream);
+            return launch_ks<T, 4, 4>(g, stream);
+        }
+    }
+    // the gather kernel (K not a multiple of 64 x waves): wide outputs and 4-way split products on 64 x 64 tiles, the rest on strips
     if ((g.N & 63) == 0 && !g.strips && (g.N >= 1536 || g.ksplit >= 4)) return launch_ks<T, 4, 4>(g, stream);
     return launch_ks<T, 4, 1>(g, stream);
 }

@@ -34,6 +34,20 @@ __global__ __launch_bounds__(512) void fill_kernel(const char* __restrict__ buf,
         for (int i = 0; i < NLOAD; ++i) v[i] = *reinterpret_cast<const u32x4*>(buf + ((size_t)(wave * NLOAD + i) * 64 + lane) * 16);
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) acc += v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
+    } else if constexpr (PATTERN == 3 || PATTERN == 4) {
+        // the coalesced skinny kernel's DMA: 8 rows x 128 B per wave instruction, rows `ld` bytes apart (3) or packed back to back (4:
+        // what a K-blocked operand layout would give), wave w owns 128-byte column block(s) w, w + 8, ...
+        const int srow = lane >> 3, ch = lane & 7;
+        u32x4 v[NLOAD];
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int grp = i % 10, blk = i / 10;  // 80 rows per block
+            const size_t row = grp * 8 + srow;
+            const size_t off = PATTERN == 3 ? row * ld + (size_t)(wave + 8 * blk) * 128 + ch * 16 : ((size_t)(wave + 8 * blk) * 80 + row) * 128 + ch * 16;
+            v[i] = *reinterpret_cast<const u32x4*>(buf + off);
+        }
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) acc += v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
     } else {
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i)
@@ -84,10 +98,11 @@ int main() {
     hipMalloc(&dbuf, 4 << 20);
     hipMemset(dbuf, 1, 4 << 20);
     hipMalloc(&sink, 4096);
-    for (int wgs : {192, 48}) {
+    for (int wgs : {192}) {
         run<0, 12>(dbuf, sink, wgs); run<1, 12>(dbuf, sink, wgs); run<2, 12>(dbuf, sink, wgs);
         run<0, 24>(dbuf, sink, wgs); run<1, 24>(dbuf, sink, wgs); run<2, 24>(dbuf, sink, wgs);
         run<0, 39>(dbuf, sink, wgs); run<1, 39>(dbuf, sink, wgs);
+        run<3, 10>(dbuf, sink, wgs); run<4, 10>(dbuf, sink, wgs); run<3, 20>(dbuf, sink, wgs); run<4, 20>(dbuf, sink, wgs); run<3, 30>(dbuf, sink, wgs); run<4, 30>(dbuf, sink, wgs);
     }
     return 0;
 }

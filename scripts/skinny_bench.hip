@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <utility>
 #include <vector>
 
 #include "gemm.h"
@@ -133,7 +134,59 @@ static void run(const char* name, int M, int N, int K, int act, int resid, int o
     hipFree(dA); hipFree(dW); hipFree(dB); hipFree(dO); hipFree(dR); hipFree(dR0); hipFree(dP); hipFree(dH); hipFree(dLw); hipFree(dLb);
 }
 
+// tile-shape sweep of the coalesced kernel at 65..256 rows (direct epilogue, f16 output): (MT, NT, waves)
+template <int MT, int NT> static void variant(const char* name, int M, int N, int K, int nw) {
+    std::vector<f16_t> hA((size_t)M * K), hW((size_t)N * K);
+    uint32_t s = 777u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hA) v = host_f2h(rnd());
+    for (auto& v : hW) v = host_f2h(rnd() * 0.05f);
+    void *dA, *dW, *dO, *dO2;
+    hipMalloc(&dA, hA.size() * 2); hipMalloc(&dW, hW.size() * 2); hipMalloc(&dO, (size_t)M * N * 2); hipMalloc(&dO2, (size_t)M * N * 2);
+    hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+    SkinnyArgs k;
+    k.A = dA; k.W = dW; k.out = dO; k.M = M; k.N = N; k.K = K; k.lda = K; k.ldw = K; k.ldr = N; k.ldo = N; k.out_f32 = 0;
+    if (K % (64 * nw) || N % (16 * NT) || (size_t)nw * 2 * (MT + NT) * 16 * 128 > 160 * 1024) { printf("  %-6s (%d,%d,%d): not applicable\n", name, MT, NT, nw); return; }
+    hipStream_t st;
+    hipStreamCreate(&st);
+    launch_lds<f16_t, MT, NT>(k, nw, st);
+    SkinnyArgs r = k; r.out = dO2; r.gather = 1;
+    launch_skinny_gemm(2, r, st);
+    hipStreamSynchronize(st);
+    std::vector<f16_t> o1((size_t)M * N), o2((size_t)M * N);
+    hipMemcpy(o1.data(), dO, o1.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(o2.data(), dO2, o2.size() * 2, hipMemcpyDeviceToHost);
+    double md = 0;
+    for (size_t i = 0; i < o1.size(); ++i) md = std::max(md, (double)fabsf(h2f_host(o1[i]) - h2f_host(o2[i])));
+    hipGraph_t gr; hipGraphExec_t ge; hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < 50; ++i) launch_lds<f16_t, MT, NT>(k, nw, st);
+    hipStreamEndCapture(st, &gr);
+    hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0);
+    hipGraphLaunch(ge, st); hipStreamSynchronize(st);
+    hipEventRecord(e0, st);
+    for (int i = 0; i < 8; ++i) hipGraphLaunch(ge, st);
+    hipEventRecord(e1, st); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const int mtd = (M + 15) / 16;
+    printf("  %-6s M=%3d (MT %d, NT %d, %d waves): %3d workgroups, %3zu KB operands each: %5.2f us | max diff vs gather kernel %.1e\n", name, M, MT, NT, nw,
+           (N / (16 * NT)) * ((mtd + MT - 1) / MT), (size_t)(MT + NT) * 16 * K * 2 / 1024, ms * 1000.f / 400.f, md);
+    hipGraphExecDestroy(ge); hipGraphDestroy(gr); hipStreamDestroy(st);
+    hipFree(dA); hipFree(dW); hipFree(dO); hipFree(dO2);
+}
+
 int main() {
+    if (getenv("SK_VARIANTS")) {
+        for (int M : {197, 100}) {
+            for (auto [name, N] : {std::pair<const char*, int>{"qkv", 2304}, {"c_fc", 3072}, {"out", 768}}) {
+                variant<4, 4>(name, M, N, 768, 4); variant<4, 4>(name, M, N, 768, 3); variant<4, 4>(name, M, N, 768, 2);
+                variant<4, 3>(name, M, N, 768, 4); variant<4, 2>(name, M, N, 768, 6); variant<4, 2>(name, M, N, 768, 4);
+                variant<4, 1>(name, M, N, 768, 6); variant<7, 2>(name, M, N, 768, 4); variant<7, 1>(name, M, N, 768, 4); variant<7, 1>(name, M, N, 768, 6);
+                variant<13, 1>(name, M, N, 768, 3); variant<8, 2>(name, M, N, 768, 3);
+            }
+        }
+        return 0;
+    }
     for (int M : {50, 100, 197, 250}) {
         run("qkv", M, 2304, 768, 0, 0, 1, 1);
         run("out_proj", M, 768, 768, 0, 1, 0, 1);
