@@ -101,6 +101,8 @@ struct arp_dt {
     DevBuf dwsf, dbsf, dtok, loss_part, gtab, gprefix, ctab, cprefix;
     int n_gemm = 0, gemm_tiles = 0, n_cs = 0, cs_tiles = 0;
     PfArgs pf;
+    DevBuf pf_pack, pf_jobs;  // fragment-major weight copies of the fused kernel's big linears and their job table (policy_fused.h)
+    int pf_njobs = 0, pf_pack_blocks = 0;
     ncclComm_t comm = nullptr;
     bool has_comm = false;
     // data-parallel step: gradient all-reduce in two buckets on a communication stream, bucket 1 (image_text_input's kernel, 94 % of
@@ -401,6 +403,35 @@ int build_fused_plan(arp_dt* c) {
     a.lnfw = c->p("policy/LayerNorm_0/scale"); a.lnfb = c->p("policy/LayerNorm_0/bias");
     a.wa0 = c->p("action_outputs_0/layers_0/kernel"); a.ba0 = c->p("action_outputs_0/layers_0/bias"); a.wa2 = c->p("action_outputs_0/layers_2/kernel");
     a.wr0 = c->p("return_outputs_0/layers_0/kernel"); a.br0 = c->p("return_outputs_0/layers_0/bias"); a.wr2 = c->p("return_outputs_0/layers_2/kernel");
+    {
+        // fragment-major copies (nt for the forward, nn for the backward) of every weight pf_lin_nt / pf_lin_nn stream; filled by
+        // pf_pack_kernel at the head of every launch of the fused kernel (the parameters change every step)
+        std::vector<PfPackJob> jobs;
+        size_t total = 0;
+        auto want = [&](const float* W, int N, int K) { jobs.push_back(PfPackJob{W, nullptr, nullptr, N, K}); total += 2 * (size_t)N * K; };
+        for (int i = 0; i < depth; ++i) {
+            want(a.blk[i].wqkv, 3 * E, E); want(a.blk[i].wo, E, E); want(a.blk[i].wfc1, H, E); want(a.blk[i].wfc2, E, H);
+        }
+        want(a.wa0, E, E); want(a.wr0, E, E);
+        ARP_TRY(c->pf_pack.ensure(total * 4));
+        float* base = c->pf_pack.as<float>();
+        int maxq = 0;
+        for (auto& jb : jobs) {
+            jb.nt = base; base += (size_t)jb.N * jb.K;
+            jb.nn = base; base += (size_t)jb.N * jb.K;
+            maxq = std::max(maxq, jb.N * jb.K / 4);
+        }
+        for (int i = 0; i < depth; ++i) {
+            PfBlk& b = a.blk[i];
+            b.wqkv_nt = jobs[4 * i].nt; b.wqkv_nn = jobs[4 * i].nn; b.wo_nt = jobs[4 * i + 1].nt; b.wo_nn = jobs[4 * i + 1].nn;
+            b.wfc1_nt = jobs[4 * i + 2].nt; b.wfc1_nn = jobs[4 * i + 2].nn; b.wfc2_nt = jobs[4 * i + 3].nt; b.wfc2_nn = jobs[4 * i + 3].nn;
+        }
+        a.wa0_nt = jobs[4 * depth].nt; a.wa0_nn = jobs[4 * depth].nn; a.wr0_nt = jobs[4 * depth + 1].nt; a.wr0_nn = jobs[4 * depth + 1].nn;
+        ARP_TRY(c->pf_jobs.ensure(jobs.size() * sizeof(PfPackJob)));
+        ARP_HIP_OK(hipMemcpy(c->pf_jobs.p, jobs.data(), jobs.size() * sizeof(PfPackJob), hipMemcpyHostToDevice));
+        c->pf_njobs = (int)jobs.size();
+        c->pf_pack_blocks = std::min((maxq + 255) / 256, 32);
+    }
     a.xf = c->xs[depth].as<float>(); a.a_in = c->a_in.as<float>(); a.r_in = c->r_in.as<float>(); a.ha = c->ha.as<float>(); a.hr = c->hr.as<float>();
     a.logits = c->logits.as<float>(); a.ret = c->ret.as<float>(); a.dlogits = c->dlogits.as<float>(); a.dret = c->dret.as<float>();
     a.dha = c->dha.as<float>(); a.dhr = c->dhr.as<float>(); a.dwsf = c->dwsf.as<float>(); a.dbsf = c->dbsf.as<float>();
@@ -494,6 +525,7 @@ int policy_fused(arp_dt* c, bool do_bwd) {
     c->pf.rtg = c->bt[c->cur].rtg.as<float>();  // the CURRENT batch slot's labels (the plan was built when the geometry last changed)
     c->pf.action = c->bt[c->cur].action.as<int>();
     const size_t lds = pf_lds_bytes(k.emb, k.mlp_ratio * k.emb, k.heads, k.depth);
+    hipLaunchKernelGGL(pf_pack_kernel, dim3(c->pf_pack_blocks, c->pf_njobs), dim3(256), 0, c->stream, static_cast<const PfPackJob*>(c->pf_jobs.p));
     if (k.emb == 128) hipLaunchKernelGGL((policy_fused_kernel<128, 512>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     else hipLaunchKernelGGL((policy_fused_kernel<64, 256>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c->stream, c->loss_part.as<float>(), c->B, c->R(), k.n_actions, k.lambda_ret,
@@ -1094,7 +1126,7 @@ int arp_dt_destroy(arp_dt* c) {
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,
-                     &c->dwsf, &c->dbsf, &c->dtok, &c->loss_part, &c->gtab, &c->gprefix, &c->ctab, &c->cprefix};
+                     &c->dwsf, &c->dbsf, &c->dtok, &c->loss_part, &c->gtab, &c->gprefix, &c->ctab, &c->cprefix, &c->pf_pack, &c->pf_jobs};
     for (auto* b : all) b->release();
     for (auto* v : {&c->xs, &c->ln0, &c->qkv, &c->att, &c->hmid, &c->ln1, &c->u, &c->gl, &c->d_x1, &c->d_u, &c->d_mid, &c->d_qkv, &c->dws0, &c->dbs0,
                     &c->dws1, &c->dbs1})

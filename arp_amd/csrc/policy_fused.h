@@ -21,6 +21,7 @@
 // Measured (B = 32, E = 128, depth 2, s_memtime stamps per phase): 378 k cycles ~ 155 us, against ~910 us for the
 // per-op path.  The eight big linears take 245 k of it; with the weight loads removed they take 145 k (the f32-MFMA
 // floor at 32 cycles per 16x16x4 issue), so weight streaming still costs ~70 % on top of the MFMAs.
+// Round 3: the weights are streamed from fragment-major copies (PfPackJob below): 154.6 -> 136.3 us per launch.
 #pragma once
 #include <utility>
 
@@ -31,8 +32,20 @@ namespace arp {
 
 constexpr int PF_THREADS = 512, PF_NW = 8, PF_MAX_DEPTH = 4;
 
+// The big linears stream their weights in FRAGMENT-MAJOR copies (pf_pack_kernel, once per launch of the fused kernel): block (tile, step) =
+// 64 lanes x 16 B in exactly the order the lanes consume it, so one wave instruction reads 1 KiB of whole 128-byte lines.  Read in place
+// from W[out][in] the same fragment is 16 rows x 64 B per instruction -- the gather that one CU pulls out of L2 at 18 B/clk where
+// whole-line instructions get 65-69 (scripts/fill_bench.hip); the weight stream was 100 k of the kernel's 378 k cycles.
+//   nt copy: block (t, s) of W[N][K], KS = K / 16 steps per 16-row tile t: lane (q, j) holds W[16 t + j][16 s + 4 q .. + 3]
+//   nn copy: block (c, s), NS = N / 16 steps per 16-column tile c:          lane (q, j) holds W[16 s + 4 q + r][16 c + j], r = 0..3
+struct PfPackJob {
+    const float* W;
+    float *nt, *nn;  // nn may be null (forward-only weights)
+    int N, K;
+};
 struct PfBlk {
     const float *ln0w, *ln0b, *wqkv, *bqkv, *wo, *bo, *ln1w, *ln1b, *wfc1, *wfc2;  // weights, device layout [out, in]
+    const float *wqkv_nt, *wo_nt, *wfc1_nt, *wfc2_nt, *wqkv_nn, *wo_nn, *wfc1_nn, *wfc2_nn;  // fragment-major copies
     float *x, *ln0, *qkv, *att, *hmid, *ln1, *u, *gl;                              // saved forward activations [B*L, .]
     float *d_x1, *d_u, *d_mid, *d_qkv, *dws0, *dbs0, *dws1, *dbs1;                 // saved output gradients / LN row terms
 };
@@ -44,6 +57,7 @@ struct PfArgs {
     const float *Wr, *emb;   // rtg_input/kernel [E], action_input/embedding [NA, E]
     PfBlk blk[PF_MAX_DEPTH];
     const float *lnfw, *lnfb, *wa0, *ba0, *wa2, *wr0, *br0, *wr2;
+    const float *wa0_nt, *wr0_nt, *wa0_nn, *wr0_nn;  // fragment-major copies
     float *xf, *a_in, *r_in, *ha, *hr, *logits, *ret;           // saved forward (head stage)
     float *dlogits, *dret, *dha, *dhr, *dwsf, *dbsf, *dtok, *dz;  // saved backward
     float* loss_part;                                           // [B][4]: sum CE, hits, sum squared error
@@ -79,6 +93,23 @@ template <int N> __device__ __forceinline__ void pf_wait_vm() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+static __global__ __launch_bounds__(256) void pf_pack_kernel(const PfPackJob* __restrict__ jobs) {
+    const PfPackJob jb = jobs[blockIdx.y];
+    const int total4 = jb.N * jb.K / 4, KS = jb.K / 16, NS = jb.N / 16;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total4; idx += gridDim.x * 256) {
+        const int lane = idx & 63, blk = idx >> 6, q = lane >> 4, j = lane & 15;
+        {
+            const int t = blk / KS, st = blk - t * KS;
+            reinterpret_cast<float4*>(jb.nt)[idx] = *reinterpret_cast<const float4*>(jb.W + (size_t)(t * 16 + j) * jb.K + st * 16 + 4 * q);
+        }
+        if (jb.nn) {
+            const int c = blk / NS, st = blk - c * NS;
+            const float* p = jb.W + (size_t)(st * 16 + 4 * q) * jb.K + c * 16 + j;
+            reinterpret_cast<float4*>(jb.nn)[idx] = make_float4(p[0], p[jb.K], p[2 * (size_t)jb.K], p[3 * (size_t)jb.K]);
+        }
+    }
+}
+
 template <int N, int K, int LDX, class Epi>
 __device__ __forceinline__ void pf_lin_nt(const float* Xs, const float* __restrict__ W, int wave, int lane, Epi epi) {
     static_assert(N % 16 == 0 && K % 16 == 0, "tile multiples");
@@ -87,14 +118,14 @@ __device__ __forceinline__ void pf_lin_nt(const float* Xs, const float* __restri
     const int tiles_w = wave < NTL ? (NTL - 1 - wave) / PF_NW + 1 : 0;
     const int NG = tiles_w * GP;
     if (NG == 0) return;
-    const float* pl = W + (size_t)(wave * 16 + j) * K + 4 * q;  // next group to load
+    const float* pl = W + ((size_t)wave * KS * 64 + lane) * 4;  // next group to load (W = the nt fragment-major copy: 256 floats per step)
     const float* xs = Xs + j * LDX + 4 * q;
     f32x4_v w[R];
     f32x4_v acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     int tile = wave, lg = 0, cg = 0;
     auto next_ptr = [&]() {
-        if (GP > 1 && ++lg < GP) pl += R * 16;
-        else { lg = 0; pl += (size_t)PF_NW * 16 * K - (GP - 1) * R * 16; }
+        if (GP > 1 && ++lg < GP) pl += R * 256;
+        else { lg = 0; pl += ((size_t)PF_NW * KS - (GP - 1) * R) * 256; }
     };
     auto mfma4 = [&](const f32x4_v& wv, const float* xp) {
         const float4 x = *reinterpret_cast<const float4*>(xp);
@@ -104,13 +135,13 @@ __device__ __forceinline__ void pf_lin_nt(const float* Xs, const float* __restri
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], x.w, acc2, 0, 0, 0);
     };
     __builtin_amdgcn_sched_barrier(0);
-    [&]<int... U>(std::integer_sequence<int, U...>) { (pf_gload4<U * 64>(w[U], pl), ...); }(std::make_integer_sequence<int, R>{});
+    [&]<int... U>(std::integer_sequence<int, U...>) { (pf_gload4<(U & 3) * 1024>(w[U], pl + (U >> 2) * 1024), ...); }(std::make_integer_sequence<int, R>{});
     __builtin_amdgcn_sched_barrier(0);
     next_ptr();
     for (int gg = 0; gg + 1 < NG; ++gg) {
         const float* xg = xs + cg * (R * 16);
         [&]<int... U>(std::integer_sequence<int, U...>) {
-            ((pf_wait_vm<R - 1>(), mfma4(w[U], xg + U * 16), __builtin_amdgcn_sched_barrier(0), pf_gload4<U * 64>(w[U], pl),
+            ((pf_wait_vm<R - 1>(), mfma4(w[U], xg + U * 16), __builtin_amdgcn_sched_barrier(0), pf_gload4<(U & 3) * 1024>(w[U], pl + (U >> 2) * 1024),
               __builtin_amdgcn_sched_barrier(0)),
              ...);
         }(std::make_integer_sequence<int, R>{});
@@ -141,19 +172,16 @@ __device__ __forceinline__ void pf_lin_nn(const float* dYs, const float* __restr
     const int tiles_w = wave < KT ? (KT - 1 - wave) / PF_NW + 1 : 0;
     const int NG = tiles_w * GP;
     if (NG == 0) return;
-    const float* pl = W + (size_t)(4 * q) * K + wave * 16 + j;
+    const float* pl = W + ((size_t)wave * NS * 64 + lane) * 4;  // W = the nn fragment-major copy: one float4 per lane and step
     const float* ys = dYs + j * LDY + 4 * q;
-    float w[R][4];  // [step][r] = contraction row 4q + r of the step, this lane's output column
+    f32x4_v w[R];  // [step][r] = contraction row 4q + r of the step, this lane's output column
     f32x4_v acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
     int tile = wave, lg = 0, cg = 0;
     auto next_ptr = [&]() {
-        if (GP > 1 && ++lg < GP) pl += (size_t)R * 16 * K;
-        else { lg = 0; pl += PF_NW * 16 - (ptrdiff_t)(GP - 1) * R * 16 * K; }
+        if (GP > 1 && ++lg < GP) pl += R * 256;
+        else { lg = 0; pl += ((size_t)PF_NW * NS - (GP - 1) * R) * 256; }
     };
-    auto load_step = [&](float(&d)[4], const float* p) {
-        pf_gload1(d[0], p); pf_gload1(d[1], p + K); pf_gload1(d[2], p + 2 * K); pf_gload1(d[3], p + 3 * K);
-    };
-    auto mfma4 = [&](const float(&wv)[4], const float* yp) {
+    auto mfma4 = [&](const f32x4_v& wv, const float* yp) {
         const float4 y = *reinterpret_cast<const float4*>(yp);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0], y.x, acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1], y.y, acc2, 0, 0, 0);
@@ -161,20 +189,16 @@ __device__ __forceinline__ void pf_lin_nn(const float* dYs, const float* __restr
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[3], y.w, acc2, 0, 0, 0);
     };
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < R; ++u) load_step(w[u], pl + (size_t)u * 16 * K);
+    [&]<int... U>(std::integer_sequence<int, U...>) { (pf_gload4<(U & 3) * 1024>(w[U], pl + (U >> 2) * 1024), ...); }(std::make_integer_sequence<int, R>{});
     __builtin_amdgcn_sched_barrier(0);
     next_ptr();
     for (int gg = 0; gg + 1 < NG; ++gg) {
         const float* yg = ys + cg * (R * 16);
-#pragma unroll
-        for (int u = 0; u < R; ++u) {
-            pf_wait_vm<4 * (R - 1)>();
-            mfma4(w[u], yg + u * 16);
-            __builtin_amdgcn_sched_barrier(0);
-            load_step(w[u], pl + (size_t)u * 16 * K);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ((pf_wait_vm<R - 1>(), mfma4(w[U], yg + U * 16), __builtin_amdgcn_sched_barrier(0), pf_gload4<(U & 3) * 1024>(w[U], pl + (U >> 2) * 1024),
+              __builtin_amdgcn_sched_barrier(0)),
+             ...);
+        }(std::make_integer_sequence<int, R>{});
         next_ptr();
         if (++cg == GP) {
             cg = 0;
@@ -187,7 +211,7 @@ __device__ __forceinline__ void pf_lin_nn(const float* dYs, const float* __restr
     {
         const float* yg = ys + cg * (R * 16);
         [&]<int... U>(std::integer_sequence<int, U...>) {
-            ((pf_wait_vm<4 * (R - 1 - U)>(), mfma4(w[U], yg + U * 16)), ...);
+            ((pf_wait_vm<R - 1 - U>(), mfma4(w[U], yg + U * 16)), ...);
         }(std::make_integer_sequence<int, R>{});
         epi(j, tile * 16 + 4 * q, acc + acc2);
     }
@@ -468,7 +492,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         const float* vb = sV + 8 * bi * E;
         pf_ln_fwd(sX, sY, ldE, vb, vb + E, E, k.ln0 + t0 * E, L, wave, lane);
         __syncthreads();
-        pf_lin_nt<3 * E, E, ldE>(sY, k.wqkv, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<3 * E, E, ldE>(sY, k.wqkv_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             const float4 bb = *reinterpret_cast<const float4*>(vb + 2 * E + n);
             v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             *reinterpret_cast<float4*>(sQ + i * ldW + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -478,7 +502,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         // causal attention (layers.py:70-90): scores * scale, masked, softmax, P.V
         pf_attn_fwd_mfma(sQ, sA, ldW, ldE, E, hd, heads, L, scale, k.att + t0 * E, wave, lane);
         __syncthreads();
-        pf_lin_nt<E, E, ldE>(sA, k.wo, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<E, E, ldE>(sA, k.wo_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             const float4 bb = *reinterpret_cast<const float4*>(vb + 5 * E + n);
             const float4 xr = *reinterpret_cast<const float4*>(sX + i * ldE + n);
             v[0] += bb.x + xr.x; v[1] += bb.y + xr.y; v[2] += bb.z + xr.z; v[3] += bb.w + xr.w;
@@ -488,7 +512,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         pf_save_rows(sM, ldE, E, k.hmid + t0 * E, L, tid);
         pf_ln_fwd(sM, sY, ldE, vb + 6 * E, vb + 7 * E, E, k.ln1 + t0 * E, L, wave, lane);
         __syncthreads();
-        pf_lin_nt<H, E, ldE>(sY, k.wfc1, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<H, E, ldE>(sY, k.wfc1_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             f32x4_v gl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) gl[r] = apply_act<ACT_GELU_TANH>(v[r]);
@@ -499,7 +523,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         pf_save_rows(sU, ldW, H, k.u + t0 * H, L, tid);
         pf_save_rows(sG, ldW, H, k.gl + t0 * H, L, tid);
         float* xnext = bi + 1 < a.depth ? a.blk[bi + 1].x : a.xf;
-        pf_lin_nt<E, H, ldW>(sG, k.wfc2, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<E, H, ldW>(sG, k.wfc2_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             const float4 mr = *reinterpret_cast<const float4*>(sM + i * ldE + n);
             v[0] += mr.x; v[1] += mr.y; v[2] += mr.z; v[3] += mr.w;
             *reinterpret_cast<float4*>(sX + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -527,14 +551,14 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         hR[t * ldE + c] = vr;
     }
     __syncthreads();
-    pf_lin_nt<E, E, ldE>(hA, a.wa0, wave, lane, [&](int i, int n, f32x4_v v) {
+    pf_lin_nt<E, E, ldE>(hA, a.wa0_nt, wave, lane, [&](int i, int n, f32x4_v v) {
         const float4 bb = *reinterpret_cast<const float4*>(sVt + 2 * E + n);
         v[0] = fmaxf(v[0] + bb.x, 0.f); v[1] = fmaxf(v[1] + bb.y, 0.f); v[2] = fmaxf(v[2] + bb.z, 0.f); v[3] = fmaxf(v[3] + bb.w, 0.f);
         if (i >= T) v = f32x4_v{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<float4*>(hHa + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
         if (i < T) store4g(a.ha + (r0 + i) * E + n, v);
     });
-    pf_lin_nt<E, E, ldE>(hR, a.wr0, wave, lane, [&](int i, int n, f32x4_v v) {
+    pf_lin_nt<E, E, ldE>(hR, a.wr0_nt, wave, lane, [&](int i, int n, f32x4_v v) {
         const float4 bb = *reinterpret_cast<const float4*>(sVt + 3 * E + n);
         v[0] = fmaxf(v[0] + bb.x, 0.f); v[1] = fmaxf(v[1] + bb.y, 0.f); v[2] = fmaxf(v[2] + bb.z, 0.f); v[3] = fmaxf(v[3] + bb.w, 0.f);
         if (i >= T) v = f32x4_v{0.f, 0.f, 0.f, 0.f};
@@ -616,10 +640,10 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
     __syncthreads();
     for (int i = tid; i < 16 * ldE; i += PF_THREADS) sA[i] = 0.f;  // sA <- d(hf): rows 3t+1 <- d a_in, rows 3t <- d r_in
     __syncthreads();
-    pf_lin_nn<E, E, ldE>(hDha, a.wa0, wave, lane, [&](int i, int c, f32x4_v v) {
+    pf_lin_nn<E, E, ldE>(hDha, a.wa0_nn, wave, lane, [&](int i, int c, f32x4_v v) {
         if (i < T) *reinterpret_cast<float4*>(sA + (3 * i + 1) * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
     });
-    pf_lin_nn<E, E, ldE>(hDhr, a.wr0, wave, lane, [&](int i, int c, f32x4_v v) {
+    pf_lin_nn<E, E, ldE>(hDhr, a.wr0_nn, wave, lane, [&](int i, int c, f32x4_v v) {
         if (i < T) *reinterpret_cast<float4*>(sA + (3 * i) * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
     });
     __syncthreads();
@@ -639,7 +663,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
             *reinterpret_cast<float4*>(sG + i * ldW + c) = *reinterpret_cast<const float4*>(k.u + (t0 + i) * H + c);
         }
         __syncthreads();
-        pf_lin_nn<E, H, ldE>(sY, k.wfc2, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<E, H, ldE>(sY, k.wfc2_nn, wave, lane, [&](int i, int c, f32x4_v v) {
             if (i < L) {
                 const float4 uu = *reinterpret_cast<const float4*>(sG + i * ldW + c);
                 v[0] *= pf_gelu_grad(uu.x); v[1] *= pf_gelu_grad(uu.y); v[2] *= pf_gelu_grad(uu.z); v[3] *= pf_gelu_grad(uu.w);
@@ -650,7 +674,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         });
         __syncthreads();
         pf_save_rows(sU, ldW, H, k.d_u + t0 * H, L, tid);
-        pf_lin_nn<H, E, ldW>(sU, k.wfc1, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<H, E, ldW>(sU, k.wfc1_nn, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
         });
         __syncthreads();
@@ -666,7 +690,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
             const int i = idx / (3 * E), c = idx - i * 3 * E;
             sQ[i * ldW + c] = k.qkv[(t0 + i) * 3 * E + c];
         }
-        pf_lin_nn<E, E, ldE>(sY, k.wo, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<E, E, ldE>(sY, k.wo_nn, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);  // d att
         });
         __syncthreads();
@@ -675,7 +699,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         __syncthreads();
         pf_attn_bwd_mfma_b(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, k.d_qkv + t0 * 3 * E, wave, lane);
         __syncthreads();
-        pf_lin_nn<3 * E, E, ldW>(sU, k.wqkv, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<3 * E, E, ldW>(sU, k.wqkv_nn, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
         });
         __syncthreads();
