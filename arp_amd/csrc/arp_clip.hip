@@ -111,6 +111,9 @@ struct arp_clip {
     // <= SKINNY_MAX_M token rows -- preprocess .. reward, ~80 launches -- replayed as ONE hipGraph per (buffers, geometry): the host then
     // pays one graph launch instead of 80 kernel launches that each cost more host time than the kernel runs
     DevBuf part;
+    DevBuf lat_stats;       // folded LayerNorm on the latency path: [rows][width / 16][2] strip sums (tower.h)
+    bool lat_fold = true;   // ARP_LAT_FOLD=0: reduce + LayerNorm kernels instead (seven launches per block instead of five)
+    bool lat_f0 = false;    // the pass being enqueued: the token-assembly kernel wrote the operand copy + statistics of block 0
     bool skinny = true;     // ARP_SKINNY=0: the output-tiled GEMMs at every size
     bool lat_h0 = false;    // ... and its token-assembly kernel already wrote ln_1 of the first block into h
     int lat_rows = 1024;    // a pass of at most this many token rows takes the latency path (ARP_SKINNY_ROWS; = the kernel's cap).  Against the
@@ -148,7 +151,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.qkv_fused = c->qkv_fused;
     t.fp8_mlp = c->fp8_mlp; t.fp8_attn = c->fp8_attn;
     t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
-    t.skinny = c->lat_now; t.h_ready0 = c->lat_now && c->lat_h0; t.part = c->part.as<float>(); t.part_floats = c->part.bytes / 4;
+    t.skinny = c->lat_now; t.h_ready0 = c->lat_now && c->lat_h0; t.lat_stats = c->lat_stats.as<float>(); t.lat_fold0 = c->lat_now && c->lat_f0; t.part = c->part.as<float>(); t.part_floats = c->part.bytes / 4;
     return t;
 }
 
@@ -302,6 +305,34 @@ static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers,
         }
     }
     tw.folded = fold;
+    // the latency path's fold (tower.h run_blocks): the same operands in the handle's own 16-bit type, vision tower only
+    if (!fold && ntok > 0 && c->lat_fold && c->skinny && emode != ARP_MODE_F32 && (d & 15) == 0) {
+        for (int i = 0; i < layers; ++i) {
+            LayerW& L = tw.L[i];
+            const std::string p = prefix + "resblocks." + std::to_string(i) + ".";
+            const HostTensor *w, *b, *lw, *lb;
+            std::vector<bf16_t> wf;
+            std::vector<float> cc, dd;
+            auto put = [&](const std::vector<bf16_t>& m, void** out) -> int {
+                void* dp = nullptr;
+                ARP_HIP_OK(hipMalloc(&dp, m.size() * 2));
+                ARP_HIP_OK(hipMemcpy(dp, m.data(), m.size() * 2, hipMemcpyHostToDevice));
+                c->owned.push_back(dp);
+                *out = dp;
+                return 0;
+            };
+            const bool half = emode == ARP_MODE_F16;
+            ARP_TRY(get_staged(c, p + "attn.in_proj_weight", {3 * d, d}, &w)); ARP_TRY(get_staged(c, p + "attn.in_proj_bias", {3 * d}, &b));
+            ARP_TRY(get_staged(c, p + "ln_1.weight", {d}, &lw)); ARP_TRY(get_staged(c, p + "ln_1.bias", {d}, &lb));
+            fold_layernorm(w->data.data(), lw->data.data(), lb->data.data(), b->data.data(), 3 * d, d, wf, cc, dd, half);
+            ARP_TRY(put(wf, &L.w_in_f)); ARP_TRY(upload_f32(c, cc, &L.c_in)); ARP_TRY(upload_f32(c, dd, &L.d_in));
+            ARP_TRY(get_staged(c, p + "mlp.c_fc.weight", {4 * d, d}, &w)); ARP_TRY(get_staged(c, p + "mlp.c_fc.bias", {4 * d}, &b));
+            ARP_TRY(get_staged(c, p + "ln_2.weight", {d}, &lw)); ARP_TRY(get_staged(c, p + "ln_2.bias", {d}, &lb));
+            fold_layernorm(w->data.data(), lw->data.data(), lb->data.data(), b->data.data(), 4 * d, d, wf, cc, dd, half);
+            ARP_TRY(put(wf, &L.w_fc_f)); ARP_TRY(upload_f32(c, cc, &L.c_fc)); ARP_TRY(upload_f32(c, dd, &L.d_fc));
+        }
+        tw.lat_folded = true;
+    }
     return 0;
 }
 
@@ -386,7 +417,7 @@ static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizeP
     c->lat_now = c->skinny && sizeof(T) == 2 && (long)nb * N <= c->lat_rows;
     struct LatGuard {
         arp_clip* c;
-        ~LatGuard() { c->lat_now = false; c->lat_h0 = false; }
+        ~LatGuard() { c->lat_now = false; c->lat_h0 = false; c->lat_f0 = false; }
     } lat_guard{c};
     if (c->pre_bilinear) {
         ProfScope ps(c->prof, c->stream, "preprocess_bilinear");
@@ -400,6 +431,7 @@ static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizeP
         ARP_TRY((launch_preprocess<T, PRE_PATCH>(*plan, frames_dev, nb, k.patch, c->lut, c->patches.p, c->stream)));
     }
     c->lat_h0 = false;
+    c->lat_f0 = false;
     bool assembled = false;
     if constexpr (sizeof(T) == 2) {
         // latency path: the patch embedding as split-K slabs, summed by the token-assembly kernel, which also applies the first ln_1
@@ -414,14 +446,17 @@ static int forward_chunk(arp_clip* c, const uint8_t* frames_dev, int nb, ResizeP
                 ARP_TRY(launch_skinny_gemm(tcode, q, c->stream));
             }
             ProfScope ps(c->prof, c->stream, "vit.assemble_ln_pre_ln_1");
+            const bool f0 = c->vis.lat_folded && c->lat_stats.p && (D & 15) == 0;
 #define ARP_ASML_CALL(NV)                                                                                                                \
     hipLaunchKernelGGL((vit_assemble_lat_kernel<T, NV>), dim3(nb * N), dim3(64), 0, c->stream, c->part.as<float>(), S, (size_t)Mp * D, c->cls, c->pos, \
-                       c->lnpre_w, c->lnpre_b, c->x.as<float>(), c->h.as<T>(), c->vis.L[0].ln1_w, c->vis.L[0].ln1_b, N, D, 1e-5f)
+                       c->lnpre_w, c->lnpre_b, c->x.as<float>(), c->h.as<T>(), c->vis.L[0].ln1_w, c->vis.L[0].ln1_b, N, D, 1e-5f,         \
+                       f0 ? c->lat_stats.as<float>() : nullptr, D >> 4)
             ARP_NV_DISPATCH(D, ARP_ASML_CALL);
 #undef ARP_ASML_CALL
             ARP_HIP_OK(hipGetLastError());
             assembled = true;
-            c->lat_h0 = true;
+            c->lat_h0 = !f0;
+            c->lat_f0 = f0;
         }
     }
     if (!assembled) {
@@ -586,6 +621,7 @@ static int make_sibling(arp_clip* c) {
     DevBuf* bufs[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards, &s->stats};
     for (auto* b : bufs) *b = DevBuf();
     s->part = DevBuf();  // the latency path never runs on a sibling (parts of >= 128 frames)
+    s->lat_stats = DevBuf();
     s->lat_graphs.clear();
     s->pin_frames = nullptr; s->pin_frames_bytes = 0; s->pin_rewards = nullptr; s->pin_rewards_n = 0;
     s->stream = nullptr;
@@ -749,6 +785,7 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     if (const char* e = getenv("ARP_CLS_ONLY")) c->cls_only_last = atoi(e) != 0;
     if (const char* e = getenv("ARP_QKV_FUSED")) c->qkv_fused = atoi(e) != 0;
     if (const char* e = getenv("ARP_SKINNY")) c->skinny = atoi(e) != 0;
+    if (const char* e = getenv("ARP_LAT_FOLD")) c->lat_fold = atoi(e) != 0;
     if (const char* e = getenv("ARP_CLIP_GRAPH")) c->lat_graph = atoi(e) != 0;
     if (const char* e = getenv("ARP_SKINNY_ROWS")) c->lat_rows = std::min(std::max(atoi(e), 1), SKINNY_MAX_M);
     if (const char* e = getenv("ARP_CLIP_PINNED")) c->lat_pinned = atoi(e) != 0;
@@ -786,6 +823,7 @@ int arp_clip_destroy(arp_clip* c) {
     c->prof.destroy();
     drop_lat_graphs(c);
     c->part.release();
+    c->lat_stats.release();
     if (c->pin_frames) (void)hipHostFree(c->pin_frames);
     if (c->pin_rewards) (void)hipHostFree(c->pin_rewards);
     for (void* p : c->owned) (void)hipFree(p);
@@ -849,6 +887,7 @@ int arp_clip_finalize_weights(arp_clip* c) {
     build_lut(lut.data());
     ARP_TRY(upload_f32(c, lut, &c->lut));
     ARP_TRY(c->part.ensure((size_t)4 * SKINNY_MAX_M * std::max(D, Tw) * 4));
+    ARP_TRY(c->lat_stats.ensure((size_t)SKINNY_MAX_M * std::max(D >> 4, 1) * 8));
     c->staged.clear();
     c->finalized = true;
     return 0;

@@ -130,7 +130,10 @@ template <typename T, int NV>
 __global__ __launch_bounds__(64) void vit_assemble_lat_kernel(const float* __restrict__ patch, int S, size_t slice_stride, const float* __restrict__ cls,
                                                               const float* __restrict__ pos, const float* __restrict__ w, const float* __restrict__ b,
                                                               float* __restrict__ x, T* __restrict__ h, const float* __restrict__ w1,
-                                                              const float* __restrict__ b1, int ntok, int D, float eps) {
+                                                              const float* __restrict__ b1, int ntok, int D, float eps,
+                                                              float* __restrict__ stats = nullptr, int parts = 0) {
+    // stats != null (LayerNorm folded into the latency path's GEMMs): h receives the operand-type copy of x instead of ln_1(x), and
+    // stats[row][0] = (sum, sum of squares) of the row, stats[row][1 .. parts) = 0 -- the layout the strip producers write
     const int lane = threadIdx.x, row = blockIdx.x;
     const int bi = row / ntok, t = row - bi * ntok;
     const float* src = (t == 0) ? cls : patch + ((size_t)bi * (ntok - 1) + (t - 1)) * D;
@@ -184,6 +187,26 @@ __global__ __launch_bounds__(64) void vit_assemble_lat_kernel(const float* __res
             v[i][2] = (v[i][2] - mean) * rstd * ww.z + bb.z; v[i][3] = (v[i][3] - mean) * rstd * ww.w + bb.w;
             store4(x + (size_t)row * D + c, v[i][0], v[i][1], v[i][2], v[i][3]);
         }
+    }
+    if (stats) {
+        float su = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < D) {
+                store4(h + (size_t)row * D + c, v[i][0], v[i][1], v[i][2], v[i][3]);
+                su += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+                sq += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+            }
+        }
+        su = wave_sum(su);
+        sq = wave_sum(sq);
+        float* st = stats + (size_t)row * parts * 2;
+        for (int p = lane; p < parts; p += 64) {
+            st[2 * p] = p == 0 ? su : 0.f;
+            st[2 * p + 1] = p == 0 ? sq : 0.f;
+        }
+        return;
     }
     ln_row_store<T, NV>(v, D, lane, w1, b1, eps, h + (size_t)row * D);
 }

@@ -30,7 +30,17 @@ struct SkinnyArgs {
     int out_f32 = 0;
     int ksplit = 1;
     size_t slice_stride = 0;
-    int strips = 0;    // 1: 16-column strips even above 64 rows (A/B switch of the harness)
+    // LayerNorm folded into the latency path (tower.h): a PRODUCER (direct residual epilogue on 16-column strips) also writes the operand-type
+    // copy of the new row and, per row and strip, (sum, sum of squares) of the 16 new values; a CONSUMER's A operand is that copy and its
+    // epilogue is  rstd_m * (acc - mu_m * ln_c[n]) + bias[n]  with W = W diag(gamma), ln_c = its row sums, bias = W beta + b.
+    void* xb = nullptr;               // producer: [M, ldxb] T
+    int ldxb = 0;
+    float* stats_out = nullptr;       // producer: [M][N / 16][2]
+    const float* ln_stats = nullptr;  // consumer: [M][ln_parts][2]
+    const float* ln_c = nullptr;      // consumer: [N]
+    int ln_parts = 0;
+    float ln_inv_d = 0.f, ln_eps = 0.f;
+    int strips = 0;    // 1: 16-column strips even above 64 rows (A/B switch of the harness; producers of LayerNorm statistics)
     int gather = 0;    // 1: the fragment-gather kernel even where the coalesced LDS-DMA kernel applies (A/B switch of the harness)
 };
 

@@ -17,6 +17,79 @@ __device__ __forceinline__ float act_rt(int act, float x) {
     }
 }
 
+// mean / rstd of the workgroup's 16 MT rows from the producers' per-strip sums, into LDS [rows][2] (consumer of a folded LayerNorm).
+// Eight lanes per row, each with every eighth strip (independent loads: a one-thread-per-row loop over 48 strips walked them one L2
+// round trip at a time), then a fixed-order butterfly over the eight lanes.
+template <int MT>
+__device__ __forceinline__ void skinny_row_stats(const SkinnyArgs& g, int mt0, float* lnst) {
+    const int sub = threadIdx.x & 7;
+    for (int r = threadIdx.x >> 3; r < MT * 16; r += blockDim.x >> 3) {
+        int m = mt0 * 16 + r;
+        m = m < g.M ? m : g.M - 1;
+        const float2* st = reinterpret_cast<const float2*>(g.ln_stats) + (size_t)m * g.ln_parts;
+        float2 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (sub + 8 * i < g.ln_parts) ? st[sub + 8 * i] : make_float2(0.f, 0.f);
+        float su = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { su += v[i].x; sq += v[i].y; }
+        for (int p = sub + 64; p < g.ln_parts; p += 8) { su += st[p].x; sq += st[p].y; }  // more than 64 strips (width > 1024)
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { su += __shfl_xor(su, o, 64); sq += __shfl_xor(sq, o, 64); }
+        if (sub == 0) {
+            const float mu = su * g.ln_inv_d;
+            lnst[2 * r] = mu;
+            lnst[2 * r + 1] = 1.0f / sqrtf(fmaxf(sq * g.ln_inv_d - mu * mu, 0.f) + g.ln_eps);
+        }
+    }
+}
+
+// One output fragment: row m (this lane), columns n .. n + 3.  EVERY lane of the wave must call it (the statistics of a producer are
+// reduced across the four lane groups of a row); rows >= M store nothing.  lrow: the row's index inside the workgroup (for lnst).
+template <typename T>
+__device__ __forceinline__ void skinny_store(const SkinnyArgs& g, int slice, int m, int n, f32x4_v v, const float* lnst, int lrow) {
+    const bool live = m < g.M;
+    if (gridDim.y > 1) {
+        if (live) *reinterpret_cast<f32x4_v*>(static_cast<float*>(g.out) + (size_t)slice * g.slice_stride + (size_t)m * g.ldo + n) = v;
+        return;
+    }
+    float r[4] = {v[0], v[1], v[2], v[3]};
+    if (g.ln_stats) {
+        const float mu = lnst[2 * lrow], rs = lnst[2 * lrow + 1];
+        const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n);
+        r[0] = rs * (r[0] - mu * c4.x); r[1] = rs * (r[1] - mu * c4.y); r[2] = rs * (r[2] - mu * c4.z); r[3] = rs * (r[3] - mu * c4.w);
+    }
+    if (g.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+        r[0] += bb.x; r[1] += bb.y; r[2] += bb.z; r[3] += bb.w;
+    }
+    if (g.act != ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = act_rt(g.act, r[i]);
+    }
+    if (g.out_f32) {
+        if (g.resid && live) {
+            const float4 q = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
+            r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
+        }
+        if (live) store4(static_cast<float*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
+        if (g.stats_out) {  // producer of the next LayerNorm: the operand copy and this strip's (sum, sum of squares) per row
+            if (live) store4(static_cast<T*>(g.xb) + (size_t)m * g.ldxb + n, r[0], r[1], r[2], r[3]);
+            float su = live ? (r[0] + r[1]) + (r[2] + r[3]) : 0.f;
+            float sq = live ? (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]) : 0.f;
+            su += __shfl_xor(su, 16, 64); sq += __shfl_xor(sq, 16, 64);
+            su += __shfl_xor(su, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            if (live && (threadIdx.x & 48) == 0) {
+                float* st = g.stats_out + ((size_t)m * (g.N >> 4) + (n >> 4)) * 2;
+                st[0] = su;
+                st[1] = sq;
+            }
+        }
+    } else if (live) {
+        store4(static_cast<T*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
+    }
+}
+
 // MT = 16-row m-tiles and NT = 16-column n-tiles per workgroup (every wave computes all MT x NT of them over its own K range),
 // KS = MFMA k-steps (32 elements) per chunk; a wave walks chunks of 32 * KS elements of its K range.
 // blockIdx.x: n-group (16 NT columns), blockIdx.y: cross-workgroup K slice, blockIdx.z: m-group (16 MT rows).
@@ -27,7 +100,8 @@ __device__ __forceinline__ float act_rt(int act, float x) {
 template <typename T, int MT, int NT, int KS>
 __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4_v* red = reinterpret_cast<f32x4_v*>(smem);  // [NW][MT * NT][64]
+    float* lnst = reinterpret_cast<float*>(smem);                     // [MT * 16][2]: mean, rstd (folded-LayerNorm consumer)
+    f32x4_v* red = reinterpret_cast<f32x4_v*>(smem + 1024);  // [NW][MT * NT][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
@@ -38,6 +112,7 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs g) {
     const int kw = kslice / NW;
     const int fr = lane & 15, fg = lane >> 4;
     const int kbase = slice * kslice + wave * kw + fg * 8;
+    if (g.ln_stats) skinny_row_stats<MT>(g, mt0, lnst);
     const T* __restrict__ wp[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) wp[u] = static_cast<const T*>(g.W) + (size_t)(n0 + u * 16 + fr) * g.ldw + kbase;
@@ -76,32 +151,10 @@ __global__ __launch_bounds__(512) void skinny_gemm_kernel(SkinnyArgs g) {
     // per (m-tile t, n-tile u) a lane holds 4 consecutive output columns n0 + 16 u + 4 fg .. + 3 of row 16 (mt0 + t) + fr
     auto epilogue = [&](int f, f32x4_v v) {
         const int t = f / NT, u = f - t * NT;
-        const int m = (mt0 + t) * 16 + fr, n = n0 + u * 16 + fg * 4;
-        if (m >= g.M) return;
-        if (gridDim.y > 1) {
-            *reinterpret_cast<f32x4_v*>(static_cast<float*>(g.out) + (size_t)slice * g.slice_stride + (size_t)m * g.ldo + n) = v;
-            return;
-        }
-        float r[4] = {v[0], v[1], v[2], v[3]};
-        if (g.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-            r[0] += b.x; r[1] += b.y; r[2] += b.z; r[3] += b.w;
-        }
-        if (g.act != ACT_NONE) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = act_rt(g.act, r[i]);
-        }
-        if (g.out_f32) {
-            if (g.resid) {
-                const float4 q = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
-                r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
-            }
-            store4(static_cast<float*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
-        } else {
-            store4(static_cast<T*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
-        }
+        skinny_store<T>(g, slice, (mt0 + t) * 16 + fr, n0 + u * 16 + fg * 4, v, lnst, t * 16 + fr);
     };
     if (NW == 1) {
+        if (g.ln_stats) __syncthreads();
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -140,7 +193,8 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyArgs g) {
     const int kw = kslice / NW, nblk = kw >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int kbase = slice * kslice + wave * kw;
-    char* my = smem + (size_t)wave * 2 * REGION;
+    float* lnst = reinterpret_cast<float*>(smem);  // [MT * 16][2]: mean, rstd (folded-LayerNorm consumer); the images start 1 KiB in
+    char* my = smem + 1024 + (size_t)wave * 2 * REGION;
     // LDS-DMA sources: lane -> (row-in-group = lane / 8, PHYSICAL chunk lane % 8 holding logical chunk (lane % 8) ^ (row & 7))
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
     const T* __restrict__ src[GROUPS];
@@ -168,6 +222,8 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyArgs g) {
         for (int u = 0; u < NT; ++u) acc[t][u] = f32x4_v{0.f, 0.f, 0.f, 0.f};
     stage(0, 0);
     if (nblk > 1) stage(1, 1);
+    // (behind the first operand blocks in the memory queue, not in front of them: the row statistics are needed at the epilogue only)
+    if (g.ln_stats) skinny_row_stats<MT>(g, mt0, lnst);
     const int sw = fr & 7;
     for (int b = 0; b < nblk; ++b) {
         // block b has landed once at most block b+1's GROUPS instructions are still in flight (loads return in issue order)
@@ -194,32 +250,10 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyArgs g) {
     }
     auto epilogue = [&](int f, f32x4_v v) {
         const int t = f / NT, u = f - t * NT;
-        const int m = (mt0 + t) * 16 + fr, n = n0 + u * 16 + fg * 4;
-        if (m >= g.M) return;
-        if (gridDim.y > 1) {
-            *reinterpret_cast<f32x4_v*>(static_cast<float*>(g.out) + (size_t)slice * g.slice_stride + (size_t)m * g.ldo + n) = v;
-            return;
-        }
-        float r[4] = {v[0], v[1], v[2], v[3]};
-        if (g.bias) {
-            const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
-            r[0] += bb.x; r[1] += bb.y; r[2] += bb.z; r[3] += bb.w;
-        }
-        if (g.act != ACT_NONE) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = act_rt(g.act, r[i]);
-        }
-        if (g.out_f32) {
-            if (g.resid) {
-                const float4 q = *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n);
-                r[0] += q.x; r[1] += q.y; r[2] += q.z; r[3] += q.w;
-            }
-            store4(static_cast<float*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
-        } else {
-            store4(static_cast<T*>(g.out) + (size_t)m * g.ldo + n, r[0], r[1], r[2], r[3]);
-        }
+        skinny_store<T>(g, slice, (mt0 + t) * 16 + fr, n0 + u * 16 + fg * 4, v, lnst, t * 16 + fr);
     };
     if (NW == 1) {
+        if (g.ln_stats) __syncthreads();
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -227,7 +261,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyArgs g) {
         return;
     }
     __syncthreads();  // every wave is done with its operand image: the partial tiles overlay them
-    f32x4_v* red = reinterpret_cast<f32x4_v*>(smem);  // [NW][MT * NT][64]
+    f32x4_v* red = reinterpret_cast<f32x4_v*>(smem + 1024);  // [NW][MT * NT][64]
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -246,14 +280,14 @@ static int lds_waves(int kslice) {
     constexpr int REGION = (MT + NT) * 16 * 128;
     if (kslice % 64) return 0;
     for (int nw : {8, 6, 4, 3, 2, 1})
-        if (kslice % (64 * nw) == 0 && (size_t)nw * 2 * REGION <= 150 * 1024 && (kslice / nw >= 128 || nw == 1)) return nw;
+        if (kslice % (64 * nw) == 0 && (size_t)nw * 2 * REGION <= 149 * 1024 && (kslice / nw >= 128 || nw == 1)) return nw;
     return 0;
 }
 template <typename T, int MT, int NT>
 int launch_lds(const SkinnyArgs& g, int nw, hipStream_t stream) {
     constexpr int REGION = (MT + NT) * 16 * 128;
     auto kern = skinny_lds_kernel<T, MT, NT>;
-    const int lds = std::max(nw * 2 * REGION, nw > 1 ? nw * MT * NT * 1024 : 0);
+    const int lds = 1024 + std::max(nw * 2 * REGION, nw > 1 ? nw * MT * NT * 1024 : 0);
     if (lds > 48 * 1024) ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int mtd = (g.M + 15) / 16;
     hipLaunchKernelGGL(kern, dim3(g.N / (16 * NT), g.ksplit, (mtd + MT - 1) / MT), dim3(nw * 64), lds, stream, g);
@@ -305,7 +339,7 @@ __global__ __launch_bounds__(64) void skinny_reduce_ln_kernel(const float* __res
 template <typename T, int MT, int NT, int KS>
 int launch_one(const SkinnyArgs& g, int nw, hipStream_t stream) {
     auto kern = skinny_gemm_kernel<T, MT, NT, KS>;
-    const int lds = nw > 1 ? nw * MT * NT * 1024 : 0;
+    const int lds = 1024 + (nw > 1 ? nw * MT * NT * 1024 : 0);
     if (lds > 48 * 1024) ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int mtd = (g.M + 15) / 16;
     hipLaunchKernelGGL(kern, dim3(g.N / (16 * NT), g.ksplit, (mtd + MT - 1) / MT), dim3(nw * 64), lds, stream, g);
@@ -366,6 +400,8 @@ int launch_skinny_gemm(int tcode, const SkinnyArgs& g, hipStream_t stream) {
     if (g.ksplit > 1 && (!g.slice_stride || (g.ldo & 3))) return fail("skinny gemm: split-K needs f32 slabs");
     if (g.resid && !g.out_f32) return fail("skinny gemm: the residual epilogue writes f32");
     if ((g.ldo & 3) || (g.resid && (g.ldr & 3))) return fail("skinny gemm: unaligned output");
+    if (g.ln_stats && (!g.ln_c || g.ln_parts < 1 || g.ksplit > 1)) return fail("skinny gemm: folded LayerNorm needs ln_c, ln_parts and an unsplit product");
+    if (g.stats_out && (!g.xb || (g.ldxb & 3) || !g.out_f32 || g.ksplit > 1 || !g.strips)) return fail("skinny gemm: a statistics producer is an unsplit f32 product on 16-column strips");
     if (tcode == 2) return launch_mt<f16_t>(g, stream);
     if (tcode == 1) return launch_mt<bf16_t>(g, stream);
     return fail("skinny gemm: 16-bit operands only");

@@ -39,6 +39,7 @@ struct LayerW {
 struct TowerW {
     int width = 0, layers = 0, heads = 0;
     bool folded = false;  // every layer carries the folded operands
+    bool lat_folded = false;  // ... in the handle's own operand type, for the LATENCY path only (run_blocks; the throughput path is unchanged)
     std::vector<LayerW> L;
 };
 
@@ -46,8 +47,9 @@ struct TowerW {
 //   LN(x) W^T + b = rstd * (x W'^T - mu * c) + d,   W' = W diag(gamma),  c[n] = sum_k W'[n,k],  d = W beta + b.
 // W' is rounded to bf16 first and c is summed from the ROUNDED values, so the mean subtraction cancels exactly
 // what the MFMA accumulates.
+// (half = true: IEEE-half operands -- the latency path's fold in f16 mode; false: bf16)
 inline void fold_layernorm(const float* W, const float* gamma, const float* beta, const float* bias, int N, int K,
-                           std::vector<bf16_t>& Wf, std::vector<float>& c, std::vector<float>& d) {
+                           std::vector<bf16_t>& Wf, std::vector<float>& c, std::vector<float>& d, bool half = false) {
     Wf.resize((size_t)N * K);
     c.assign(N, 0.f);
     d.assign(N, 0.f);
@@ -55,11 +57,17 @@ inline void fold_layernorm(const float* W, const float* gamma, const float* beta
         double cs = 0.0, ds = bias ? (double)bias[n] : 0.0;
         for (int k = 0; k < K; ++k) {
             const float w = W[(size_t)n * K + k];
-            const bf16_t wb = host_f2bf(w * gamma[k]);
-            Wf[(size_t)n * K + k] = wb;
-            uint32_t u = (uint32_t)wb << 16;
             float wf;
-            memcpy(&wf, &u, 4);
+            if (half) {
+                const f16_t wh = host_f2h(w * gamma[k]);
+                Wf[(size_t)n * K + k] = __builtin_bit_cast(bf16_t, wh);  // raw 16 bits either way
+                wf = (float)__builtin_bit_cast(_Float16, wh);
+            } else {
+                const bf16_t wb = host_f2bf(w * gamma[k]);
+                Wf[(size_t)n * K + k] = wb;
+                uint32_t u = (uint32_t)wb << 16;
+                memcpy(&wf, &u, 4);
+            }
             cs += (double)wf;
             ds += (double)w * (double)beta[k];
         }
@@ -135,6 +143,9 @@ struct TowerCtx {
     bool skinny = false;       // set by the owner for a pass of at most SKINNY_MAX_M rows IN TOTAL (never per GEMM: a batch cut into
                                // parts must give the same bits whatever the part size, tests/test_clip_gpu.py two-stream test)
     bool h_ready0 = false;     // the caller already wrote ln_1 of the first block into h (the latency path's token-assembly kernel)
+    float* lat_stats = nullptr; // folded LayerNorm on the latency path: per row and 16-column strip (sum, sum of squares), [rows][width / 16][2];
+                               // h then holds the operand-type copy of x and the caller's token-assembly kernel has written both for block 0
+    bool lat_fold0 = false;
     float* part = nullptr;     // split-K slabs, f32 [<= 4][rows][width]; null: out_proj / c_proj stay single launches
     size_t part_floats = 0;
     // multi-scale export: after every block, one row per sample of the residual stream -- what the forward
@@ -405,10 +416,42 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
     const bool lat = sizeof(T) == 2 && c.skinny && c.gemm_force == 0 && !c.fp8_mlp && c.part && M <= SKINNY_MAX_M && S_out && S_proj &&
                      (size_t)std::max(S_out, S_proj) * M * D <= c.part_floats && skinny_supported(M, 3 * D, D, D, D) && skinny_supported(M, 4 * D, D, D, D);
     const std::string s_red2 = t + ".out_reduce_ln_2", s_red1 = t + ".proj_reduce_ln_1";
-    bool h_ready = lat && c.h_ready0;  // h already holds ln_1 of this block (written by the previous block's reduction)
+    // ... with LayerNorm folded into the consumer GEMMs where the tower carries the folded operands (TowerW::lat_folded) and the caller's
+    // token-assembly kernel has written the operand copy and the statistics of block 0
+    const bool fold = lat && tw.lat_folded && c.lat_stats && c.lat_fold0 && (D & 15) == 0 && skinny_supported(M, D, 4 * D, 4 * D, 4 * D);
+    bool h_ready = lat && !fold && c.h_ready0;  // h already holds ln_1 of this block (written by the previous block's reduction)
     for (int i = 0; i < tw.layers; ++i) {
         const LayerW& L = tw.L[i];
         if constexpr (sizeof(T) == 2) {
+            if (fold && !(c.cls_only_last && i == tw.layers - 1 && N > 1)) {
+                // LayerNorm folded into the consumers (W diag(gamma); mean / rstd from the producers' per-strip sums): qkv, attention,
+                // out_proj, c_fc, c_proj -- five launches, no reduce + LayerNorm kernels; h = the operand-type copy of x throughout
+                const int tcode = __is_same(T, bf16_t) ? 1 : 2;
+                auto consumer = [&](const char* site, const void* Wf, const float* dvec, const float* cvec, void* out, int Nout, int act) -> int {
+                    SkinnyArgs k;
+                    k.A = h; k.W = Wf; k.bias = dvec; k.out = out; k.M = M; k.N = Nout; k.K = D; k.lda = D; k.ldw = D; k.ldo = Nout; k.act = act;
+                    k.ln_stats = c.lat_stats; k.ln_c = cvec; k.ln_parts = D >> 4; k.ln_inv_d = 1.0f / (float)D; k.ln_eps = eps;
+                    ProfScope ps(*c.prof, c.stream, site);
+                    return launch_skinny_gemm(tcode, k, c.stream);
+                };
+                auto producer = [&](const char* site, const void* A, const void* W, const float* bias, int K) -> int {
+                    SkinnyArgs k;
+                    k.A = A; k.W = W; k.bias = bias; k.resid = x; k.out = x; k.M = M; k.N = D; k.K = K; k.lda = K; k.ldw = K; k.ldr = D; k.ldo = D;
+                    k.out_f32 = 1; k.strips = 1; k.xb = h; k.ldxb = D; k.stats_out = c.lat_stats;
+                    ProfScope ps(*c.prof, c.stream, site);
+                    return launch_skinny_gemm(tcode, k, c.stream);
+                };
+                ARP_TRY(consumer(s_qkv.c_str(), L.w_in_f, L.d_in, L.c_in, qkv, 3 * D, ACT_NONE));
+                {
+                    ProfScope ps(*c.prof, c.stream, s_attn.c_str());
+                    ARP_TRY(launch_attention<T>(c.stream, c.attn_impl, qkv, ao, B, N, D, tw.heads, causal));
+                }
+                ARP_TRY(producer(s_out.c_str(), ao, L.w_out, L.b_out, D));
+                ARP_TRY(consumer(s_fc1.c_str(), L.w_fc_f, L.d_fc, L.c_fc, fc, 4 * D, ACT));
+                ARP_TRY(producer(s_fc2.c_str(), fc, L.w_proj, L.b_proj, 4 * D));
+                ARP_TRY(tower_export_rows(c, x, D, i, B, N));
+                continue;
+            }
             if (lat && !(c.cls_only_last && i == tw.layers - 1 && N > 1)) {
                 if (!h_ready) ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));
                 ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn.c_str(), s_qa.c_str(), h, qkv, ao, B, N, causal, 0)));

@@ -124,7 +124,7 @@ def test_online_single_frame_reward(gpu_lib):
 
 @pytest.mark.parametrize("name", ["ViT-B/32", "ViT-B/16"])
 def test_latency_path_full_size(gpu_lib, name, monkeypatch):
-    """Row N4 at the real geometry: single-frame calls (skinny GEMMs, split-K + reduce + LayerNorm kernels, small preprocess tiles, the
+    """Row N4 at the real geometry: single-frame calls (skinny GEMMs with LayerNorm folded into them, small preprocess tiles, the
     pass replayed as a hipGraph, pinned staging) within north_star's 1e-4 cosine of the fp32 oracle in f16 mode; the graph replays the
     same bits as launch-by-launch; a call of more token rows than the path's limit (1024) leaves it; a new prompt drops the
     captured passes."""
@@ -147,12 +147,21 @@ def test_latency_path_full_size(gpu_lib, name, monkeypatch):
     m.profile(True)  # profiling: launch by launch, one event pair per site
     prof = np.concatenate([m.label(fr[i:i + 1]) for i in range(6)])
     sites = m.profile_read(); m.profile(False)
-    assert (prof == one).all() and "vit.proj_reduce_ln_1" in sites and "vit.qkv_attn" not in sites
+    # five launches per block: LayerNorm folded into the consumer GEMMs (no reduce + LayerNorm kernels, no fused QKV + attention kernel)
+    assert (prof == one).all() and "vit.proj_reduce_ln_1" not in sites and "vit.qkv_attn" not in sites and "vit.c_proj" in sites
+    assert sites["vit.qkv"]["calls"] == 6 * cfg.layers and sites["vit.ln_1"]["calls"] == 6  # ln_1 runs for the class-token-only last block alone
     big = m.label(np.concatenate([fr] * 4))  # 24 frames: 1200 / 4728 token rows, past the path's row limit: the throughput kernels
     assert np.abs(big - np.concatenate([ref] * 4)).max() / 100.0 < COS_TOL_F16
     assert np.abs(m.label(fr[:3]) - ref[:3]).max() / 100.0 < COS_TOL_F16  # 150 / 591 rows: several frames per call on the latency path
     m.set_text(tok2)
     assert np.abs(np.concatenate([m.label(fr[i:i + 1]) for i in range(2)]) - ref2).max() / 100.0 < COS_TOL_F16
+    m.close()
+    # the unfolded latency path (split-K slabs + reduce / residual / LayerNorm kernels): seven launches per block, same tolerance
+    monkeypatch.setenv("ARP_LAT_FOLD", "0")
+    m = clip.ClipLabeller(cfg, Wt, mode="f16", n_streams=1).set_text(tok)
+    m.profile(True)
+    unf = np.concatenate([m.label(fr[i:i + 1]) for i in range(6)])
+    assert "vit.proj_reduce_ln_1" in m.profile_read() and np.abs(unf - ref).max() / 100.0 < COS_TOL_F16
     m.close()
     monkeypatch.setenv("ARP_SKINNY", "0"); monkeypatch.setenv("ARP_CLIP_GRAPH", "0"); monkeypatch.setenv("ARP_CLIP_PINNED", "0")
     m = clip.ClipLabeller(cfg, Wt, mode="f16", n_streams=1).set_text(tok)
