@@ -181,6 +181,14 @@ def test_latency_path_tiny_bf16_and_crop(gpu_lib):
         got = np.concatenate([m.label(fr[i:i + 2], use_crop=True) for i in (0, 2, 4)])
         assert np.abs(got - ref).max() / scale < tol
         m.close()
+    # other frame geometries through the small-tile preprocess plan of a latency-path call: native Procgen size, non-square
+    for (H, W_) in ((64, 64), (96, 128), (300, 200)):
+        ocfg, Wt, fr, tok, ref = _setup(TINY, 3, seed=43, H=H, W=W_)
+        m = clip.ClipLabeller(clip.ClipConfig(**TINY), Wt, mode="f16", n_streams=1).set_text(tok)
+        got = np.concatenate([m.label(fr[i:i + 1]) for i in range(3)])
+        assert np.abs(got - ref).max() / float(np.exp(Wt["logit_scale"])) < 2 * COS_TOL_F16, (H, W_)
+        assert (np.concatenate([m.label(fr[i:i + 1]) for i in range(3)]) == got).all()  # replayed
+        m.close()
 
 
 def test_two_stream_split_matches_single_stream(gpu_lib):
