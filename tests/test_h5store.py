@@ -200,6 +200,23 @@ def test_streamed_and_collected_writes_give_the_same_file_content(tmp_path, monk
     assert out["1"]["ob_clip_reward"][0].shape == (186, F) and out["1"]["ob_clip_pos_rtg"][0].shape == (400, F)
 
 
+def test_a_failing_writer_thread_fails_the_call(tmp_path, monkeypatch):
+    """RowSink's writer thread must not swallow an error: label_reward raises it, and the file handle is still closed (a second open works)."""
+    from arp_amd import label_reward as L
+    p = str(tmp_path / "data.hdf5")
+    _recorder_file(p, [30, 70], hw=8, seed=5)
+
+    def boom(self, *a, **k):
+        raise h5store.H5Error("disk full")
+
+    monkeypatch.setattr(h5store.H5Store, "create_dataset", boom)
+    with pytest.raises(h5store.H5Error, match="disk full"):
+        L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=p, clip_model=_FakeClip(), tokens=np.zeros((1, 77), np.int32))
+    monkeypatch.undo()
+    with h5store.H5Store(p, "a") as f:
+        assert "ob_clip_reward" not in f.keys()
+
+
 def test_default_path_layout(tmp_path):
     """data_path=None builds <base>/<env>_<mode>_level<start>to<num>_num<demos>_frame<frames>[_<env_type>]/data.hdf5 (label_reward.py:62-68)."""
     from arp_amd import label_reward as L
