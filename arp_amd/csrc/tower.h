@@ -420,10 +420,25 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
     // token-assembly kernel has written the operand copy and the statistics of block 0
     const bool fold = lat && tw.lat_folded && c.lat_stats && c.lat_fold0 && (D & 15) == 0 && skinny_supported(M, D, 4 * D, 4 * D, 4 * D);
     bool h_ready = lat && !fold && c.h_ready0;  // h already holds ln_1 of this block (written by the previous block's reduction)
+    bool qkv_ready = false;  // the class-token-only last block of a folded pass: in_proj already ran as a folded consumer
     for (int i = 0; i < tw.layers; ++i) {
         const LayerW& L = tw.L[i];
         if constexpr (sizeof(T) == 2) {
-            if (fold && !(c.cls_only_last && i == tw.layers - 1 && N > 1)) {
+            const bool cls_blk = c.cls_only_last && i == tw.layers - 1 && N > 1;
+            // (a folded pass reaches the class-token-only last block with h = the operand copy of x and its statistics in place: that
+            //  block's in_proj is a consumer too -- no ln_1 launch -- and only its class rows go on through the unfolded kernels)
+            if (fold && cls_blk && i > 0) {
+                const int tcode = __is_same(T, bf16_t) ? 1 : 2;
+                SkinnyArgs k;
+                k.A = h; k.W = L.w_in_f; k.bias = L.d_in; k.out = qkv; k.M = M; k.N = 3 * D; k.K = D; k.lda = D; k.ldw = D; k.ldo = 3 * D;
+                k.ln_stats = c.lat_stats; k.ln_c = L.c_in; k.ln_parts = D >> 4; k.ln_inv_d = 1.0f / (float)D; k.ln_eps = eps;
+                {
+                    ProfScope ps(*c.prof, c.stream, s_qkv.c_str());
+                    ARP_TRY(launch_skinny_gemm(tcode, k, c.stream));
+                }
+                qkv_ready = true;
+            }
+            if (fold && !cls_blk) {
                 // LayerNorm folded into the consumers (W diag(gamma); mean / rstd from the producers' per-strip sums): qkv, attention,
                 // out_proj, c_fc, c_proj -- five launches, no reduce + LayerNorm kernels; h = the operand-type copy of x throughout
                 const int tcode = __is_same(T, bf16_t) ? 1 : 2;
@@ -469,8 +484,13 @@ static int run_blocks(TowerCtx& c, const TowerW& tw, const char* tag, float* x, 
             const std::string s_attn1 = t + ".attn_cls", s_out1 = t + ".out_proj_cls", s_ln21 = t + ".ln_2_cls", s_fc11 = t + ".c_fc_cls",
                               s_fc21 = t + ".c_proj_cls";
             const int ND = N * D;  // row stride of the class-token rows inside the [B*N, D] buffers
-            if (!h_ready) ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));  // K and V need every token
-            ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn1.c_str(), s_qa1.c_str(), h, qkv, ao, B, N, causal, 1)));
+            if (qkv_ready) {
+                ProfScope ps(*c.prof, c.stream, s_attn1.c_str());
+                ARP_TRY(launch_attention<T>(c.stream, c.attn_impl, qkv, ao, B, N, D, tw.heads, causal, 1));
+            } else {
+                if (!h_ready) ARP_TRY(tower_layernorm<T>(c, s_ln1.c_str(), x, D, h, D, L.ln1_w, L.ln1_b, M, D, eps));  // K and V need every token
+                ARP_TRY((tower_qkv_attention<T, SB + SITE_QKV>(c, tw, L, s_qkv.c_str(), s_attn1.c_str(), s_qa1.c_str(), h, qkv, ao, B, N, causal, 1)));
+            }
             ARP_TRY((tower_gemm<T, float, ACT_NONE, true, SB + SITE_OUT>(c, s_out1.c_str(), ao, L.w_out, L.b_out, x, x, B, D, D, nullptr, ND, ND, ND)));
             ARP_TRY(tower_layernorm<T>(c, s_ln21.c_str(), x, ND, h, D, L.ln2_w, L.ln2_b, B, D, eps));
             ARP_TRY((tower_gemm<T, T, ACT, false, SB + SITE_FC1>(c, s_fc11.c_str(), h, L.w_fc, L.b_fc, nullptr, fc, B, 4 * D, D)));
