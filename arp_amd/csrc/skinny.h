@@ -5,14 +5,18 @@
 // (37 us per c_proj launch at one frame: profiles/r3_latency_sites_before.txt).  At this size the product is neither MFMA- nor
 // HBM-bound but LATENCY-bound: what matters is that every byte of W is requested at once, from as many CUs as there are.
 //
-// So this kernel tiles W instead:  one workgroup = 16 output columns (16 rows of W), NW waves, wave w owns the K range
-// [w, w+1) * K / NW of those rows.  A wave issues ALL its loads up front -- its W fragments (16 rows x 64 B per MFMA k-step,
-// straight into the MFMA operand layout: no LDS staging, no barrier) and the activation fragments of every 16-row m-tile
-// (L2-resident: the activations are a few hundred KB) -- then MT x KS MFMAs, then the NW partial tiles are summed through LDS
-// in a fixed order (deterministic) and the epilogue (bias, activation, f32 residual, f32 / 16-bit store) runs on the sum.
-// grid.x = N / 16 (48 - 192 workgroups for the tower's GEMMs), grid.y = cross-workgroup K split (c_proj, K = 3072: raw f32
-// partial slabs, summed by skinny_reduce_ln_kernel together with bias + residual + the NEXT LayerNorm, which is a launch the
-// tower needs anyway).
+// So this kernel tiles W instead: a workgroup owns 64 rows x 16 NT columns of the output and ALL of K, split over its waves; the waves'
+// partial tiles are summed through LDS in a fixed order (deterministic) and the epilogue (bias, activation, f32 residual, f32 / 16-bit
+// store, or a raw split-K slab) runs on the sum.  grid.x = n-groups, grid.y = cross-workgroup K split, grid.z = m-groups of 64 rows.
+// Two ways of bringing the operands in (skinny.hip):
+//   * the coalesced kernel (K a multiple of 64 x waves -- every shape of the towers): each wave DMAs its K range into its own double-
+//     buffered LDS image, 8 rows x 128 B per instruction, and reads the MFMA fragments back; no workgroup barrier in the loop.  One CU
+//     fills from L2 at 65-69 B/clk with such whole-line instructions and at 18 B/clk with a 16-row x 64-B fragment gather
+//     (scripts/fill_bench.hip), and above the launch floor the operand fill IS a small GEMM's time;
+//   * the gather kernel (any K % 32 == 0): fragments straight into MFMA operand layout, all loads issued up front.
+// LayerNorm can be folded in (tower.h): a producer's epilogue also writes the operand-type copy of its rows and per-strip (sum, sum of
+// squares); a consumer runs on W diag(gamma) and un-normalised rows and applies rstd (acc - mu c) + d in its epilogue.
+// skinny_reduce_ln_kernel sums split-K slabs, adds bias and residual and applies the next LayerNorm (the unfolded form).
 #pragma once
 #include "common.h"
 
