@@ -118,7 +118,7 @@ struct arp_dt {
     struct GraphRec {
         hipGraphExec_t exec = nullptr;
         int B = 0, images = -1, eager = 0;
-    } graphs[2][3];
+    } graphs[2][4];  // [batch slot][stage: 0 whole step, 1 / 2 the two halves of the overlapped step, 3 forward only]
     Profiler prof;
 
     size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
@@ -902,6 +902,7 @@ int apply_update(arp_dt* c, float lr) {
 }
 
 template <typename T> int fwd_bwd(arp_dt* c, int stage = 0) {
+    if (stage == 3) return forward<T>(c, false);  // forward only (arp_dt_forward, arp_dt_val_step: greedy_action / validation)
     if (stage != 2) ARP_TRY(forward<T>(c, true));
     return backward<T>(c, stage);
 }
@@ -924,12 +925,17 @@ template <typename T> int fwd_bwd_graphed(arp_dt* c, int stage = 0) {
             ARP_TRY(refresh_shadows<T>(c));
         }
     }
+    if constexpr (sizeof(T) == 2) {
+        // the forward-only chain is captured WITHOUT the shadow refresh (the parameters do not change between greedy_action calls):
+        // stale shadows are rebuilt here, eagerly, before the capture or the replay
+        if (stage == 3 && c->shadows_stale) ARP_TRY(refresh_shadows<T>(c));
+    }
     if (!gr.exec) {
         if (gr.eager < 2) {
             gr.eager++;
             return fwd_bwd<T>(c, stage);
         }
-        if (stage != 2) c->shadows_stale = true;  // the captured chain always refreshes the operand shadows
+        if (stage != 2 && stage != 3) c->shadows_stale = true;  // the captured chain always refreshes the operand shadows
         // The uploader thread of prefetch_to_device must not issue HIP calls while this thread captures: its hipEventSynchronize on the
         // slot's `use` event (last recorded on THIS stream, before the capture) is refused while the stream captures ("operation not
         // permitted on an event last recorded in a capturing stream") and the refusal invalidates the capture ("operation failed due to
@@ -1313,7 +1319,8 @@ int arp_dt_forward(arp_dt* c, float* action_logits, float* return_pred, float* m
     if (!c) return fail("null handle");
     if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : (c->cfg.mode == ARP_MODE_F16 ? forward<f16_t>(c) : forward<float>(c)));
+    // (replayed as a hipGraph from the third call of a geometry on: ~25 dependent launches, host-bound at batch 1)
+    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? fwd_bwd_graphed<bf16_t>(c, 3) : (c->cfg.mode == ARP_MODE_F16 ? fwd_bwd_graphed<f16_t>(c, 3) : fwd_bwd_graphed<float>(c, 3)));
     const int R = c->R();
     if (action_logits) ARP_HIP_OK(hipMemcpyAsync(action_logits, c->logits.p, (size_t)R * c->cfg.n_actions * 4, hipMemcpyDeviceToHost, c->stream));
     if (return_pred) ARP_HIP_OK(hipMemcpyAsync(return_pred, c->ret.p, (size_t)R * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1356,7 +1363,7 @@ int arp_dt_val_step(arp_dt* c, float* aux4) {
     if (!c || !aux4) return fail("null argument");
     if (c->B <= 0) return fail("no batch staged: call arp_dt_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? forward<bf16_t>(c) : (c->cfg.mode == ARP_MODE_F16 ? forward<f16_t>(c) : forward<float>(c)));
+    ARP_TRY(c->cfg.mode == ARP_MODE_BF16 ? fwd_bwd_graphed<bf16_t>(c, 3) : (c->cfg.mode == ARP_MODE_F16 ? fwd_bwd_graphed<f16_t>(c, 3) : fwd_bwd_graphed<float>(c, 3)));
     const bool comm = c->has_comm && (c->cfg.world > 1 || c->force_comm);
     if (comm && rccl_api()->AllReduce(c->metrics.p, c->metrics.p, 4, ncclFloat, ncclSum, c->comm, c->stream) != ncclSuccess)
         return fail("ncclAllReduce(metrics) failed");
