@@ -166,6 +166,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     const int sw = fr & 7;  // (row & 7) for every fragment row of this lane (tile bases are multiples of 16)
 
     f32x4_v acc[4][4];  // [ni][mi]
+    const int mfrag_live = min(4, max(0, (g.M - m0 - wr * 64 + 15) >> 4));  // this wave's 16-row m-fragments that hold a real row
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -211,6 +212,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     if constexpr (sizeof(T) == 2) {
                         acc[ni][mi] = mfma16<T>(wf[ni], af[mi], acc[ni][mi]);
                     } else {
+                        // f32: a handful of rows against a long K (the policy's f32 image_text_input at batch 1: 4 rows x 197 376) would
+                        // spend 16x its useful time in 16x16x4 MFMAs on clamped rows; m-fragments wholly past M are skipped (wave-uniform)
+                        if (mi >= mfrag_live) continue;
                         // 16 floats of K per (ks): lane group fg holds k = 16*ks + 4*fg + j in element j
                         // of BOTH operands, so the four 16x16x4 MFMAs (j = 0..3) cover them all.
 #pragma unroll
