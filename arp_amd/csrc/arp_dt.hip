@@ -82,8 +82,9 @@ struct arp_dt {
         hipEvent_t up = nullptr;   // recorded on the copy stream behind the slot's upload
         hipEvent_t use = nullptr;  // recorded on the compute stream behind the last step that read the slot
         bool up_pending = false, used = false;
-    } bt[2];
-    int cur = 0;
+    } bt[3];  // 0 / 1: the prefetcher's slots (arp_dt_upload_batch*_async); 2: the synchronous arp_dt_set_batch* calls -- a validation
+              // step or a greedy action in between prefetched train steps must not write into a slot the uploader thread may be filling
+    int cur = 2;
     // one copy stream per slot; an upload waits on the HOST for the slot's last reader (upload_async) and then runs on a stream with
     // nothing else queued, beside the step on the other slot
     hipStream_t copy_stream[2] = {nullptr, nullptr};
@@ -118,7 +119,7 @@ struct arp_dt {
     struct GraphRec {
         hipGraphExec_t exec = nullptr;
         int B = 0, images = -1, eager = 0;
-    } graphs[2][4];  // [batch slot][stage: 0 whole step, 1 / 2 the two halves of the overlapped step, 3 forward only]
+    } graphs[3][4];  // [batch slot][stage: 0 whole step, 1 / 2 the two halves of the overlapped step, 3 forward only]
     Profiler prof;
 
     size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
@@ -1097,7 +1098,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking));
-        for (hipEvent_t* e : {&c->ev_b1, &c->ev_b2, &c->ev_comm, &c->bt[0].up, &c->bt[0].use, &c->bt[1].up, &c->bt[1].use})
+        for (hipEvent_t* e : {&c->ev_b1, &c->ev_b2, &c->ev_comm, &c->bt[0].up, &c->bt[0].use, &c->bt[1].up, &c->bt[1].use, &c->bt[2].up, &c->bt[2].use})
             ARP_HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
         for (auto* b : fb) {
@@ -1125,10 +1126,10 @@ int arp_dt_destroy(arp_dt* c) {
         for (auto& gr : slot)
             if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
-    for (hipEvent_t e : {c->ev_b1, c->ev_b2, c->ev_comm, c->bt[0].up, c->bt[0].use, c->bt[1].up, c->bt[1].use})
+    for (hipEvent_t e : {c->ev_b1, c->ev_b2, c->ev_comm, c->bt[0].up, c->bt[0].use, c->bt[1].up, c->bt[1].use, c->bt[2].up, c->bt[2].use})
         if (e) (void)hipEventDestroy(e);
     c->prof.destroy();
-    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->W2t, &c->Wit, &c->colpart, &c->Y32, &c->bt[0].enc32, &c->bt[0].img32, &c->bt[0].action, &c->bt[0].rtg, &c->bt[1].enc32, &c->bt[1].img32, &c->bt[1].action, &c->bt[1].rtg, &c->Xb, &c->XbT,
+    DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->W2t, &c->Wit, &c->colpart, &c->Y32, &c->bt[0].enc32, &c->bt[0].img32, &c->bt[0].action, &c->bt[0].rtg, &c->bt[1].enc32, &c->bt[1].img32, &c->bt[1].action, &c->bt[1].rtg, &c->bt[2].enc32, &c->bt[2].img32, &c->bt[2].action, &c->bt[2].rtg, &c->Xb, &c->XbT,
                      &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,
@@ -1241,7 +1242,8 @@ static int stage_slot(arp_dt* c, int si, hipStream_t st, const float* enc, const
 int arp_dt_set_batch(arp_dt* c, const float* enc, const int32_t* action, const float* rtg, int B) {
     if (!c || !enc || !action || !rtg || B <= 0) return fail("bad argument");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    ARP_TRY(stage_slot(c, c->cur, c->stream, enc, nullptr, action, rtg, B));
+    c->cur = 2;  // the synchronous slot
+    ARP_TRY(stage_slot(c, 2, c->stream, enc, nullptr, action, rtg, B));
     ARP_TRY(ensure_buffers(c, B));
     c->use_images = false;
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
@@ -1308,7 +1310,8 @@ int arp_dt_set_batch_images(arp_dt* c, const float* images, const int32_t* actio
     if (!c || !images || !action || !rtg || B <= 0) return fail("bad argument");
     if (!c->enc) return fail("no encoder attached: call arp_dt_attach_encoder first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
-    ARP_TRY(stage_slot(c, c->cur, c->stream, nullptr, images, action, rtg, B));
+    c->cur = 2;  // the synchronous slot
+    ARP_TRY(stage_slot(c, 2, c->stream, nullptr, images, action, rtg, B));
     ARP_TRY(ensure_buffers(c, B));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     c->use_images = true;

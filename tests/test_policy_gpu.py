@@ -443,6 +443,41 @@ def test_bucketed_overlapped_allreduce_equals_serial(gpu_lib, monkeypatch, mode)
         assert [a["loss"] for a in res["plain"][1]] == [a["loss"] for a in res[other][1]]
 
 
+def test_validation_and_greedy_actions_between_prefetched_steps_leave_the_trajectory_alone(gpu_lib):
+    """A validation step or a greedy action in between prefetched train steps stages its batch synchronously -- into a slot of its own
+    (slot 2), never into one of the two slots the uploader thread may be filling at that moment (found by scripts/soak_policy.py:
+    with two slots the training losses changed from run to run)."""
+    from arp_amd import synth_policy as S
+    from arp_amd.train import TrainState, create_train_step, create_val_step, prefetch_to_device
+    cfg, ocfg, P, _, Pt, tb = _setup(SMALL, 4, 31)
+    batches = []
+    for i in range(5):
+        enc, act, rtg = S.policy_batch(cfg, 4, seed=60 + i)
+        batches.append({"image": {"ob": enc}, "action": act, "rtg": {"ob": rtg}})
+    one = S.policy_batch(cfg, 1, seed=77)
+
+    def run(interleave):
+        state = TrainState.create(cfg, P, mode="f32")
+        fn, vfn = create_train_step(cfg, lambda s: 1e-3, cfg.weight_decay), create_val_step(cfg)
+        rng, losses, extras = np.array([0, 3], np.uint32), [], []
+        for i, b in enumerate(prefetch_to_device((batches[j % 5] for j in range(25)), 2, state.trainer)):
+            state, aux, rng = fn(state, b, rng)
+            losses.append(aux["loss"])
+            if interleave and i % 3 == 1:
+                extras.append(vfn(state, batches[(i + 2) % 5], rng)[0]["loss"])
+            if interleave and i % 4 == 2:
+                extras.append(float(state.trainer.greedy_action(*one)[0]))
+        p = state.params
+        state.trainer.close()
+        return losses, extras, p
+
+    la, _, pa = run(False)
+    lb, eb, pb = run(True)
+    lc, ec, _ = run(True)
+    assert la == lb == lc and eb == ec and len(eb) > 10
+    assert all(np.array_equal(pa[k], pb[k]) for k in pa)
+
+
 def test_prefetched_slots_equal_synchronous_upload(gpu_lib):
     """prefetch_to_device (main_procgen.py:703): batches uploaded into the two device slots by a background thread while the step on
     the other slot runs give the same trajectory as the synchronous set_batch path; val_step_fn leaves the state alone."""
