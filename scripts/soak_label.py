@@ -35,6 +35,8 @@ while time.time() - t0 < seconds:
         check((prompt, "big"), m.label(big))
     elif kind == 4:
         m.label_submit(0, big); m.label_submit(1, big[:512])
+        if rng.integers(0, 2):  # other calls while both slots are in flight
+            check((prompt, "one", 5), m.label(base[5:6])); check((prompt, "mid", 64), m.label(big[:64]))
         check((prompt, "big"), m.label_collect(0)); check((prompt, "half"), m.label_collect(1))
     elif kind == 5:
         prompt ^= 1; m.set_text(toks[prompt])

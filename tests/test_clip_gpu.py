@@ -191,6 +191,48 @@ def test_latency_path_tiny_bf16_and_crop(gpu_lib):
         m.close()
 
 
+def test_interleaved_calls_on_one_handle_repeat_bit_for_bit(gpu_lib):
+    """A short version of scripts/soak_label.py: single frames (captured graphs, pinned staging), a few frames, batches on two streams,
+    the asynchronous pair with other calls while both slots are in flight, prompt changes, crops and feature calls, interleaved at random
+    on ONE handle; every repeat of a call must give the bits of its first occurrence (stale captures, workspace growth under live
+    graphs, slot reuse would show here)."""
+    from arp_amd import clip, synth
+    cfg = clip.ClipConfig(**MID)
+    m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=5), mode="f16", max_batch=256, n_streams=2)
+    toks = [synth.prompt_tokens(1, 5, ctx=cfg.ctx, vocab=cfg.vocab, seed=4), synth.prompt_tokens(1, 7, ctx=cfg.ctx, vocab=cfg.vocab, seed=8)]
+    base = synth.procgen_like_frames(32, seed=3)
+    big = np.ascontiguousarray(np.tile(base, (8, 1, 1, 1)))
+    ref, rng, prompt = {}, np.random.default_rng(1), 0
+
+    def check(key, val):
+        if key not in ref:
+            ref[key] = val.copy()
+        assert np.array_equal(ref[key], val), key
+
+    m.set_text(toks[prompt])
+    for _ in range(400):
+        kind = int(rng.integers(0, 7))
+        if kind == 0:
+            i = int(rng.integers(0, 32)); check((prompt, "one", i), m.label(base[i:i + 1]))
+        elif kind == 1:
+            n = int(rng.integers(2, 21)); check((prompt, "few", n), m.label(base[:n]))
+        elif kind == 2:
+            n = int(rng.choice([21, 64, 130])); check((prompt, "mid", n), m.label(big[:n]))
+        elif kind == 3:
+            check((prompt, "big"), m.label(big))
+        elif kind == 4:
+            m.label_submit(0, big); m.label_submit(1, big[:128])
+            if rng.integers(0, 2):
+                check((prompt, "one", 5), m.label(base[5:6])); check((prompt, "mid", 64), m.label(big[:64]))
+            check((prompt, "big"), m.label_collect(0)); check((prompt, "half"), m.label_collect(1))
+        elif kind == 5:
+            prompt ^= 1; m.set_text(toks[prompt])
+        else:
+            check((prompt, "crop", 1), m.label(base[:1], use_crop=True)); check(("enc", 3), m.encode_image(base[:3]))
+    assert len(ref) > 40
+    m.close()
+
+
 def test_two_stream_split_matches_single_stream(gpu_lib):
     """n_streams = 2 labels the two halves of a batch on two HIP streams; results are bit-identical to one stream."""
     from arp_amd import clip, synth
