@@ -438,7 +438,7 @@ int apply_update(arp_ft* c, float lr) {
     }
     const float gscale = 1.0f / ((float)std::max(c->world, 1) * c->grad_scale());
 #define ARP_FT_ADAMW(TM)                                                                                                                          \
-    hipLaunchKernelGGL((ft_adamw_kernel<TM>), dim3(cdiv(c->P, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(),        \
+    hipLaunchKernelGGL((ft_adamw_kernel<TM>), dim3(cdiv(c->P, 1024)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(),       \
                        c->mu.as<float>(), c->nu.as<float>(), gscale, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P, \
                        c->mirror.as<TM>(), skip)
     if (c->cfg.mode == ARP_MODE_BF16) ARP_FT_ADAMW(bf16_t);
