@@ -53,6 +53,13 @@ struct arp_ft {
     size_t P = 0;
     DevBuf params, grads, mu, nu;
     long long step = 0;
+    // AdamW inside the weight-gradient GEMMs (gemm.h, GEMM_SITE_ADAMW): in a single-process step the seven big dW products update their
+    // weights from the epilogue instead of storing 1.9 GB of gradient for a separate pass to read back (ARP_FT_FUSE_ADAM=0 disables;
+    // never with a communicator: the gradient has to be all-reduced first; never in arp_ft_backward: its caller reads the gradients)
+    bool fuse_adam = true, fuse_now = false;
+    float fuse_lr = 0.f, fuse_bc1 = 1.f, fuse_bc2 = 1.f;
+    std::vector<std::pair<size_t, size_t>> fused;  // flat [lo, hi) ranges already updated this step
+    std::vector<std::pair<size_t, size_t>> grads_gone;  // ... of the LAST step: their gradients were consumed inside the GEMMs, never stored
     bool shadows_stale = true;   // the host wrote parameters: rebuild the bf16 mirror from f32
     bool transposed_stale = true; // parameters moved (host write or AdamW): rebuild the transposed shadows
     int B = 0;
@@ -159,6 +166,19 @@ int ft_gemm(arp_ft* c, const char* site, const void* A, int lda, const void* W, 
     g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw;
     if (S == 1 && act == ACT_NONE && !resid && tiles >= 256) {  // big output, short contraction: the weight-gradient GEMMs
         g.bias = bias; g.resid = nullptr; g.out = out; g.ldr = ldo; g.ldo = ldo;
+        if constexpr (sizeof(T) == 2 && sizeof(OutT) == 4) {
+            const float* gb = c->grads.as<float>();
+            const float* o = reinterpret_cast<const float*>(out);
+            if (c->fuse_now && !bias && ldo == N && (N & 7) == 0 && o >= gb && o + (size_t)M * N <= gb + c->P) {
+                const size_t off = (size_t)(o - gb);
+                g.adam_p = c->params.as<float>() + off; g.adam_m = c->mu.as<float>() + off; g.adam_v = c->nu.as<float>() + off;
+                g.adam_mirror = c->mirror.p ? static_cast<void*>(c->mirror.as<T>() + off) : nullptr;
+                g.adam_gscale = 1.0f / c->grad_scale(); g.adam_lr = c->fuse_lr; g.adam_wd = c->cfg.weight_decay; g.adam_b1 = c->cfg.b1; g.adam_b2 = c->cfg.b2;
+                g.adam_eps = c->cfg.eps; g.adam_bc1 = c->fuse_bc1; g.adam_bc2 = c->fuse_bc2;
+                c->fused.emplace_back(off, off + (size_t)M * N);
+                return launch_gemm_nt<T, float, ACT_NONE, false, GEMM_SITE_ADAMW>(g, c->stream);
+            }
+        }
         return launch_gemm_auto<T, OutT, ACT_NONE, false, SITE_FT>(g, c->stream, 0);
     }
     ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
@@ -437,14 +457,33 @@ int apply_update(arp_ft* c, float lr) {
         skip_span("text_residual_weight", "text_residual_weight");
     }
     const float gscale = 1.0f / ((float)std::max(c->world, 1) * c->grad_scale());
+    // the segments of the flat parameter vector that the weight-gradient GEMMs have NOT already updated (all of it when nothing was fused)
+    std::sort(c->fused.begin(), c->fused.end());
+    std::vector<std::pair<size_t, size_t>> todo;
+    size_t at = 0;
+    for (const auto& f : c->fused) {
+        if (f.first > at) todo.emplace_back(at, f.first);
+        at = std::max(at, f.second);
+    }
+    if (at < c->P) todo.emplace_back(at, c->P);
+    c->grads_gone = c->fused;
+    c->fused.clear();
+    for (const auto& seg : todo) {
+        const size_t lo = seg.first, n = seg.second - seg.first;  // lo and n are multiples of 4 (tensor offsets and padded sizes are)
+        FtSkip sk = skip;  // the kernel indexes from its own base: shift the skip ranges
+        for (int r = 0; r < FT_SKIP_RANGES; ++r) {
+            sk.lo[r] = skip.lo[r] > lo ? skip.lo[r] - lo : 0;
+            sk.hi[r] = skip.hi[r] > lo ? skip.hi[r] - lo : 0;
+        }
 #define ARP_FT_ADAMW(TM)                                                                                                                          \
-    hipLaunchKernelGGL((ft_adamw_kernel<TM>), dim3(cdiv(c->P, 1024)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(),       \
-                       c->mu.as<float>(), c->nu.as<float>(), gscale, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P, \
-                       c->mirror.as<TM>(), skip)
-    if (c->cfg.mode == ARP_MODE_BF16) ARP_FT_ADAMW(bf16_t);
-    else if (c->cfg.mode == ARP_MODE_F16) ARP_FT_ADAMW(f16_t);
-    else ARP_FT_ADAMW(float);
+    hipLaunchKernelGGL((ft_adamw_kernel<TM>), dim3(cdiv(n, 1024)), dim3(256), 0, c->stream, c->params.as<float>() + lo, c->grads.as<float>() + lo, \
+                       c->mu.as<float>() + lo, c->nu.as<float>() + lo, gscale, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, n, \
+                       c->mirror.p ? c->mirror.as<TM>() + lo : nullptr, sk)
+        if (c->cfg.mode == ARP_MODE_BF16) ARP_FT_ADAMW(bf16_t);
+        else if (c->cfg.mode == ARP_MODE_F16) ARP_FT_ADAMW(f16_t);
+        else ARP_FT_ADAMW(float);
 #undef ARP_FT_ADAMW
+    }
     ARP_HIP_OK(hipGetLastError());
     c->step += 1;
     c->transposed_stale = true;
@@ -464,7 +503,21 @@ template <typename T> int step_impl(arp_ft* c, float lr, float* aux) {
         ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
         c->grads_summed = true;
     } else {
-        ARP_TRY(backward<T>(c));
+        // single process: the big weight-gradient GEMMs apply AdamW themselves (the step's lr and bias corrections are known here)
+        c->fused.clear();
+        if (c->fuse_adam && !comm && sizeof(T) == 2) {
+            const double t = (double)(c->step + 1);
+            c->fuse_lr = lr;
+            c->fuse_bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t));
+            c->fuse_bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
+            c->fuse_now = true;
+        }
+        const int rc = backward<T>(c);
+        c->fuse_now = false;
+        if (rc != 0) {
+            c->fused.clear();
+            return rc;
+        }
     }
     if (comm && !c->overlap_comm) {
         // the serial form: every rank ran its shard; ONE all-reduce(sum) of the flat f32 gradient (1.9 GB at full size) plus one of
@@ -514,6 +567,7 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
         ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
         if (const char* e = getenv("ARP_FT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
         if (const char* e = getenv("ARP_FT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
+        if (const char* e = getenv("ARP_FT_FUSE_ADAM")) c->fuse_adam = atoi(e) != 0;
         DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
         for (auto* b : fb) {
             ARP_TRY(b->ensure(c->P * 4));
@@ -591,6 +645,11 @@ static int ft_tensor_io(arp_ft* c, const char* name, int which, float* host, int
         ARP_HIP_OK(hipMemcpy(dev, host, pi.size * 4, hipMemcpyHostToDevice));
         if (which == 0) c->shadows_stale = true;
     } else {
+        if (which == 1)
+            for (const auto& r : c->grads_gone)
+                if (pi.off >= r.first && pi.off < r.second)
+                    return fail(std::string(name) + ": the last step applied this weight's gradient inside its GEMM and never stored it "
+                                "(arp_ft_backward materialises every gradient; ARP_FT_FUSE_ADAM=0 makes arp_ft_train_step do so too)");
         ARP_HIP_OK(hipMemcpy(host, dev, pi.size * 4, hipMemcpyDeviceToHost));
         // gradients carry the f16 mode's seed scale on the device and, after a data-parallel step, the SUM over ranks (the mean is
         // folded into AdamW): the getter returns what the optimizer consumed -- the un-scaled rank MEAN
@@ -691,6 +750,7 @@ int arp_ft_backward(arp_ft* c) {
     if (!c) return fail("null handle");
     if (c->B <= 0) return fail("no batch staged: call arp_ft_set_batch first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    c->grads_gone.clear();  // every gradient is stored by this call
     if (c->cfg.mode == ARP_MODE_BF16) { ARP_TRY(forward<bf16_t>(c)); ARP_TRY(backward<bf16_t>(c)); }
     else if (c->cfg.mode == ARP_MODE_F16) { ARP_TRY(forward<f16_t>(c)); ARP_TRY(backward<f16_t>(c)); }
     else { ARP_TRY(forward<float>(c)); ARP_TRY(backward<float>(c)); }

@@ -52,7 +52,14 @@ struct GemmArgs {
     int ldm = 0;
     float* colsum_part = nullptr;     // [ceil(M / 256)][N] f32: column sums of the ROUNDED masked output over each tile's rows
     int ovl = 0;              // gemm256, 16-bit output: a workgroup with another tile to do drains this tile's stores under that tile's first phases
+    // gemm_nt_kernel, SITE == GEMM_SITE_ADAMW only (the fine-tune head's weight-gradient GEMMs, arp_ft.hip): the product IS the gradient
+    // of the [M, N] weight at adam_p; instead of storing it, the epilogue applies torch.optim.AdamW to that weight in place (reads p, m,
+    // v, writes p, m, v and the operand-type mirror): 26 bytes per parameter instead of 4 (store dW) + 30 (a separate AdamW pass).
+    float *adam_p = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    void* adam_mirror = nullptr;
+    float adam_gscale = 1.f, adam_lr = 0.f, adam_wd = 0.f, adam_b1 = 0.f, adam_b2 = 0.f, adam_eps = 0.f, adam_bc1 = 1.f, adam_bc2 = 1.f;
 };
+constexpr int GEMM_SITE_ADAMW = 26;
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
 constexpr int GEMM_ROW_BYTES = 128;                                   // one LDS row = one K-tile of one row
@@ -315,8 +322,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                             const float4 r = rres[it];
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                         }
+                        if constexpr (SITE == GEMM_SITE_ADAMW && !RESID && sizeof(T) == 2) {
+                            // v = this weight's raw gradient: AdamW in place (ftops.h::ft_adamw_kernel's arithmetic, element for element)
+                            const size_t idx = (size_t)m * g.ldo + n;
+                            const float4 pv = *reinterpret_cast<const float4*>(g.adam_p + idx), mv = *reinterpret_cast<const float4*>(g.adam_m + idx),
+                                         vv = *reinterpret_cast<const float4*>(g.adam_v + idx);
+                            float gg[4] = {v.x, v.y, v.z, v.w}, pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w}, nn[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float gi = gg[e] * g.adam_gscale;
+                                if (!(fabsf(gi) < 3.0e38f)) gi = 0.f;
+                                mm[e] = g.adam_b1 * mm[e] + (1.f - g.adam_b1) * gi;
+                                nn[e] = g.adam_b2 * nn[e] + (1.f - g.adam_b2) * gi * gi;
+                                const float pd = pp[e] * (1.f - g.adam_lr * g.adam_wd);
+                                pp[e] = pd - (g.adam_lr / g.adam_bc1) * mm[e] / (sqrtf(nn[e]) / sqrtf(g.adam_bc2) + g.adam_eps);
+                            }
+                            *reinterpret_cast<float4*>(g.adam_m + idx) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                            *reinterpret_cast<float4*>(g.adam_v + idx) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+                            *reinterpret_cast<float4*>(g.adam_p + idx) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                            if (g.adam_mirror) store4(static_cast<T*>(g.adam_mirror) + idx, pp[0], pp[1], pp[2], pp[3]);
+                        } else {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
                         if (g.xb_out) store4(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, v.x, v.y, v.z, v.w);
+                        }
                     }
                     if (g.stats_out) {  // one 128-column segment per 32-lane half
                         const float s = half_wave_sum((v.x + v.y) + (v.z + v.w));

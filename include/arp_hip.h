@@ -255,7 +255,9 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out);
 int arp_ft_destroy(arp_ft* h);
 int arp_ft_num_params(arp_ft* h, int64_t* total, int32_t* n_tensors);
 int arp_ft_param_info(arp_ft* h, int i, char* name_buf, int name_len, int64_t* shape4, int32_t* ndim);
-/* which: 0 = parameter, 1 = gradient, 2 = AdamW exp_avg, 3 = AdamW exp_avg_sq */
+/* which: 0 = parameter, 1 = gradient, 2 = AdamW exp_avg, 3 = AdamW exp_avg_sq.  Gradients: arp_ft_backward stores every one; a single-process
+ * arp_ft_train_step applies the seven big weight gradients inside their GEMMs and never stores them -- reading one of those afterwards is an error
+ * (ARP_FT_FUSE_ADAM=0 restores the stored gradients and the separate AdamW pass). */
 int arp_ft_set_tensor(arp_ft* h, const char* name, int which, const float* data);
 int arp_ft_get_tensor(arp_ft* h, const char* name, int which, float* out);
 int arp_ft_set_step(arp_ft* h, int64_t step);

@@ -438,6 +438,47 @@ def test_f16_head_training_tracks_f32_over_many_steps(gpu_lib):
     assert rel[:10].max() < 1e-2 and rel.max() < 0.1, (float(rel[:10].max()), float(rel.max()))
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_adamw_fused_into_the_weight_gradient_gemms(gpu_lib, monkeypatch, mode):
+    """Single-process steps at the full geometry apply AdamW to the seven big weights from inside their dW GEMMs (gemm.h,
+    GEMM_SITE_ADAMW: 26 bytes per parameter instead of 34).  Against ARP_FT_FUSE_ADAM=0 -- the same steps with the gradients stored and
+    one AdamW pass -- parameters, moments and losses agree to f32 round-off of the gradient (two GEMM kernels, same operands), the
+    getter refuses the gradients that were never stored, and arp_ft_backward still materialises all of them."""
+    import ctypes as C
+    from arp_amd import _ffi, finetune as FT
+    cfg = FT.FinetuneConfig()
+    P = FT.synth_params(cfg, seed=0)
+    batch = FT.synth_batch(cfg, 64, seed=1)
+    probe = ("image_intermediate_linear.weight", "text_adapter.layers.3.weight", "image_adapter.layers.0.weight", "inverse_layer.layers.0.weight",
+             "inverse_layer.layers.3.bias", "image_residual_weight")
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("ARP_FT_FUSE_ADAM", fuse)
+        tr = FT.FinetuneTrainer(cfg, mode=mode)
+        tr.set_params(P)
+        tr.set_batch(*batch)
+        aux = [tr.train_step(1e-4) for _ in range(3)]
+        got = {}
+        for k in probe:
+            for which in (0, 2, 3):  # parameter, first moment, second moment
+                a = np.empty(tr.shapes[k], np.float32)
+                _ffi.check(_ffi.lib.arp_ft_get_tensor(tr._h, k.encode(), which, _ffi.as_ptr(a, C.c_float)))
+                got[(k, which)] = a
+        g = np.empty(tr.shapes[probe[0]], np.float32)
+        rc = _ffi.lib.arp_ft_get_tensor(tr._h, probe[0].encode(), 1, _ffi.as_ptr(g, C.c_float))
+        assert (rc != 0) == (fuse == "1")  # fused: that gradient never existed in memory
+        tr.backward()
+        _ffi.check(_ffi.lib.arp_ft_get_tensor(tr._h, probe[0].encode(), 1, _ffi.as_ptr(g, C.c_float)))
+        assert np.isfinite(g).all() and np.abs(g).max() > 0
+        out[fuse] = ([a["loss"] for a in aux], got)
+        tr.close()
+    la, lb = out["1"][0], out["0"][0]
+    assert max(abs(x - y) for x, y in zip(la, lb)) < 1e-5 * max(1.0, abs(lb[0])), (la, lb)
+    for key, a in out["1"][1].items():
+        b = out["0"][1][key]
+        assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-12) + 1e-12, key
+
+
 @pytest.mark.parametrize("mode", ["f32", "f16"])
 def test_finetune_bucketed_allreduce_equals_serial(gpu_lib, monkeypatch, mode):
     """seven gradient buckets leave in production order from inside the backward, on a communication
