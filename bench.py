@@ -454,9 +454,24 @@ def bench_finetune(a):
     tr.sync()
     prof = tr.profile_read()
     aux = tr.train_step(lr)
-    # dominant kernel: AdamW, HBM-bound -- reads p, g, m, v and writes p, m, v: 7 x 4 B per parameter
-    site = "ft.adamw"
-    nbytes = 28.0 * tr.n_params
+    # dominant kernel, HBM-bound either way.  Single-process f16 / bf16 steps apply AdamW from inside the seven weight-gradient GEMMs
+    # (arp_ft.hip, GEMM_SITE_ADAMW): the largest of them reads p, m, v and writes p, m, v + the 16-bit mirror of its weight = 26 B per
+    # parameter (the operands, <= 192 rows each, are noise).  With ARP_FT_FUSE_ADAM=0, f32 mode or a communicator: the separate AdamW
+    # pass -- p, g, m, v read, p, m, v written: 7 x 4 B per parameter.
+    dw_sites = {"ft.image_fc2_dW": "image_adapter.layers.3.weight", "ft.text_fc2_dW": "text_adapter.layers.3.weight",
+                "ft.image_fc1_dW": "image_adapter.layers.0.weight", "ft.text_fc1_dW": "text_adapter.layers.0.weight",
+                "ft.image_inter_dW": "image_intermediate_linear.weight", "ft.text_inter_dW": "text_intermediate_linear.weight",
+                "ft.inverse_fc1_dW": "inverse_layer.layers.0.weight"}
+    adamw_ms = prof["ft.adamw"]["ms"] / max(prof["ft.adamw"]["calls"], 1)
+    fused = [k for k in dw_sites if k in prof and prof[k]["ms"] / max(prof[k]["calls"], 1) > adamw_ms]
+    if fused and a.mode != "f32" and world == 1:
+        site = max(fused, key=lambda k: prof[k]["ms"])
+        nbytes = 26.0 * float(np.prod(tr.shapes[dw_sites[site]]))
+        kern = f"gemm_nt_kernel<GEMM_SITE_ADAMW> @ {site} (weight gradient + AdamW in one launch)"
+    else:
+        site = "ft.adamw"
+        nbytes = 28.0 * tr.n_params
+        kern = f"ft_adamw_kernel @ {site}"
     avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
     flops = FT.flops_per_sample(cfg) * a.finetune_batch
     if rank != 0:
@@ -474,7 +489,7 @@ def bench_finetune(a):
                                f"(BASELINE.json configs[4])", "parallelism": "single GPU (as the reference)" if world == 1 else f"dp{world}: one RCCL all-reduce(sum) of the "
                                f"flat f32 gradient ({tr.n_params * 4 / 1e9:.1f} GB) per step"},
         "roofline": {"bound": "hbm", "achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": f"ft_adamw_kernel @ {site}",
+                     "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": kern,
                      "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms},
         "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12},
         "cpu_baseline": cpu, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
