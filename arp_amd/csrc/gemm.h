@@ -324,6 +324,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                         }
                         if constexpr (SITE == GEMM_SITE_ADAMW && !RESID && sizeof(T) == 2) {
                             // v = this weight's raw gradient: AdamW in place (ftops.h::ft_adamw_kernel's arithmetic, element for element)
+                            // (requesting the pass's 24 p / m / v rows ahead of the staging, as the residual epilogue does with its 8, measured
+                            //  SLOWER: 4.4 instead of 5.5 TB/s -- 96 more live registers under the staging loop)
                             const size_t idx = (size_t)m * g.ldo + n;
                             const float4 pv = *reinterpret_cast<const float4*>(g.adam_p + idx), mv = *reinterpret_cast<const float4*>(g.adam_m + idx),
                                          vv = *reinterpret_cast<const float4*>(g.adam_v + idx);
