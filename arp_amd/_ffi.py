@@ -144,6 +144,7 @@ SIGNATURES = {
     "arp_ft_get_tensor": (_i, [_vp, C.c_char_p, _i, _fp]),
     "arp_ft_set_step": (_i, [_vp, C.c_int64]),
     "arp_ft_get_step": (_i, [_vp, _i64p]),
+    "arp_ft_dropped_gradients": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "arp_ft_set_batch": (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i32p, _i]),
     "arp_ft_forward": (_i, [_vp, _fp, _fp, _fp]),
     "arp_ft_encode": (_i, [_vp, _i, _fp, _fp, _i, _fp]),

@@ -296,11 +296,11 @@ static int load_tower(arp_clip* c, const std::string& prefix, int d, int layers,
             };
             ARP_TRY(get_staged(c, p + "attn.in_proj_weight", {3 * d, d}, &w)); ARP_TRY(get_staged(c, p + "attn.in_proj_bias", {3 * d}, &b));
             ARP_TRY(get_staged(c, p + "ln_1.weight", {d}, &lw)); ARP_TRY(get_staged(c, p + "ln_1.bias", {d}, &lb));
-            fold_layernorm(w->data.data(), lw->data.data(), lb->data.data(), b->data.data(), 3 * d, d, wf, cc, dd);
+            fold_layernorm(w->data.data(), lw->data.data(), lb->data.data(), b->data.data(), 3 * d, d, wf, cc, dd, emode == ARP_MODE_F16);
             ARP_TRY(put(wf, &L.w_in_f)); ARP_TRY(upload_f32(c, cc, &L.c_in)); ARP_TRY(upload_f32(c, dd, &L.d_in));
             ARP_TRY(get_staged(c, p + "mlp.c_fc.weight", {4 * d, d}, &w)); ARP_TRY(get_staged(c, p + "mlp.c_fc.bias", {4 * d}, &b));
             ARP_TRY(get_staged(c, p + "ln_2.weight", {d}, &lw)); ARP_TRY(get_staged(c, p + "ln_2.bias", {d}, &lb));
-            fold_layernorm(w->data.data(), lw->data.data(), lb->data.data(), b->data.data(), 4 * d, d, wf, cc, dd);
+            fold_layernorm(w->data.data(), lw->data.data(), lb->data.data(), b->data.data(), 4 * d, d, wf, cc, dd, emode == ARP_MODE_F16);
             ARP_TRY(put(wf, &L.w_fc_f)); ARP_TRY(upload_f32(c, cc, &L.c_fc)); ARP_TRY(upload_f32(c, dd, &L.d_fc));
         }
     }
@@ -869,7 +869,7 @@ int arp_clip_finalize_weights(arp_clip* c) {
     ARP_TRY(get_staged(c, "visual.ln_post.weight", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpost_w));
     ARP_TRY(get_staged(c, "visual.ln_post.bias", {D}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnpost_b));
     ARP_TRY(get_staged(c, "visual.proj", {D, E}, &t)); ARP_TRY(upload_mat(c, t->data.data(), D, E, true, &c->proj_t));
-    ARP_TRY(load_tower(c, "visual.transformer.", D, k.layers, k.heads, c->vis, c->ln_fold && k.mode == ARP_MODE_BF16 && (D & 127) == 0, -1, c->ntok()));
+    ARP_TRY(load_tower(c, "visual.transformer.", D, k.layers, k.heads, c->vis, c->ln_fold && (k.mode == ARP_MODE_BF16 || k.mode == ARP_MODE_F16) && (D & 127) == 0, -1, c->ntok()));
     ARP_TRY(get_staged(c, "token_embedding.weight", {k.vocab, Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->tok_emb));
     ARP_TRY(get_staged(c, "positional_embedding", {k.ctx, Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->tpos));
     ARP_TRY(get_staged(c, "ln_final.weight", {Tw}, &t)); ARP_TRY(upload_f32(c, t->data, &c->lnf_w));

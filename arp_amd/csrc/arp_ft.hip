@@ -65,6 +65,7 @@ struct arp_ft {
     int B = 0;
     // operand-type weight shadows: forward layout [out, in] (aliases the f32 parameters in f32 mode) and, where the
     // backward needs dX, the transposed layout [in, out]
+    DevBuf dropped;  // one counter: non-finite gradient elements AdamW treated as missing (f16 mode only), cumulative
     DevBuf mirror;  // bf16 mode: bf16 copy of the flat parameter vector (same offsets) = every forward-layout operand
     DevBuf sW1t[2], sW2t[2], sV1t;
     // inputs
@@ -149,6 +150,31 @@ int ft_transpose(arp_ft* c, const TI* in, int ldi, const TM* mask, TO* outN, int
     return 0;
 }
 
+// Parameters that receive no gradient in this configuration (torch leaves a parameter whose .grad is None alone -- no decay, no moment
+// update): ranges [lo, hi) of the flat parameter vector, padded offsets.  Used by apply_update AND by the fused AdamW epilogue's gate.
+static FtSkip ft_skip_ranges(arp_ft* c) {
+    FtSkip skip;
+    for (int r = 0; r < FT_SKIP_RANGES; ++r) skip.lo[r] = skip.hi[r] = 0;
+    int nskip = 0;
+    auto skip_span = [&](const char* first, const char* last) {  // [first, end of last), padded offsets
+        const FtParam& a = c->infos[c->index.at(first)];
+        const FtParam& b = c->infos[c->index.at(last)];
+        skip.lo[nskip] = a.off;
+        skip.hi[nskip] = b.off + ((b.size + 3) & ~(size_t)3);
+        ++nskip;
+    };
+    if (!c->cfg.use_id) {
+        skip_span("inverse_layer.layers.0.weight", "inverse_layer.layers.3.bias");
+        skip_span("lambda_id", "lambda_id");
+    }
+    if (c->cfg.goal_conditioned) {
+        skip_span("text_intermediate_linear.weight", "text_intermediate_linear.weight");
+        skip_span("text_adapter.layers.0.weight", "text_adapter.layers.3.bias");
+        skip_span("text_residual_weight", "text_residual_weight");
+    }
+    return skip;
+}
+
 // out[M, N] (ldo) = act(A[M, K] . W[N, K]^T + bias) (+ resid, same view as out).  Split over K whenever the 128x128
 // grid alone would leave most of the chip idle (the row counts of this step are <= 192).
 template <typename T, typename OutT>
@@ -169,12 +195,19 @@ int ft_gemm(arp_ft* c, const char* site, const void* A, int lda, const void* W, 
         if constexpr (sizeof(T) == 2 && sizeof(OutT) == 4) {
             const float* gb = c->grads.as<float>();
             const float* o = reinterpret_cast<const float*>(out);
-            if (c->fuse_now && !bias && ldo == N && (N & 7) == 0 && o >= gb && o + (size_t)M * N <= gb + c->P) {
+            bool skipped = false;  // a weight that gets no gradient in this configuration (use_id = 0: the inverse model) must not be decayed:
+            if (c->fuse_now && o >= gb) {  // ADVICE r3 -- the fused epilogue would apply p *= 1 - lr wd with g = 0 where AdamW leaves the tensor alone
+                const FtSkip sk = ft_skip_ranges(c);
+                const size_t lo = (size_t)(o - gb), hi = lo + (size_t)M * N;
+                for (int r = 0; r < FT_SKIP_RANGES; ++r) skipped |= sk.lo[r] < hi && lo < sk.hi[r];
+            }
+            if (c->fuse_now && !skipped && !bias && ldo == N && (N & 7) == 0 && o >= gb && o + (size_t)M * N <= gb + c->P) {
                 const size_t off = (size_t)(o - gb);
                 g.adam_p = c->params.as<float>() + off; g.adam_m = c->mu.as<float>() + off; g.adam_v = c->nu.as<float>() + off;
                 g.adam_mirror = c->mirror.p ? static_cast<void*>(c->mirror.as<T>() + off) : nullptr;
                 g.adam_gscale = 1.0f / c->grad_scale(); g.adam_lr = c->fuse_lr; g.adam_wd = c->cfg.weight_decay; g.adam_b1 = c->cfg.b1; g.adam_b2 = c->cfg.b2;
                 g.adam_eps = c->cfg.eps; g.adam_bc1 = c->fuse_bc1; g.adam_bc2 = c->fuse_bc2;
+                g.adam_mask = c->cfg.mode == ARP_MODE_F16; g.adam_dropped = c->dropped.as<unsigned int>();
                 c->fused.emplace_back(off, off + (size_t)M * N);
                 return launch_gemm_nt<T, float, ACT_NONE, false, GEMM_SITE_ADAMW>(g, c->stream);
             }
@@ -437,25 +470,7 @@ int apply_update(arp_ft* c, float lr) {
     const double t = (double)(c->step + 1);
     const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
     // parameters that received no gradient this step are left alone, as torch does for .grad is None
-    FtSkip skip;
-    for (int r = 0; r < FT_SKIP_RANGES; ++r) skip.lo[r] = skip.hi[r] = 0;
-    int nskip = 0;
-    auto skip_span = [&](const char* first, const char* last) {  // [first, end of last), padded offsets
-        const FtParam& a = c->infos[c->index.at(first)];
-        const FtParam& b = c->infos[c->index.at(last)];
-        skip.lo[nskip] = a.off;
-        skip.hi[nskip] = b.off + ((b.size + 3) & ~(size_t)3);
-        ++nskip;
-    };
-    if (!c->cfg.use_id) {
-        skip_span("inverse_layer.layers.0.weight", "inverse_layer.layers.3.bias");
-        skip_span("lambda_id", "lambda_id");
-    }
-    if (c->cfg.goal_conditioned) {
-        skip_span("text_intermediate_linear.weight", "text_intermediate_linear.weight");
-        skip_span("text_adapter.layers.0.weight", "text_adapter.layers.3.bias");
-        skip_span("text_residual_weight", "text_residual_weight");
-    }
+    const FtSkip skip = ft_skip_ranges(c);
     const float gscale = 1.0f / ((float)std::max(c->world, 1) * c->grad_scale());
     // the segments of the flat parameter vector that the weight-gradient GEMMs have NOT already updated (all of it when nothing was fused)
     std::sort(c->fused.begin(), c->fused.end());
@@ -478,7 +493,7 @@ int apply_update(arp_ft* c, float lr) {
 #define ARP_FT_ADAMW(TM)                                                                                                                          \
     hipLaunchKernelGGL((ft_adamw_kernel<TM>), dim3(cdiv(n, 1024)), dim3(256), 0, c->stream, c->params.as<float>() + lo, c->grads.as<float>() + lo, \
                        c->mu.as<float>() + lo, c->nu.as<float>() + lo, gscale, lr, c->cfg.weight_decay, c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, n, \
-                       c->mirror.p ? c->mirror.as<TM>() + lo : nullptr, sk)
+                       c->mirror.p ? c->mirror.as<TM>() + lo : nullptr, sk, c->cfg.mode == ARP_MODE_F16 ? 1 : 0, c->dropped.as<unsigned int>())
         if (c->cfg.mode == ARP_MODE_BF16) ARP_FT_ADAMW(bf16_t);
         else if (c->cfg.mode == ARP_MODE_F16) ARP_FT_ADAMW(f16_t);
         else ARP_FT_ADAMW(float);
@@ -574,6 +589,8 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
             ARP_HIP_OK(hipMemset(b->p, 0, c->P * 4));
         }
         const size_t e = c->esz(), Fd = c->F(), Hd = c->Hd(), Hi = k.hidden;
+        ARP_TRY(c->dropped.ensure(16));
+        ARP_HIP_OK(hipMemset(c->dropped.p, 0, 16));
         if (k.mode != ARP_MODE_F32) ARP_TRY(c->mirror.ensure(c->P * e));
         for (int w = 0; w < 2; ++w) { ARP_TRY(c->sW1t[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2t[w].ensure(Hd * Fd * e)); }
         ARP_TRY(c->sV1t.ensure(Hi * 4 * Fd * e));
@@ -664,6 +681,15 @@ int arp_ft_get_tensor(arp_ft* c, const char* name, int which, float* out) { retu
 int arp_ft_set_step(arp_ft* c, int64_t step) {
     if (!c || step < 0) return fail("bad argument");
     c->step = step;
+    return 0;
+}
+int arp_ft_dropped_gradients(arp_ft* c, uint64_t* count) {
+    if (!c || !count) return fail("bad argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    unsigned int v = 0;
+    ARP_HIP_OK(hipMemcpy(&v, c->dropped.p, 4, hipMemcpyDeviceToHost));
+    *count = v;
     return 0;
 }
 int arp_ft_get_step(arp_ft* c, int64_t* step) {

@@ -205,7 +205,8 @@ struct FtSkip { size_t lo[FT_SKIP_RANGES], hi[FT_SKIP_RANGES]; };  // flat range
 template <typename TM>
 static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
                                                               float* __restrict__ nu, float gscale, float lr, float wd, float b1, float b2,
-                                                              float eps, float bc1, float bc2, size_t n, TM* __restrict__ mirror, FtSkip skip) {
+                                                              float eps, float bc1, float bc2, size_t n, TM* __restrict__ mirror, FtSkip skip,
+                                                              int mask_nonfinite, unsigned int* __restrict__ dropped) {
     // one float4 per thread (every tensor's offset and padded size are multiples of 4, so are the skip ranges): 14.3 GB per step at
     // full size is the fine-tune step's largest item
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -223,8 +224,13 @@ static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict_
     for (int e = 0; e < 4; ++e) {
         float gi = gg[e] * gscale;
         // f16 mode seeds every gradient x 1024 (arp_ft.hip): an entry that overflowed binary16 on the way arrives as inf / NaN and would
-        // poison this parameter and both moments for good -- it is treated as a missing (zero) gradient for this step
-        if (!(fabsf(gi) < 3.0e38f)) gi = 0.f;
+        // poison this parameter and both moments for good -- it is treated as a missing (zero) gradient for this step AND COUNTED
+        // (arp_ft_dropped_gradients).  In the other modes a non-finite gradient is a diverged step or a bug and stays visible as NaNs,
+        // as in torch.
+        if (mask_nonfinite && !(fabsf(gi) < 3.0e38f)) {
+            gi = 0.f;
+            atomicAdd(dropped, 1u);
+        }
         mm[e] = b1 * mm[e] + (1.f - b1) * gi;
         nn[e] = b2 * nn[e] + (1.f - b2) * gi * gi;
         const float pd = pp[e] * (1.f - lr * wd);

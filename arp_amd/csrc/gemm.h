@@ -57,6 +57,8 @@ struct GemmArgs {
     // v, writes p, m, v and the operand-type mirror): 26 bytes per parameter instead of 4 (store dW) + 30 (a separate AdamW pass).
     float *adam_p = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     void* adam_mirror = nullptr;
+    int adam_mask = 0;                     // f16 mode: a non-finite gradient entry counts as missing (and is counted into adam_dropped)
+    unsigned int* adam_dropped = nullptr;
     float adam_gscale = 1.f, adam_lr = 0.f, adam_wd = 0.f, adam_b1 = 0.f, adam_b2 = 0.f, adam_eps = 0.f, adam_bc1 = 1.f, adam_bc2 = 1.f;
 };
 constexpr int GEMM_SITE_ADAMW = 26;
@@ -333,7 +335,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float gi = gg[e] * g.adam_gscale;
-                                if (!(fabsf(gi) < 3.0e38f)) gi = 0.f;
+                                if (g.adam_mask && !(fabsf(gi) < 3.0e38f)) {
+                                    gi = 0.f;
+                                    atomicAdd(g.adam_dropped, 1u);
+                                }
                                 mm[e] = g.adam_b1 * mm[e] + (1.f - g.adam_b1) * gi;
                                 nn[e] = g.adam_b2 * nn[e] + (1.f - g.adam_b2) * gi * gi;
                                 const float pd = pp[e] * (1.f - g.adam_lr * g.adam_wd);

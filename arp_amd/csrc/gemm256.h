@@ -78,7 +78,7 @@ __device__ __forceinline__ void wait_units(int allow) {
     else wait_vmcnt<0>();
 }
 
-#if defined(ARP_G2_STAMPS) || defined(ARP_G2_FINE)
+#if defined(ARP_G2_STAMPS) || defined(ARP_G2_FINE) || defined(ARP_G2_CLOCK)
 __device__ long long* arp_g2_stamps = nullptr;  // scripts/gemm256_bench.hip: per-tile, per-wave phase time stamps
 #endif
 // Register cap (round 3 experiment, OFF): at 2 x 240 registers a SIMD has 32 left, exactly one wave of the row-wise kernels
@@ -91,16 +91,45 @@ __device__ long long* arp_g2_stamps = nullptr;  // scripts/gemm256_bench.hip: pe
 #ifndef ARP_G2_MAX_VGPR
 #define ARP_G2_MAX_VGPR 128
 #endif
-template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+// MFMA shape of the 16-bit K loop (round 4 A/B, VERDICT r3 next #2a).  M32 = v_mfma_f32_32x32x16: the wave's 128x64 block is 2x2
+// quadrants of 2x1 fragments of 32x32; a K-tile is four 16-deep steps; same LDS bytes per K-tile (a wave reads its 128 + 64 rows
+// once either way) but 32 MFMAs of 32 cycles per K-tile instead of 64 of 16, each holding the SIMD's vector issue port 8 cycles:
+// 256 instead of 512 port cycles per K-tile for the partner wave's reads and LDS-DMA to share.  The 16-byte chunk swizzle key is
+// (row >> 1) & 7 there (with row & 7 the 32-row fragment read is two-way conflicted: rows r and r + 8 of a lane group meet).
+// MEASURED AND REJECTED (profiles/r4_mfma32_ab.txt; both shapes in one process, interleaved rounds, random operands; results bit-identical
+// to the 16x16x32 loop): 12-26 % SLOWER by wall on every shape (qkv 187 -> 224 us, c_fc 256 -> 303, c_proj 263 -> 302, 4096^3 1296 -> 1031 TF).
+// Two separate effects.  (i) With fragment reads and LDS-DMA ablated (MFMAs + barriers only) the 32x32 K-tile takes FEWER cycles (1 992 -
+// 2 030 against 2 115) but the launch is 7-9 % longer: the chip holds a lower clock on this shape (MI355X_MICROARCH, DVFS item 7).  (ii) In
+// the full loop the phase-B load segment (8 reads + 6 LDS-DMA) takes 740-780 cycles beside the partner's 32x32 MFMAs where it takes 400
+// beside 16x16 ones -- with the reads ablated and the DMA kept the gap is still there (4096^3 137 vs 99 us), with the DMA ablated it closes
+// (103 vs 98): an LDS-DMA issue costs ~2.4x as much next to this shape; s_setprio off and the k-steps of a fragment back to back change nothing.
+#ifndef ARP_G2_MFMA32
+#define ARP_G2_MFMA32 0
+#endif
+#ifndef ARP_G2_ABL  // harness ablations: bit 0 = no fragment reads after the first K-tile, bit 1 = no LDS-DMA after the prologue (wrong results, timing only)
+#define ARP_G2_ABL 0
+#endif
+typedef __attribute__((ext_vector_type(16))) float f32x16_v;
+template <typename T> __device__ __forceinline__ f32x16_v mfma32(u32x4_v a, u32x4_v b, f32x16_v c) {
+    if constexpr (__is_same(T, f16_t))
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a), __builtin_bit_cast(f16x8_v, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
+}
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0)>
 __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G2_MAX_VGPR))) void gemm256_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPB = 128 / (int)sizeof(T);
     constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr bool W32 = M32 && sizeof(T) == 2;  // the 32x32x16 loop exists for the 16-bit operand types only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
+#ifdef ARP_G2_CLOCK  // diagnostic build only: the clock this workgroup ran at = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH, DVFS item 6)
+    const long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- persistent tile loop ---------------------------------------------------------------------------
     // The launcher starts at most one workgroup per CU; each walks tiles blockIdx.x, + gridDim.x, ...  Between
@@ -140,7 +169,6 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
 
     // ---- LDS-DMA plan: unit u in {0:A q-row 0, 1:W q-col 0, 2:W q-col 1, 3:A q-row 1}, 2 instr / thread
     const int srow = lane >> 3;
-    const int schunk = (lane & 7) ^ srow;
     const T* src[4][2];
     int dst[4][2];  // byte offset inside a K-tile buffer (wave-uniform)
     auto setup_src = [&]() {
@@ -153,6 +181,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             const int q = (u == 0 || u == 1) ? 0 : 1;
             const int row0 = isA ? ((lr0 >> 6) * 128 + q * 64 + (lr0 & 63)) : ((lr0 >> 5) * 64 + q * 32 + (lr0 & 31));
             const int row = row0 + srow;
+            const int schunk = (lane & 7) ^ (W32 ? ((row >> 1) & 7) : srow);
             dst[u][i] = (isA ? 0 : G2_B_REGION) + row0 * 128;
             if (isA) {
                 int am = m0 + row;
@@ -170,6 +199,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     // issue unit index gi (tile gi>>2, unit U) if it exists; U is a compile-time constant per phase
     auto issue = [&](int gi, auto U) {
         constexpr int u = decltype(U)::value;
+        if ((ARP_G2_ABL & 2) && gi >= 12) return;
         if (gi < G) {
             const int tt = gi >> 2;
             char* base = smem + (tt & 1) * G2_BUF_BYTES;
@@ -187,37 +217,72 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     using I1 = std::integral_constant<int, 1>;
 
     // ---- fragment addressing ----------------------------------------------------------------------
-    const int fr = lane & 15, fg = lane >> 4;
+    const int fr = W32 ? (lane & 31) : (lane & 15), fg = W32 ? (lane >> 5) : (lane >> 4);
     const int a_base = (wr * 128 + fr) * 128;
     const int b_base = G2_B_REGION + (wc * 64 + fr) * 128;
-    const int coff0 = ((0 * 4 + fg) ^ (fr & 7)) << 4;
-    const int coff1 = ((1 * 4 + fg) ^ (fr & 7)) << 4;
+    const int skey = W32 ? ((lane >> 1) & 7) : (fr & 7);
+    // 16x16x32: k-step ks reads chunk ks * 4 + fg; 32x32x16: step s reads chunk 2 s + fg
+    const int coff0 = ((0 * 4 + fg) ^ skey) << 4;
+    const int coff1 = ((W32 ? 2 + fg : 1 * 4 + fg) ^ skey) << 4;
+    const int coff2 = ((4 + fg) ^ skey) << 4;  // W32 only
+    const int coff3 = ((6 + fg) ^ skey) << 4;
 
-    f32x4_v acc[2][2][2][4];  // [mq][nq][ni][mi]
-    u32x4_v areg[4][2];  // [mi][ks]   A sub-tile of the current quadrant-row
-    u32x4_v breg[2][2][2];  // [nq][ni][ks]  both W sub-tiles of the K-tile stay in registers: quadrant (1,0) reuses
+    // accumulators: 16x16 fragments [mq][nq][ni][mi] (4 registers each) or 32x32 fragments [mq][nq][mi] (16 each); the epilogue
+    // reads both through acc4(mq, nq, ni, mi) = four consecutive columns of one row:
+    //   row = wr*128 + mq*64 + mi*RSTEP + rl,  col = wc*64 + nq*32 + ni*CSTEP + cl
+    constexpr int NI = W32 ? 4 : 2, MI = W32 ? 2 : 4, RSTEP = 64 / MI, CSTEP = 32 / NI;
+    const int rl = fr, cl = fg * 4;
+    f32x4_v acc[W32 ? 1 : 2][2][2][4];  // [mq][nq][ni][mi]
+    f32x16_v acc32[W32 ? 2 : 1][2][2];  // [mq][nq][mi]
+    auto acc4 = [&](int mq, int nq, int ni, int mi) -> f32x4_v {
+        if constexpr (W32) {
+            const f32x16_v& a = acc32[mq][nq][mi];
+            return f32x4_v{a[4 * ni], a[4 * ni + 1], a[4 * ni + 2], a[4 * ni + 3]};
+        } else {
+            return acc[mq][nq][ni][mi];
+        }
+    };
+    u32x4_v areg[W32 ? 2 : 4][W32 ? 4 : 2];  // [mi][ks]   A sub-tile of the current quadrant-row
+    u32x4_v breg[2][W32 ? 1 : 2][W32 ? 4 : 2];  // [nq][ni][ks]  both W sub-tiles of the K-tile stay in registers: quadrant (1,0) reuses
                             // sub-tile 0 without re-reading LDS, so every LDS region is last read >= 3 phases before
                             // the LDS-DMA that overwrites it is issued (WAR margin for the staggered wave groups)
 
+    int abl_kt = 0;
     auto load_a = [&](const char* buf, int mq) {
+        if ((ARP_G2_ABL & 1) && abl_kt > 0) return;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const char* p = buf + a_base + (mq * 64 + mi * 16) * 128;
+        for (int mi = 0; mi < MI; ++mi) {
+            const char* p = buf + a_base + (mq * 64 + mi * RSTEP) * 128;
             areg[mi][0] = *reinterpret_cast<const u32x4_v*>(p + coff0);
             areg[mi][1] = *reinterpret_cast<const u32x4_v*>(p + coff1);
+            if constexpr (W32) {
+                areg[mi][2] = *reinterpret_cast<const u32x4_v*>(p + coff2);
+                areg[mi][3] = *reinterpret_cast<const u32x4_v*>(p + coff3);
+            }
         }
     };
     auto load_b = [&](const char* buf, auto NQ) {
         constexpr int nq = decltype(NQ)::value;
+        if ((ARP_G2_ABL & 1) && abl_kt > 0) return;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < (W32 ? 1 : 2); ++ni) {
             const char* p = buf + b_base + (nq * 32 + ni * 16) * 128;
             breg[nq][ni][0] = *reinterpret_cast<const u32x4_v*>(p + coff0);
             breg[nq][ni][1] = *reinterpret_cast<const u32x4_v*>(p + coff1);
+            if constexpr (W32) {
+                breg[nq][ni][2] = *reinterpret_cast<const u32x4_v*>(p + coff2);
+                breg[nq][ni][3] = *reinterpret_cast<const u32x4_v*>(p + coff3);
+            }
         }
     };
     auto mfma_quadrant = [&](auto MQ, auto NQ) {
         constexpr int mq = decltype(MQ)::value, nq = decltype(NQ)::value;
+        if constexpr (W32) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc32[mq][nq][mi] = mfma32<T>(breg[nq][0][ks], areg[mi][ks], acc32[mq][nq][mi]);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -237,6 +302,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                                 __uint_as_float(breg[nq][ni][ks][j]), __uint_as_float(areg[mi][ks][j]), acc[mq][nq][ni][mi], 0, 0, 0);
                     }
                 }
+        }
     };
     // one phase = [reads + LDS-DMA issue + counted wait] barrier [MFMAs] barrier
     auto phase_tail = [&](int ph) {
@@ -322,6 +388,16 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + n),
                                          (__attribute__((address_space(3))) void*)bias_s, 16, 0, 0);
     }
+    if constexpr (W32) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) acc32[a][b][c][d] = 0.f;
+    } else {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -330,6 +406,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    }
 #ifdef ARP_G2_FINE  // scripts/gemm256_bench.hip -DARP_G2_FINE: s_memtime around every segment of the middle K-tile
     long long f_[12];
     for (int i = 0; i < 12; ++i) f_[i] = 0;
@@ -357,6 +434,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     for (int kt = 0; kt < nk; ++kt) {
         const char* buf = smem + (kt & 1) * G2_BUF_BYTES;
         const int p = 2 * kt;
+        abl_kt = kt;
         // phase A: quadrants (0,0) and (0,1)
         ARP_FST(0);
         load_a(buf, 0);
@@ -449,9 +527,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < NI; ++c)
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) sacc += acc[a][b][c][d][0] + acc[a][b][c][d][1] + acc[a][b][c][d][2] + acc[a][b][c][d][3];
+                    for (int d = 0; d < MI; ++d) {
+                        const f32x4_v t = acc4(a, b, c, d);
+                        sacc += t[0] + t[1] + t[2] + t[3];
+                    }
         if (sacc == 12345.678f) Elem<OutT>::st(out, sacc);
         return;
     }
@@ -466,26 +547,26 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         // Reading them per fragment inside the loop -- behind a per-fragment `n < N` branch -- put 32 dependent LDS round trips
         // and 64 exec-mask branches on the staging path: 6.0 k of a 45.8 k-cycle qkv tile (in-kernel s_memtime stamps,
         // scripts/gemm256_bench.hip -DARP_G2_STAMPS).  Columns past N hold the clamped load's finite values and are never stored.
-        float4 bq[2][2];
+        float4 bq[2][NI];
 #pragma unroll
         for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                bq[nq][ni] = g.bias ? *reinterpret_cast<const float4*>(bias_s + wc * 64 + nq * 32 + ni * 16 + fg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ni = 0; ni < NI; ++ni)
+                bq[nq][ni] = g.bias ? *reinterpret_cast<const float4*>(bias_s + wc * 64 + nq * 32 + ni * CSTEP + cl) : make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (sizeof(OutT) == 1) {
             // fp8 output (the MLP's hidden activation): out_scale * act(alpha * acc + bias), 4 values per dword, 256-B rows out
             constexpr int RS8 = 256 + 16;
 #pragma unroll
             for (int mq = 0; mq < 2; ++mq)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    const int row = wr * 128 + mq * 64 + mi * 16 + fr;
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int row = wr * 128 + mq * 64 + mi * RSTEP + rl;
 #pragma unroll
                     for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
-                            const f32x4_v a4 = acc[mq][nq][ni][mi];
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const int col = wc * 64 + nq * 32 + ni * CSTEP + cl;
+                            const f32x4_v a4 = acc4(mq, nq, ni, mi);
                             const float4 b = bq[nq][ni];
                             float v[4] = {a4[0] * g.alpha + b.x, a4[1] * g.alpha + b.y, a4[2] * g.alpha + b.z, a4[3] * g.alpha + b.w};
 #pragma unroll
@@ -507,16 +588,16 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
 #pragma unroll
                 for (int mq = 0; mq < 2; ++mq)
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        const int row = wr * 128 + mq * 64 + mi * 16 + fr;
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int row = wr * 128 + mq * 64 + mi * RSTEP + rl;
                         float mu = 0.f, rs = 1.f;
                         if constexpr (LN.value) ln_row_stats(g, min(m0 + row, g.M - 1), mu, rs);  // folded LayerNorm (gemm.h)
 #pragma unroll
                         for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
-                            for (int ni = 0; ni < 2; ++ni) {
-                                const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
-                                const f32x4_v a4 = acc[mq][nq][ni][mi];
+                            for (int ni = 0; ni < NI; ++ni) {
+                                const int col = wc * 64 + nq * 32 + ni * CSTEP + cl;
+                                const f32x4_v a4 = acc4(mq, nq, ni, mi);
                                 float v[4] = {a4[0], a4[1], a4[2], a4[3]};
                                 if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
                                 if constexpr (LN.value) {
@@ -653,14 +734,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                     }
                 }
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            const int lrow = wr * 64 + mi * 16 + fr;
-                            const int col = wc * 64 + nq * 32 + ni * 16 + fg * 4;
-                            const f32x4_v a4 = acc[p][nq][ni][mi];
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const int lrow = wr * 64 + mi * RSTEP + rl;
+                            const int col = wc * 64 + nq * 32 + ni * CSTEP + cl;
+                            const f32x4_v a4 = acc4(p, nq, ni, mi);
                             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
                             if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
                             const float4 b = bq[nq][ni];
@@ -702,16 +783,16 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
 #pragma unroll
     for (int mq = 0; mq < 2; ++mq)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wr * 128 + mq * 64 + mi * 16 + fr;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wr * 128 + mq * 64 + mi * RSTEP + rl;
             if (m >= g.M) continue;
 #pragma unroll
             for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int n = n0 + wc * 64 + nq * 32 + ni * 16 + fg * 4;
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int n = n0 + wc * 64 + nq * 32 + ni * CSTEP + cl;
                     if (n >= g.N) continue;
-                    const f32x4_v a4 = acc[mq][nq][ni][mi];
+                    const f32x4_v a4 = acc4(mq, nq, ni, mi);
                     float v[4] = {a4[0], a4[1], a4[2], a4[3]};
                     if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
                     if (vec_ok) {
@@ -777,9 +858,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         pre_issued = true;
     }
     }  // tile loop
+#ifdef ARP_G2_CLOCK
+    if (arp_g2_stamps && threadIdx.x == 0) {
+        arp_g2_stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - clk_c0;
+        arp_g2_stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+#endif
 }
 
-template <typename T, typename OutT, int ACT, bool RESID, int SITE>
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0)>
 inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     constexpr int EPB = 128 / (int)sizeof(T);
     if (g.M <= 0) return 0;
@@ -788,7 +875,7 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
                     " K=" + std::to_string(g.K));
     if (g.mask && (!G2_MASK_SITE(SITE) || sizeof(OutT) != 2 || ((g.N | g.ldo | g.ldm | g.ldr) & 7) || (g.flags & 3)))
         return fail("gemm256_nt: the masked epilogue needs a 16-bit output and N, ldo, ldm multiples of 8");
-    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE>;
+    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE, M32>;
     static bool attr_set = false;
     if (!attr_set) {
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

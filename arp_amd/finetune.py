@@ -137,6 +137,14 @@ class FinetuneTrainer:
     def step(self, v):
         check(lib.arp_ft_set_step(self._h, int(v)))
 
+    @property
+    def dropped_gradients(self):
+        """f16 mode: gradient elements that reached AdamW as inf / NaN (binary16 overflow in the scaled backward) and were treated as missing,
+        cumulative.  Always 0 in the other modes, where nothing is masked (a non-finite gradient shows up as NaN parameters, as in torch)."""
+        n = C.c_uint64()
+        check(lib.arp_ft_dropped_gradients(self._h, C.byref(n)))
+        return n.value
+
     # -- compute --------------------------------------------------------------------------------------
     def set_batch(self, img_inter, img_final, txt_inter, txt_final, r, action):
         """img_inter [3,B,layers*width_v], img_final [3,B,embed] (image0..2), txt_inter [B,layers*width_t], txt_final [B,embed],

@@ -220,15 +220,19 @@ class RowSink:
         self.q = queue.Queue()
         self.err = None
         self.rows = 0
+        self.created, self.grown = [], {}  # what abort() has to undo: datasets this pass created / grew (key -> former row count)
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
     def _dataset(self, key):
         ds = self.store.get(key) if hasattr(self.store, "get") else None
         if ds is None:
-            return self.store.create_dataset(key, shape=(self.total_rows, self.num_frames), dtype=self.dtype, compression="gzip",
-                                             chunks=(1, self.num_frames), maxshape=(None, self.num_frames))
+            ds = self.store.create_dataset(key, shape=(self.total_rows, self.num_frames), dtype=self.dtype, compression="gzip",
+                                           chunks=(1, self.num_frames), maxshape=(None, self.num_frames))
+            self.created.append(key)
+            return ds
         if ds.shape[0] < self.total_rows:
+            self.grown[key] = ds.shape[0]
             ds.resize(self.total_rows, axis=0)
         return ds
 
@@ -256,7 +260,29 @@ class RowSink:
         self.q.put(None)
         self.t.join()
         if self.err is not None:
+            self.abort()
             raise self.err
+
+    def abort(self):
+        """The pass failed part-way (a GPU error, a reader exception, a failed write): the reference writes only after everything is
+        labelled (label_reward.py:273-289), so a failed run leaves the file as it found it.  Here rows were already streaming in: datasets
+        this pass CREATED are deleted and datasets it GREW are cut back to their former length, so that no later reader meets well-formed
+        datasets whose tail is fill values.  Rows of a pre-existing dataset that were already overwritten stay overwritten --
+        with correct labels of this configuration, which is what the completed pass would have left there."""
+        if self.t.is_alive():
+            self.q.put(None)
+            self.t.join()
+        for key in self.created:
+            try:
+                del self.store[key]
+            except Exception:  # noqa: BLE001 -- best effort on the error path; the original error is what the caller sees
+                pass
+        for key, n in self.grown.items():
+            try:
+                self.store[key].resize(n, axis=0)
+            except Exception:  # noqa: BLE001
+                pass
+        self.created, self.grown = [], {}
 
 
 def label_store(store, clip_model, compute_reward, image_keys="ob", model_type="clip", inst_type="none", use_crop=False,
@@ -524,9 +550,12 @@ def label_reward(
         try:
             results = label_store(store, clip_model, compute_reward, image_keys=image_keys, model_type=model_type,
                                   inst_type=inst_type, use_crop=use_crop, rank=rank, world=world, text=text, sink=sink)
-        finally:
+        except BaseException:
             if sink is not None:
-                sink.close()
+                sink.abort()  # no half-labelled datasets stay behind (the reference writes nothing before the labelling is complete)
+            raise
+        if sink is not None:
+            sink.close()
         if is_hdf5 and world > 1:
             store.close()  # before the gather: it is the barrier after which no rank holds the file
             file_open = False

@@ -417,13 +417,32 @@ class DeviceBatch:
             self._release = None
 
 
+_SLOT_OWNER_LOCK = __import__("threading").Lock()
+
+
 def prefetch_to_device(iterator, size, trainer, *, rank=0, world=1, device_axis=False):
     """``flax.jax_utils.prefetch_to_device(iterator, size, devices)`` as the reference uses it (main_procgen.py:703,706: size 2):
     host batches (the reference's batch dicts) are uploaded into the trainer's two device slots by a background thread -- the
     ctypes call releases the GIL, the copy runs on the handle's copy stream -- while the main thread is inside ``train_step_fn``
-    on the other slot.  Yields :class:`DeviceBatch`.  ``size`` > 2 is clamped: the library keeps two slots."""
+    on the other slot.  Yields :class:`DeviceBatch`.  ``size`` > 2 is clamped: the library keeps two slots.
+
+    The two device slots belong to the TRAINER, and one prefetcher at a time owns them.  The reference opens ``train_iter`` and
+    ``val_iter`` side by side on the same state (main_procgen.py:703-708); here the prefetcher that starts first owns the slots and a
+    second one opened while it is live yields prepared HOST batches instead -- ``train_step_fn`` / ``val_step_fn`` stage those through the
+    handle's third, synchronous slot -- so a validation upload can never land in a slot that holds an uploaded-but-unconsumed training
+    batch, and neither iterator can starve the other of slots."""
     import queue
     import threading
+
+    with _SLOT_OWNER_LOCK:
+        owner = getattr(trainer, "_prefetch_owner", None) is None
+        if owner:
+            token = object()
+            trainer._prefetch_owner = token
+    if not owner:
+        for batch in iterator:  # no device slots for this one: the host-side preparation only
+            yield batch
+        return
 
     free = queue.Queue()
     for s in range(min(max(int(size), 1), 2)):
@@ -457,6 +476,10 @@ def prefetch_to_device(iterator, size, trainer, *, rank=0, world=1, device_axis=
     finally:
         stop.set()
         free.put(0)  # wake a worker blocked on a free slot
+        th.join(timeout=30)  # an upload in flight finishes before the slots change hands
+        with _SLOT_OWNER_LOCK:
+            if getattr(trainer, "_prefetch_owner", None) is token:
+                trainer._prefetch_owner = None
 
 
 def _stage(tr, batch, rank, world, device_axis):

@@ -133,11 +133,14 @@ def run_secondary(a):
         "finetune": ["--path", "finetune"],
         "label_vit_b16": ["--model", "ViT-B/16", "--batch", "256"],
         "online": ["--path", "online"],
+        "h5": ["--path", "h5"],
     }
+    # path (2) and row N2 carry their own CPU baseline (a bounded ~5 s sample of the torch-CPU port of the same step, oracle/cpu_baseline_*.py)
+    cpu_s = {"policy": 5.0, "finetune": 5.0} if a.cpu_seconds > 0 else {}
     extra = {}
     for name, args in runs.items():
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup), "--cpu-seconds", "0",
-               "--no-secondary"] + args
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup), "--cpu-seconds",
+               str(cpu_s.get(name, 0)), "--no-secondary"] + args
         try:
             r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -145,6 +148,33 @@ def run_secondary(a):
         except Exception as e:  # a secondary line must never cost the headline one
             extra[name] = {"error": repr(e)}
     return extra
+
+
+def summarize_extra(extra, seam):
+    """value / ms per step / CPU baseline of every secondary line + the host-fed seam rates, compact enough for the head of the JSON line"""
+    out = {}
+    if seam:
+        out["seam_host_fed_frames_per_s"] = {"sync_call": round(seam["frames_per_s"]), "pipelined_calls": round(seam["pipelined_frames_per_s"])}
+    for name, d in (extra or {}).items():
+        if not isinstance(d, dict) or "value" not in d:
+            out[name] = "failed"
+            continue
+        e = {"value": round(d["value"], 4 if d.get("unit") == "ms" else 1), "unit": d.get("unit"), "ms_per_step": round(d.get("ms_per_step", 0.0), 4)}
+        cb = d.get("cpu_baseline")
+        if cb and cb.get("value"):
+            e["cpu_baseline"] = {"value": round(cb["value"], 1), "cores": cb.get("cores")}
+        par = d.get("parity")
+        if par and par.get("max_logit_err_vs_oracle") is not None:
+            e["parity_err"] = float(f"{par['max_logit_err_vs_oracle']:.3g}")
+        if par and par.get("max_cosine_err_vs_oracle") is not None:
+            e["parity_err"] = float(f"{par['max_cosine_err_vs_oracle']:.3g}")
+        if name == "online":
+            e = {"reward_ms": {k: v["latency_ms"] for k, v in d.get("reward", {}).items()}, "greedy_action_ms": d.get("greedy_action", {}).get("latency_ms")}
+            e.update({k: v for k, v in d.get("more_rewards_ms", {}).items()})
+        if name == "h5":
+            e = {"file_to_file_frames_per_s": d.get("value"), "later_pass": d.get("later_pass_frames_per_s"), "rows": d.get("rows")}
+        out[name] = e
+    return out
 
 
 def gather_rates(dist, world, units, elapsed_local):
@@ -168,6 +198,17 @@ def policy_sites(cfg, B, n_params):
         "dt.image_text_input_dX": ("mfma", iti),
         # norms pass reads p, g; the update reads p, g, mu, nu and writes p, mu, nu: 9 x 4 B per parameter
         "dt.clip_adam": ("hbm", 36.0 * n_params),
+    }
+
+
+def encoder_sites(ecfg, frames):
+    """Algorithmic FLOPs per launch of the frozen M3AE encoder's GEMM call sites (one launch covers all `frames` frames of the step)."""
+    m, d = frames * ecfg.tokens, ecfg.width
+    return {
+        "m3ae.image_embedding": ("mfma", 2.0 * frames * (ecfg.tokens - 1) * d * 3 * ecfg.patch * ecfg.patch),
+        "m3ae.qkv": ("mfma", 2.0 * m * 3 * d * d), "m3ae.out_proj": ("mfma", 2.0 * m * d * d),
+        "m3ae.c_fc": ("mfma", 2.0 * m * ecfg.mlp_ratio * d * d), "m3ae.c_proj": ("mfma", 2.0 * m * ecfg.mlp_ratio * d * d),
+        "m3ae.attn": ("mfma", 4.0 * frames * ecfg.tokens * ecfg.tokens * d),
     }
 
 
@@ -201,18 +242,39 @@ def bench_policy(a):
     cfg = PolicyConfig(lambda_ret=0.01)
     # parity gate (rank 0): the mode timed below, real geometry (257 x 768 encodings, K = 197 376), B = 2, against the fp64 oracle
     parity = None
+    parity_geometry = "B = 2, window 4, 257 x 768 encodings in (K = 197 376)"
     if rank == 0 and a.parity_frames > 0:
         from oracle import arpdt_torch as O
         Pp = S.policy_params(cfg, seed=3)
-        enc, act, rtg = S.policy_batch(cfg, 2, seed=4)
-        ref = O.forward({k: torch.from_numpy(v).double() for k, v in Pp.items()}, O.PolicyConfig(lambda_ret=0.01), torch.from_numpy(enc).double(),
-                        torch.from_numpy(act).long(), torch.from_numpy(rtg).double())
         t0 = PolicyTrainer(cfg, mode=a.mode, device=local_rank)
         t0.set_params(Pp)
-        t0.set_batch(enc, act, rtg)
-        out = t0.forward()
-        t0.close()
-        parity = float(np.abs(out["action_pred"] - ref["action_pred"].numpy()).max())
+        if a.with_encoder:
+            # the configuration that is timed: FRAMES in, the frozen encoder in the timed mode in front of the policy in the timed mode, against
+            # oracle/m3ae_np -> oracle/arpdt_torch in fp64 on the same frames (tests/test_m3ae_gpu.py, full geometry)
+            from arp_amd import m3ae
+            from oracle import m3ae_np as MO
+            ecfg0 = m3ae.EncoderConfig()
+            EP = S.m3ae_params(MO.EncConfig(), seed=50)
+            frames0 = S.normalized_frames(2 * cfg.window, 256, seed=80).reshape(2, cfg.window, 256, 256, 3)
+            _, act, rtg = S.policy_batch(PolicyConfig(enc_tokens=1, enc_dim=4), 2, seed=4)
+            codes = MO.forward_representation(EP, MO.EncConfig(), frames0.reshape(-1, 256, 256, 3)).reshape(2, cfg.window, ecfg0.tokens, ecfg0.width)
+            ref = O.forward({k: torch.from_numpy(v).double() for k, v in Pp.items()}, O.PolicyConfig(lambda_ret=0.01),
+                            torch.from_numpy(np.asarray(codes, np.float64)), torch.from_numpy(act).long(), torch.from_numpy(rtg).double())
+            enc0 = m3ae.M3AEEncoder(ecfg0, EP, mode=a.mode, device=local_rank, max_frames=2 * cfg.window)
+            t0.attach_encoder(enc0)
+            t0.set_batch_images(frames0, act, rtg)
+            out = t0.forward()
+            t0.close()
+            enc0.close()
+            parity_geometry = "B = 2, window 4, 8 frames [256,256,3] in -> frozen M3AE ViT-B/16 encoder (257 tokens) -> policy, vs oracle/m3ae_np -> oracle/arpdt_torch (fp64)"
+        else:
+            enc, act, rtg = S.policy_batch(cfg, 2, seed=4)
+            ref = O.forward({k: torch.from_numpy(v).double() for k, v in Pp.items()}, O.PolicyConfig(lambda_ret=0.01), torch.from_numpy(enc).double(),
+                            torch.from_numpy(act).long(), torch.from_numpy(rtg).double())
+            t0.set_batch(enc, act, rtg)
+            out = t0.forward()
+            t0.close()
+        parity = max(float(np.abs(out["action_pred"] - ref["action_pred"].numpy()).max()), float(np.abs(out["return_pred"] - ref["return_pred"].numpy()).max()))
     tr = PolicyTrainer(cfg, mode=a.mode, device=local_rank)
     tr.set_params(S.policy_params(cfg, seed=0))
     if world > 1:  # RCCL id from rank 0 over gloo, communicator, sync_state_fn
@@ -286,6 +348,8 @@ def bench_policy(a):
                 "call": "train_step_fn(state, host batch dict, rng) incl. the H2D upload of the f32 encodings and the aux read-back"}
     if rank == 0:
         sites = policy_sites(cfg, a.policy_batch, tr.num_params)
+        if enc is not None:  # the frozen encoder's launches are part of this step: the dominant site is chosen over them as well
+            sites.update(encoder_sites(ecfg, a.policy_batch * cfg.window))
         known = {k: v for k, v in prof.items() if k in sites and v["calls"]}
         site = max(known, key=lambda k: known[k]["ms"])  # the call site that takes the most time per step
         kind, work = sites[site]
@@ -293,6 +357,8 @@ def bench_policy(a):
         peak = PEAK_TFLOPS[a.mode] if kind == "mfma" else 8000.0
         achieved = work / (avg_ms * 1e-3) / (1e12 if kind == "mfma" else 1e9)
         flops = policy_step_flops(cfg, a.policy_batch)
+        if enc is not None:  # + the frozen encoder's forward: 46.4 GFLOP per frame, 4 frames per sample (193.5 GF per sample in all)
+            flops += m3ae.flops_per_frame(ecfg) * a.policy_batch * cfg.window
         # HBM bytes of the dominant site from the PMC counters (scripts/prof_policy_pmc.sh -> profiles/pmc_traffic_policy.json; measured
         # at the default geometry, B = 32 per GPU)
         traffic = None
@@ -307,16 +373,21 @@ def bench_policy(a):
                       "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
-            "config": {"workload": f"ARPDT policy train_step, {a.policy_batch} samples/GPU x window 4, random-init encodings [B,4,257,768] f32 "
-                                   f"resident in HBM, 26.9 M trainable params (BASELINE.json configs[3])", "parallelism": f"dp{world}",
-                       "collective": "one RCCL all-reduce(sum) of the flat f32 gradient (107.5 MB) + one of 4 scalars per step" if world > 1 else "none (1 rank)"},
+            "config": {"workload": (f"ARPDT policy train_step, {a.policy_batch} samples/GPU x window 4, FRAMES in: normalised f32 frames [B,4,256,256,3] resident in "
+                                    f"HBM -> frozen random-init M3AE ViT-B/16 encoder (257 tokens, {a.mode}) -> 26.9 M trainable params (SURVEY row N1; "
+                                    f"BASELINE.json configs[3] with the reference's own boundary)") if enc is not None else
+                                   (f"ARPDT policy train_step, {a.policy_batch} samples/GPU x window 4, random-init encodings [B,4,257,768] f32 "
+                                    f"resident in HBM, 26.9 M trainable params (BASELINE.json configs[3])"), "parallelism": f"dp{world}",
+                       "collective": ("RCCL all-reduce(sum) of the flat f32 gradient (107.5 MB) in two buckets on a communication stream -- bucket 1 "
+                                      "(image_text_input + transformer + heads, 94 % of the bytes) under the adapter's backward, bucket 2 + 4 loss scalars after it") if world > 1 else "none (1 rank)"},
             "roofline": {"bound": kind, "achieved": achieved, "peak": peak, "unit": "TFLOP/s" if kind == "mfma" else "GB/s",
                          "frac": achieved / peak, "traffic": traffic, "kernel": f"{'gemm' if kind == 'mfma' else 'norms_partial + adam_kernel'} @ {site}",
                          ("flops_per_launch" if kind == "mfma" else "bytes_per_launch"): work, "avg_launch_ms": avg_ms,
+                         "traffic_source": None if traffic is None else "profiles/pmc_traffic_policy.json (committed rocprofv3 --pmc passes, not measured in this run)",
                          "note": "the call site with the largest share of the step (sites_ms_per_step)"},
             "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12,
                            "mfma_frac_of_peak": flops / (elapsed / a.steps) / 1e12 / PEAK_TFLOPS[a.mode]},
-            "parity": {"max_logit_err_vs_oracle": parity, "geometry": "B = 2, window 4, 257 x 768 encodings (K = 197 376)", "tolerance": 1e-3,
+            "parity": {"max_logit_err_vs_oracle": parity, "geometry": parity_geometry, "tolerance": 1e-3,
                        "within_tolerance": None if parity is None else bool(parity < 1e-3)},
             "cpu_baseline": cpu, "seam": seam, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
@@ -381,6 +452,61 @@ def bench_online(a):
                      "config": {"workload": "get_torch_clip_reward: one 256x256x3 uint8 host frame in, one f32 reward out per call (ViT-B/32; the same for "
                                             "ViT-B/16 under reward); greedy_action: one [1,4,257,768] f32 window of encodings in, one action out"},
                      "reward": lat, "greedy_action": ga}))
+
+
+def bench_h5(a):
+    """Secondary benchmark: label_reward(data_path=...) end to end on a recorder-style HDF5 file -- open, scan `done`, inflate the last
+    frame of every row, label (ViT-B/32, host-fed), write both reward datasets as gzip chunks, close (label_reward.py:69-87,256-289)."""
+    import tempfile
+    from arp_amd import _ffi, clip, h5store, label_reward as L, synth
+    _ffi.require_gpu()
+    _ffi.check(_ffi.lib.arp_set_device(0))
+    rows, tlen, F = a.h5_rows, 256, 8
+    path = os.path.join(tempfile.gettempdir(), f"arp_bench_h5_{os.getpid()}.hdf5")
+    t0 = time.perf_counter()
+    with h5store.H5Store(path, "w") as f:
+        f.attrs["env_name"] = "coinrun"
+        for s0 in range(0, rows, tlen):
+            n = min(tlen, rows - s0)
+            # Procgen renders 64x64 natively; the recorded 256x256 observation is that picture enlarged (what gzip sees in a real file)
+            rng = np.random.default_rng(s0)
+            base = rng.integers(0, 6, (n, 16, 16, 1)).repeat(4, 1).repeat(4, 2) * 40 + rng.integers(0, 3, (n, 64, 64, 3)) * 5
+            fr = base.astype(np.uint8).repeat(4, 1).repeat(4, 2)
+            idx = np.clip(np.arange(n)[:, None] + np.arange(-F + 1, 1)[None, :], 0, None)  # the recorder's sliding window of 8 observations
+            d = np.zeros((n, F), np.float32)
+            d[-1, -1] = 1
+            if s0 == 0:
+                f.create_dataset("ob", data=fr[idx], compression="gzip", chunks=(1, F, 256, 256, 3), maxshape=(None, F, 256, 256, 3))
+                f.create_dataset("done", data=d, compression="gzip", chunks=(1, F), maxshape=(None, F))
+            else:
+                for k, v in (("ob", fr[idx]), ("done", d)):
+                    ds = f[k]
+                    n0 = ds.shape[0]
+                    ds.resize(n0 + n, axis=0)
+                    ds[n0:] = v
+    t_write = time.perf_counter() - t0
+    size_mb = os.path.getsize(path) / 1e6
+    cfg = clip.MODELS["ViT-B/32"]
+    m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), mode=a.mode, device=0)
+    tok = synth.prompt_tokens(1, 8, seed=2)
+    rates = []
+    try:
+        for _ in range(3):
+            t = time.perf_counter()
+            L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=path, clip_model=m, tokens=tok)
+            rates.append(rows / (time.perf_counter() - t))
+        with h5store.H5Store(path, "r") as f:
+            same = bool(np.array_equal(f["ob_clip_reward"][0:64, -1], m.label(f["ob"][0:64, -1])))
+    finally:
+        m.close()
+        os.remove(path)
+    emit(json.dumps({"metric": "frames/sec label_reward(data_path=HDF5 file) end to end (file -> file)", "value": round(rates[0], 1), "unit": "frames/s",
+                     "later_pass_frames_per_s": round(max(rates[1:]), 1), "n_gpus": 1, "steps": 3, "warmup": 0, "ms_per_step": rows / rates[0] * 1e3,
+                     "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic", "rows": rows,
+                     "config": {"workload": f"recorder-schema file: ob uint8 [{rows},8,256,256,3] in gzip chunks of one row ({size_mb:.0f} MB on disk, "
+                                            f"{rows * F * 196608 / 1e9:.1f} GB raw; written here in {t_write:.1f} s, page-cache resident), trajectories of {tlen} rows; "
+                                            "first pass creates ob_clip_reward / ob_clip_pos_rtg, later passes overwrite them"},
+                     "file_rewards_equal_direct_labelling": same}))
 
 
 def bench_finetune(a):
@@ -516,7 +642,8 @@ def main():
     ap.add_argument("--parity-frames", type=int, default=8, help="frames checked against the oracle before timing (rank 0)")
     ap.add_argument("--streams", type=int, default=2, help="label path: N = each batch is labelled in N contiguous parts on N HIP streams of "
                     "the same GPU (one half's LayerNorm/attention/GEMM tails overlap the other half's GEMMs); 1 = single stream")
-    ap.add_argument("--path", default="label", choices=["label", "policy", "finetune", "online"],
+    ap.add_argument("--h5-rows", type=int, default=4096, help="--path h5: rows (= labelled frames) of the generated demonstration file")
+    ap.add_argument("--path", default="label", choices=["label", "policy", "finetune", "online", "h5"],
                     help="label = headline metric (BASELINE.json configs[1]); policy = ARPDT train_step (configs[3], secondary); "
                          "finetune = CLIP multi-scale adapter head step (configs[4], secondary); online = latency of one single-frame reward / one "
                          "greedy action (the rollout loop, SURVEY row N4; secondary)")
@@ -547,6 +674,8 @@ def main():
         return bench_finetune(a)
     if a.path == "online":
         return bench_online(a)
+    if a.path == "h5":
+        return bench_h5(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -742,6 +871,8 @@ def main():
             "vs_baseline": None,
             "dtype": a.mode,
             "data": "synthetic",
+            # the secondary lines of this run in brief (the full lines are under `extra` at the end; a log tail may cut them off)
+            "extra_summary": summarize_extra(extra, seam),
             "config": {"workload": f"CLIP {a.model} reward labelling, batch {a.batch} synthetic 256x256x3 uint8 frames per GPU resident in HBM "
                                    f"(BASELINE.json configs[1]), random-init weights, text tower cached", "frames_per_gpu_per_step": a.batch,
                        "operands": {"f16": "IEEE half MFMA operands (same 2.5 PF dense rate as bf16), f32 accumulate / residual / LayerNorm / softmax; "
@@ -751,7 +882,10 @@ def main():
                                     "headline configuration; see parity)" if a.fp8_mlp else ""),
                        "parallelism": f"shard{world} (no collective)", "streams_per_gpu": nsplit},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "mfma_util_pct": mfma_util, "kernel": f"{kname} @ {dom}",
+                         "traffic": traffic, "mfma_util_pct": mfma_util,
+                         "traffic_source": None if traffic is None else "profiles/pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, scaled to this launch's frames; NOT measured in this run",
+                         "mfma_util_source": None if mfma_util is None else "profiles/pmc_traffic.json: committed rocprofv3 --pmc MfmaUtil pass (kernel alone on the chip); NOT measured in this run",
+                         "kernel": f"{kname} @ {dom}",
                          "note": (f"each launch covers {-(-a.batch // nsplit)} frames; with --streams {nsplit} that many such launches (the parts of a batch) share "
                                   "the chip, so a launch's HIP-event duration includes time it ran beside the other stream's kernels; "
                                   "--streams 1 gives the isolated per-kernel figure") if nsplit > 1 else "single stream", "flops_per_launch": sites[dom],

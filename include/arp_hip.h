@@ -260,6 +260,10 @@ int arp_ft_param_info(arp_ft* h, int i, char* name_buf, int name_len, int64_t* s
  * (ARP_FT_FUSE_ADAM=0 restores the stored gradients and the separate AdamW pass). */
 int arp_ft_set_tensor(arp_ft* h, const char* name, int which, const float* data);
 int arp_ft_get_tensor(arp_ft* h, const char* name, int which, float* out);
+/* f16 mode only: gradient elements that arrived at AdamW as inf / NaN (a binary16 overflow in the x 1024-seeded backward) and were treated
+   as missing for that step -- cumulative since create.  The other modes never mask: a non-finite gradient shows as NaN parameters, as in
+   torch.optim.AdamW (finetune_module/finetune.py:141). */
+int arp_ft_dropped_gradients(arp_ft* h, uint64_t* count);
 int arp_ft_set_step(arp_ft* h, int64_t step);
 int arp_ft_get_step(arp_ft* h, int64_t* step);
 /* img_inter [3, B, layers*width_v] and img_final [3, B, embed]: frames image0, image1, image2 of each sample

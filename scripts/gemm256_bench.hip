@@ -1,6 +1,8 @@
 // Standalone timing / checksum harness for gemm256.h variants (kernel development loop: 20 s per build instead of the library's 4 min):
 //   cd arp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++20 -I. [-DARP_G2_...=..] ../../scripts/gemm256_bench.hip -o ../../scripts/gemm256_bench.bin
 // Prints microseconds, TFLOP/s and an FNV checksum of the output per shape (variants that keep the MFMA order must agree bit for bit).
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -106,21 +108,75 @@ template <typename OutT, int ACT, bool RESID> static void run(const char* name, 
     }
     return;
 #endif
-    std::vector<uint8_t> out((size_t)M * N * sizeof(OutT));
-    hipMemcpy(out.data(), g.out, out.size(), hipMemcpyDeviceToHost);
-    const uint64_t sum = fnv(out.data(), out.size());
+    // ---- both MFMA shapes in ONE process, interleaved rounds (cdna_hip_programming.md rule 24), random operands (rule 25) ----
+    auto go16 = [&]() { return launch_gemm256_nt<f16_t, OutT, ACT, RESID, 6, false>(g, nullptr); };
+    auto go32 = [&]() { return launch_gemm256_nt<f16_t, OutT, ACT, RESID, 6, true>(g, nullptr); };
+    std::vector<uint8_t> out16((size_t)M * N * sizeof(OutT)), out32(out16.size());
+    auto h2f = [](f16_t h) { _Float16 x; memcpy(&x, &h, 2); return (float)x; };
+    auto as_f = [&](const std::vector<uint8_t>& o, size_t i) { if (sizeof(OutT) == 4) { float f; memcpy(&f, &o[i * 4], 4); return f; } f16_t h; memcpy(&h, &o[i * 2], 2); return h2f(h); };
+    if (RESID) hipMemset(dR, 0, (size_t)M * N * 4);
+    go16(); hipDeviceSynchronize();
+    hipMemcpy(out16.data(), g.out, out16.size(), hipMemcpyDeviceToHost);
+    if (RESID) hipMemset(dR, 0, (size_t)M * N * 4);
+    go32(); hipDeviceSynchronize();
+    hipMemcpy(out32.data(), g.out, out32.size(), hipMemcpyDeviceToHost);
+    double maxd = 0, maxref16 = 0, maxref32 = 0;
+    for (size_t i = 0; i < (size_t)M * N; i += 7) maxd = std::max(maxd, (double)std::fabs(as_f(out16, i) - as_f(out32, i)));
+    {   // a sample of entries against a float64 reference (the 32x32 layout is new: rows / columns / k-steps must all line up)
+        uint32_t t = 777u;
+        for (int c = 0; c < 400; ++c) {
+            t = t * 1664525u + 1013904223u; const int m = (c < 40) ? (M - 1 - c * 7 % std::min(M, 300)) : (int)((t >> 8) % M);
+            t = t * 1664525u + 1013904223u; const int n = (c < 40) ? (N - 1 - c * 5 % std::min(N, 300)) : (int)((t >> 8) % N);
+            double r = hb[n];
+            for (int k = 0; k < K; ++k) r += (double)h2f(hA[(size_t)m * (getenv("G256_LDA0") ? 0 : K) + k]) * h2f(hW[(size_t)n * K + k]);
+            if (ACT == ACT_QGELU) r = r / (1.0 + std::exp(-1.702 * r));
+            maxref16 = std::max(maxref16, std::fabs(r - as_f(out16, (size_t)m * N + n)) / (1.0 + std::fabs(r)));
+            maxref32 = std::max(maxref32, std::fabs(r - as_f(out32, (size_t)m * N + n)) / (1.0 + std::fabs(r)));
+        }
+    }
+    const uint64_t sum = fnv(out16.data(), out16.size());
+#ifdef ARP_G2_CLOCK
+    long long* dS;
+    const int nblk = ((M + 255) / 256) * ((N + 255) / 256);
+    hipMalloc(&dS, (size_t)nblk * 16);
+    hipMemcpyToSymbol(HIP_SYMBOL(arp_g2_stamps), &dS, sizeof(dS));
+    auto clock_of = [&](auto&& fn) {
+        for (int i = 0; i < 200; ++i) fn();  // the chip settles under the load first
+        hipDeviceSynchronize();
+        std::vector<long long> h((size_t)nblk * 2);
+        hipMemcpy(h.data(), dS, h.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> c;
+        for (int b = 0; b < nblk; ++b) if (h[2 * b + 1] > 0) c.push_back(100.0 * h[2 * b] / h[2 * b + 1]);
+        std::sort(c.begin(), c.end());
+        return c.empty() ? 0.0 : c[c.size() / 2];
+    };
+    const double mhz16 = clock_of(go16), mhz32 = clock_of(go32);
+#endif
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) go();
-    const int iters = 20;
-    hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) go();
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    ms /= iters;
-    printf("%-10s M=%d N=%d K=%d: %8.1f us %7.1f TFLOP/s  fnv %016llx\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9, (unsigned long long)sum);
+    for (int i = 0; i < 3; ++i) { go16(); go32(); }
+    const int iters = 10, rounds = 7;
+    std::vector<float> t16, t32;
+    for (int r = 0; r < rounds; ++r) {
+        for (int v = 0; v < 2; ++v) {
+            hipEventRecord(e0);
+            for (int i = 0; i < iters; ++i) { if (v) go32(); else go16(); }
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            (v ? t32 : t16).push_back(ms / iters);
+        }
+    }
+    std::sort(t16.begin(), t16.end()); std::sort(t32.begin(), t32.end());
+    const float m16 = t16[rounds / 2], m32 = t32[rounds / 2];
+    printf("%-11s M=%d N=%d K=%d: 16x16x32 %7.1f us (min %7.1f) %7.1f TF | 32x32x16 %7.1f us (min %7.1f) %7.1f TF | 32/16 %.3f | err vs f64: %.1e / %.1e, |16-32| %.1e  fnv16 %016llx\n",
+           name, M, N, K, m16 * 1e3, t16[0] * 1e3, 2.0 * M * N * K / m16 / 1e9, m32 * 1e3, t32[0] * 1e3, 2.0 * M * N * K / m32 / 1e9, m32 / m16,
+           maxref16, maxref32, maxd, (unsigned long long)sum);
+#ifdef ARP_G2_CLOCK
+    printf("            in-kernel clock (median over workgroups, after 200 launches): 16x16x32 %.0f MHz | 32x32x16 %.0f MHz\n", mhz16, mhz32);
+    hipFree(dS);
+#endif
     hipFree(dA); hipFree(dW); hipFree(dB); hipFree(dO); hipFree(dR);
 }
 
@@ -169,7 +225,7 @@ static bool check_masked(int M, int N, int K) {
 }
 
 int main() {
-#ifndef ARP_G2_STAMPS
+#if !defined(ARP_G2_STAMPS) && !ARP_G2_ABL
     bool ok = check_masked(512, 256, 128) & check_masked(1000, 520, 192) & check_masked(32896, 768, 768);
     if (!ok) return 1;
 #endif

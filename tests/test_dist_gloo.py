@@ -321,3 +321,29 @@ def test_oracle_shard_mean_equals_full_batch_gradient_two_ranks():
     err = q.get(timeout=120)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs) and err < 1e-12
+
+
+def test_the_two_rank_rccl_test_workers_run_dry_on_gloo():
+    """tests/test_multi_gpu.py has never executed (no box with two GPUs).  Its worker functions are driven here as they are --
+    same spawn, same rendezvous, same arp_amd imports, same DataParallel wrappers, same queue protocol -- with only the trainer class replaced
+    by a gloo-backed stand-in, so everything except the RCCL calls themselves is known to work: rank 0's id reaches both ranks, comm_init comes
+    before the state broadcast, rank 1's differently-seeded parameters are overwritten, the shards differ, and both ranks end equal."""
+    import test_multi_gpu as M
+    ctx = mp.get_context("spawn")
+    for worker, args in ((M._policy_worker, (1, "f16", True)), (M._ft_worker, ("f16", True))):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, 2, port, q) + args) for r in range(2)]
+        [p.start() for p in procs]
+        res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+        [p.join(60) for p in procs]
+        assert all(p.exitcode == 0 for p in procs), worker.__name__
+        p0, p1, c0, c1 = res[0][1], res[1][1], res[0][-1], res[1][-1]
+        assert p0.keys() == p1.keys() and all(np.array_equal(p0[k], p1[k]) for k in p0), "ranks diverged"
+        assert [a["loss"] for a in res[0][2]] == [a["loss"] for a in res[1][2]]
+        assert c0[0] == ("create", "f16", 0) and c1[0] == ("create", "f16", 1)         # one device per rank
+        assert c0[1] == "new_unique_id" and "new_unique_id" not in c1
+        assert c0[2][0] == c1[1][0] == "comm_init" and c0[2][1] == c1[1][1] and (c0[2][2], c0[2][3]) == (2, 0) and (c1[1][2], c1[1][3]) == (2, 1)
+        assert c0[3] == c1[2] == "broadcast_state"
+        sb0, sb1 = [c for c in c0 if c[0] == "set_batch"], [c for c in c1 if c[0] == "set_batch"]
+        assert len(sb0) == len(sb1) == len(res[0][2]) and sb0[0][1:] == sb1[0][1:]      # equal-sized shards, one per step

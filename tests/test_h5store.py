@@ -217,6 +217,52 @@ def test_a_failing_writer_thread_fails_the_call(tmp_path, monkeypatch):
         assert "ob_clip_reward" not in f.keys()
 
 
+def test_a_failure_in_the_middle_of_a_pass_leaves_no_half_labelled_datasets(tmp_path, monkeypatch):
+    """with the streamed writes a GPU error (here: a labeller that fails on its third batch) used to leave reward datasets created at
+    full length with a prefix of real rows and fill values behind it.  The reference writes only after everything is labelled
+    (label_reward.py:273-289): a failed pass deletes the datasets it created and cuts the ones it grew back to their former length."""
+    from arp_amd import label_reward as L
+    tok = np.zeros((1, 77), np.int32)
+
+    class Flaky(_FakeClip):
+        def __init__(self, fail_after):
+            self.calls, self.fail_after = 0, fail_after
+
+        def label(self, frames, use_crop=False):
+            self.calls += 1
+            if self.calls > self.fail_after:
+                raise RuntimeError("GPU fell over")
+            return super().label(frames, use_crop)
+
+    monkeypatch.setattr(L, "_BATCH_FRAMES_DEFAULT", 64, raising=False)
+    # (a) fresh file: nothing may remain
+    p = str(tmp_path / "fresh.hdf5")
+    _recorder_file(p, [700, 650, 900, 800], hw=8, seed=3)
+    with pytest.raises(RuntimeError, match="GPU fell over"):
+        L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=p, clip_model=Flaky(2), tokens=tok)
+    with h5store.H5Store(p, "r") as f:
+        assert not [k for k in f.keys() if k.startswith("ob_clip")], "a failed pass left datasets behind"
+    # (b) datasets exist but are shorter (a file that was extended after an earlier labelling): back to their former length, former rows intact or relabelled
+    p2 = str(tmp_path / "grown.hdf5")
+    _recorder_file(p2, [700, 650], hw=8, seed=3)
+    L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=p2, clip_model=_FakeClip(), tokens=tok)
+    with h5store.H5Store(p2, "r") as f:
+        before = {k: f[k][...] for k in f.keys() if k.startswith("ob_clip")}
+    with h5store.H5Store(p2, "a") as f:  # the recorder appends two more trajectories
+        rng = np.random.default_rng(9)
+        for L_ in (900, 800):
+            fr = rng.integers(0, 256, (L_, 8, 8, 3), dtype=np.uint8)
+            idx = np.clip(np.arange(L_)[:, None] + np.arange(-F + 1, 1)[None, :], 0, None)
+            d = np.zeros((L_, F), np.float32); d[-1, -1] = 1
+            for k, v in (("ob", fr[idx]), ("done", d)):
+                ds = f[k]; n0 = ds.shape[0]; ds.resize(n0 + L_, axis=0); ds[n0:] = v
+    with pytest.raises(RuntimeError, match="GPU fell over"):
+        L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=p2, clip_model=Flaky(2), tokens=tok)
+    with h5store.H5Store(p2, "r") as f:
+        for k, v in before.items():
+            assert f[k].shape == v.shape and np.array_equal(f[k][...], v), k
+
+
 def test_default_path_layout(tmp_path):
     """data_path=None builds <base>/<env>_<mode>_level<start>to<num>_num<demos>_frame<frames>[_<env_type>]/data.hdf5 (label_reward.py:62-68)."""
     from arp_amd import label_reward as L

@@ -325,3 +325,52 @@ def test_finetune_bucket_plan_tiles_the_flat_gradient_exactly_once():
     buckets, total = bucket_plan(FinetuneConfig())
     last = sum(hi - lo for lo, hi in buckets[-1])
     assert last / total < 0.1
+
+
+def test_two_prefetchers_on_one_trainer_never_share_device_slots():
+    """the reference opens train_iter AND val_iter with prefetch_to_device(..., 2) on the same state (main_procgen.py:703-708).
+    The trainer's two device slots have ONE owner at a time: the second live prefetcher yields host batches (staged synchronously by the step
+    functions), so no upload can land in a slot that holds an uploaded-but-unconsumed batch of the other iterator.  Stub trainer, no GPU."""
+    from arp_amd.train import DeviceBatch, PolicyConfig, prefetch_to_device
+    import threading
+
+    class Stub:
+        cfg = PolicyConfig(emb=8, depth=1, heads=2, window=2, enc_tokens=2, enc_dim=4)
+
+        def __init__(self):
+            self.holds = {}  # slot -> tag of the uploaded-but-unconsumed batch in it
+            self.lock = threading.Lock()
+            self.clobbered = []
+
+        def upload_async(self, slot, enc, act, rtg, images=False):
+            with self.lock:
+                if slot in self.holds:
+                    self.clobbered.append((slot, self.holds[slot], float(enc.flat[0])))
+                self.holds[slot] = float(enc.flat[0])
+
+    def batches(tag, n):
+        for i in range(n):
+            yield {"image": {"ob": np.full((2, 2, 2, 4), tag + i, np.float32)}, "action": np.zeros((2, 2), np.int32), "rtg": {"ob": np.zeros((2, 2, 1), np.float32)}}
+
+    tr = Stub()
+    train_it = prefetch_to_device(batches(100, 6), 2, tr)
+    val_it = prefetch_to_device(batches(900, 3), 2, tr)
+    seen_train, seen_val = [], []
+    for step in range(6):
+        b = next(train_it)
+        assert isinstance(b, DeviceBatch)
+        with tr.lock:
+            seen_train.append(tr.holds.pop(b.slot))  # the step consumes what the slot holds
+        b.done()
+        if step % 2 == 1:
+            v = next(val_it)
+            assert isinstance(v, dict), "the second live prefetcher must not use the trainer's device slots"
+            seen_val.append(float(v["image"]["ob"].flat[0]))
+    assert seen_train == [100.0 + i for i in range(6)] and seen_val == [900.0, 901.0, 902.0]
+    assert tr.clobbered == []
+    train_it.close()
+    val_it.close()
+    # once the owner is gone the slots can be claimed again
+    again = prefetch_to_device(batches(500, 1), 2, tr)
+    assert isinstance(next(again), DeviceBatch)
+    again.close()
