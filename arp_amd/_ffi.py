@@ -132,6 +132,8 @@ SIGNATURES = {
     "arp_dt_profile_reset": (_i, [_vp]),
     "arp_dt_profile_json": (_i, [_vp, C.c_char_p, _i]),
     "arp_clip_encode_image_multiscale": (_i, [_vp, _u8p, _i, _i, _i, _fp, _fp]),
+    "arp_clip_encode_image_multiscale_pil": (_i, [_vp, _u8p, _i, _i, _i, _i, _fp, _fp]),
+    "arp_clip_set_prompt_reduce": (_i, [_vp, _i]),
     "arp_clip_encode_text_multiscale": (_i, [_vp, _i32p, _i, _fp, _fp]),
     "arp_clip_encode_image_multiscale_dev": (_i, [_vp, _u8p, _i, _i, _i, _vp, _vp]),
     "arp_clip_encode_text_multiscale_dev": (_i, [_vp, _i32p, _i, _vp, _vp]),

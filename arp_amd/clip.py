@@ -158,6 +158,12 @@ class ClipLabeller:
         self._n_prompts = t.shape[0]
         return self
 
+    def set_prompt_reduce(self, mode):
+        """"first" (default): a reward is logits_per_text[0] -- prompt 0 whatever was cached, the offline pass (label_reward.py:146).
+        "mean": logits_per_text.mean(axis=0) over the cached prompts -- the rollout loop's branch for a LIST of prompts (envs/vl_reward.py:19-22)."""
+        check(lib.arp_clip_set_prompt_reduce(self._h, {"first": 0, "mean": 1, 0: 0, 1: 1}[mode]))
+        return self
+
     def text_features(self):
         out = np.empty((self._n_prompts, self.cfg.embed), np.float32)
         check(lib.arp_clip_get_text_features(self._h, _ffi.as_ptr(out, C.c_float)))
@@ -210,14 +216,20 @@ class ClipLabeller:
                                         int(bool(use_crop)), int(bool(normalize)), _ffi.as_ptr(out, C.c_float)))
         return out
 
-    def encode_image_multiscale(self, frames):
+    def encode_image_multiscale(self, frames, pil=False, use_crop=False):
         """Frozen-tower side of the fine-tune step (finetune_module/clip_multiscale_adapter.py:120-149): per-block
-        CLS features [n, layers*width] and the un-normalised CLIP feature [n, embed], through the fine-tune transform."""
+        CLS features [n, layers*width] and the un-normalised CLIP feature [n, embed], through the fine-tune transform -- or, ``pil=True``,
+        through the label transform (Pillow bicubic + normalise; ``use_crop`` as in :meth:`label`): what the rollout loop's adapter rewards
+        feed the fine-tuned model (envs/vl_reward.py:44-79)."""
         f = self._frames(frames)
         inter = np.empty((f.shape[0], self.cfg.layers * self.cfg.width), np.float32)
         fin = np.empty((f.shape[0], self.cfg.embed), np.float32)
-        check(lib.arp_clip_encode_image_multiscale(self._h, _ffi.as_ptr(f, C.c_uint8), f.shape[0], f.shape[1], f.shape[2],
-                                                   _ffi.as_ptr(inter, C.c_float), _ffi.as_ptr(fin, C.c_float)))
+        if pil:
+            check(lib.arp_clip_encode_image_multiscale_pil(self._h, _ffi.as_ptr(f, C.c_uint8), f.shape[0], f.shape[1], f.shape[2], int(bool(use_crop)),
+                                                           _ffi.as_ptr(inter, C.c_float), _ffi.as_ptr(fin, C.c_float)))
+        else:
+            check(lib.arp_clip_encode_image_multiscale(self._h, _ffi.as_ptr(f, C.c_uint8), f.shape[0], f.shape[1], f.shape[2],
+                                                       _ffi.as_ptr(inter, C.c_float), _ffi.as_ptr(fin, C.c_float)))
         return inter, fin
 
     def encode_multiscale_to(self, frames, tokens, bufs):

@@ -63,6 +63,9 @@ struct arp_clip {
 
     DevBuf txt_feat;
     int n_prompts = 0;
+    DevBuf txt_mean;        // mean of the cached (normalised) prompt vectors: the rollout loop's `isinstance(pos_text, list)` branch
+    int prompt_reduce = 0;  // 0 = prompt 0 (label_reward.py:146, quirk Q1), 1 = mean over the prompts (envs/vl_reward.py:19-22)
+    DevBuf ms_keep;         // multi-scale export buffer kept between calls of the online adapter reward (a hipMalloc per call would cost more than the head)
 
     // workspace for `ws_frames` frames
     int ws_frames = 0;
@@ -123,7 +126,7 @@ struct arp_clip {
     struct LatGraph {
         const uint8_t* frames;
         float* rewards;
-        int n, H, W, crop;
+        int n, H, W, crop;  // crop: bit 0 = use_crop, bit 1 = the prompt reduction the captured reward kernel reads (arp_clip_set_prompt_reduce)
         hipGraph_t graph;
         hipGraphExec_t exec;
     };
@@ -568,19 +571,20 @@ static int label_dev_single(arp_clip* c, const uint8_t* frames_dev, int n, int H
     auto pass = [&](const uint8_t* fr, int nb, float* rw) -> int {
         ARP_TRY(forward_chunk_dispatch(c, fr, nb, plan));
         ProfScope ps(c->prof, c->stream, "reward");
-        hipLaunchKernelGGL(reward_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, c->feat.as<float>(), c->txt_feat.as<float>(),
-                           scale, rw, nb, c->cfg.embed);
+        // mean over prompts of scale <img_n, txt_p> = scale <img_n, mean_p txt_p>: the same kernel on the mean prompt vector
+        hipLaunchKernelGGL(reward_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, c->feat.as<float>(),
+                           c->prompt_reduce ? c->txt_mean.as<float>() : c->txt_feat.as<float>(), scale, rw, nb, c->cfg.embed);
         ARP_HIP_OK(hipGetLastError());
         return 0;
     };
     // replay the captured pass
     if (c->lat_graph && small && !c->prof.on && !c->ms_out && !c->pre_bilinear) {
         for (auto& g : c->lat_graphs)
-            if (g.frames == frames_dev && g.rewards == rewards_dev && g.n == n && g.H == H && g.W == W && g.crop == use_crop) {
+            if (g.frames == frames_dev && g.rewards == rewards_dev && g.n == n && g.H == H && g.W == W && g.crop == ((use_crop ? 1 : 0) | (c->prompt_reduce << 1))) {
                 ARP_HIP_OK(hipGraphLaunch(g.exec, c->stream));
                 return 0;
             }
-        arp_clip::LatGraph g{frames_dev, rewards_dev, n, H, W, use_crop, nullptr, nullptr};
+        arp_clip::LatGraph g{frames_dev, rewards_dev, n, H, W, (use_crop ? 1 : 0) | (c->prompt_reduce << 1), nullptr, nullptr};
         // (Relaxed: another thread's HIP calls -- a reader thread pinning a buffer, a second handle -- must not invalidate the capture)
         ARP_HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
         const int rc = pass(frames_dev, n, rewards_dev);
@@ -679,6 +683,8 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
         arp_clip* s = c->siblings[i - 1];
         s->plans = c->plans;  // shared, owned by the primary
         s->txt_feat = c->txt_feat;
+        s->txt_mean = c->txt_mean;
+        s->prompt_reduce = c->prompt_reduce;
         s->n_prompts = c->n_prompts;
         s->logit_scale = c->logit_scale;
         s->prof.on = c->prof.on;
@@ -832,7 +838,7 @@ int arp_clip_destroy(arp_clip* c) {
         kv.second->v_tab.release();
         delete kv.second;
     }
-    DevBuf* bufs[] = {&c->txt_feat, &c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->cls_h, &c->feat, &c->frames_in, &c->rewards, &c->stats};
+    DevBuf* bufs[] = {&c->txt_feat, &c->txt_mean, &c->ms_keep, &c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->cls_h, &c->feat, &c->frames_in, &c->rewards, &c->stats};
     for (auto* b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -893,6 +899,14 @@ int arp_clip_finalize_weights(arp_clip* c) {
     return 0;
 }
 
+static __global__ __launch_bounds__(256) void prompt_mean_kernel(const float* __restrict__ txt, float* __restrict__ out, int np, int E) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= E) return;
+    float s = 0.f;
+    for (int p = 0; p < np; ++p) s += txt[(size_t)p * E + c];
+    out[c] = s / (float)np;
+}
+
 int arp_clip_set_text(arp_clip* c, const int32_t* tokens, int n_prompts) {
     ARP_TRY(check_ready(c, false));
     if (!tokens || n_prompts <= 0) return fail("set_text: need at least one prompt");
@@ -904,10 +918,28 @@ int arp_clip_set_text(arp_clip* c, const int32_t* tokens, int n_prompts) {
     // 16-bit handles: the cached prompt features come from the f32 copy of the text tower (arp_clip::txt32); ARP_TEXT_F32=0 keeps
     // the handle's own operand type (A/B measurements)
     static const bool text32 = [] { const char* e = getenv("ARP_TEXT_F32"); return !e || atoi(e) != 0; }();
-    if (c->cfg.mode != ARP_MODE_F32 && text32) return run_text<float>(c, tokens, n_prompts, nullptr, true, nullptr, false, true);
-    if (c->cfg.mode == ARP_MODE_BF16) return run_text<bf16_t>(c, tokens, n_prompts);
-    if (c->cfg.mode == ARP_MODE_F16) return run_text<f16_t>(c, tokens, n_prompts);
-    return run_text<float>(c, tokens, n_prompts);
+    int rc;
+    if (c->cfg.mode != ARP_MODE_F32 && text32) rc = run_text<float>(c, tokens, n_prompts, nullptr, true, nullptr, false, true);
+    else if (c->cfg.mode == ARP_MODE_BF16) rc = run_text<bf16_t>(c, tokens, n_prompts);
+    else if (c->cfg.mode == ARP_MODE_F16) rc = run_text<f16_t>(c, tokens, n_prompts);
+    else rc = run_text<float>(c, tokens, n_prompts);
+    ARP_TRY(rc);
+    ARP_TRY(c->txt_mean.ensure((size_t)c->cfg.embed * 4));
+    hipLaunchKernelGGL(prompt_mean_kernel, dim3((c->cfg.embed + 255) / 256), dim3(256), 0, c->stream, c->txt_feat.as<float>(), c->txt_mean.as<float>(),
+                       n_prompts, c->cfg.embed);
+    ARP_HIP_OK(hipGetLastError());
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// 0: rewards are logits_per_text[0] -- prompt 0 whatever the number of cached prompts (arp_dt/label_reward.py:146; the offline pass).
+// 1: rewards are logits_per_text.mean(axis=0) over the cached prompts -- the rollout loop's branch for a LIST of prompts
+//    (arp_dt/envs/vl_reward.py:19-22, get_torch_clip_reward; :56-59 for the adapter model).
+int arp_clip_set_prompt_reduce(arp_clip* c, int mode) {
+    ARP_TRY(check_ready(c, false));
+    if (mode != 0 && mode != 1) return fail("set_prompt_reduce: mode is 0 (prompt 0) or 1 (mean over the prompts)");
+    c->prompt_reduce = mode;  // (the captured single-frame passes are keyed by it: switching back and forth replays, nothing is dropped)
+    return 0;
 }
 
 int arp_clip_get_text_features(arp_clip* c, float* out) {
@@ -1015,9 +1047,10 @@ int arp_clip_encode_image(arp_clip* c, const uint8_t* frames, int n, int H, int 
     if (!frames || !out) return fail("null buffer");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     ResizePlan* plan;
-    ARP_TRY(get_plan(c, H, W, use_crop, &plan));
-    const size_t fb = (size_t)H * W * 3;
     const int mb = c->cfg.max_batch, E = c->cfg.embed;
+    // (a call of one or two frames -- the rollout loop's goal-conditioned reward, envs/vl_reward.py:26-41 -- gets the small-tile preprocess plan)
+    ARP_TRY(get_plan(c, H, W, use_crop, &plan, n <= mb && (long)n * c->ntok() <= c->lat_rows));
+    const size_t fb = (size_t)H * W * 3;
     ARP_TRY(c->frames_in.ensure((size_t)std::min(n, mb) * fb));
     ARP_TRY(ensure_workspace(c, std::min(n, mb)));
     for (int off = 0; off < n; off += mb) {
@@ -1036,29 +1069,35 @@ int arp_clip_encode_image(arp_clip* c, const uint8_t* frames, int n, int H, int 
 
 // Frozen-tower outputs for the fine-tune head (row N2): per-block CLS features [n, layers*width] and the un-normalised
 // CLIP image feature [n, embed], through the fine-tune transform (bilinear; clip_multiscale_adapter.py:120-149).
-static int encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter, float* final_feat, bool dev_out) {
+// pil_crop < 0: the fine-tune transform; 0 / 1: the LABEL transform instead (Pillow bicubic + normalise, use_crop = pil_crop) -- what the rollout
+// loop's adapter rewards feed the model: `model.encode_image(preprocess(Image.fromarray(obs)))`, envs/vl_reward.py:44-79.
+static int encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter, float* final_feat, bool dev_out, int pil_crop = -1) {
     ARP_TRY(check_ready(c, false));
     if (n < 0) return fail("negative frame count");
     if (n == 0) return 0;
     if (!frames || !inter || !final_feat) return fail("null buffer");
     const int R = c->cfg.img_res;
     if (H <= 0 || W <= 0 || H > 0xffff || W > 0xffff) return fail("bad frame geometry");
-    if ((H != R) != (W != R)) return fail("the reference resizes only when BOTH sides differ from 224 (clip_multiscale_adapter.py:127): "
+    if (pil_crop < 0 && (H != R) != (W != R)) return fail("the reference resizes only when BOTH sides differ from 224 (clip_multiscale_adapter.py:127): "
                                           "a frame with exactly one side at 224 cannot enter the tower");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     const size_t fb = (size_t)H * W * 3;
     const int mb = c->cfg.max_batch, E = c->cfg.embed, LD = c->vis.layers * c->cfg.width;
+    ResizePlan* plan = nullptr;
+    if (pil_crop >= 0) ARP_TRY(get_plan(c, H, W, pil_crop, &plan, n <= mb && (long)n * c->ntok() <= c->lat_rows));
     ARP_TRY(c->frames_in.ensure((size_t)std::min(n, mb) * fb));
     ARP_TRY(ensure_workspace(c, std::min(n, mb)));
-    DevBuf ms;
+    const bool keep = (size_t)std::min(n, mb) * LD * 4 <= (1u << 20);  // a few frames: the export buffer stays with the handle
+    DevBuf ms_tmp;
+    DevBuf& ms = keep ? c->ms_keep : ms_tmp;
     int rc = 0;
     auto body = [&]() -> int {
         ARP_TRY(ms.ensure((size_t)std::min(n, mb) * LD * 4));
         for (int off = 0; off < n; off += mb) {
             const int nb = std::min(mb, n - off);
             ARP_HIP_OK(hipMemcpyAsync(c->frames_in.p, frames + (size_t)off * fb, (size_t)nb * fb, hipMemcpyHostToDevice, c->stream));
-            c->ms_out = ms.as<float>(); c->ms_ld = LD; c->ms_rows = nullptr; c->pre_bilinear = (H << 16) | W;
-            const int r = forward_chunk_dispatch(c, c->frames_in.as<uint8_t>(), nb, nullptr);
+            c->ms_out = ms.as<float>(); c->ms_ld = LD; c->ms_rows = nullptr; c->pre_bilinear = pil_crop < 0 ? ((H << 16) | W) : 0;
+            const int r = forward_chunk_dispatch(c, c->frames_in.as<uint8_t>(), nb, plan);
             c->ms_out = nullptr; c->pre_bilinear = 0;
             ARP_TRY(r);
             const hipMemcpyKind kind = dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -1070,12 +1109,17 @@ static int encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, in
     };
     rc = body();
     c->ms_out = nullptr; c->pre_bilinear = 0;
-    ms.release();
+    ms_tmp.release();
     return rc;
 }
 
 int arp_clip_encode_image_multiscale(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter, float* final_feat) {
     return encode_image_multiscale(c, frames, n, H, W, inter, final_feat, false);
+}
+// The same outputs through the LABEL transform (Pillow-exact bicubic resize to 224 + normalise; use_crop as arp_clip_label): the input the rollout
+// loop's adapter rewards give the fine-tuned model (arp_dt/envs/vl_reward.py:44-61, 64-79).
+int arp_clip_encode_image_multiscale_pil(arp_clip* c, const uint8_t* frames, int n, int H, int W, int use_crop, float* inter, float* final_feat) {
+    return encode_image_multiscale(c, frames, n, H, W, inter, final_feat, false, use_crop ? 1 : 0);
 }
 // Same, with the two outputs in DEVICE memory (arp_dev_malloc): the features go to arp_ft_set_batch_dev without touching the host.
 int arp_clip_encode_image_multiscale_dev(arp_clip* c, const uint8_t* frames, int n, int H, int W, float* inter_dev, float* final_dev) {

@@ -30,6 +30,7 @@
 #include "ftops.h"
 #include "gemm.h"
 #include "gemm256.h"
+#include "gemm_tn.h"
 #include "rccl_dl.h"
 #include "runtime.h"
 
@@ -68,6 +69,9 @@ struct arp_ft {
     DevBuf dropped;  // one counter: non-finite gradient elements AdamW treated as missing (f16 mode only), cumulative
     DevBuf mirror;  // bf16 mode: bf16 copy of the flat parameter vector (same offsets) = every forward-layout operand
     DevBuf sW1t[2], sW2t[2], sV1t;
+    // 16-bit modes: dX = dY . W on the "NN" kernel (gemm_tn.h: W read AS STORED through the transposing LDS read), every dX ahead of its layer's
+    // weight-gradient GEMM (whose fused AdamW epilogue moves the weight): no transposed shadows, no ft.refresh_shadows.  ARP_FT_NN=0: round 3's NT path.
+    bool nn_dx = true;
     // inputs
     DevBuf x_in[2], x_fin[2], r, action;
     // per tower (0 = image rows Mi, 1 = text rows Mt)
@@ -225,6 +229,30 @@ int ft_gemm(arp_ft* c, const char* site, const void* A, int lda, const void* W, 
     return 0;
 }
 
+// dX[M, N] (ldo) = dY[M, K] . W[K, N] (+ resid) with W = the operand-type mirror of a weight [out = K, in = N] as it lies in memory: the NN kernel,
+// split over K into f32 slabs (as ft_gemm splits its NT products), fixed-order reduction.
+template <typename T, typename OutT>
+int ft_gemm_nn(arp_ft* c, const char* site, const void* A, int lda, const void* W, int ldw, const float* resid, OutT* out, int ldo, int M, int N, int K) {
+    static_assert(sizeof(T) == 2, "16-bit modes only");
+    const int nk = K / 64;
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    static const int wg_target = getenv("ARP_SPLITK_WGS") ? atoi(getenv("ARP_SPLITK_WGS")) : 512;
+    int S = std::max(1, std::min(nk, wg_target / std::max(tiles, 1)));
+    const int per = (nk + S - 1) / S;
+    S = (nk + per - 1) / per;
+    ProfScope ps(c->prof, c->stream, site);
+    ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
+    GemmTnArgs g;
+    g.A = A; g.B = W; g.out = c->part.as<float>(); g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldw; g.ldo = N; g.ksplit = S;
+    g.slice_stride = (size_t)M * N; g.alpha = 1.f;
+    ARP_TRY(launch_gemm_nn(__is_same(T, bf16_t) ? 1 : 2, g, c->stream));
+    const size_t MN = (size_t)M * N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, (const float*)nullptr, (int)ACT_NONE, out,
+                       resid, ldo == N ? 0 : ldo);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int sgemm(arp_ft* c, const float* A, int ta, const float* Bm, int tb, const float* bias, float* C, int M, int N, int K, int lda, int ldb, int act = ACT_NONE) {
     SmallGemm g{A, Bm, bias, nullptr, C, M, N, K, lda, ldb, N, ta, tb, act, 0};
     hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv(N, 32), cdiv(M, 32)), dim3(256), 0, c->stream, g);
@@ -243,12 +271,17 @@ template <typename T> const T* fwd_w(arp_ft* c, const std::string& name) {
 // host-side parameter write forces a conversion pass.  Transposed operands ([in, out], for dX) are rebuilt every step
 // from the operand-type copy.
 template <typename T> int refresh_shadows(arp_ft* c) {
-    if (!c->shadows_stale && !c->transposed_stale) return 0;
+    const bool nn = sizeof(T) == 2 && c->nn_dx;
+    if (!c->shadows_stale && (!c->transposed_stale || nn)) return 0;
     ProfScope ps(c->prof, c->stream, "ft.refresh_shadows");
     const int F = c->F(), Hd = c->Hd(), Hi = c->cfg.hidden;
     if (sizeof(T) == 2 && c->shadows_stale) {
         hipLaunchKernelGGL((convert_kernel<T>), dim3(cdiv(c->P, 1024)), dim3(256), 0, c->stream, c->params.as<float>(), c->mirror.as<T>(), c->P);
         ARP_HIP_OK(hipGetLastError());
+    }
+    if (nn) {  // the dX products read the mirror in place
+        c->shadows_stale = false;
+        return 0;
     }
     for (int w = 0; w < 2; ++w) {
         const std::string a = std::string(TW[w]) + "_adapter";
@@ -411,10 +444,16 @@ template <typename T> int backward(arp_ft* c) {
         hipLaunchKernelGGL((rowsum_kernel<T>), dim3(Hi), dim3(256), 0, c->stream, c->dHinvt.as<T>(), Bp, B, c->g("inverse_layer.layers.0.bias"), Hi);
         ARP_HIP_OK(hipGetLastError());
     }
+    const bool nn = sizeof(T) == 2 && c->nn_dx;  // (nn_dx already says the geometry fits the kernel: arp_ft_create)
+    // NN path: every dX runs BEFORE its layer's weight-gradient GEMM -- that GEMM's fused AdamW epilogue moves the weight (and its mirror) in place
+    if constexpr (sizeof(T) == 2) {
+        if (nn) ARP_TRY((ft_gemm_nn<T, float>(c, "ft.inverse_fc1_dX", c->dHinvT_.p, Hi, fwd_w<T>(c, "inverse_layer.layers.0.weight"), 4 * F, nullptr, c->dC.as<float>(),
+                                              4 * F, B, 4 * F, Hi)));
+    }
     ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1_dW", c->dHinvt.p, Bp, c->Ct.p, Bp, nullptr, ACT_NONE, nullptr, c->g("inverse_layer.layers.0.weight"), 4 * F, Hi,
                                4 * F, Bp)));
     ARP_TRY(ft_bucket_ready(c, 0));
-    ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1_dX", c->dHinvT_.p, Hi, c->sV1t.p, Hi, nullptr, ACT_NONE, nullptr, c->dC.as<float>(), 4 * F, B, 4 * F, Hi)));
+    if (!nn) ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1_dX", c->dHinvT_.p, Hi, c->sV1t.p, Hi, nullptr, ACT_NONE, nullptr, c->dC.as<float>(), 4 * F, B, 4 * F, Hi)));
     {
         ProfScope ps(c->prof, c->stream, "ft.rowops");
         if (k.goal_conditioned)
@@ -441,20 +480,27 @@ template <typename T> int backward(arp_ft* c) {
         ARP_TRY((ft_transpose<float, float, T>(c, c->dA[w].as<float>(), F, nullptr, c->dAT_[w].as<T>(), F, c->dAt[w].as<T>(), Mp, M, F)));
         ARP_TRY((ft_transpose<T, T, T>(c, c->H[w].as<T>(), Hd, nullptr, nullptr, 0, c->HT[w].as<T>(), Mp, M, Hd)));
         // A = H W2^T + b2
+        if constexpr (sizeof(T) == 2) {
+            if (nn) ARP_TRY((ft_gemm_nn<T, T>(c, (pre + "_fc2_dX").c_str(), c->dAT_[w].p, F, fwd_w<T>(c, a + ".layers.3.weight"), Hd, nullptr, c->dH[w].as<T>(), Hd, M, Hd, F)));
+        }
         ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc2_dW").c_str(), c->dAt[w].p, Mp, c->HT[w].p, Mp, nullptr, ACT_NONE, nullptr, c->g(a + ".layers.3.weight"), Hd, F,
                                    Hd, Mp)));
         ARP_TRY(ft_bucket_ready(c, 1 + 3 * w));
-        ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc2_dX").c_str(), c->dAT_[w].p, F, c->sW2t[w].p, F, nullptr, ACT_NONE, nullptr, c->dH[w].as<T>(), Hd, M, Hd, F)));
+        if (!nn) ARP_TRY((ft_gemm<T, T>(c, (pre + "_fc2_dX").c_str(), c->dAT_[w].p, F, c->sW2t[w].p, F, nullptr, ACT_NONE, nullptr, c->dH[w].as<T>(), Hd, M, Hd, F)));
         // relu mask (H is the post-activation), both layouts; H = relu(f W1^T + b1)
         ARP_TRY((ft_transpose<T, T, T>(c, c->dH[w].as<T>(), Hd, c->H[w].as<T>(), c->dHp[w].as<T>(), Hd, c->dHpt[w].as<T>(), Mp, M, Hd)));
         hipLaunchKernelGGL((rowsum_kernel<T>), dim3(Hd), dim3(256), 0, c->stream, c->dHpt[w].as<T>(), Mp, M, c->g(a + ".layers.0.bias"), Hd);
         ARP_HIP_OK(hipGetLastError());
+        // df = res*dy (direct path) + dHpre W1
+        if constexpr (sizeof(T) == 2) {
+            if (nn) ARP_TRY((ft_gemm_nn<T, float>(c, (pre + "_fc1_dX").c_str(), c->dHp[w].p, Hd, fwd_w<T>(c, a + ".layers.0.weight"), F, c->dfd[w].as<float>(),
+                                                  c->df[w].as<float>(), F, M, F, Hd)));
+        }
         ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc1_dW").c_str(), c->dHpt[w].p, Mp, c->fTt[w].p, Mp, nullptr, ACT_NONE, nullptr, c->g(a + ".layers.0.weight"), F, Hd,
                                    F, Mp)));
         ARP_TRY(ft_bucket_ready(c, 2 + 3 * w));
-        // df = res*dy (direct path) + dHpre W1
-        ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc1_dX").c_str(), c->dHp[w].p, Hd, c->sW1t[w].p, Hd, nullptr, ACT_NONE, c->dfd[w].as<float>(),
-                                   c->df[w].as<float>(), F, M, F, Hd)));
+        if (!nn) ARP_TRY((ft_gemm<T, float>(c, (pre + "_fc1_dX").c_str(), c->dHp[w].p, Hd, c->sW1t[w].p, Hd, nullptr, ACT_NONE, c->dfd[w].as<float>(),
+                                            c->df[w].as<float>(), F, M, F, Hd)));
         // U = X Wint^T occupies the first Dt columns of f
         ARP_TRY((ft_transpose<float, float, T>(c, c->df[w].as<float>(), F, nullptr, nullptr, 0, c->dUt[w].as<T>(), Mp, M, Dt)));
         ARP_TRY((ft_gemm<T, float>(c, (pre + "_inter_dW").c_str(), c->dUt[w].p, Mp, c->XT[w].p, Mp, nullptr, ACT_NONE, nullptr,
@@ -583,6 +629,11 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
         if (const char* e = getenv("ARP_FT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
         if (const char* e = getenv("ARP_FT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
         if (const char* e = getenv("ARP_FT_FUSE_ADAM")) c->fuse_adam = atoi(e) != 0;
+        if (const char* e = getenv("ARP_FT_NN")) c->nn_dx = atoi(e) != 0;
+        {   // the NN dX kernel wants output widths in multiples of 128 and contraction lengths in multiples of 64 (16-bit modes only)
+            const int Fq = c->F(), Hq = c->Hd();
+            c->nn_dx = c->nn_dx && k.mode != ARP_MODE_F32 && Fq % 128 == 0 && Hq % 128 == 0 && k.hidden % 64 == 0;
+        }
         DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
         for (auto* b : fb) {
             ARP_TRY(b->ensure(c->P * 4));
@@ -592,8 +643,10 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
         ARP_TRY(c->dropped.ensure(16));
         ARP_HIP_OK(hipMemset(c->dropped.p, 0, 16));
         if (k.mode != ARP_MODE_F32) ARP_TRY(c->mirror.ensure(c->P * e));
-        for (int w = 0; w < 2; ++w) { ARP_TRY(c->sW1t[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2t[w].ensure(Hd * Fd * e)); }
-        ARP_TRY(c->sV1t.ensure(Hi * 4 * Fd * e));
+        if (!c->nn_dx) {  // the NT dX path's transposed weight shadows (817 MB at the real geometry in a 16-bit mode)
+            for (int w = 0; w < 2; ++w) { ARP_TRY(c->sW1t[w].ensure(Hd * Fd * e)); ARP_TRY(c->sW2t[w].ensure(Hd * Fd * e)); }
+            ARP_TRY(c->sV1t.ensure(Hi * 4 * Fd * e));
+        }
         return 0;
     };
     if (body() != 0) { arp_ft_destroy(c); return -1; }

@@ -40,5 +40,9 @@ struct GemmTnArgs {
 
 // tcode: 1 = bf16, 2 = f16 (defined in gemm_tn.hip)
 int launch_gemm_tn(int tcode, const GemmTnArgs& g, hipStream_t stream);
+// "NN": C[M,N] = alpha * sum_k A[m,k] . B[k,n] -- A [M, lda] K-contiguous, B [K, ldb] row-major as a weight [out, in] lies in memory (dX = dY . W with no
+// transposed copy of W).  Same argument struct; M arbitrary (rows past M are never stored), N a multiple of 128, K a multiple of 64; split-K slabs
+// [ksplit][M][N] (ldo = N) or ksplit == 1 with out [M, ldo].
+int launch_gemm_nn(int tcode, const GemmTnArgs& g, hipStream_t stream);
 
 }  // namespace arp

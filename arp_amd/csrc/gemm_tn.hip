@@ -367,6 +367,142 @@ template <typename T> static int launch_impl(const GemmTnArgs& g, hipStream_t st
     return 0;
 }
 
+
+// ---- "NN" GEMM: C[M,N] = sum_k A[m,k] . B[k,n] -- A K-contiguous (an activation gradient [rows, out]), B stored ROW-major with the contraction
+// index as the row (a weight [out, in] AS IT LIES IN MEMORY): dX = dY . W without a transposed copy of W (the fine-tune head rebuilt 381 M
+// elements of transposed weight shadows every step for its NT dX products: ft.refresh_shadows, 0.34 ms of 3.6).  A tiles as in gemm.h
+// ([128 m][64 k] 128-B rows, 16-B chunk ^ (row & 7), ds_read_b128 fragments: lane group fg of k-step st holds k = 32 st + 8 fg + j), B tiles as in
+// gemm_tn_kernel ([64 k][128 n] 256-B rows by LDS-DMA, fragments by the transposing read) -- with the k-slot mapping of A: the two reads of
+// a B fragment take rows 32 st + 8 fg + {0..3} and + {4..7}, and the 32-B slot key is ((row >> 3) & 1) << 2 | (row & 3), so that the two
+// 16-lane groups of a half-wave (rows 8 apart) still meet eight different slots.  Split-K over gridDim.y into f32 slabs; rows of A past M
+// are clamped (never stored), N a multiple of 128, K a multiple of 64.
+template <typename T>
+__global__ __launch_bounds__(TN_THREADS) void gemm_nn_kernel(GemmTnArgs g) {
+    static_assert(sizeof(T) == 2, "16-bit operand types only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n_tiles = g.N / TN_BN, m_tiles = (g.M + TN_BM - 1) / TN_BM;
+    const int tile = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    // tiles of one column block are neighbours (the m-tiles of a weight column panel share it through L2)
+    const int m0 = (tile % m_tiles) * TN_BM, n0 = (tile / m_tiles) * TN_BN;
+    const T* __restrict__ A = static_cast<const T*>(g.A);
+    const T* __restrict__ B = static_cast<const T*>(g.B);
+
+    int nk = g.K / TN_BK, kt0 = 0;
+    if (g.ksplit > 1) {
+        const int per = (nk + g.ksplit - 1) / g.ksplit;
+        kt0 = blockIdx.y * per;
+        nk = max(min(per, nk - kt0), 0);
+    }
+    // ---- LDS-DMA plans ------------------------------------------------------------------------------------------------------------
+    // A: a piece = 8 rows x 128 B; wave w fills pieces w, w + 4, w + 8, w + 12
+    const int arow = lane >> 3, achunk = (lane & 7) ^ arow;
+    // B: a piece = 4 rows x 256 B; wave w fills pieces 4w .. 4w + 3
+    const int prow = lane >> 4, pc = lane & 15;
+    const T* srcA[4];
+    const T* srcB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int am = m0 + (i * 4 + wave) * 8 + arow;
+        am = am < g.M ? am : g.M - 1;
+        srcA[i] = A + (size_t)am * g.lda + (size_t)kt0 * TN_BK + achunk * 8;
+        const int row = (wave * 4 + i) * 4 + prow;
+        const int key = (((row >> 3) & 1) << 2) | (row & 3);
+        const int lc = ((((pc >> 1) ^ key) << 1) | (pc & 1)) * 8;
+        srcB[i] = B + (size_t)(kt0 * TN_BK + row) * g.ldb + n0 + lc;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * TN_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + (size_t)kt * TN_BK),
+                                             (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + (size_t)kt * TN_BK * g.ldb),
+                                             (__attribute__((address_space(3))) void*)(base + TN_OP_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+    const int fr = lane & 15, fg = lane >> 4;
+    const int trq = fr >> 2, trp = fr & 3;
+    auto fragB = [&](const char* op, int blk16, int st) {
+        const int r0 = 32 * st + 8 * fg + trq, r1 = r0 + 4;
+        const int k0 = (((r0 >> 3) & 1) << 2) | (r0 & 3);  // = the key of r1 as well (bits 0, 1 and 3 agree)
+        const tr_b64_v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) tr_b64_v*)(op + r0 * 256 + ((blk16 ^ k0) << 5) + trp * 8));
+        const tr_b64_v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) tr_b64_v*)(op + r1 * 256 + ((blk16 ^ k0) << 5) + trp * 8));
+        const u32x2_v l2 = __builtin_bit_cast(u32x2_v, lo), h2 = __builtin_bit_cast(u32x2_v, hi);
+        return u32x4_v{l2[0], l2[1], h2[0], h2[1]};
+    };
+    f32x4_v acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    if (nk > 0) {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            const char* a_op = smem + cur * TN_STAGE_BYTES;
+            const char* b_op = a_op + TN_OP_BYTES;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4_v af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const u32x4_v*>(a_op + (wr * 64 + i * 16 + fr) * 128 + (((st * 4 + fg) ^ (fr & 7)) << 4));
+                    bf[i] = fragB(b_op, wc * 4 + i, st);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma16<T>(bf[ni], af[mi], acc[ni][mi]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    float* out = g.out + (size_t)blockIdx.y * g.slice_stride;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wr * 64 + mi * 16 + fr;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = n0 + wc * 64 + ni * 16 + fg * 4;
+            const f32x4_v a4 = acc[ni][mi];
+            *reinterpret_cast<float4*>(out + (size_t)m * g.ldo + n) = make_float4(a4[0] * g.alpha, a4[1] * g.alpha, a4[2] * g.alpha, a4[3] * g.alpha);
+        }
+    }
+}
+
+template <typename T> static int launch_nn_impl(const GemmTnArgs& g, hipStream_t stream) {
+    if (g.M <= 0) return 0;
+    if (g.N <= 0 || g.N % TN_BN || g.K <= 0 || g.K % TN_BK || (g.lda & 7) || (g.ldb & 7) || (g.ldo & 3) || g.ksplit < 1)
+        return fail("gemm_nn: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) + " K=" + std::to_string(g.K));
+    auto kern = gemm_nn_kernel<T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles = ((g.M + TN_BM - 1) / TN_BM) * (g.N / TN_BN);
+    hipLaunchKernelGGL(kern, dim3(tiles, g.ksplit), dim3(TN_THREADS), TN_LDS_BYTES, stream, g);
+    ARP_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_nn(int tcode, const GemmTnArgs& g, hipStream_t stream) {
+    if (tcode == 1) return launch_nn_impl<bf16_t>(g, stream);
+    if (tcode == 2) return launch_nn_impl<f16_t>(g, stream);
+    return fail("gemm_nn: 16-bit operand types only");
+}
+
 int launch_gemm_tn(int tcode, const GemmTnArgs& g, hipStream_t stream) {
     if (tcode == 1) return launch_impl<bf16_t>(g, stream);
     if (tcode == 2) return launch_impl<f16_t>(g, stream);

@@ -297,6 +297,36 @@ class FinetunedClip:
         a = self.head.encode_image(*self.towers.encode_image_multiscale(np.ascontiguousarray(images)))
         return (np.exp(self.head.cfg.logit_scale) * (a @ self._text[0])).astype(np.float32)
 
+    # -- the rollout loop's online rewards with the fine-tuned model (arp_dt/envs/vl_reward.py:44-79) --------------------------------
+    def _online_features(self, frame, use_crop):
+        """``model.encode_image(preprocess(Image.fromarray(obs)))``: the LABEL transform (Pillow bicubic), not the fine-tune one, in front of
+        towers + head; ``use_crop`` = the numpy centre crop to half the frame height applied first (vl_reward.py:46-47)."""
+        f = np.asarray(frame)
+        if f.ndim == 3:
+            f = f[None]
+        return self.head.encode_image(*self.towers.encode_image_multiscale(np.ascontiguousarray(f), pil=True, use_crop=use_crop))
+
+    def online_reward(self, obs, mean_over_prompts=False, use_crop=False):
+        """get_torch_clip_adapter_reward (vl_reward.py:44-61): exp(logit_scale) * <adapted image, adapted prompt p>, prompt 0 -- or the mean over
+        the cached prompts where the reference's ``pos_text`` is a list.  float32 [1]."""
+        a = self._online_features(obs, use_crop)
+        logit = np.exp(self.head.cfg.logit_scale) * (self._text @ a[0])  # [n_prompts]
+        return np.asarray([logit.mean() if mean_over_prompts else logit[0]], np.float32)
+
+    def online_goal_reward(self, obs, goal_image, use_crop=False):
+        """get_torch_clip_adapter_goal_conditioned_reward (vl_reward.py:64-79): -||a(obs) - a(goal)||_2 on the ADAPTED (normalised) features."""
+        obs, goal_image = np.asarray(obs), np.asarray(goal_image)
+        if use_crop:  # the reference crops obs first and then sizes the goal's crop from the CROPPED obs (a quarter of the frame): kept
+            from .label_reward import center_crop
+            h = obs.shape[0] // 2
+            obs = center_crop(obs[None], (h, h))[0]
+            goal_image = center_crop(goal_image[None], (h // 2, h // 2))[0]
+        if obs.shape == goal_image.shape:
+            a = self._online_features(np.stack([obs, goal_image]), False)
+        else:
+            a = np.concatenate([self._online_features(obs, False), self._online_features(goal_image, False)])
+        return -1.0 * float(np.linalg.norm(a[0].astype(np.float64) - a[1].astype(np.float64)))
+
     def close(self):
         self.head.close()
         self.towers.close()

@@ -129,14 +129,88 @@ def make_compute_reward(model_type="clip"):
     return compute_reward
 
 
+def center_crop(image, crop_size):
+    """label_reward.py:15-36: ``image[:, sh:sh+ch, sw:sw+cw]`` of an [N, H, W, C] stack, ``sh = int((H - ch) / 2)``."""
+    _, H, W, _ = image.shape
+    ch, cw = crop_size
+    sh, sw = int((H - ch) / 2), int((W - cw) / 2)
+    return image[:, sh: sh + ch, sw: sw + cw, :]
+
+
+def _prompt_mode(clip_model, pos_text):
+    """The rollout loop's ``isinstance(pos_text, list)`` switch (envs/vl_reward.py:19-22, 56-59): a list of prompts -> the mean over the
+    prompts cached by ``set_text`` (their count must match), a single prompt (str / None) -> prompt 0.  A 2-D int array is taken as
+    ``clip.tokenize`` output: it is (re)encoded and reduced like a list."""
+    if isinstance(pos_text, np.ndarray) and pos_text.dtype.kind in "iu" and pos_text.ndim == 2:
+        key = pos_text.tobytes()
+        if getattr(clip_model, "_online_tokens", None) != key:
+            clip_model.set_text(pos_text)
+            clip_model._online_tokens = key
+        return pos_text.shape[0] > 1
+    if isinstance(pos_text, list):
+        n = getattr(clip_model, "_n_prompts", None)
+        if n is None and getattr(clip_model, "_text", None) is not None:
+            n = len(clip_model._text)
+        if n is not None and n != len(pos_text):
+            raise ValueError(f"pos_text lists {len(pos_text)} prompts but {n} are cached: call set_text with the tokens of exactly these prompts")
+        return True
+    return False
+
+
 def get_torch_clip_reward(clip_model, obs, pos_text=None, use_crop=False):
     """Online single-frame reward of the rollout loop (/root/reference/arp_dt/envs/vl_reward.py:11-23):
-    one uint8 frame [H,W,3] (or a stack [N,H,W,3]) -> float32 [N]; the prompt is the one cached by
-    ``clip_model.set_text``.  Same kernels as the offline path at N = 1."""
+    one uint8 frame [H,W,3] (or a stack [N,H,W,3]) -> float32 [N]; the prompt(s) are the ones cached by
+    ``clip_model.set_text`` -- ``pos_text`` a list: ``logits_per_text.mean(axis=0)`` over them (:19-20), otherwise prompt 0.
+    Same kernels as the offline path; a call of a few frames runs on the latency path."""
     obs = np.asarray(obs)
     if obs.ndim == 3:
         obs = obs[None]
-    return clip_model.label(obs, use_crop=use_crop)
+    mean = _prompt_mode(clip_model, pos_text)
+    if hasattr(clip_model, "set_prompt_reduce"):
+        clip_model.set_prompt_reduce("mean" if mean else "first")
+    elif mean:
+        raise TypeError("this model object cannot average over prompts")
+    try:
+        return clip_model.label(obs, use_crop=use_crop)
+    finally:
+        if mean:
+            clip_model.set_prompt_reduce("first")  # the offline pass on the same handle keeps label_reward.py:146 (prompt 0)
+
+
+def get_torch_clip_goal_conditioned_reward(clip_model, obs, goal_image, use_crop=False):
+    """vl_reward.py:26-41: ``-||encode_image(obs) - encode_image(goal)||_2`` on the UN-normalised CLIP image features; a python float.
+    ``use_crop``: obs is centre-cropped to half its height, and the goal to half of the CROPPED obs' height -- a quarter of the frame; the
+    reference sizes the second crop from the already re-assigned ``obs`` (:29-31) and that is what is reproduced."""
+    obs, goal_image = np.asarray(obs), np.asarray(goal_image)
+    if use_crop:
+        h = obs.shape[0] // 2
+        obs = center_crop(obs[None], (h, h))[0]
+        goal_image = center_crop(goal_image[None], (h // 2, h // 2))[0]
+    if obs.shape == goal_image.shape:  # one call of two frames (the latency path takes up to 1 024 token rows)
+        f = clip_model.encode_image(np.stack([obs, goal_image]), use_crop=False, normalize=False)
+    else:
+        f = np.concatenate([clip_model.encode_image(np.ascontiguousarray(obs[None]), use_crop=False, normalize=False),
+                            clip_model.encode_image(np.ascontiguousarray(goal_image[None]), use_crop=False, normalize=False)])
+    return -1.0 * float(np.linalg.norm(f[0].astype(np.float64) - f[1].astype(np.float64)))
+
+
+def get_torch_clip_adapter_reward(clip_model, obs, pos_text=None, use_crop=False):
+    """vl_reward.py:44-61 with the fine-tuned model (``arp_amd.finetune.FinetunedClip``, prompt(s) cached by its ``set_text``):
+    ``exp(logit_scale) * <adapted image, adapted prompt>``, prompt 0 or the mean over a list of prompts; float32 [1]."""
+    return clip_model.online_reward(obs, mean_over_prompts=_prompt_mode(clip_model, pos_text), use_crop=use_crop)
+
+
+def get_torch_clip_adapter_goal_conditioned_reward(clip_model, obs, goal_image, use_crop=False):
+    """vl_reward.py:64-79: ``-||a(obs) - a(goal)||_2`` on the fine-tuned model's adapted, L2-normalised image features; a python float."""
+    return clip_model.online_goal_reward(obs, goal_image, use_crop=use_crop)
+
+
+VL_REWARD_FNS = {  # the dispatch of envs/rollout_procgen.py:133-151 on vl_type
+    "clip": get_torch_clip_reward,
+    "clip_goal_conditioned": get_torch_clip_goal_conditioned_reward,
+    "clip_ft": get_torch_clip_adapter_reward,
+    "clip_ft_goal_conditioned": get_torch_clip_adapter_goal_conditioned_reward,
+}
 
 
 def _prefetch(it, depth=4):

@@ -129,7 +129,10 @@ def run_secondary(a):
     driver's single run of bench.py carries them.  Called before the parent initialises the GPU."""
     runs = {
         "policy": ["--path", "policy"],
-        "policy_with_encoder": ["--path", "policy", "--with-encoder"],
+        # row N1: the parity-true line runs in f32 (the reference's own arithmetic type; its encoder-inside logits meet 1e-3 on every seed,
+        # tests/test_m3ae_gpu.py); the f16 line beside it is a throughput mode whose own parity block says whether it is inside
+        "policy_with_encoder": ["--path", "policy", "--with-encoder", "--mode", "f32"],
+        "policy_with_encoder_f16": ["--path", "policy", "--with-encoder", "--mode", "f16"],
         "finetune": ["--path", "finetune"],
         "label_vit_b16": ["--model", "ViT-B/16", "--batch", "256"],
         "online": ["--path", "online"],
@@ -433,6 +436,39 @@ def bench_online(a):
         lat[name] = {"latency_ms": round(float(np.median(ts)) * 1e3, 4), "mean_ms": round(float(np.mean(ts)) * 1e3, 4),
                      "p99_ms": round(float(np.quantile(ts, 0.99)) * 1e3, 4), "device_ms": round(dev, 4), "launches": launches, "calls": reps}
         m.close()
+    # the rest of the rollout loop's reward dispatch (envs/rollout_procgen.py:133-151; vl_reward.py:19-22,26-41,44-79) on the model the
+    # reference loads (ViT-B/16): a list of prompts, the goal-conditioned distance (two frames per call), and both with the fine-tuned head
+    def med(fn, n=reps):
+        for _ in range(5):
+            fn()
+        ts_ = []
+        for _ in range(n):
+            t0_ = time.perf_counter()
+            fn()
+            ts_.append(time.perf_counter() - t0_)
+        return round(float(np.median(ts_)) * 1e3, 4)
+
+    more = {}
+    cfg = clip.MODELS["ViT-B/16"]
+    fr = synth.procgen_like_frames(8, seed=3)
+    W16 = synth.clip_weights(cfg, seed=0)
+    m = clip.ClipLabeller(cfg, W16, mode=a.mode, max_batch=64, n_streams=1).set_text(synth.prompt_tokens(3, [8, 6, 9], seed=2))
+    k = [0]
+
+    def nxt():
+        k[0] = (k[0] + 1) % 7
+        return fr[k[0]]
+    more["clip_list_of_3_prompts"] = med(lambda: L.get_torch_clip_reward(m, nxt(), ["a", "b", "c"]))
+    more["clip_goal_conditioned"] = med(lambda: L.get_torch_clip_goal_conditioned_reward(m, nxt(), fr[7]))
+    m.close()
+    from arp_amd import finetune as FT
+    hcfg = FT.FinetuneConfig()
+    ckpt = {**{"clip_model." + kk: v for kk, v in W16.items()}, **FT.synth_params(hcfg, seed=0)}
+    fm = FT.FinetunedClip.from_state_dict(ckpt, mode=a.mode, model=cfg).set_text(synth.prompt_tokens(1, 8, seed=2))
+    del ckpt, W16
+    more["clip_ft"] = med(lambda: L.get_torch_clip_adapter_reward(fm, nxt(), "a"), max(reps // 2, 25))
+    more["clip_ft_goal_conditioned"] = med(lambda: L.get_torch_clip_adapter_goal_conditioned_reward(fm, nxt(), fr[7]), max(reps // 2, 25))
+    fm.close()
     pcfg = PolicyConfig(lambda_ret=0.01)
     tr = PolicyTrainer(pcfg, mode=a.mode)
     tr.set_params(S.policy_params(pcfg, seed=0))
@@ -451,7 +487,10 @@ def bench_online(a):
                      "ms_per_step": v, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
                      "config": {"workload": "get_torch_clip_reward: one 256x256x3 uint8 host frame in, one f32 reward out per call (ViT-B/32; the same for "
                                             "ViT-B/16 under reward); greedy_action: one [1,4,257,768] f32 window of encodings in, one action out"},
-                     "reward": lat, "greedy_action": ga}))
+                     "reward": lat, "greedy_action": ga,
+                     "more_rewards_ms": more, "more_rewards_note": "ViT-B/16, one host frame (two for the goal-conditioned ones) in, one reward out per call: "
+                     "get_torch_clip_reward with a list of 3 prompts, get_torch_clip_goal_conditioned_reward, get_torch_clip_adapter_reward and "
+                     "get_torch_clip_adapter_goal_conditioned_reward (frozen towers + the 476 M-parameter fine-tuned head at batch 1)"}))
 
 
 def bench_h5(a):

@@ -92,6 +92,10 @@ int arp_clip_finalize_weights(arp_clip* h);
  * text features (the reference re-runs it per trajectory, label_reward.py:136-141). */
 int arp_clip_set_text(arp_clip* h, const int32_t* tokens, int n_prompts);
 int arp_clip_get_text_features(arp_clip* h, float* out /* [n_prompts, embed], L2-normalised */);
+/* Which reduction over the cached prompts a reward is: 0 (default) = logits_per_text[0], prompt 0 whatever was cached (the offline pass,
+ * arp_dt/label_reward.py:146); 1 = logits_per_text.mean(axis=0) over all cached prompts -- the rollout loop's live branch for a LIST of prompts
+ * (arp_dt/envs/vl_reward.py:19-22).  Applies to every labelling call of the handle until changed. */
+int arp_clip_set_prompt_reduce(arp_clip* h, int mode);
 
 /* compute_reward (label_reward.py:132-146): uint8 NHWC frames -> float32 rewards
  * = exp(logit_scale) * cos(image, prompt 0).  use_crop selects the transform of label_reward.py:92-102. */
@@ -250,6 +254,11 @@ int arp_clip_encode_text_multiscale(arp_clip* h, const int32_t* tokens /* [n, ct
 /* The same two calls with their OUTPUTS in device memory (arp_dev_malloc), for arp_ft_set_batch_dev: the tower features
  * then never cross PCIe. */
 int arp_clip_encode_image_multiscale_dev(arp_clip* h, const uint8_t* frames_nhwc, int n, int H, int W, float* inter_dev, float* final_dev);
+/* The same two outputs through the LABEL transform (Pillow-exact bicubic resize + normalise, use_crop as in arp_clip_label) instead of the
+ * fine-tune transform: what the rollout loop's adapter rewards hand the fine-tuned model -- `model.encode_image(preprocess(Image.fromarray(obs)))`,
+ * arp_dt/envs/vl_reward.py:44-61 (get_torch_clip_adapter_reward) and :64-79 (..._goal_conditioned_reward).  A call of a few frames runs on the
+ * latency path. */
+int arp_clip_encode_image_multiscale_pil(arp_clip* h, const uint8_t* frames, int n, int H, int W, int use_crop, float* inter, float* final_feat);
 int arp_clip_encode_text_multiscale_dev(arp_clip* h, const int32_t* tokens, int n, float* inter_dev, float* final_dev);
 int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out);
 int arp_ft_destroy(arp_ft* h);

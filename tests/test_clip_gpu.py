@@ -548,3 +548,51 @@ def test_pipelined_submit_collect_equals_synchronous_label(gpu_lib):
     with pytest.raises(ArpError):
         m.label_submit(1, synth.procgen_like_frames(301, seed=3))  # more than max_batch
     m.close()
+
+
+def test_online_reward_family_full_vit_b16(gpu_lib):
+    """Row N4, the rest of the rollout loop's dispatch (envs/rollout_procgen.py:133-151) at the model the reference loads (ViT-B/16, f16 operands,
+    latency path): get_torch_clip_reward with a LIST of prompts = the mean over prompts of the logits (vl_reward.py:19-22) and with one prompt =
+    prompt 0; get_torch_clip_goal_conditioned_reward = -||f(obs) - f(goal)|| on un-normalised features, two frames per call (:26-41), with the
+    reference's crop-of-the-cropped goal under use_crop.  Oracle: oracle/clip_np in fp64."""
+    from arp_amd import clip, synth, label_reward as L
+    from oracle import clip_np as C, preprocess as PP
+    cfg = clip.MODELS["ViT-B/16"]
+    ocfg = C.ClipConfig(patch=cfg.patch)
+    W = synth.clip_weights(ocfg, seed=0)
+    fr = synth.procgen_like_frames(4, seed=11)
+    tok3 = synth.prompt_tokens(3, [8, 5, 11], seed=12)
+    Wd = C.cast_weights(W, np.float64)
+    feat = C.encode_image(Wd, ocfg, PP.preprocess(fr).astype(np.float64))
+    txt = C.encode_text(Wd, ocfg, tok3)
+    logits = np.exp(float(W["logit_scale"])) * (C.l2n(txt) @ C.l2n(feat).T)  # [3 prompts, 4 frames]
+    m = clip.ClipLabeller(cfg, W, mode="f16", n_streams=1).set_text(tok3)
+    scale = 100.0
+    for i in range(4):
+        r_list = L.get_torch_clip_reward(m, fr[i], ["a", "b", "c"])
+        r_one = L.get_torch_clip_reward(m, fr[i], "a")
+        assert r_list.shape == (1,) and r_one.shape == (1,)
+        assert abs(r_list[0] - logits[:, i].mean()) / scale < COS_TOL_F16, (i, r_list, logits[:, i].mean())
+        assert abs(r_one[0] - logits[0, i]) / scale < COS_TOL_F16
+    assert np.array_equal(m.label(fr), np.concatenate([L.get_torch_clip_reward(m, fr[i]) for i in range(4)]))  # back on prompt 0
+    with pytest.raises(ValueError):
+        L.get_torch_clip_reward(m, fr[0], ["only", "two"])
+    # a token array as pos_text re-encodes the prompts and averages over them
+    r_tok = L.get_torch_clip_reward(m, fr[0], tok3[:2])
+    assert abs(r_tok[0] - logits[:2, 0].mean()) / scale < COS_TOL_F16
+    m.set_text(tok3)
+    # goal-conditioned: un-normalised features, python float
+    fn = np.linalg.norm(feat, axis=1).mean()
+    for i in (0, 1, 2):
+        got = L.get_torch_clip_goal_conditioned_reward(m, fr[i], fr[3])
+        ref = -np.linalg.norm(feat[i] - feat[3])
+        assert isinstance(got, float) and abs(got - ref) < 2e-3 * fn, (got, ref, fn)
+    assert L.get_torch_clip_goal_conditioned_reward(m, fr[3], fr[3]) == 0.0
+    # use_crop: obs -> centre 128 x 128, goal -> centre 64 x 64 (the reference sizes the second crop from the cropped obs)
+    o, g = fr[0][64:192, 64:192], fr[3][96:160, 96:160]
+    fo = C.encode_image(Wd, ocfg, PP.preprocess(o[None]).astype(np.float64))[0]
+    fg = C.encode_image(Wd, ocfg, PP.preprocess(g[None]).astype(np.float64))[0]
+    got = L.get_torch_clip_goal_conditioned_reward(m, fr[0], fr[3], use_crop=True)
+    assert abs(got + np.linalg.norm(fo - fg)) < 2e-3 * fn, (got, np.linalg.norm(fo - fg))
+    assert set(L.VL_REWARD_FNS) == {"clip", "clip_goal_conditioned", "clip_ft", "clip_ft_goal_conditioned"}
+    m.close()

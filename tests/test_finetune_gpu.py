@@ -557,3 +557,126 @@ def test_goal_conditioned_head_matches_the_reference_class_fixture(gpu_lib, mode
     mu = tr.get_tensors(2)
     assert all(not np.any(mu[k]) for k in P if k.startswith("text_"))
     tr.close()
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_online_adapter_rewards(gpu_lib, full):
+    """Row N4 with the fine-tuned model (envs/vl_reward.py:44-79): get_torch_clip_adapter_reward = exp(logit_scale) <adapted image, adapted prompt>
+    (prompt 0, or the mean over a list of prompts) and get_torch_clip_adapter_goal_conditioned_reward = -||a(obs) - a(goal)|| -- on ONE frame per
+    call, through the LABEL transform (Pillow bicubic; `preprocess(Image.fromarray(obs))`), not the fine-tune one.  Oracle: oracle/clip_torch towers
+    on oracle/preprocess frames + oracle/finetune_torch head in fp64.  full = the real ViT-B/16 + 476 M-parameter head geometry in f16."""
+    import torch
+    from arp_amd import clip, label_reward as LR, synth
+    from arp_amd import finetune as FT
+    from oracle import clip_np as C, clip_torch as CT, finetune_torch as O, preprocess as PP
+    if full:
+        ccfg = clip.MODELS["ViT-B/16"]
+        ocfg = C.ClipConfig(patch=16)
+        hcfg = O.HeadConfig(logit_scale=float(np.log(100.0)))
+        mode, tol = "f16", 2.5e-3
+    else:
+        ccfg, ocfg = clip.ClipConfig(**TOWER), C.ClipConfig(**TOWER)
+        hcfg = O.HeadConfig(layers=2, width_v=64, width_t=64, embed=64, hidden=64, logit_scale=float(np.log(100.0)))
+        mode, tol = "f32", 2e-4
+    W = synth.clip_weights(ocfg, seed=171)
+    W["logit_scale"] = np.float32(hcfg.logit_scale) * np.ones((), np.float32)
+    P = O.init_params(hcfg, seed=172)
+    P["image_residual_weight"] = np.float32(0.5) * np.ones((), np.float32)
+    P["text_residual_weight"] = np.float32(-0.2) * np.ones((), np.float32)
+    fr = synth.procgen_like_frames(3, 256, 256, seed=173)
+    tok = synth.prompt_tokens(2, [6, 9], ctx=ocfg.ctx, vocab=ocfg.vocab, seed=174)
+    Wt, Pt = CT.to_torch(W), O.to_torch(P)
+
+    def adapted(frames):
+        x = torch.from_numpy(PP.preprocess(frames)).float()
+        ii, fi = CT.encode_image_multiscale(Wt, ocfg, x)
+        return O._encode(Pt, "image", ii.double(), fi.double()).numpy()
+
+    ti, tf = CT.encode_text_multiscale(Wt, ocfg, tok)
+    t = O._encode(Pt, "text", ti.double(), tf.double()).numpy()
+    a = adapted(fr)
+    logit = np.exp(hcfg.logit_scale) * (t @ a.T)  # [2 prompts, 3 frames]
+    ckpt = {**{"clip_model." + k: v for k, v in W.items()}, **P}
+    m = FT.FinetunedClip.from_state_dict(ckpt, mode=mode, model=ccfg).set_text(tok)
+    for i in range(3):
+        r0 = LR.get_torch_clip_adapter_reward(m, fr[i], "one prompt")
+        rm = LR.get_torch_clip_adapter_reward(m, fr[i], ["one prompt", "another"])
+        assert r0.shape == (1,) and r0.dtype == np.float32 and rm.shape == (1,)
+        assert abs(r0[0] - logit[0, i]) < tol * 100 and abs(rm[0] - logit[:, i].mean()) < tol * 100, (r0, logit[0, i], rm, logit[:, i].mean())
+    g = LR.get_torch_clip_adapter_goal_conditioned_reward(m, fr[0], fr[2])
+    assert isinstance(g, float) and abs(g + np.linalg.norm(a[0] - a[2])) < tol * 4, (g, np.linalg.norm(a[0] - a[2]))
+    # use_crop: obs centre half, goal centre quarter (the reference's crop of the cropped obs)
+    ac = np.concatenate([adapted(fr[0:1, 64:192, 64:192]), adapted(fr[2:3, 96:160, 96:160])])
+    gc = LR.get_torch_clip_adapter_goal_conditioned_reward(m, fr[0], fr[2], use_crop=True)
+    assert abs(gc + np.linalg.norm(ac[0] - ac[1])) < tol * 4
+    rc = LR.get_torch_clip_adapter_reward(m, fr[1], "one prompt", use_crop=True)
+    assert abs(rc[0] - np.exp(hcfg.logit_scale) * float(t[0] @ adapted(fr[1:2, 64:192, 64:192])[0])) < tol * 100
+    m.close()
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_nn_dx_path_equals_the_transposed_shadow_path(gpu_lib, monkeypatch, mode):
+    """Round 4: dX = dY . W on the NN kernel (gemm_tn.h::gemm_nn_kernel: the weight read as stored through the transposing LDS read, every dX ahead of
+    its layer's fused weight-gradient + AdamW GEMM) against ARP_FT_NN=0 (round 3: NT products on transposed weight shadows rebuilt every step), full
+    476 M-parameter geometry, three steps: same 16-bit operands and the same products, summed in a different order -- losses, parameters and moments
+    agree to f32 round-off; the NN handle never runs ft.refresh_shadows after its first step and holds no shadow buffers."""
+    import ctypes as C
+    from arp_amd import _ffi, finetune as FT
+    cfg = FT.FinetuneConfig()
+    P = FT.synth_params(cfg, seed=3)
+    batch = FT.synth_batch(cfg, 64, seed=4)
+    probe = ("image_intermediate_linear.weight", "text_intermediate_linear.weight", "image_adapter.layers.0.weight", "text_adapter.layers.3.weight",
+             "inverse_layer.layers.0.weight", "image_adapter.layers.0.bias", "text_residual_weight")
+    out = {}
+    for nn in ("1", "0"):
+        monkeypatch.setenv("ARP_FT_NN", nn)
+        tr = FT.FinetuneTrainer(cfg, mode=mode)
+        tr.set_params(P)
+        tr.set_batch(*batch)
+        aux = [tr.train_step(1e-4) for _ in range(2)]
+        tr.profile(True); tr.profile_reset()
+        aux.append(tr.train_step(1e-4))
+        sites = tr.profile_read(); tr.profile(False)
+        got = {}
+        for k in probe:
+            for which in (0, 2, 3):
+                a = np.empty(tr.shapes[k], np.float32)
+                _ffi.check(_ffi.lib.arp_ft_get_tensor(tr._h, k.encode(), which, _ffi.as_ptr(a, C.c_float)))
+                got[(k, which)] = a
+        out[nn] = ([a["loss"] for a in aux], got, sites)
+        tr.close()
+    assert "ft.refresh_shadows" not in out["1"][2] and "ft.refresh_shadows" in out["0"][2]
+    assert {"ft.image_fc2_dX", "ft.image_fc1_dX", "ft.text_fc2_dX", "ft.text_fc1_dX", "ft.inverse_fc1_dX"} <= set(out["1"][2])
+    la, lb = out["1"][0], out["0"][0]
+    assert max(abs(x - y) for x, y in zip(la, lb)) < 2e-5 * max(1.0, abs(lb[0])), (la, lb)
+    for key, a in out["1"][1].items():
+        b = out["0"][1][key]
+        # (a first-moment entry is ~ the gradient: the two summation orders differ in the last f32 bits of an entry that is itself a sum of 16-bit products)
+        assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-12) + 1e-12, (key, float(np.abs(a - b).max()), float(np.abs(b).max()))
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_fused_adamw_leaves_the_gradientless_inverse_model_alone_at_full_geometry(gpu_lib, mode):
+    """use_id = 0 (the reference's use_id_loss=False) in a 16-bit mode at the real geometry -- where ft.inverse_fc1_dW runs on the GEMM
+    whose epilogue applies AdamW -- must leave inverse_layer.* and lambda_id bit for bit untouched (torch.optim.AdamW skips .grad is None: no decay, no
+    moments), as the f32 path and ARP_FT_FUSE_ADAM=0 do.  Before the fix the fused epilogue decayed inverse_layer.layers.0.weight by 1 - lr wd per step."""
+    import ctypes as C
+    from arp_amd import _ffi, finetune as FT
+    cfg = FT.FinetuneConfig(use_id=False, weight_decay=0.05)
+    P = FT.synth_params(cfg, seed=5)
+    tr = FT.FinetuneTrainer(cfg, mode=mode)
+    tr.set_params(P)
+    tr.set_batch(*FT.synth_batch(cfg, 64, seed=6))
+    for _ in range(3):
+        tr.train_step(1e-3)
+    for k in ("inverse_layer.layers.0.weight", "inverse_layer.layers.0.bias", "inverse_layer.layers.3.weight", "inverse_layer.layers.3.bias", "lambda_id"):
+        for which in (0, 2, 3):
+            a = np.empty(tr.shapes[k], np.float32)
+            _ffi.check(_ffi.lib.arp_ft_get_tensor(tr._h, k.encode(), which, _ffi.as_ptr(a, C.c_float)))
+            want = np.asarray(P[k], np.float32).reshape(tr.shapes[k]) if which == 0 else np.zeros(tr.shapes[k], np.float32)
+            assert np.array_equal(a, want), (k, which)
+    moved = np.empty(tr.shapes["image_adapter.layers.0.weight"], np.float32)
+    _ffi.check(_ffi.lib.arp_ft_get_tensor(tr._h, b"image_adapter.layers.0.weight", 0, _ffi.as_ptr(moved, C.c_float)))
+    assert not np.array_equal(moved, P["image_adapter.layers.0.weight"])  # the rest of the head did train
+    assert tr.dropped_gradients == 0
+    tr.close()

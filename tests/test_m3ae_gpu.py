@@ -70,13 +70,17 @@ def test_train_step_with_encoder_inside(gpu_lib):
     a.close(); b.close(); enc.close()
 
 
-def test_policy_logits_with_the_f16_encoder_inside_full_geometry(gpu_lib):
-    """VERDICT r2 next #2a: the configuration `bench.py --path policy --with-encoder` times -- frames in, f16 encoder (ViT-B/16 at
-    256 x 256, 257 tokens) in front of the f16 policy -- against oracle/m3ae_np -> oracle/arpdt_torch in fp64, at the real geometry.
-    Measured (round 3): 0.74-1.01e-3 on the logits with the policy's f32 image_text_input forward (the default; 1.04-1.25e-3
-    without it) -- the twelve f16 encoder layers alone leave 3e-3 max / 5.5e-4 rms on the LayerNorm'ed encodings -- so this row
-    (N1) sits AT north_star's 1e-3 in f16, not safely inside it, and well inside only in the f32 mode (2e-6).  The test pins the
-    measured level with headroom for other seeds; README / DESIGN say so."""
+def test_policy_logits_with_the_encoder_inside_full_geometry(gpu_lib):
+    """Row N1 at the real geometry (VERDICT r3 next #1a): frames in, the frozen encoder (ViT-B/16 at 256 x 256, 257 tokens) in front of the policy,
+    against oracle/m3ae_np -> oracle/arpdt_torch in fp64, EIGHT seeds.
+    * f32 mode -- the mode `bench.py`'s `policy_with_encoder` line times, and the reference's own arithmetic type (its JAX model runs in float32):
+      asserted at north_star's 1e-3 on every seed (measured 1.4e-6 ... 2.1e-6).
+    * f16 mode -- a THROUGHPUT mode with a stated error, NOT a parity claim: measured over these eight seeds (scripts/n1_parity_probe.py,
+      profiles/r4_n1_probe.txt) 0.74e-3 ... 1.54e-3, four seeds outside 1e-3.  The probe also separates the two sources: f16 encoder in front of an
+      f32 policy 0.50 ... 1.31e-3, f32 encoder in front of the f16 policy 0.57 ... 1.23e-3 -- each about one f16 rounding step (2^-11) per operand
+      of a chain of dependent contractions whose outputs are themselves random sums, so there is no averaging to count on; halving it needs
+      hi + lo operand pairs on both sides of every GEMM and an f32 attention, i.e. three MFMAs per product.  Asserted here at the
+      measured level with headroom, on four seeds."""
     import torch
     from arp_amd import m3ae, synth_policy as S
     from arp_amd.train import PolicyConfig, PolicyTrainer
@@ -85,7 +89,7 @@ def test_policy_logits_with_the_f16_encoder_inside_full_geometry(gpu_lib):
     pcfg, pocfg = PolicyConfig(lambda_ret=0.01), O.PolicyConfig(lambda_ret=0.01)
     B, T = 2, pcfg.window
     errs = {}
-    for seed in (0, 1):
+    for seed in range(8):
         EP = S.m3ae_params(eocfg, seed=50 + seed)
         P = S.policy_params(pcfg, seed=60 + seed)
         rng = np.random.default_rng(70 + seed)
@@ -95,7 +99,7 @@ def test_policy_logits_with_the_f16_encoder_inside_full_geometry(gpu_lib):
         codes = M.forward_representation(EP, eocfg, frames.reshape(-1, 256, 256, 3)).reshape(B, T, ecfg.tokens, ecfg.width)
         Pt = {k: torch.from_numpy(v).double() for k, v in P.items()}
         ref = O.forward(Pt, pocfg, torch.from_numpy(np.asarray(codes, np.float64)), torch.from_numpy(act).long(), torch.from_numpy(rtg).double())
-        for mode in ("f16", "f32"):
+        for mode in ("f32",) + (("f16",) if seed < 4 else ()):
             enc = m3ae.M3AEEncoder(ecfg, EP, mode=mode)
             tr = PolicyTrainer(pcfg, mode=mode)
             tr.set_params(P)
@@ -106,8 +110,10 @@ def test_policy_logits_with_the_f16_encoder_inside_full_geometry(gpu_lib):
             errs[(mode, seed)] = e
             tr.close(); enc.close()
     print("policy logits / return with the encoder inside, full geometry: " + ", ".join(f"{m} seed {s}: {e:.2e}" for (m, s), e in errs.items()))
-    assert max(e for (m, s), e in errs.items() if m == "f32") < 5e-5
-    assert max(e for (m, s), e in errs.items() if m == "f16") < 1.6e-3  # NOT north_star's 1e-3: see the docstring
+    f32 = [e for (m, s), e in errs.items() if m == "f32"]
+    assert len(f32) == 8 and max(f32) < 1e-3  # north_star, on every seed, in the mode that is timed
+    assert max(f32) < 5e-5
+    assert max(e for (m, s), e in errs.items() if m == "f16") < 2.5e-3  # NOT north_star's 1e-3: see the docstring
 
 
 def test_prefetched_frames_with_the_encoder_inside_equal_the_synchronous_path(gpu_lib):
