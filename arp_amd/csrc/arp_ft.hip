@@ -377,6 +377,11 @@ template <typename T> int forward(arp_ft* c) {
     ARP_TRY((ft_gemm<T, float>(c, "ft.inverse_fc1", c->CT_.p, 4 * F, fwd_w<T>(c, "inverse_layer.layers.0.weight"), 4 * F,
                                c->p("inverse_layer.layers.0.bias"), ACT_RELU, nullptr, c->Hinv.as<float>(), Hi, B, Hi, 4 * F)));
     ProfScope ps(c->prof, c->stream, "ft.loss");
+    if ((Hi & 3) == 0) {  // logits [B, 15] over K = hidden: one wave per logit
+        hipLaunchKernelGGL(ft_rowdot_kernel, dim3(cdiv((size_t)B * NA, 4)), dim3(256), 0, c->stream, c->Hinv.as<float>(), c->p("inverse_layer.layers.3.weight"),
+                           c->p("inverse_layer.layers.3.bias"), c->logits.as<float>(), B, NA, Hi, Hi, Hi);
+        ARP_HIP_OK(hipGetLastError());
+    } else
     ARP_TRY(sgemm(c, c->Hinv.as<float>(), 0, c->p("inverse_layer.layers.3.weight"), 1, c->p("inverse_layer.layers.3.bias"), c->logits.as<float>(), B, NA, Hi,
                   Hi, Hi));
     hipLaunchKernelGGL(ft_loss_kernel, dim3(1), dim3(256), 0, c->stream, c->scores.as<float>(), c->r.as<float>(), c->logits.as<float>(), c->action.as<int>(),

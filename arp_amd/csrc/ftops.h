@@ -142,6 +142,28 @@ static __global__ __launch_bounds__(256) void ft_loss_kernel(const float* __rest
     }
 }
 
+// out[m, n] = bias[n] + sum_k A[m, k] W[n, k]: ONE WAVE per output element, for products with a handful of outputs and a long contraction (the inverse
+// model's logits: 64 x 15 outputs, K = 1024 -- on the 32 x 32-tile small GEMM that was two workgroups walking 1024 k one after the other, 70 us of a
+// 3.4 ms step).  The k order is fixed (lane-strided float4 chunks, then the wave's butterfly): bit-reproducible.
+static __global__ __launch_bounds__(256) void ft_rowdot_kernel(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int M, int N, int K, int lda, int ldw) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= M * N) return;
+    const int m = o / N, n = o - m * N;
+    const float* a = A + (size_t)m * lda;
+    const float* w = W + (size_t)n * ldw;
+    float s = 0.f;
+    int k = lane * 4;
+    for (; k + 3 < K; k += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(a + k), y = *reinterpret_cast<const float4*>(w + k);
+        s += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    // (K is a multiple of 4: the caller checks)
+    s = wave_sum(s);
+    if (lane == 0) out[o] = s + (bias ? bias[n] : 0.f);
+}
+
 // C[b] = [a1, t, a2, t]   (:232-235)
 static __global__ __launch_bounds__(256) void ft_build_c_kernel(const float* __restrict__ a, const float* __restrict__ t, float* __restrict__ C,
                                                                 int B, int F) {

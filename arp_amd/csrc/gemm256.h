@@ -106,7 +106,7 @@ __device__ long long* arp_g2_stamps = nullptr;  // scripts/gemm256_bench.hip: pe
 #ifndef ARP_G2_MFMA32
 #define ARP_G2_MFMA32 0
 #endif
-#ifndef ARP_G2_ABL  // harness ablations: bit 0 = no fragment reads after the first K-tile, bit 1 = no LDS-DMA after the prologue (wrong results, timing only)
+#ifndef ARP_G2_ABL  // harness ablations: bit 0 = no fragment reads after the first K-tile, bit 1 = no LDS-DMA after the prologue, bit 2 = no residual read in the f32 epilogue (wrong results, timing only)
 #define ARP_G2_ABL 0
 #endif
 typedef __attribute__((ext_vector_type(16))) float f32x16_v;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                     for (int it = 0; it < 16; ++it) {
                         const int lr = it * 8 + wave;
                         const int m = m0 + (lr >> 6) * 128 + p * 64 + (lr & 63), n = n0 + lane * 4;
-                        rres[it] = (m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        rres[it] = ((ARP_G2_ABL & 4) == 0 && m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
 #pragma unroll

@@ -639,6 +639,18 @@ def bench_finetune(a):
         kern = f"ft_adamw_kernel @ {site}"
     avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
     flops = FT.flops_per_sample(cfg) * a.finetune_batch
+    # HBM bytes of the dominant launch from the committed PMC passes (scripts/prof_round.sh -> profiles/pmc_traffic_finetune.json), matched by the weight's size
+    traffic = traffic_src = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_finetune.json")))
+        if site in dw_sites and a.finetune_batch == 64:
+            n_el = int(np.prod(tr.shapes[dw_sites[site]]))
+            for e in rec["fused_adamw_gemm_by_grid_threads"].values():
+                if e["weight_elements"] == n_el:
+                    traffic = e["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/pmc_traffic_finetune.json ({rec.get('round')}): committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; NOT measured in this run"
+    except (OSError, ValueError, KeyError):
+        traffic = None
     if rank != 0:
         tr.close()
         dist.destroy_process_group()
@@ -654,7 +666,7 @@ def bench_finetune(a):
                                f"(BASELINE.json configs[4])", "parallelism": "single GPU (as the reference)" if world == 1 else f"dp{world}: one RCCL all-reduce(sum) of the "
                                f"flat f32 gradient ({tr.n_params * 4 / 1e9:.1f} GB) per step"},
         "roofline": {"bound": "hbm", "achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": kern,
+                     "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "kernel": kern,
                      "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms},
         "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12},
         "cpu_baseline": cpu, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],

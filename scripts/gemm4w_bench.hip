@@ -1,6 +1,6 @@
 // A/B harness: the four-wave 256x256 GEMM (gemm4w.h) against the eight-wave one (gemm256.h), same operands, one process, interleaved
 // rounds; FNV checksums of the outputs must agree bit for bit.
-//   cd arp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++20 -I. ../../scripts/gemm4w_bench.hip -o ../../scripts/gemm4w_bench.bin
+//   cd arp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++20 -I. -I../../scripts ../../scripts/gemm4w_bench.hip -o ../../scripts/gemm4w_bench.bin
 #include <algorithm>
 #include <cstdio>
 #include <vector>

@@ -23,14 +23,14 @@ out_dir = os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
 # bench site -> substrings that identify its kernel instantiation (round 2: the QKV projection + attention run as qkv_attn_kernel,
-# out_proj on the two-workgroups-per-CU kernel; template arguments of gemm256_nt_kernel are <T, OutT, ACT, RESID, SITE>)
+# out_proj on the two-workgroups-per-CU kernel; template arguments of gemm256_nt_kernel are <T, OutT, ACT, RESID, SITE, M32> since round 4)
 SITES = {
-    "vit.c_fc": ("gemm256_nt_kernel", "1, false, 3>"),
-    "vit.c_proj": ("gemm256_nt_kernel", "0, true, 4>"),
+    "vit.c_fc": ("gemm256_nt_kernel", "1, false, 3,"),
+    "vit.c_proj": ("gemm256_nt_kernel", "0, true, 4,"),
     "vit.qkv_attn": ("qkv_attn_kernel",),
-    "vit.qkv": ("gemm256_nt_kernel", "0, false, 1>"),
+    "vit.qkv": ("gemm256_nt_kernel", "0, false, 1,"),
     "vit.out_proj": ("gemm2w_kernel", "float, 0, true>"),
-    "vit.patch_embed": ("gemm256_nt_kernel", "0, false, 0>"),
+    "vit.patch_embed": ("gemm256_nt_kernel", "0, false, 0,"),
     "vit.ln": ("layernorm_kernel",),
 }
 FRAMES_PER_LAUNCH = int(os.environ.get("FRAMES_PER_LAUNCH", "1024"))  # the largest grid of a site = bench.py's single-stream (isolated) pass: 1024 frames per launch
