@@ -16,7 +16,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libarp_hip.so")
 
-MODE_F32, MODE_BF16, MODE_F16 = 0, 1, 2
+MODE_F32, MODE_BF16, MODE_F16, MODE_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_QGELU, ACT_RELU, ACT_TANH, ACT_GELU_TANH = 0, 1, 2, 3, 4
 
 

@@ -55,6 +55,31 @@ __global__ __launch_bounds__(256) void enc_assemble_kernel(const float* __restri
     store4(x + i, v[0], v[1], v[2], v[3]);
 }
 
+// ARP_MODE_F16X3: f32 [rows, K] -> binary16 [rows, 3K] = [hi | lo | hi], hi = rn16(x), lo = rn16(x - hi): the A operand of a K-concatenated product against
+// [W_hi | W_hi | W_lo] -- x.W to ~2^-22 on three 16-bit MFMAs (hi.hi is exact in the f32 accumulator; lo.lo, ~2^-24, is dropped).  Values whose lo falls below
+// binary16's normal range keep an absolute error <= 3e-8 (subnormals are not flushed on this path).  8 elements per thread.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, f16_t* __restrict__ out, size_t rows, int K) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= rows * (size_t)K) return;
+    const size_t r = i / K;
+    const int k = (int)(i - r * K);
+    float va[4], vb[4];
+    load4(x + i, va);
+    load4(x + i + 4, vb);
+    const float v[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float h0 = h2f(f2h(v[2 * j])), h1 = h2f(f2h(v[2 * j + 1]));
+        hi[j] = pack_h2(h0, h1);
+        lo[j] = pack_h2(v[2 * j] - h0, v[2 * j + 1] - h1);
+    }
+    f16_t* o = out + r * 3 * (size_t)K + k;
+    *reinterpret_cast<uint4*>(o) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(o + K) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *reinterpret_cast<uint4*>(o + 2 * (size_t)K) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+}
+
 struct HostTensor {
     std::vector<float> data;
     std::vector<int64_t> shape;
@@ -73,10 +98,11 @@ struct arp_enc {
     float *b_emb = nullptr, *cls = nullptr, *pos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
     int ws_frames = 0;
     DevBuf patches, pe, x, h, qkv, ao, fc, img_in, out;
+    DevBuf a3;  // ARP_MODE_F16X3: the [hi | lo | hi] operand of the current GEMM, binary16 [rows, 3 * (mlp_ratio * width)]
     Profiler prof;
     int gemm_force = 0;
     int tokens() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
-    size_t esz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
+    size_t esz() const { return (cfg.mode == ARP_MODE_F32 || cfg.mode == ARP_MODE_F16X3) ? 4 : 2; }  // element size of the ACTIVATION buffers
 };
 
 namespace {
@@ -96,6 +122,24 @@ int up_kernel(arp_enc* c, const float* src, int in, int out_, void** out) {
     for (int i = 0; i < in; ++i)
         for (int o = 0; o < out_; ++o) t[(size_t)o * in + i] = src[(size_t)i * out_ + o];
     void* p = nullptr;
+    if (c->cfg.mode == ARP_MODE_F16X3) {  // [out, 3 in] = [W_hi | W_hi | W_lo]
+        std::vector<f16_t> hb(3 * n);
+        for (int o = 0; o < out_; ++o)
+            for (int i = 0; i < in; ++i) {
+                const float w = t[(size_t)o * in + i];
+                const f16_t h = host_f2h(w);
+                const float hf = (float)__builtin_bit_cast(_Float16, h.b);
+                f16_t* row = hb.data() + (size_t)o * 3 * in;
+                row[i] = h;
+                row[in + i] = h;
+                row[2 * in + i] = host_f2h(w - hf);
+            }
+        ARP_HIP_OK(hipMalloc(&p, 3 * n * 2));
+        ARP_HIP_OK(hipMemcpy(p, hb.data(), 3 * n * 2, hipMemcpyHostToDevice));
+        c->owned.push_back(p);
+        *out = p;
+        return 0;
+    }
     ARP_HIP_OK(hipMalloc(&p, std::max<size_t>(n * c->esz(), 16)));
     if (c->cfg.mode == ARP_MODE_BF16) {
         std::vector<bf16_t> hb(n);
@@ -128,6 +172,7 @@ int ensure_ws(arp_enc* c, int frames) {
     ARP_TRY(c->pe.ensure(B * G * G * D * 4));
     ARP_TRY(c->x.ensure(M * D * 4)); ARP_TRY(c->h.ensure(M * D * e)); ARP_TRY(c->qkv.ensure(M * 3 * D * e));
     ARP_TRY(c->ao.ensure(M * D * e)); ARP_TRY(c->fc.ensure(M * k.mlp_ratio * D * e));
+    if (k.mode == ARP_MODE_F16X3) ARP_TRY(c->a3.ensure(std::max(M * 3 * k.mlp_ratio * D, B * G * G * 3 * k.patch * k.patch * 3) * 2));
     c->ws_frames = frames;
     return 0;
 }
@@ -159,6 +204,58 @@ template <typename T> int forward_chunk(arp_enc* c, hipStream_t stream, const fl
     return 0;
 }
 
+// ARP_MODE_F16X3: the same network with every GEMM as a K-concatenated (hi, lo) product on the f16 kernels and everything between the GEMMs in f32
+// (LayerNorm outputs, the exact-f32 attention kernel, the tanh-GELU'd hidden activation): 12 x (ln -> split -> in_proj -> attention -> split -> out_proj -> ln ->
+// split -> fc1 -> split -> fc2).  Three MFMAs per product plus the split passes: ~4x the plain f16 step, ~2x faster than the f32-MFMA mode, f32-level error.
+int forward_chunk_x3(arp_enc* c, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
+    const arp_enc_cfg& k = c->cfg;
+    const int G = k.img_res / k.patch, N = c->tokens(), D = k.width, KP = k.patch * k.patch * 3, H = k.mlp_ratio * D, M = nb * N;
+    TowerCtx t;
+    t.stream = stream; t.prof = &c->prof; t.attn_impl = 1; t.gemm_force = c->gemm_force;
+    f16_t* a3 = c->a3.as<f16_t>();
+    auto split = [&](const char* site, const float* src, size_t rows, int K) -> int {
+        if (K % 8) return fail("f16x3: widths must be multiples of 8");
+        ProfScope ps(c->prof, stream, site);
+        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((rows * K / 8 + 255) / 256)), dim3(256), 0, stream, src, a3, rows, K);
+        ARP_HIP_OK(hipGetLastError());
+        return 0;
+    };
+    {
+        ProfScope ps(c->prof, stream, "m3ae.patchify");
+        const size_t tot = (size_t)nb * G * G * KP;
+        hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, c->patches.as<float>(), nb, k.img_res, k.patch);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    ARP_TRY(split("m3ae.split", c->patches.as<float>(), (size_t)nb * G * G, KP));
+    ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", a3, c->w_emb, c->b_emb, nullptr, c->pe.p, nb * G * G, D, 3 * KP)));
+    {
+        ProfScope ps(c->prof, stream, "m3ae.assemble");
+        const size_t tot = (size_t)nb * N * D;
+        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, c->pe.as<float>(), c->cls, c->pos, c->x.as<float>(), nb * N, N, D);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    float *x = c->x.as<float>(), *h = c->h.as<float>(), *qkv = c->qkv.as<float>(), *ao = c->ao.as<float>(), *fc = c->fc.as<float>();
+    for (int i = 0; i < k.layers; ++i) {
+        const LayerW& L = c->tower.L[i];
+        ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_1", x, D, h, D, L.ln1_w, L.ln1_b, M, D, 1e-6f));
+        ARP_TRY(split("m3ae.split", h, M, D));
+        ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_QKV>(t, "m3ae.qkv", a3, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, 3 * D)));
+        {
+            ProfScope ps(c->prof, stream, "m3ae.attn");
+            ARP_TRY(launch_attention<float>(stream, 1, qkv, ao, nb, N, D, k.heads, 0));
+        }
+        ARP_TRY(split("m3ae.split", ao, M, D));
+        ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, true, 8 + SITE_OUT>(t, "m3ae.out_proj", a3, L.w_out, L.b_out, x, x, M, D, 3 * D)));
+        ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_2", x, D, h, D, L.ln2_w, L.ln2_b, M, D, 1e-6f));
+        ARP_TRY(split("m3ae.split", h, M, D));
+        ARP_TRY((tower_gemm<f16_t, float, ACT_GELU_TANH, false, 8 + SITE_FC1>(t, "m3ae.c_fc", a3, L.w_fc, L.b_fc, nullptr, fc, M, H, 3 * D)));
+        ARP_TRY(split("m3ae.split", fc, M, H));
+        ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, true, 8 + SITE_FC2>(t, "m3ae.c_proj", a3, L.w_proj, L.b_proj, x, x, M, D, 3 * H)));
+    }
+    ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_final", x, (size_t)D, out_dev, D, c->lnf_w, c->lnf_b, M, D, 1e-6f));
+    return 0;
+}
+
 }  // namespace
 
 namespace arp {
@@ -171,7 +268,8 @@ int enc_forward_on(arp_enc* c, hipStream_t stream, const float* images_dev, int 
     const size_t fi = (size_t)c->cfg.img_res * c->cfg.img_res * 3, fo = (size_t)c->tokens() * c->cfg.width;
     for (int off = 0; off < n; off += mb) {
         const int nb = std::min(mb, n - off);
-        if (c->cfg.mode == ARP_MODE_BF16) ARP_TRY(forward_chunk<bf16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
+        if (c->cfg.mode == ARP_MODE_F16X3) ARP_TRY(forward_chunk_x3(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
+        else if (c->cfg.mode == ARP_MODE_BF16) ARP_TRY(forward_chunk<bf16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
         else if (c->cfg.mode == ARP_MODE_F16) ARP_TRY(forward_chunk<f16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
         else ARP_TRY(forward_chunk<float>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
     }
@@ -190,7 +288,7 @@ extern "C" {
 int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
     if (!cfg || !out) return fail("null argument");
     const arp_enc_cfg& k = *cfg;
-    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16 && k.mode != ARP_MODE_F16) return fail("bad mode");
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16 && k.mode != ARP_MODE_F16 && k.mode != ARP_MODE_F16X3) return fail("bad mode");
     if (k.patch <= 0 || k.img_res % k.patch || k.width % k.heads || k.width % 4) return fail("bad geometry");
     const int kq = k.mode == ARP_MODE_F32 ? 32 : 64;
     if (k.width % kq || (k.patch * k.patch * 3) % kq) return fail("width and 3*patch^2 must be multiples of " + std::to_string(kq));
@@ -216,7 +314,7 @@ int arp_enc_destroy(arp_enc* c) {
     (void)hipDeviceSynchronize();
     c->prof.destroy();
     for (void* p : c->owned) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->img_in, &c->out};
+    DevBuf* bufs[] = {&c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->img_in, &c->out, &c->a3};
     for (auto* b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _ffi
-from ._ffi import MODE_BF16, MODE_F16, MODE_F32, check, lib
+from ._ffi import MODE_BF16, MODE_F16, MODE_F16X3, MODE_F32, check, lib
 
 
 @dataclass(frozen=True)
@@ -39,9 +39,12 @@ def flops_per_frame(cfg):
 
 class M3AEEncoder:
     def __init__(self, cfg, params, mode="bf16", device=0, max_frames=128, attn_impl=0):
+        """mode: "f16" / "bf16" (16-bit GEMM operands: throughput modes with a stated error), "f32" (f32-input MFMA: the parity mode) or
+        "f16x3" (every GEMM operand an (hi, lo) pair of binary16 values, three 16-bit MFMAs per product, attention / LayerNorm in f32: f32-level error at
+        about twice the f32 mode's speed)."""
         _ffi.require_gpu()
         self.cfg = cfg
-        c = _ffi.EncCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.mlp_ratio, cfg.img_res, {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32}[mode],
+        c = _ffi.EncCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.mlp_ratio, cfg.img_res, {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32, "f16x3": MODE_F16X3}[mode],
                         device, max_frames, attn_impl)
         h = C.c_void_p()
         check(lib.arp_enc_create(C.byref(c), C.byref(h)))

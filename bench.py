@@ -132,6 +132,7 @@ def run_secondary(a):
         # row N1: the parity-true line runs in f32 (the reference's own arithmetic type; its encoder-inside logits meet 1e-3 on every seed,
         # tests/test_m3ae_gpu.py); the f16 line beside it is a throughput mode whose own parity block says whether it is inside
         "policy_with_encoder": ["--path", "policy", "--with-encoder", "--mode", "f32"],
+        "policy_with_encoder_f16x3": ["--path", "policy", "--with-encoder", "--mode", "f32", "--encoder-mode", "f16x3"],  # f32-accurate on the 16-bit MFMA
         "policy_with_encoder_f16": ["--path", "policy", "--with-encoder", "--mode", "f16"],
         "finetune": ["--path", "finetune"],
         "label_vit_b16": ["--model", "ViT-B/16", "--batch", "256"],
@@ -263,7 +264,7 @@ def bench_policy(a):
             codes = MO.forward_representation(EP, MO.EncConfig(), frames0.reshape(-1, 256, 256, 3)).reshape(2, cfg.window, ecfg0.tokens, ecfg0.width)
             ref = O.forward({k: torch.from_numpy(v).double() for k, v in Pp.items()}, O.PolicyConfig(lambda_ret=0.01),
                             torch.from_numpy(np.asarray(codes, np.float64)), torch.from_numpy(act).long(), torch.from_numpy(rtg).double())
-            enc0 = m3ae.M3AEEncoder(ecfg0, EP, mode=a.mode, device=local_rank, max_frames=2 * cfg.window)
+            enc0 = m3ae.M3AEEncoder(ecfg0, EP, mode=a.encoder_mode or a.mode, device=local_rank, max_frames=2 * cfg.window)
             t0.attach_encoder(enc0)
             t0.set_batch_images(frames0, act, rtg)
             out = t0.forward()
@@ -286,7 +287,7 @@ def bench_policy(a):
     if a.with_encoder:
         from arp_amd import m3ae
         ecfg = m3ae.EncoderConfig()
-        enc = m3ae.M3AEEncoder(ecfg, S.m3ae_params(ecfg, seed=0), mode=a.mode, device=local_rank, max_frames=a.policy_batch * cfg.window)
+        enc = m3ae.M3AEEncoder(ecfg, S.m3ae_params(ecfg, seed=0), mode=a.encoder_mode or a.mode, device=local_rank, max_frames=a.policy_batch * cfg.window)
         tr.attach_encoder(enc)
         _, act_, rtg_ = S.policy_batch(PolicyConfig(enc_tokens=1, enc_dim=4), a.policy_batch, seed=100 + rank)
         frames = S.normalized_frames(a.policy_batch * cfg.window, 256, seed=100 + rank).reshape(a.policy_batch, cfg.window, 256, 256, 3)
@@ -357,7 +358,9 @@ def bench_policy(a):
         site = max(known, key=lambda k: known[k]["ms"])  # the call site that takes the most time per step
         kind, work = sites[site]
         avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
-        peak = PEAK_TFLOPS[a.mode] if kind == "mfma" else 8000.0
+        emode = a.encoder_mode or a.mode
+        # the matrix pipe a site runs on: the encoder's sites follow the encoder's mode (f16x3: the 16-bit MFMA, three instructions per algorithmic product)
+        peak = (PEAK_TFLOPS["f16" if emode == "f16x3" else emode] if site.startswith("m3ae.") else PEAK_TFLOPS[a.mode]) if kind == "mfma" else 8000.0
         achieved = work / (avg_ms * 1e-3) / (1e12 if kind == "mfma" else 1e9)
         flops = policy_step_flops(cfg, a.policy_batch)
         if enc is not None:  # + the frozen encoder's forward: 46.4 GFLOP per frame, 4 frames per sample (193.5 GF per sample in all)
@@ -375,9 +378,10 @@ def bench_policy(a):
             "metric": "samples/sec ARPDT train_step (frames in, frozen M3AE encoder inside)" if enc is not None else
                       "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode if enc is None or (a.encoder_mode or a.mode) == a.mode else f"encoder {a.encoder_mode}, policy {a.mode}",
+            "data": "synthetic",
             "config": {"workload": (f"ARPDT policy train_step, {a.policy_batch} samples/GPU x window 4, FRAMES in: normalised f32 frames [B,4,256,256,3] resident in "
-                                    f"HBM -> frozen random-init M3AE ViT-B/16 encoder (257 tokens, {a.mode}) -> 26.9 M trainable params (SURVEY row N1; "
+                                    f"HBM -> frozen random-init M3AE ViT-B/16 encoder (257 tokens, {a.encoder_mode or a.mode}) -> 26.9 M trainable params, policy in {a.mode} (SURVEY row N1; "
                                     f"BASELINE.json configs[3] with the reference's own boundary)") if enc is not None else
                                    (f"ARPDT policy train_step, {a.policy_batch} samples/GPU x window 4, random-init encodings [B,4,257,768] f32 "
                                     f"resident in HBM, 26.9 M trainable params (BASELINE.json configs[3])"), "parallelism": f"dp{world}",
@@ -389,7 +393,7 @@ def bench_policy(a):
                          "traffic_source": None if traffic is None else "profiles/pmc_traffic_policy.json (committed rocprofv3 --pmc passes, not measured in this run)",
                          "note": "the call site with the largest share of the step (sites_ms_per_step)"},
             "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12,
-                           "mfma_frac_of_peak": flops / (elapsed / a.steps) / 1e12 / PEAK_TFLOPS[a.mode]},
+                           "mfma_frac_of_peak": flops / (elapsed / a.steps) / 1e12 / (PEAK_TFLOPS["f16" if (a.encoder_mode or a.mode) == "f16x3" else (a.encoder_mode or a.mode)] if enc is not None else PEAK_TFLOPS[a.mode])},
             "parity": {"max_logit_err_vs_oracle": parity, "geometry": parity_geometry, "tolerance": 1e-3,
                        "within_tolerance": None if parity is None else bool(parity < 1e-3)},
             "cpu_baseline": cpu, "seam": seam, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
@@ -705,6 +709,8 @@ def main():
     ap.add_argument("--with-towers", action="store_true", help="finetune path: run the frozen CLIP ViT-B/16 towers inside the timed step "
                     "(uint8 frames + tokens in) instead of feeding pre-computed tower features")
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
+    ap.add_argument("--encoder-mode", default=None, choices=["bf16", "f16", "f32", "f16x3"], help="policy path with --with-encoder: operand mode of the frozen encoder "
+                    "(default: --mode).  f16x3 = (hi, lo) binary16 operand pairs, three 16-bit MFMAs per product, f32 attention: f32-level error")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
     ap.add_argument("--all-secondary", dest="all_secondary", action="store_true", default=True,

@@ -27,6 +27,11 @@ extern "C" {
                            (arp_clip, arp_dt, arp_ft, arp_enc): the 16-bit mode that meets north_star's 1e-4 / 1e-3; the train steps
                            carry an exact power-of-two scale on their backward activations (binary16's exponent range) */
 
+#define ARP_MODE_F16X3 3 /* arp_enc only: f32-accurate products on the 16-bit MFMA -- every GEMM operand is an (hi, lo) pair of binary16 values and a
+                           product is hi.hi + lo.hi + hi.lo (three MFMAs, ~2^-22 relative; a K-concatenated operand [x_hi | x_lo | x_hi] against
+                           [W_hi | W_hi | W_lo] on the ordinary f16 kernels), attention / LayerNorm / residual stream in f32.  The 16-bit mode of row N1
+                           that meets north_star's 1e-3 on the policy logits (the plain f16 encoder does not: DESIGN 6b) */
+
 #define ARP_ACT_NONE 0
 #define ARP_ACT_QGELU 1
 #define ARP_ACT_RELU 2
@@ -320,7 +325,7 @@ typedef struct arp_enc_cfg {
     int32_t heads;      /* 12  */
     int32_t mlp_ratio;  /* 4   */
     int32_t img_res;    /* 256 -> 257 tokens */
-    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_F16 | ARP_MODE_BF16 (follows the policy handle it is attached to) */
+    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_F16 | ARP_MODE_BF16 | ARP_MODE_F16X3 (need not equal the mode of the policy handle it is attached to) */
     int32_t device;
     int32_t max_frames; /* frames per internal pass; <= 0 -> 128 */
     int32_t attn_impl;  /* 0 auto, 1 VALU */
