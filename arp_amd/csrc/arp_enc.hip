@@ -211,7 +211,7 @@ int forward_chunk_x3(arp_enc* c, hipStream_t stream, const float* img_dev, int n
     const arp_enc_cfg& k = c->cfg;
     const int G = k.img_res / k.patch, N = c->tokens(), D = k.width, KP = k.patch * k.patch * 3, H = k.mlp_ratio * D, M = nb * N;
     TowerCtx t;
-    t.stream = stream; t.prof = &c->prof; t.attn_impl = 1; t.gemm_force = c->gemm_force;
+    t.stream = stream; t.prof = &c->prof; t.attn_impl = k.attn_impl; t.gemm_force = c->gemm_force;
     f16_t* a3 = c->a3.as<f16_t>();
     auto split = [&](const char* site, const float* src, size_t rows, int K) -> int {
         if (K % 8) return fail("f16x3: widths must be multiples of 8");
@@ -242,7 +242,7 @@ int forward_chunk_x3(arp_enc* c, hipStream_t stream, const float* img_dev, int n
         ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_QKV>(t, "m3ae.qkv", a3, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, 3 * D)));
         {
             ProfScope ps(c->prof, stream, "m3ae.attn");
-            ARP_TRY(launch_attention<float>(stream, 1, qkv, ao, nb, N, D, k.heads, 0));
+            ARP_TRY(launch_attention<float>(stream, k.attn_impl, qkv, ao, nb, N, D, k.heads, 0));
         }
         ARP_TRY(split("m3ae.split", ao, M, D));
         ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, true, 8 + SITE_OUT>(t, "m3ae.out_proj", a3, L.w_out, L.b_out, x, x, M, D, 3 * D)));

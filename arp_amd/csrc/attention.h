@@ -66,6 +66,95 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
     }
 }
 
+
+// ---- exact-f32 MFMA kernel (head_dim 64): the parity mode's attention, and the attention of the f16x3 encoder mode ---------------------------------
+// v_mfma_f32_16x16x4_f32 is a k-ordered f32 fmaf chain (MI355X_MICROARCH: 64 FLOP/clk/SIMD, the f32 vector rate -- but it leaves the VALU to the softmax
+// and needs one operand register per lane instead of a 64-deep row per lane).  Same plan as the 16-bit kernel: S^T = K.Q^T so that the softmax'd accumulator
+// IS the B operand of O^T = V^T.P^T: register r of key tile kt holds P[key kt*16 + 4g + r][query j] in lane (g, j), and the MFMA that consumes it takes
+// V[kt*16 + 4g + r][d] as its A operand -- the contraction order over the keys is free.  K and V of one (sample, head) in LDS as f32 rows of 68 floats
+// (conflict-free for both operand reads: bank = 4 j + g for K, 16 g + j for V); one 16-query block per wave at a time, NT key tiles of accumulators
+// (68 registers at 257 tokens).  The M3AE encoder's 257-token attention in f32: 22.7 ms per step on attn_valu_kernel (one query per lane, a 64-deep
+// register row, 13 TFLOP/s) -- see DESIGN 6b for what this kernel takes.
+template <int NT>
+__global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int D, int heads, float scale,
+                                                            int causal, int nq) {
+    constexpr int HD = 64, LS = 68;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + NT * 16 * LS;
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const size_t ld = 3 * (size_t)D;
+    const float* base = qkv + (size_t)b * N * ld + h * HD;
+    for (int i = threadIdx.x; i < NT * 16 * 16; i += 256) {  // rows past N are zero keys (masked below) and zero values
+        const int t = i >> 4, c4 = (i & 15) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (t < N) {
+            kv = *reinterpret_cast<const float4*>(base + t * ld + D + c4);
+            vv = *reinterpret_cast<const float4*>(base + t * ld + 2 * D + c4);
+        }
+        *reinterpret_cast<float4*>(Ks + t * LS + c4) = kv;
+        *reinterpret_cast<float4*>(Vs + t * LS + c4) = vv;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    for (int q0 = wave * 16; q0 < nq; q0 += 64) {
+        const int qi = q0 + j;
+        const float* qrow = base + (size_t)min(qi, N - 1) * ld;
+        float qreg[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) qreg[s] = qrow[4 * s + g] * scale;
+        f32x4_v acc[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) acc[kt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)  // NT independent accumulators per k-step: no dependent-issue stall
+                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(kt * 16 + j) * LS + 4 * s + g], qreg[s], acc[kt], 0, 0, 0);
+        // softmax over the keys of query j: this lane holds keys kt*16 + 4g + r; the other three lane groups hold the rest
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                if (key >= N || (causal && key > qi)) acc[kt][r] = -INFINITY;
+                m = fmaxf(m, acc[kt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = expf(acc[kt][r] - m);  // exp(-inf) = 0 for the masked keys; key 0 is never masked, so m is finite
+                acc[kt][r] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4_v o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(kt * 16 + 4 * g + r) * LS + dt * 16 + j], acc[kt][r], o[dt], 0, 0, 0);
+        if (qi < nq) {
+            const float inv = 1.0f / l;
+            float* orow = out + ((size_t)b * N + qi) * D + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<float4*>(orow + dt * 16 + 4 * g) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+        }
+    }
+}
+
 // ---- MFMA kernel (bf16, head_dim 64) -------------------------------------------------------------
 // NT = number of 16-key tiles (keys padded to a multiple of 32, i.e. NT even).
 // LDS: K [NT*16 keys][128 B] and V [NT*16 keys][128 B], both row-major with the 16-byte chunk index XOR-swizzled

@@ -249,6 +249,28 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
         }
     }
     if (out8 != 0.f) return fail("attention: the e4m3 output exists on the MFMA kernel only");
+    if constexpr (sizeof(T) == 4) {
+        // exact-f32 attention on the f32-input MFMA (attention.h): head_dim 64, up to 288 keys in LDS
+        if (impl == 0 && hd == 64 && N <= 288 && (D & 3) == 0) {
+            const int need = (N + 15) / 16;
+#define ARP_ATTN32_CASE(nt)                                                                                                        \
+    if (need <= nt) {                                                                                                              \
+        auto kern = attn_f32_mfma_kernel<nt>;                                                                                      \
+        const int lds32 = 2 * nt * 16 * 68 * 4;                                                                                    \
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds32));   \
+        hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds32, stream, qkv, out, N, D, heads, scale, causal, nq);               \
+        ARP_HIP_OK(hipGetLastError());                                                                                             \
+        return 0;                                                                                                                  \
+    }
+            ARP_ATTN32_CASE(1)
+            ARP_ATTN32_CASE(4)
+            ARP_ATTN32_CASE(5)
+            ARP_ATTN32_CASE(13)
+            ARP_ATTN32_CASE(17)
+            ARP_ATTN32_CASE(18)
+#undef ARP_ATTN32_CASE
+        }
+    }
     const size_t lds = (size_t)2 * N * hd * 4;
     if (lds > 160 * 1024) return fail("attention: sequence too long for the LDS-resident kernel");
     const int threads = N <= 64 ? 64 : (N <= 128 ? 128 : 256);

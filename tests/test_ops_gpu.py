@@ -177,7 +177,7 @@ ATTN_CASES = [  # B, N, D, heads, causal
 
 
 @pytest.mark.parametrize("case", ATTN_CASES)
-@pytest.mark.parametrize("mode,impl", [(0, 1), (1, 1), (1, 0), (2, 1), (2, 0)])
+@pytest.mark.parametrize("mode,impl", [(0, 1), (0, 0), (1, 1), (1, 0), (2, 1), (2, 0)])  # (0, 0): the exact-f32 MFMA kernel where head_dim is 64
 def test_attention(gpu_lib, case, mode, impl):
     B, N, D, heads, causal = case
     rng = np.random.default_rng(N * 13 + D)
