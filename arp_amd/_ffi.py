@@ -33,7 +33,7 @@ class ClipCfg(C.Structure):
 class DtCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "emb", "depth", "heads", "mlp_ratio", "n_actions", "window", "enc_tokens", "enc_dim", "use_adapter", "mode",
-        "device", "world", "rank")] + [(n, C.c_float) for n in ("lambda_ret", "weight_decay", "clip_norm", "b1", "b2", "eps")]
+        "device", "world", "rank")] + [(n, C.c_float) for n in ("lambda_ret", "weight_decay", "clip_norm", "b1", "b2", "eps")] + [("alibi_bias", C.c_int32)]
 
 
 class FtCfg(C.Structure):

@@ -102,6 +102,7 @@ struct arp_dt {
     DevBuf dwsf, dbsf, dtok, loss_part, gtab, gprefix, ctab, cprefix;
     int n_gemm = 0, gemm_tiles = 0, n_cs = 0, cs_tiles = 0;
     PfArgs pf;
+    DevBuf alibi;  // per-head slopes of config.alibi_bias (null pointer semantics: cfg.alibi_bias == 0 -> the kernels get nullptr / zeros)
     DevBuf pf_pack, pf_jobs;  // fragment-major weight copies of the fused kernel's big linears and their job table (policy_fused.h)
     int pf_njobs = 0, pf_pack_blocks = 0;
     ncclComm_t comm = nullptr;
@@ -231,7 +232,8 @@ template <typename T> int small_attention_fwd(arp_dt* c, const float* qkv, float
     const size_t lds = (size_t)2 * L * hd * 4;
     const int threads = 64;
 #define ARP_DT_ATT(HD)                                                                                                   \
-    hipLaunchKernelGGL((attn_valu_kernel<float, HD>), dim3(B * heads), dim3(threads), lds, c->stream, qkv, out, L, E, heads, scale, 1, L)
+    hipLaunchKernelGGL((attn_valu_kernel<float, HD>), dim3(B * heads), dim3(threads), lds, c->stream, qkv, out, L, E, heads, scale, 1, L, \
+                       c->cfg.alibi_bias ? c->alibi.as<float>() : nullptr)
     if (hd == 16) ARP_DT_ATT(16);
     else if (hd == 32) ARP_DT_ATT(32);
     else if (hd == 64) ARP_DT_ATT(64);
@@ -364,6 +366,26 @@ bool fused_eligible(const arp_dt_cfg& k) {
 }
 
 // kernel arguments of policy_fused_kernel and the problem tables of the two grouped gradient launches
+// _get_attention_slopes (arp_dt/layers.py:97-110): the ALiBi head slopes -- 2^(-8 i / n) for a power-of-two head count n, otherwise the
+// slopes of the next lower power of two followed by every other slope of the next higher one.
+std::vector<float> alibi_slopes(int n) {
+    auto pow2 = [](int m) {
+        std::vector<float> v;
+        const double start = std::pow(2.0, -std::pow(2.0, -(std::log2((double)m) - 3.0)));
+        double x = start;
+        for (int i = 0; i < m; ++i, x *= start) v.push_back((float)x);
+        return v;
+    };
+    if (n <= 0) return {};
+    if ((n & (n - 1)) == 0) return pow2(n);
+    int c = 1;
+    while (c * 2 <= n) c *= 2;
+    std::vector<float> v = pow2(c);
+    const std::vector<float> w = alibi_slopes(2 * c);
+    for (int i = 0; i < (int)w.size() && (int)v.size() < n; i += 2) v.push_back(w[i]);
+    return v;
+}
+
 int build_fused_plan(arp_dt* c) {
     const arp_dt_cfg& k = c->cfg;
     const int E = k.emb, H = k.mlp_ratio * E, T = k.window, L = 3 * T, NA = k.n_actions, depth = k.depth;
@@ -371,6 +393,10 @@ int build_fused_plan(arp_dt* c) {
     PfArgs& a = c->pf;
     memset(&a, 0, sizeof(a));
     a.T = T; a.L = L; a.E = E; a.H = H; a.heads = k.heads; a.NA = NA; a.depth = depth; a.do_bwd = 1; a.R = R; a.lambda = k.lambda_ret;
+    {
+        const std::vector<float> sl = alibi_slopes(k.heads);
+        for (int h = 0; h < 16; ++h) a.alibi[h] = (k.alibi_bias && h < k.heads) ? sl[h] : 0.f;
+    }
     a.img = c->img.as<float>(); a.rtg = c->bt[c->cur].rtg.as<float>(); a.action = c->bt[c->cur].action.as<int>();
     a.Wr = c->p("rtg_input/kernel"); a.emb = c->p("action_input/embedding");
     std::vector<SmallGemm> gj;
@@ -801,7 +827,7 @@ template <typename T> int backward(arp_dt* c, int stage = 0) {
                 const int hd = E / k.heads;
                 const size_t lds = ((size_t)4 * L * hd + 2 * L * L) * 4;
                 hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(c->B * k.heads), dim3(64), lds, c->stream, c->qkv[i].as<float>(), c->t3.as<float>(),
-                                   c->dqkv.as<float>(), L, E, k.heads, 1.0f / sqrtf((float)hd));
+                                   c->dqkv.as<float>(), L, E, k.heads, 1.0f / sqrtf((float)hd), k.alibi_bias ? c->alibi.as<float>() : nullptr);
                 ARP_HIP_OK(hipGetLastError());
             }
             ARP_TRY(linear_bwd(c, c->ln0[i].as<float>(), c->p(p + "Attention_0/Dense_0/kernel"), c->dqkv.as<float>(), c->g(p + "Attention_0/Dense_0/kernel"),
@@ -1110,6 +1136,12 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
         if (k.mode != ARP_MODE_F32) ARP_TRY(c->mirror.ensure(c->n_mirror * e));
         if (k.use_adapter) ARP_TRY(c->W2t.ensure(D * D * e));
         ARP_TRY(c->Wit.ensure(Kin * k.emb * e));
+        if (k.alibi_bias) {
+            if (k.heads > 16) return fail("alibi_bias: at most 16 heads");
+            const std::vector<float> sl = alibi_slopes(k.heads);
+            ARP_TRY(c->alibi.ensure(64));
+            ARP_HIP_OK(hipMemcpy(c->alibi.p, sl.data(), sl.size() * 4, hipMemcpyHostToDevice));
+        }
         return 0;
     };
     if (body() != 0) { arp_dt_destroy(c); return -1; }

@@ -23,7 +23,7 @@ namespace arp {
 
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int D,
-                                                        int heads, float scale, int causal, int nq) {
+                                                        int heads, float scale, int causal, int nq, const float* __restrict__ alibi = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ks = reinterpret_cast<float*>(smem);
     float* Vs = Ks + (size_t)N * HD;
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
         Vs[i] = Elem<T>::ld(base + t * ld + 2 * D + d);
     }
     __syncthreads();
+    const float slope = alibi ? alibi[h] : 0.f;  // config.alibi_bias of the policy transformer (arp_dt/layers.py:74-78): + slope_h * key index
     for (int qi = threadIdx.x; qi < nq; qi += blockDim.x) {  // nq = N, or fewer when only the first rows are consumed
         float q[HD], acc[HD];
 #pragma unroll
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) s = fmaf(q[d], kr[d], s);
+            s += slope * (float)k;
             const float mn = fmaxf(m, s);
             const float alpha = expf(m - mn);  // exp(-inf) = 0 on the first key
             const float p = expf(s - mn);

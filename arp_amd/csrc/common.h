@@ -122,6 +122,17 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
 __device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_h2(a, b), pack_h2(c, d));
 }
+// (hi, lo) binary16 pair of four f32 values in the K-concatenated operand layout of ARP_MODE_F16X3: hi at p, lo at p + n, hi again at p + 2 n
+// ([x_hi | x_lo | x_hi] against [W_hi | W_hi | W_lo]: x.W on three 16-bit MFMAs to ~2^-22).  8-byte aligned like store4.
+__device__ __forceinline__ void store_split3(f16_t* p, size_t n, float a, float b, float c, float d) {
+    const float ha = h2f(f2h(a)), hb = h2f(f2h(b)), hc = h2f(f2h(c)), hd = h2f(f2h(d));
+    const uint2 hi = make_uint2(pack_h2(ha, hb), pack_h2(hc, hd));
+    *reinterpret_cast<uint2*>(p) = hi;
+    *reinterpret_cast<uint2*>(p + n) = make_uint2(pack_h2(a - ha, b - hb), pack_h2(c - hc, d - hd));
+    *reinterpret_cast<uint2*>(p + 2 * n) = hi;
+}
+template <typename T> __device__ __forceinline__ void store_split3(T* p, size_t n, float a, float b, float c, float d) { store4(p, a, b, c, d); }  // f16 operands only
+
 __device__ __forceinline__ void load4(const f16_t* p, float (&v)[4]) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
     const f16x2_v a = __builtin_bit_cast(f16x2_v, t.x), b = __builtin_bit_cast(f16x2_v, t.y);

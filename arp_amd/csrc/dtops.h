@@ -456,10 +456,12 @@ static __global__ __launch_bounds__(256) void ln_bwd_f32_kernel(const float* __r
 // qkv [B*L, 3E], dout [B*L, E] -> dqkv [B*L, 3E].  One workgroup per (sample, head); probabilities are
 // recomputed (arp_dt/layers.py:70-90: scale, masked fill, softmax).
 static __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                            float* __restrict__ dqkv, int L, int E, int heads, float scale) {
+                                                            float* __restrict__ dqkv, int L, int E, int heads, float scale,
+                                                            const float* __restrict__ alibi = nullptr) {
     extern __shared__ float sm[];
     const int hd = E / heads;
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const float slope = alibi ? alibi[h] : 0.f;  // config.alibi_bias: a constant added to the scores -- it changes P, not the form of dS
     float* q = sm;                // [L][hd]
     float* k = q + L * hd;        // [L][hd]
     float* v = k + L * hd;        // [L][hd]
@@ -482,7 +484,7 @@ static __global__ __launch_bounds__(64) void attn_bwd_small_kernel(const float* 
         for (int j = 0; j <= i; ++j) {
             float s = 0.f;
             for (int d = 0; d < hd; ++d) s = fmaf(q[i * hd + d], k[j * hd + d], s);
-            s *= scale;
+            s = s * scale + slope * (float)j;
             P[i * L + j] = s;
             mx = fmaxf(mx, s);
         }

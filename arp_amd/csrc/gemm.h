@@ -40,6 +40,8 @@ struct GemmArgs {
     // Producer side (the f32 residual epilogue): also emit the operand-type copy of the new row and its partial sums
     void* xb_out = nullptr;           // [M, ldxb] T
     int ldxb = 0;
+    int split3 = 0;                   // f32-output epilogues, T = f16: xb_out rows are [hi | lo | hi], N wide each (store_split3: the next GEMM's operand in
+                                      // ARP_MODE_F16X3); `out` may then be null
     float* stats_out = nullptr;       // [M][N/128][2]
     int group_m = 0;          // gemm256: tile-rows per L2 group (0 = default)
     int stagger_groups = 0;   // >1: the first wave of workgroups starts in `stagger_groups` phase groups spread over
@@ -349,8 +351,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                             *reinterpret_cast<float4*>(g.adam_p + idx) = make_float4(pp[0], pp[1], pp[2], pp[3]);
                             if (g.adam_mirror) store4(static_cast<T*>(g.adam_mirror) + idx, pp[0], pp[1], pp[2], pp[3]);
                         } else {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
-                        if (g.xb_out) store4(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, v.x, v.y, v.z, v.w);
+                        if (g.out) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
+                        if (g.xb_out) {
+                            if (g.split3) store_split3(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, (size_t)g.N, v.x, v.y, v.z, v.w);
+                            else store4(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, v.x, v.y, v.z, v.w);
+                        }
                         }
                     }
                     if (g.stats_out) {  // one 128-column segment per 32-lane half

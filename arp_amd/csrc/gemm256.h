@@ -719,20 +719,30 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
         } else {
             constexpr int RSF = 256 * 4 + 16;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (p) __syncthreads();
-                // the pass's 16 residual rows per thread are requested BEFORE the tile is staged: all in flight at once
-                // instead of four dependent rounds of load -> add -> store (the operand registers are dead by now)
-                float4 rres[16];
+            // A pass's 16 residual rows per thread are requested BEFORE its tile is staged: all in flight at once instead of four dependent rounds
+            // of load -> add -> store (the operand registers are dead by now).  Round 4: pass 1's rows are requested before pass 0's STORES are
+            // issued -- a wave's loads and stores retire through one in-order counter, so requested behind those 16 stores the rows could not be
+            // used before every one of them had completed (the write latency of a round in which all CUs drain together); requested ahead of them
+            // they have been in flight for the whole of pass 0's copy-out.  (ARP_G2_RES_EARLY=0: round 3's order.)
+#ifndef ARP_G2_RES_EARLY
+#define ARP_G2_RES_EARLY 1
+#endif
+            float4 rres[2][16];
+            auto load_res = [&](int p) {
                 if constexpr (RESID) {
 #pragma unroll
                     for (int it = 0; it < 16; ++it) {
                         const int lr = it * 8 + wave;
                         const int m = m0 + (lr >> 6) * 128 + p * 64 + (lr & 63), n = n0 + lane * 4;
-                        rres[it] = ((ARP_G2_ABL & 4) == 0 && m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        rres[p][it] = ((ARP_G2_ABL & 4) == 0 && m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
+            };
+            load_res(0);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (p) __syncthreads();
+                if (p && !ARP_G2_RES_EARLY) load_res(1);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -751,6 +761,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                             *reinterpret_cast<float4*>(smem + lrow * RSF + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                 __syncthreads();
+                if (p == 0 && ARP_G2_RES_EARLY) load_res(1);
 #pragma unroll
                 for (int it = 0; it < 16; ++it) {
                     const int lr = it * 8 + wave;
@@ -760,11 +771,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                     if (ok) {
                         v = *reinterpret_cast<const float4*>(smem + lr * RSF + lane * 16);
                         if constexpr (RESID) {
-                            const float4 r = rres[it];
+                            const float4 r = rres[p][it];
                             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                         }
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
-                        if (g.xb_out) store4(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, v.x, v.y, v.z, v.w);
+                        if (g.out) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;
+                        if (g.xb_out) {
+                            if (g.split3) store_split3(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, (size_t)g.N, v.x, v.y, v.z, v.w);
+                            else store4(static_cast<T*>(g.xb_out) + (size_t)m * g.ldxb + n, v.x, v.y, v.z, v.w);
+                        }
                     }
                     if (g.stats_out) {  // folded-LayerNorm producer: one 128-column segment per 32-lane half
                         const float s = half_wave_sum((v.x + v.y) + (v.z + v.w));

@@ -186,20 +186,29 @@ __global__ __launch_bounds__(W2_THREADS, 2) __attribute__((amdgpu_num_vgpr(W2_MA
         }
     } else {
         constexpr int RSF = W2_BN * 4 + 16;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            if (p) __syncthreads();
-            float4 rres[12];
-            if constexpr (RESID) {  // the pass's residual rows are requested before the tile is staged: all in flight at once
+        // a pass's residual rows are requested before its tile is staged (all in flight at once); pass 1's are requested AHEAD of pass 0's stores --
+        // behind them they could not be used before all twelve stores had completed (one in-order counter per wave): gemm256.h, round 4
+#ifndef W2_RES_EARLY
+#define W2_RES_EARLY 1
+#endif
+        float4 rres[2][12];
+        auto load_res = [&](int p) {
+            if constexpr (RESID) {
 #pragma unroll
                 for (int it = 0; it < 12; ++it) {
                     const int idx = it * W2_THREADS + tid;
                     const int lr = idx / 48, ch = idx - lr * 48;
                     const int m = m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), n = n0 + ch * 4;
-                    rres[it] = (m < g.M && (full_n || n + 4 <= g.N)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n)
-                                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rres[p][it] = (m < g.M && (full_n || n + 4 <= g.N)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n)
+                                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
+        };
+        load_res(0);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (p) __syncthreads();
+            if (p && !W2_RES_EARLY) load_res(1);
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) __attribute__((amdgpu_num_vgpr(W2_MA
                     *reinterpret_cast<float4*>(smem + lrow * RSF + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             __syncthreads();
+            if (p == 0 && W2_RES_EARLY) load_res(1);
 #pragma unroll
             for (int it = 0; it < 12; ++it) {
                 const int idx = it * W2_THREADS + tid;
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) __attribute__((amdgpu_num_vgpr(W2_MA
                 if (m < g.M && (full_n || n + 4 <= g.N)) {
                     float4 v = *reinterpret_cast<const float4*>(smem + lr * RSF + ch * 16);
                     if constexpr (RESID) {
-                        const float4 r = rres[it];
+                        const float4 r = rres[p][it];
                         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                     }
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)m * g.ldo + n) = v;

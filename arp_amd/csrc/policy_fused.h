@@ -52,6 +52,7 @@ struct PfBlk {
 struct PfArgs {
     int T, L, E, H, heads, NA, depth, do_bwd, R;
     float lambda;
+    float alibi[16];         // per-head slope of config.alibi_bias (layers.py:74-78), zeros when off: score += slope * key index
     const float *img, *rtg;  // [R, E] tanh'd image embedding, [R]
     const int* action;       // [R]
     const float *Wr, *emb;   // rtg_input/kernel [E], action_input/embedding [NA, E]
@@ -322,7 +323,7 @@ __device__ __forceinline__ void pf_ln_bwd(const float* xs, const float* dys, flo
 // ---- causal attention of one sample on MFMA (head_dim a multiple of 16, <= 16 tokens): one wave per head ------------
 // S^T[key][i] = sum_d K[key][d] Q[i][d] lands as lane (q, j) <-> query i = j, keys 4q..4q+3, so the softmax is two
 // cross-group shuffles and P^T is already the B operand of O^T = V^T . P^T.
-__device__ __forceinline__ f32x4_v pf_attn_probs(const float* sQ, int ldW, int E, int hd, int h, int L, float scale, int q, int j) {
+__device__ __forceinline__ f32x4_v pf_attn_probs(const float* sQ, int ldW, int E, int hd, int h, int L, float scale, int q, int j, float slope = 0.f) {
     f32x4_v st = {0.f, 0.f, 0.f, 0.f};
     for (int d0 = 0; d0 < hd; d0 += 16) {
         const float4 kk = *reinterpret_cast<const float4*>(sQ + j * ldW + E + h * hd + d0 + 4 * q);
@@ -336,7 +337,7 @@ __device__ __forceinline__ f32x4_v pf_attn_probs(const float* sQ, int ldW, int E
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const bool ok = (4 * q + r) <= j && j < L;
-        st[r] = ok ? st[r] * scale : -INFINITY;
+        st[r] = ok ? st[r] * scale + slope * (float)(4 * q + r) : -INFINITY;  // + alibi bias on the key index (a constant: the backward's dS is unchanged)
         mx = fmaxf(mx, st[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -356,10 +357,10 @@ __device__ __forceinline__ f32x4_v pf_attn_probs(const float* sQ, int ldW, int E
     return st;
 }
 __device__ __forceinline__ void pf_attn_fwd_mfma(const float* sQ, float* sA, int ldW, int ldE, int E, int hd, int heads, int L, float scale,
-                                                 float* __restrict__ att_save, int wave, int lane) {
+                                                 float* __restrict__ att_save, int wave, int lane, const float* alibi) {
     const int q = lane >> 4, j = lane & 15;
     for (int h = wave; h < heads; h += PF_NW) {
-        const f32x4_v p = pf_attn_probs(sQ, ldW, E, hd, h, L, scale, q, j);
+        const f32x4_v p = pf_attn_probs(sQ, ldW, E, hd, h, L, scale, q, j, alibi[h & 15]);
         for (int d0 = 0; d0 < hd; d0 += 16) {
             f32x4_v o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -372,10 +373,10 @@ __device__ __forceinline__ void pf_attn_fwd_mfma(const float* sQ, float* sA, int
 }
 // pass a: P and dS (to LDS as [i][key]) and dQ;  pass b (after a barrier): dK and dV from the LDS copies
 __device__ __forceinline__ void pf_attn_bwd_mfma_a(const float* sQ, const float* sA, float* sU, float* sP, float* sS, int ldW, int ldE, int E, int hd,
-                                                   int heads, int L, float scale, float* __restrict__ dqkv_save, int wave, int lane) {
+                                                   int heads, int L, float scale, float* __restrict__ dqkv_save, int wave, int lane, const float* alibi) {
     const int q = lane >> 4, j = lane & 15;
     for (int h = wave; h < heads; h += PF_NW) {
-        const f32x4_v p = pf_attn_probs(sQ, ldW, E, hd, h, L, scale, q, j);
+        const f32x4_v p = pf_attn_probs(sQ, ldW, E, hd, h, L, scale, q, j, alibi[h & 15]);
         f32x4_v dp = {0.f, 0.f, 0.f, 0.f};  // dP^T[key][i] = sum_d V[key][d] dO[i][d]
         for (int d0 = 0; d0 < hd; d0 += 16) {
             const float4 vv = *reinterpret_cast<const float4*>(sQ + j * ldW + 2 * E + h * hd + d0 + 4 * q);
@@ -500,7 +501,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         __syncthreads();
         pf_save_rows(sQ, ldW, 3 * E, k.qkv + t0 * 3 * E, L, tid);
         // causal attention (layers.py:70-90): scores * scale, masked, softmax, P.V
-        pf_attn_fwd_mfma(sQ, sA, ldW, ldE, E, hd, heads, L, scale, k.att + t0 * E, wave, lane);
+        pf_attn_fwd_mfma(sQ, sA, ldW, ldE, E, hd, heads, L, scale, k.att + t0 * E, wave, lane, a.alibi);
         __syncthreads();
         pf_lin_nt<E, E, ldE>(sA, k.wo_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             const float4 bb = *reinterpret_cast<const float4*>(vb + 5 * E + n);
@@ -695,7 +696,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         });
         __syncthreads();
         // attention backward: probabilities recomputed; dS = P * (dP - sum_j P dP) * scale
-        pf_attn_bwd_mfma_a(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, scale, k.d_qkv + t0 * 3 * E, wave, lane);
+        pf_attn_bwd_mfma_a(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, scale, k.d_qkv + t0 * 3 * E, wave, lane, a.alibi);
         __syncthreads();
         pf_attn_bwd_mfma_b(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, k.d_qkv + t0 * 3 * E, wave, lane);
         __syncthreads();

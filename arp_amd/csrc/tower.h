@@ -115,6 +115,7 @@ struct GemmFold {
     void* xb_out = nullptr;        // producer
     int ldxb = 0;
     float* stats_out = nullptr;
+    int split3 = 0;                // xb_out rows are (hi, lo, hi) binary16 triples of the f32 result (GemmArgs::split3)
 };
 
 // what a tower launch needs from its owner
@@ -178,7 +179,7 @@ static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* 
     GemmArgs g;
     if (f) {
         g.ln_stats = f->stats; g.ln_c = f->c; g.ln_parts = f->parts; g.ln_inv_d = f->inv_d; g.ln_eps = f->eps;
-        g.xb_out = f->xb_out; g.ldxb = f->ldxb; g.stats_out = f->stats_out;
+        g.xb_out = f->xb_out; g.ldxb = f->ldxb; g.stats_out = f->stats_out; g.split3 = f->split3;
     }
     g.A = A; g.W = W; g.bias = bias; g.resid = resid; g.out = out;
     g.M = M; g.N = N; g.K = K; g.lda = lda ? lda : K; g.ldw = K; g.ldr = ldr ? ldr : N; g.ldo = ldo ? ldo : N;
@@ -277,15 +278,15 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
     if (hd == 64) {
         auto kern = attn_valu_kernel<T, 64>;
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq);
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq, (const float*)nullptr);
     } else if (hd == 32) {
         auto kern = attn_valu_kernel<T, 32>;
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq);
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq, (const float*)nullptr);
     } else if (hd == 16) {
         auto kern = attn_valu_kernel<T, 16>;
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq);
+        hipLaunchKernelGGL(kern, dim3(B * heads), dim3(threads), lds, stream, qkv, out, N, D, heads, scale, causal, nq, (const float*)nullptr);
     } else {
         return fail("attention: unsupported head_dim " + std::to_string(hd));
     }

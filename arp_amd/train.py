@@ -44,6 +44,7 @@ class PolicyConfig:
     use_adapter: bool = True
     lambda_ret: float = 1.0
     use_symlog: bool = False  # config.use_symlog (ARPDT.py:55): symlog of every return-to-go view before their mean
+    alibi_bias: bool = False  # config.alibi_bias (ARPDT.py:88, layers.py:74-78): slope_h * key index on the attention scores; off as shipped
     weight_decay: float = 5e-5
     clip_norm: float = 10.0
     b1: float = 0.9
@@ -61,7 +62,7 @@ class PolicyTrainer:
         self.cfg = cfg
         c = _ffi.DtCfg(cfg.emb, cfg.depth, cfg.heads, cfg.mlp_ratio, cfg.n_actions, cfg.window, cfg.enc_tokens, cfg.enc_dim,
                        int(cfg.use_adapter), {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32}[mode], device, 1, 0, cfg.lambda_ret,
-                       cfg.weight_decay, cfg.clip_norm, cfg.b1, cfg.b2, cfg.eps)
+                       cfg.weight_decay, cfg.clip_norm, cfg.b1, cfg.b2, cfg.eps, int(getattr(cfg, "alibi_bias", False)))
         h = C.c_void_p()
         check(lib.arp_dt_create(C.byref(c), C.byref(h)))
         self._h = h

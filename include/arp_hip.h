@@ -167,6 +167,8 @@ typedef struct arp_dt_cfg {
     float weight_decay;  /* coefficient of the explicit 0.5*wd*||p||^2 term (main_procgen.py:114-117) */
     float clip_norm;     /* optax.clip_by_global_norm */
     float b1, b2, eps;   /* adam */
+    int32_t alibi_bias;  /* config.alibi_bias (arp_dt/layers.py:74-78; off in the shipped configuration): slope_h * key_index added to the policy
+                            transformer's attention scores, slopes as _get_attention_slopes (layers.py:97-110) */
 } arp_dt_cfg;
 
 int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out);

@@ -47,6 +47,7 @@ class PolicyConfig:
     b1: float = 0.9
     b2: float = 0.999
     eps: float = 1e-8
+    alibi_bias: bool = False  # config.alibi_bias (ARPDT.py:88 -> layers.py:74-78); off in the shipped configuration
 
 
 def param_shapes(cfg):
@@ -86,6 +87,21 @@ def num_params(cfg):
     return int(sum(np.prod(v) for v in param_shapes(cfg).values()))
 
 
+def alibi_slopes(n):
+    """arp_dt/layers.py:97-110 (_get_attention_slopes): 2^(-8 (i + 1) / n) for a power-of-two head count, otherwise the slopes of the next lower power
+    of two followed by every other slope of the next higher one."""
+    import math
+
+    def pow2(m):
+        start = 2 ** (-(2 ** -(math.log2(m) - 3)))
+        return [start * start ** i for i in range(m)]
+
+    if math.log2(n).is_integer():
+        return pow2(n)
+    c = 2 ** math.floor(math.log2(n))
+    return pow2(c) + alibi_slopes(2 * c)[0::2][: n - c]
+
+
 def forward(P, cfg, enc, action, rtg):
     """P: dict name -> tensor.  enc [B,T,tokens,dim], action int64 [B,T], rtg [B,T,1].
     Returns dict(action_pred [B,T,n_actions], return_pred [B,T,1], loss, acc, trans_loss, return_loss)."""
@@ -111,6 +127,9 @@ def forward(P, cfg, enc, action, rtg):
         qkv = y @ P[p + "Attention_0/Dense_0/kernel"] + P[p + "Attention_0/Dense_0/bias"]
         q, k, v = (t.reshape(B, L, cfg.heads, hd).transpose(1, 2) for t in qkv.split(E, dim=-1))
         att = (q @ k.transpose(-2, -1)) * hd ** -0.5
+        if getattr(cfg, "alibi_bias", False):  # layers.py:74-78: slopes[:, None, None] * arange(n)[None, None, :] -- a bias on the KEY index
+            sl = torch.tensor(alibi_slopes(cfg.heads), dtype=att.dtype, device=att.device)
+            att = att + sl[None, :, None, None] * torch.arange(L, dtype=att.dtype, device=att.device)[None, None, None, :]
         att = att.masked_fill(~mask, torch.finfo(att.dtype).min).softmax(-1)
         y = (att @ v).transpose(1, 2).reshape(B, L, E)
         h = h + y @ P[p + "Attention_0/Dense_1/kernel"] + P[p + "Attention_0/Dense_1/bias"]

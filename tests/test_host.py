@@ -374,3 +374,14 @@ def test_two_prefetchers_on_one_trainer_never_share_device_slots():
     again = prefetch_to_device(batches(500, 1), 2, tr)
     assert isinstance(next(again), DeviceBatch)
     again.close()
+
+
+def test_alibi_slopes_known_answers():
+    """_get_attention_slopes (arp_dt/layers.py:97-110) in the oracle: the published ALiBi slopes -- 1/2 ... 1/256 for 8 heads, 2^(-8 i / n) in general for a
+    power of two, and for 12 heads the 8-head slopes followed by every other 16-head slope."""
+    from oracle import arpdt_torch as O
+    assert np.allclose(O.alibi_slopes(8), [2.0 ** -(i + 1) for i in range(8)], rtol=1e-12)
+    assert np.allclose(O.alibi_slopes(4), [2.0 ** -(2 * (i + 1)) for i in range(4)], rtol=1e-12)
+    s16 = [2.0 ** -(0.5 * (i + 1)) for i in range(16)]
+    assert np.allclose(O.alibi_slopes(16), s16, rtol=1e-12)
+    assert np.allclose(O.alibi_slopes(12), [2.0 ** -(i + 1) for i in range(8)] + s16[0::2][:4], rtol=1e-12)

@@ -518,3 +518,34 @@ def test_prefetched_slots_equal_synchronous_upload(gpu_lib):
     f = tr.forward()
     tr.close()
     assert abs(f["loss"] - va["loss"]) < 1e-6 and abs(f["acc"] * 100 - va["acc"]) < 1e-4 and abs(f["return_loss"] - va["return_loss"]) < 1e-6
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("kw", [dict(TINY, alibi_bias=True), dict(emb=128, depth=2, heads=8, window=4, enc_tokens=5, enc_dim=64, lambda_ret=0.5, alibi_bias=True),
+                                dict(emb=64, depth=1, heads=2, window=7, enc_tokens=3, enc_dim=64, lambda_ret=1.0, alibi_bias=True)])
+def test_alibi_bias_branch(gpu_lib, monkeypatch, kw, fused):
+    """config.alibi_bias (arp_dt/ARPDT.py:88 -> layers.py:74-78, off in the shipped configuration): slope_h * key index added to the attention scores of the
+    policy transformer, slopes = _get_attention_slopes (layers.py:97-110).  Forward and every gradient against the oracle with the same switch, on the fused
+    kernel and on the per-op path (the third geometry -- 21 tokens, 2 heads of 32 -- runs the per-op path either way); and the switch really changes the logits."""
+    from arp_amd.train import PolicyConfig, PolicyTrainer
+    from oracle import arpdt_torch as O
+    monkeypatch.setenv("ARP_DT_FUSED", fused)
+    cfg, ocfg, P, (enc, act, rtg), Pt, tb = _setup(kw, 3, 21)
+    ref = O.forward(Pt, ocfg, *tb)
+    g_ref, _, _ = O.grads(Pt, ocfg, *tb)
+    tr = PolicyTrainer(cfg, mode="f32")
+    tr.set_params(P)
+    tr.set_batch(enc, act, rtg)
+    out = tr.forward()
+    assert np.abs(out["action_pred"] - ref["action_pred"].numpy()).max() < 2e-5 and np.abs(out["return_pred"] - ref["return_pred"].numpy()).max() < 2e-5
+    tr.backward()
+    g = tr.get_grads()
+    bad = [(k, float(np.abs(g[k] - g_ref[k].numpy()).max() / max(np.abs(g_ref[k].numpy()).max(), 1e-6))) for k in P]
+    bad = [b for b in bad if not b[1] < 1e-4]
+    assert not bad, bad
+    tr.close()
+    off = PolicyTrainer(PolicyConfig(**dict(kw, alibi_bias=False)), mode="f32")
+    off.set_params(P)
+    off.set_batch(enc, act, rtg)
+    assert np.abs(off.forward()["action_pred"] - out["action_pred"]).max() > 1e-4
+    off.close()
