@@ -221,6 +221,8 @@ int ft_gemm(arp_ft* c, const char* site, const void* A, int lda, const void* W, 
     ARP_TRY(c->part.ensure((size_t)S * M * N * 4));
     g.bias = nullptr; g.resid = nullptr; g.out = c->part.p; g.ldr = N; g.ldo = N;
     g.ksplit = S; g.slice_stride = (size_t)M * N;
+    static const int mfast = getenv("ARP_FT_MFAST") ? atoi(getenv("ARP_FT_MFAST")) : 1;
+    g.m_fast = (mfast && M <= 4 * GEMM_BM) ? 1 : 0;  // the image tower's 192 rows = two row tiles over the same weight stream
     ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_FT + 1>(g, c->stream)));
     const size_t MN = (size_t)M * N;
     hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out, resid,

@@ -40,6 +40,8 @@ struct GemmArgs {
     // Producer side (the f32 residual epilogue): also emit the operand-type copy of the new row and its partial sums
     void* xb_out = nullptr;           // [M, ldxb] T
     int ldxb = 0;
+    int m_fast = 0;                   // gemm_nt_kernel: walk the tiles m-fastest, so the m-tiles of one weight column panel are neighbours on one XCD and share the
+                                      // panel through its L2 (a few rows against a long weight stream: the fine-tune head's M = 192 products read W once, not twice)
     int split3 = 0;                   // f32-output epilogues, T = f16: xb_out rows are [hi | lo | hi], N wide each (store_split3: the next GEMM's operand in
                                       // ARP_MODE_F16X3); `out` may then be null
     float* stats_out = nullptr;       // [M][N/128][2]
@@ -112,8 +114,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     const int n_tiles = (g.N + GEMM_BN - 1) / GEMM_BN;
     const int m_tiles = (g.M + GEMM_BM - 1) / GEMM_BM;
     const int tile = xcd_remap(blockIdx.x, m_tiles * n_tiles);
-    const int m0 = (tile / n_tiles) * GEMM_BM;
-    const int n0 = (tile % n_tiles) * GEMM_BN;
+    const int m0 = (g.m_fast ? tile % m_tiles : tile / n_tiles) * GEMM_BM;
+    const int n0 = (g.m_fast ? tile / m_tiles : tile % n_tiles) * GEMM_BN;
 
     const T* __restrict__ A = static_cast<const T*>(g.A);
     const T* __restrict__ W = static_cast<const T*>(g.W);
