@@ -235,20 +235,20 @@ int forward_chunk_x3(arp_enc* c, hipStream_t stream, const float* img_dev, int n
         hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, c->pe.as<float>(), c->cls, c->pos, c->x.as<float>(), nb * N, N, D);
         ARP_HIP_OK(hipGetLastError());
     }
-    float *x = c->x.as<float>(), *h = c->h.as<float>(), *qkv = c->qkv.as<float>(), *ao = c->ao.as<float>();
+    float *x = c->x.as<float>(), *qkv = c->qkv.as<float>(), *ao = c->ao.as<float>();
     for (int i = 0; i < k.layers; ++i) {
         const LayerW& L = c->tower.L[i];
-        ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_1", x, D, h, D, L.ln1_w, L.ln1_b, M, D, 1e-6f));
-        ARP_TRY(split("m3ae.split", h, M, D));
+        // LayerNorm and the attention write the (hi, lo, hi) triples of their f32 results themselves (f16x3_t / out3): no f32 copy, no split pass
+        const bool direct = k.attn_impl == 0 && D / k.heads == 64 && N <= 288;  // (the VALU attention has no such output: it keeps the split pass)
+        ARP_TRY(tower_layernorm<f16x3_t>(t, "m3ae.ln_1", x, D, reinterpret_cast<f16x3_t*>(a3), 3 * D, L.ln1_w, L.ln1_b, M, D, 1e-6f));
         ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_QKV>(t, "m3ae.qkv", a3, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, 3 * D)));
         {
             ProfScope ps(c->prof, stream, "m3ae.attn");
-            ARP_TRY(launch_attention<float>(stream, k.attn_impl, qkv, ao, nb, N, D, k.heads, 0));
+            ARP_TRY(launch_attention<float>(stream, k.attn_impl, qkv, ao, nb, N, D, k.heads, 0, 0, 0.f, direct ? a3 : nullptr));
         }
-        ARP_TRY(split("m3ae.split", ao, M, D));
+        if (!direct) ARP_TRY(split("m3ae.split", ao, M, D));
         ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, true, 8 + SITE_OUT>(t, "m3ae.out_proj", a3, L.w_out, L.b_out, x, x, M, D, 3 * D)));
-        ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_2", x, D, h, D, L.ln2_w, L.ln2_b, M, D, 1e-6f));
-        ARP_TRY(split("m3ae.split", h, M, D));
+        ARP_TRY(tower_layernorm<f16x3_t>(t, "m3ae.ln_2", x, D, reinterpret_cast<f16x3_t*>(a3), 3 * D, L.ln2_w, L.ln2_b, M, D, 1e-6f));
         // c_fc's epilogue writes the (hi, lo, hi) triples of the tanh-GELU'd hidden activation itself: no f32 copy of it, no split pass (2.4 ms of a 30.9 ms step)
         f16_t* a3b = a3 + (size_t)M * 3 * D;
         GemmFold pair;

@@ -74,12 +74,15 @@ __global__ __launch_bounds__(256) void attn_valu_kernel(const T* __restrict__ qk
 // and needs one operand register per lane instead of a 64-deep row per lane).  Same plan as the 16-bit kernel: S^T = K.Q^T so that the softmax'd accumulator
 // IS the B operand of O^T = V^T.P^T: register r of key tile kt holds P[key kt*16 + 4g + r][query j] in lane (g, j), and the MFMA that consumes it takes
 // V[kt*16 + 4g + r][d] as its A operand -- the contraction order over the keys is free.  K and V of one (sample, head) in LDS as f32 rows of 68 floats
-// (conflict-free for both operand reads: bank = 4 j + g for K, 16 g + j for V); one 16-query block per wave at a time, NT key tiles of accumulators
+// (272-byte rows: the ds_read_b128 of both operands meets one doubly used bank group per sixteen lanes); one 16-query block per wave at a time, NT key tiles of accumulators
 // (68 registers at 257 tokens).  The M3AE encoder's 257-token attention in f32: 22.7 ms per step on attn_valu_kernel (one query per lane, a 64-deep
 // register row, 13 TFLOP/s) -- see DESIGN 6b for what this kernel takes.
+// out3 != null: the output row is written as the binary16 triple [hi | lo | hi] (3 D wide), the next GEMM's operand in ARP_MODE_F16X3, instead of f32.
+// (The hardware exp2 in place of libm's expf was measured on the encoder's 257-token attention: 7.09 against 7.03-7.47 ms per step -- the softmax is not
+//  what this kernel waits for -- at 7x the error of the encoder output, 5.4e-5 against 8.1e-6; not kept.)
 template <int NT>
 __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int D, int heads, float scale,
-                                                            int causal, int nq) {
+                                                            int causal, int nq, f16_t* __restrict__ out3 = nullptr) {
     constexpr int HD = 64, LS = 68;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ks = reinterpret_cast<float*>(smem);
@@ -87,33 +90,61 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const size_t ld = 3 * (size_t)D;
     const float* base = qkv + (size_t)b * N * ld + h * HD;
-    for (int i = threadIdx.x; i < NT * 16 * 16; i += 256) {  // rows past N are zero keys (masked below) and zero values
-        const int t = i >> 4, c4 = (i & 15) * 4;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (t < N) {
-            kv = *reinterpret_cast<const float4*>(base + t * ld + D + c4);
-            vv = *reinterpret_cast<const float4*>(base + t * ld + 2 * D + c4);
+    {   // K and V of this (sample, head) -> LDS; rows past N are zero keys (masked below) and zero values.  Every load of the thread is requested before the
+        // first LDS store (2 NT float4 in registers): written as load -> store per row, the NT rounds paid a memory latency each -- half of the kernel's time
+        float4 kreg[NT], vreg[NT];
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const int i = it * 256 + threadIdx.x, t = i >> 4, c4 = (i & 15) * 4;
+            kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vreg[it] = kreg[it];
+            if (t < N) {
+                kreg[it] = *reinterpret_cast<const float4*>(base + t * ld + D + c4);
+                vreg[it] = *reinterpret_cast<const float4*>(base + t * ld + 2 * D + c4);
+            }
         }
-        *reinterpret_cast<float4*>(Ks + t * LS + c4) = kv;
-        *reinterpret_cast<float4*>(Vs + t * LS + c4) = vv;
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const int i = it * 256 + threadIdx.x, t = i >> 4, c4 = (i & 15) * 4;
+            *reinterpret_cast<float4*>(Ks + t * LS + c4) = kreg[it];
+            *reinterpret_cast<float4*>(Vs + t * LS + c4) = vreg[it];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     for (int q0 = wave * 16; q0 < nq; q0 += 64) {
+        // K and V in LDS are invariant over this loop, and left alone the compiler hoists all 2 x 16 NT operand values out of it (544 registers at NT = 17:
+        // every VGPR and AGPR, 72 spilled, and a v_accvgpr_read in front of each MFMA).  The fence makes each query block read its operands again.
+        asm volatile("" ::: "memory");
         const int qi = q0 + j;
         const float* qrow = base + (size_t)min(qi, N - 1) * ld;
-        float qreg[16];
+        // The contraction order over d is free as long as both operands agree: MFMA (u, e) takes d = 16 u + 4 g + e from lane group g, so that a lane's
+        // four e are ONE float4 of its query row (4 loads up front; read as d = 4 s + g the compiler fetched each of 16 dwords right before its use and
+        // waited vmcnt(0) for it) and ONE ds_read_b128 of a key row (68 LDS reads per query block instead of 272).
+        float4 q4[4];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) qreg[s] = qrow[4 * s + g] * scale;
+        for (int u = 0; u < 4; ++u) {
+            q4[u] = *reinterpret_cast<const float4*>(qrow + 16 * u + 4 * g);
+            q4[u].x *= scale; q4[u].y *= scale; q4[u].z *= scale; q4[u].w *= scale;
+        }
         f32x4_v acc[NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) acc[kt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int u = 0; u < 4; ++u) {
+            float4 k4[NT];
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt)  // NT independent accumulators per k-step: no dependent-issue stall
-                acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(kt * 16 + j) * LS + 4 * s + g], qreg[s], acc[kt], 0, 0, 0);
+            for (int kt = 0; kt < NT; ++kt) k4[kt] = *reinterpret_cast<const float4*>(Ks + (kt * 16 + j) * LS + 16 * u + 4 * g);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[kt].x, q4[u].x, acc[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[kt].y, q4[u].y, acc[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[kt].z, q4[u].z, acc[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[kt].w, q4[u].w, acc[kt], 0, 0, 0);
+        }
         // softmax over the keys of query j: this lane holds keys kt*16 + 4g + r; the other three lane groups hold the rest
         float m = -INFINITY;
 #pragma unroll
@@ -137,22 +168,33 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
             }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
+        // O^T = V^T . P^T: MFMA (kt, r) contracts over the keys kt*16 + 4 g' + r (g' = the four k-slots); its A operand row i (lane j) is ONE d.  The four
+        // output tiles take d = 4 j + dt, so that the lane's four A values are one float4 of the V row: o[dt][reg] <-> d = 16 g + 4 reg + dt for query j.
         f32x4_v o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(kt * 16 + 4 * g + r) * LS + dt * 16 + j], acc[kt][r], o[dt], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                const float4 v4 = *reinterpret_cast<const float4*>(Vs + (kt * 16 + 4 * g + r) * LS + 4 * j);
+                o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.x, acc[kt][r], o[0], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.y, acc[kt][r], o[1], 0, 0, 0);
+                o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.z, acc[kt][r], o[2], 0, 0, 0);
+                o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4.w, acc[kt][r], o[3], 0, 0, 0);
+            }
         if (qi < nq) {
             const float inv = 1.0f / l;
-            float* orow = out + ((size_t)b * N + qi) * D + h * HD;
+            if (out3) {
+                f16_t* orow3 = out3 + ((size_t)b * N + qi) * 3 * D + h * HD + 16 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<float4*>(orow + dt * 16 + 4 * g) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+                for (int reg = 0; reg < 4; ++reg) store_split3(orow3 + 4 * reg, (size_t)D, o[0][reg] * inv, o[1][reg] * inv, o[2][reg] * inv, o[3][reg] * inv);
+            } else {
+                float* orow = out + ((size_t)b * N + qi) * D + h * HD + 16 * g;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    *reinterpret_cast<float4*>(orow + 4 * reg) = make_float4(o[0][reg] * inv, o[1][reg] * inv, o[2][reg] * inv, o[3][reg] * inv);
+            }
         }
     }
 }

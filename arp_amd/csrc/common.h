@@ -11,6 +11,8 @@ namespace arp {
 typedef uint16_t bf16_t;  // raw bf16 bits; arithmetic always happens in f32
 // raw IEEE binary16 bits as a distinct type (ARP_MODE_F16: same MFMA rate as bf16, 11 significand bits instead of 8)
 struct f16_t { uint16_t b; };
+// output tag of row kernels in ARP_MODE_F16X3: a row of D values is stored as the binary16 triple [hi | lo | hi] (3 D wide; store_split3 below)
+struct f16x3_t { uint16_t b; };
 // raw OCP e4m3fn bits (no infinities, max 448, NaN = 0x7f / 0xff): operand type of the scaled fp8 MFMA (BASELINE configs[4])
 struct fp8_t { uint8_t b; };
 typedef __attribute__((ext_vector_type(8))) int i32x8_v;

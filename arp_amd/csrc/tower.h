@@ -219,7 +219,8 @@ static int tower_layernorm(TowerCtx& c, const char* site, const float* in, size_
 }
 
 template <typename T>
-static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, int B, int N, int D, int heads, int causal, int nq = 0, float out8 = 0.f) {
+static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, int B, int N, int D, int heads, int causal, int nq = 0, float out8 = 0.f,
+                            f16_t* out3 = nullptr) {  // out3 (T = float, the f32-MFMA kernel only): (hi, lo, hi) binary16 rows instead of f32
     const int hd = D / heads;
     if (nq <= 0 || nq > N) nq = N;  // query rows produced per sample
     const float scale = 1.0f / sqrtf((float)hd);
@@ -256,10 +257,10 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
             const int need = (N + 15) / 16;
 #define ARP_ATTN32_CASE(nt)                                                                                                        \
     if (need <= nt) {                                                                                                              \
-        auto kern = attn_f32_mfma_kernel<nt>;                                                                                      \
         const int lds32 = 2 * nt * 16 * 68 * 4;                                                                                    \
+        auto kern = attn_f32_mfma_kernel<nt>;                                                                                      \
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds32));   \
-        hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds32, stream, qkv, out, N, D, heads, scale, causal, nq);               \
+        hipLaunchKernelGGL(kern, dim3(B* heads), dim3(256), lds32, stream, qkv, out, N, D, heads, scale, causal, nq, out3);         \
         ARP_HIP_OK(hipGetLastError());                                                                                             \
         return 0;                                                                                                                  \
     }
@@ -272,6 +273,7 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
 #undef ARP_ATTN32_CASE
         }
     }
+    if (out3) return fail("attention: the (hi, lo, hi) output exists on the f32-MFMA kernel only (head_dim 64, <= 288 tokens)");
     const size_t lds = (size_t)2 * N * hd * 4;
     if (lds > 160 * 1024) return fail("attention: sequence too long for the LDS-resident kernel");
     const int threads = N <= 64 ? 64 : (N <= 128 ? 128 : 256);

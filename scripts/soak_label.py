@@ -11,7 +11,7 @@ seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 45.0
 name = sys.argv[2] if len(sys.argv) > 2 else "ViT-B/32"
 cfg = clip.MODELS[name]
 m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), mode="f16", max_batch=1024, n_streams=2)
-toks = [synth.prompt_tokens(1, 8, seed=2), synth.prompt_tokens(1, 5, seed=9)]
+toks = [synth.prompt_tokens(3, [8, 6, 9], seed=2), synth.prompt_tokens(2, [5, 7], seed=9)]  # several prompts each: the online list-of-prompts (mean) branch is in the mix
 base = synth.procgen_like_frames(64, seed=3)
 big = np.ascontiguousarray(np.tile(base, (16, 1, 1, 1)))
 ref = {}
@@ -24,7 +24,7 @@ rng = np.random.default_rng(0)
 t0, it, prompt = time.time(), 0, 0
 m.set_text(toks[prompt])
 while time.time() - t0 < seconds:
-    kind = rng.integers(0, 7)
+    kind = rng.integers(0, 9)
     if kind == 0:
         i = int(rng.integers(0, 64)); check((prompt, "one", i), m.label(base[i:i + 1]))
     elif kind == 1:
@@ -40,6 +40,15 @@ while time.time() - t0 < seconds:
         check((prompt, "big"), m.label_collect(0)); check((prompt, "half"), m.label_collect(1))
     elif kind == 5:
         prompt ^= 1; m.set_text(toks[prompt])
+    elif kind == 7:  # round 4: the rollout loop's other reward functions on the same handle (captured passes keyed by the prompt reduction)
+        from arp_amd import label_reward as L
+        i = int(rng.integers(0, 64))
+        check((prompt, "mean", i), L.get_torch_clip_reward(m, base[i], ["x"] * len(toks[prompt])))
+        check((prompt, "one", i), L.get_torch_clip_reward(m, base[i], "x"))
+    elif kind == 8:
+        from arp_amd import label_reward as L
+        i = int(rng.integers(0, 8))
+        check(("goal", i), np.float64(L.get_torch_clip_goal_conditioned_reward(m, base[i], base[63])).reshape(1))
     else:
         check((prompt, "crop", 1), m.label(base[:1], use_crop=True)); check((prompt, "enc", 3), m.encode_image(base[:3]))
     it += 1
