@@ -105,6 +105,9 @@ struct arp_dt {
     DevBuf alibi;  // per-head slopes of config.alibi_bias (null pointer semantics: cfg.alibi_bias == 0 -> the kernels get nullptr / zeros)
     DevBuf pf_pack, pf_jobs;  // fragment-major weight copies of the fused kernel's big linears and their job table (policy_fused.h)
     int pf_njobs = 0, pf_pack_blocks = 0;
+    // 16-bit modes: the fused kernel's big linears on (hi, lo) binary16 operand pairs (policy_fused.h::pf_lin_x3: f32-level products at 5.3x the f32 MFMA
+    // rate); the f32 parity mode keeps v_mfma_f32_16x16x4_f32.  ARP_PF_X3=0/1 overrides either way (A/B, tests).
+    bool pf_x3 = false;
     ncclComm_t comm = nullptr;
     bool has_comm = false;
     // data-parallel step: gradient all-reduce in two buckets on a communication stream, bucket 1 (image_text_input's kernel, 94 % of
@@ -435,7 +438,8 @@ int build_fused_plan(arp_dt* c) {
         // pf_pack_kernel at the head of every launch of the fused kernel (the parameters change every step)
         std::vector<PfPackJob> jobs;
         size_t total = 0;
-        auto want = [&](const float* W, int N, int K) { jobs.push_back(PfPackJob{W, nullptr, nullptr, N, K}); total += 2 * (size_t)N * K; };
+        const int x3 = c->pf_x3 ? 1 : 0;
+        auto want = [&](const float* W, int N, int K) { jobs.push_back(PfPackJob{W, nullptr, nullptr, N, K, x3}); total += 2 * (size_t)N * K; };
         for (int i = 0; i < depth; ++i) {
             want(a.blk[i].wqkv, 3 * E, E); want(a.blk[i].wo, E, E); want(a.blk[i].wfc1, H, E); want(a.blk[i].wfc2, E, H);
         }
@@ -446,7 +450,7 @@ int build_fused_plan(arp_dt* c) {
         for (auto& jb : jobs) {
             jb.nt = base; base += (size_t)jb.N * jb.K;
             jb.nn = base; base += (size_t)jb.N * jb.K;
-            maxq = std::max(maxq, jb.N * jb.K / 4);
+            maxq = std::max(maxq, jb.N * jb.K / (x3 ? 8 : 4));
         }
         for (int i = 0; i < depth; ++i) {
             PfBlk& b = a.blk[i];
@@ -484,6 +488,8 @@ int build_fused_plan(arp_dt* c) {
     if (!attr_set) {
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_fused_kernel<128, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_fused_kernel<64, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_fused_kernel<128, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(policy_fused_kernel<64, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     return 0;
@@ -553,7 +559,9 @@ int policy_fused(arp_dt* c, bool do_bwd) {
     c->pf.action = c->bt[c->cur].action.as<int>();
     const size_t lds = pf_lds_bytes(k.emb, k.mlp_ratio * k.emb, k.heads, k.depth);
     hipLaunchKernelGGL(pf_pack_kernel, dim3(c->pf_pack_blocks, c->pf_njobs), dim3(256), 0, c->stream, static_cast<const PfPackJob*>(c->pf_jobs.p));
-    if (k.emb == 128) hipLaunchKernelGGL((policy_fused_kernel<128, 512>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
+    if (k.emb == 128 && c->pf_x3) hipLaunchKernelGGL((policy_fused_kernel<128, 512, true>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
+    else if (k.emb == 128) hipLaunchKernelGGL((policy_fused_kernel<128, 512>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
+    else if (c->pf_x3) hipLaunchKernelGGL((policy_fused_kernel<64, 256, true>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     else hipLaunchKernelGGL((policy_fused_kernel<64, 256>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c->stream, c->loss_part.as<float>(), c->B, c->R(), k.n_actions, k.lambda_ret,
                        c->metrics.as<float>());
@@ -1114,6 +1122,8 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (c->cfg.world <= 0) c->cfg.world = 1;
     if (const char* e = getenv("ARP_DT_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FUSE_RELU_BWD")) c->relu_fuse_mode = atoi(e);
+    c->pf_x3 = k.mode != ARP_MODE_F32;
+    if (const char* e = getenv("ARP_PF_X3")) c->pf_x3 = atoi(e) != 0;
     c->iti_f32 = k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_ITI_F32")) c->iti_f32 = atoi(e) != 0 && k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;

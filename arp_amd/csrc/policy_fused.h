@@ -38,10 +38,13 @@ constexpr int PF_THREADS = 512, PF_NW = 8, PF_MAX_DEPTH = 4;
 // whole-line instructions get 65-69 (scripts/fill_bench.hip); the weight stream was 100 k of the kernel's 378 k cycles.
 //   nt copy: block (t, s) of W[N][K], KS = K / 16 steps per 16-row tile t: lane (q, j) holds W[16 t + j][16 s + 4 q .. + 3]
 //   nn copy: block (c, s), NS = N / 16 steps per 16-column tile c:          lane (q, j) holds W[16 s + 4 q + r][16 c + j], r = 0..3
+// x3 copies (PfPackJob::x3, the 16-bit modes of the step): the same blocks for v_mfma_f32_16x16x32_f16 on (hi, lo) binary16 pairs -- block (t, s) is
+// one 32-deep contraction step = 2 KiB: lane (q, j) holds the eight values k = 32 s + 8 q .. + 7 of its row (nt) / column (nn), times 2^8, as
+// hi = f16(w') at byte 16 lane and lo = f16(w' - hi) at byte 1024 + 16 lane.  Same bytes as the f32 copy, whole 128-byte lines per instruction.
 struct PfPackJob {
     const float* W;
     float *nt, *nn;  // nn may be null (forward-only weights)
-    int N, K;
+    int N, K, x3;
 };
 struct PfBlk {
     const float *ln0w, *ln0b, *wqkv, *bqkv, *wo, *bo, *ln1w, *ln1b, *wfc1, *wfc2;  // weights, device layout [out, in]
@@ -94,8 +97,51 @@ template <int N> __device__ __forceinline__ void pf_wait_vm() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// The weights are packed times 2^8: their lo halves (2^-12 of the value) stay binary16 normals down to |w| = 2^-10, and anything smaller is off by less
+// than 2^-33 absolute; |w| >= 256 would overflow the hi half (a LayerNorm'd 128-wide transformer's weights are O(1)).
+constexpr float PF_W_SCALE = 256.f;
+// (hi, lo) of eight consecutive operands: x * s = hi + lo up to 2^-22 relative; s is a power of two
+__device__ __forceinline__ void pf_split8(const float (&x)[8], float s, f16x8_v& hi, f16x8_v& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float xs = x[e] * s;
+        const _Float16 h = (_Float16)xs;
+        hi[e] = h;
+        lo[e] = (_Float16)(xs - (float)h);
+    }
+}
+
 static __global__ __launch_bounds__(256) void pf_pack_kernel(const PfPackJob* __restrict__ jobs) {
     const PfPackJob jb = jobs[blockIdx.y];
+    if (jb.x3) {
+        const int total8 = jb.N * jb.K / 8, KS = jb.K / 32, NS = jb.N / 32;
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total8; idx += gridDim.x * 256) {
+            const int lane = idx & 63, blk = idx >> 6, q = lane >> 4, j = lane & 15;
+            float v[8];
+            f16x8_v hi, lo;
+            {
+                const int t = blk / KS, st = blk - t * KS;
+                const float* p = jb.W + (size_t)(t * 16 + j) * jb.K + st * 32 + 8 * q;
+                load4(p, *reinterpret_cast<float(*)[4]>(v));
+                load4(p + 4, *reinterpret_cast<float(*)[4]>(v + 4));
+                pf_split8(v, PF_W_SCALE, hi, lo);
+                char* o = reinterpret_cast<char*>(jb.nt) + (size_t)blk * 2048 + lane * 16;
+                *reinterpret_cast<f16x8_v*>(o) = hi;
+                *reinterpret_cast<f16x8_v*>(o + 1024) = lo;
+            }
+            if (jb.nn) {
+                const int c = blk / NS, st = blk - c * NS;
+                const float* p = jb.W + (size_t)(st * 32 + 8 * q) * jb.K + c * 16 + j;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = p[(size_t)e * jb.K];
+                pf_split8(v, PF_W_SCALE, hi, lo);
+                char* o = reinterpret_cast<char*>(jb.nn) + (size_t)blk * 2048 + lane * 16;
+                *reinterpret_cast<f16x8_v*>(o) = hi;
+                *reinterpret_cast<f16x8_v*>(o + 1024) = lo;
+            }
+        }
+        return;
+    }
     const int total4 = jb.N * jb.K / 4, KS = jb.K / 16, NS = jb.N / 16;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total4; idx += gridDim.x * 256) {
         const int lane = idx & 63, blk = idx >> 6, q = lane >> 4, j = lane & 15;
@@ -111,9 +157,108 @@ static __global__ __launch_bounds__(256) void pf_pack_kernel(const PfPackJob* __
     }
 }
 
-template <int N, int K, int LDX, class Epi>
+// The same linear on 16-bit MFMA (the 16-bit modes of the step): out[i][tile 16 t + r] = sum_k Xs[i][k] * Wt[r][k] with BOTH operands as (hi, lo)
+// binary16 pairs and the product as hi.hi + lo.hi + hi.lo -- three v_mfma_f32_16x16x32_f16 per 32-deep step (48 matrix-pipe cycles) where the f32
+// form takes eight 16x16x4 (256), at 2^-22 relative per product instead of 2^-24: f32-level, nowhere near what one binary16 rounding costs (2^-11).
+// W = the x3 fragment-major copy (nt copy: Wt = W rows; nn copy: Wt = W columns; the two forms differ only there).  The token operand is split in
+// registers from the f32 LDS tile, eight values per lane and step (24 VALU instructions: this, not the matrix pipe, is what the loop is bound by),
+// after a per-linear power-of-two scale s that puts the tile's largest magnitude at 2^14..2^15: backward operands are 1e-3 .. 1e-8 and would sit in
+// binary16's subnormals unscaled.  Every wave reads the whole 16 x KC tile through its own fragments, so each wave finds the same s on its own: no
+// barrier, no LDS scratch.  What falls below 2^-14 of the maximum loses relative precision but not absolute (block floating point): its error is
+// below the f32 rounding of the largest terms of the same sum.  A wave with several output tiles and a short contraction (qkv, fc1, d fc2: KC = E)
+// splits its fragments once and keeps them (8 registers per step).
+template <int NTL, int KC, int LD, class Epi>
+__device__ __forceinline__ void pf_lin_x3(const float* Xs, const float* __restrict__ W, int wave, int lane, Epi epi) {
+    static_assert(KC % 32 == 0, "32-deep contraction steps");
+    constexpr int KS = KC / 32, R = (KS % 8 == 0) ? 8 : (KS % 4 == 0 ? 4 : (KS % 2 == 0 ? 2 : 1)), GP = KS / R;
+    constexpr bool KEEP = NTL > PF_NW && KS <= 4;  // more than one tile per wave: split once
+    const int q = lane >> 4, j = lane & 15;
+    const int tiles_w = wave < NTL ? (NTL - 1 - wave) / PF_NW + 1 : 0;
+    const int NG = tiles_w * GP;
+    if (NG == 0) return;
+    const float* pl = W + ((size_t)wave * KS * 128 + lane) * 4;  // 512 floats per step: hi at 16 B x lane, lo 1 KiB further
+    const float* xs = Xs + j * LD + 8 * q;
+    f32x4_v wh[R], wl[R];
+    f32x4_v acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    int tile = wave, lg = 0, cg = 0;
+    auto next_ptr = [&]() {
+        if (GP > 1 && ++lg < GP) pl += R * 512;
+        else { lg = 0; pl += ((size_t)PF_NW * KS - (GP - 1) * R) * 512; }
+    };
+    auto load_slot = [&]<int U>(std::integral_constant<int, U>) {
+        pf_gload4<((2 * U) & 3) * 1024>(wh[U], pl + ((2 * U) >> 2) * 1024);
+        pf_gload4<((2 * U + 1) & 3) * 1024>(wl[U], pl + ((2 * U + 1) >> 2) * 1024);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    [&]<int... U>(std::integer_sequence<int, U...>) { (load_slot(std::integral_constant<int, U>{}), ...); }(std::make_integer_sequence<int, R>{});
+    __builtin_amdgcn_sched_barrier(0);
+    next_ptr();
+    // the tile's scale, while the first weights are on their way
+    float amax = 0.f;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+        const float4 a = *reinterpret_cast<const float4*>(xs + 32 * st), b = *reinterpret_cast<const float4*>(xs + 32 * st + 4);
+        // (fmaxf canonicalises each operand first: two instructions per element where v_max3_f32 with |.| source modifiers takes half of one)
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(a.x), "v"(a.y));
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(a.z), "v"(a.w));
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(b.x), "v"(b.y));
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(b.z), "v"(b.w));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    // s = 2^(14 - floor(log2 amax)), clamped to a finite normal power of two; an all-zero (or non-finite) tile takes s = 1
+    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xff);
+    const int sb = (eb == 0 || eb == 255) ? 127 : min(max(268 - eb, 1), 254);
+    const float sc = __uint_as_float((unsigned)sb << 23);
+    const float inv = __uint_as_float((unsigned)(254 - sb) << 23) * (1.0f / PF_W_SCALE);
+    auto split = [&](const float* xp, f16x8_v& xh, f16x8_v& xl) {
+        float v[8];
+        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(xp);
+        *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(xp + 4);
+        pf_split8(v, sc, xh, xl);
+    };
+    f16x8_v kh[KEEP ? KS : 1], kl[KEEP ? KS : 1];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int st = 0; st < KS; ++st) split(xs + 32 * st, kh[st], kl[st]);
+    }
+    // the two cross terms go to a second accumulator: two independent MFMA chains, and the small terms are summed among themselves first
+    auto step = [&](const f32x4_v& h, const f32x4_v& l, int st) {
+        f16x8_v xh, xl;
+        if constexpr (KEEP) { xh = kh[st]; xl = kl[st]; }
+        else split(xs + 32 * st, xh, xl);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_v, h), xh, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_v, l), xh, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_v, h), xl, acc2, 0, 0, 0);
+    };
+    auto result = [&]() { return (acc + acc2) * inv; };
+    for (int gg = 0; gg + 1 < NG; ++gg) {
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ((pf_wait_vm<2 * R - 2>(), step(wh[U], wl[U], cg * R + U), __builtin_amdgcn_sched_barrier(0), load_slot(std::integral_constant<int, U>{}),
+              __builtin_amdgcn_sched_barrier(0)),
+             ...);
+        }(std::make_integer_sequence<int, R>{});
+        next_ptr();
+        if (++cg == GP) {
+            cg = 0;
+            epi(j, tile * 16 + 4 * q, result());
+            acc = f32x4_v{0.f, 0.f, 0.f, 0.f};
+            acc2 = f32x4_v{0.f, 0.f, 0.f, 0.f};
+            tile += PF_NW;
+        }
+    }
+    {
+        [&]<int... U>(std::integer_sequence<int, U...>) {
+            ((pf_wait_vm<2 * (R - 1 - U)>(), step(wh[U], wl[U], cg * R + U)), ...);
+        }(std::make_integer_sequence<int, R>{});
+        epi(j, tile * 16 + 4 * q, result());  // the last group always closes a tile
+    }
+}
+
+template <int N, int K, int LDX, bool X3 = false, class Epi>
 __device__ __forceinline__ void pf_lin_nt(const float* Xs, const float* __restrict__ W, int wave, int lane, Epi epi) {
     static_assert(N % 16 == 0 && K % 16 == 0, "tile multiples");
+    if constexpr (X3) return pf_lin_x3<N / 16, K, LDX>(Xs, W, wave, lane, epi);
     constexpr int KS = K / 16, R = (KS % 8 == 0) ? 8 : (KS % 4 == 0 ? 4 : (KS % 2 == 0 ? 2 : 1)), GP = KS / R, NTL = N / 16;
     const int q = lane >> 4, j = lane & 15;
     const int tiles_w = wave < NTL ? (NTL - 1 - wave) / PF_NW + 1 : 0;
@@ -165,9 +310,10 @@ __device__ __forceinline__ void pf_lin_nt(const float* Xs, const float* __restri
 }
 
 // out[i][c] = sum_n dYs[i][n] * W[n][c]   (NN; contraction over the N rows of W, output over its K columns).
-template <int N, int K, int LDY, class Epi>
+template <int N, int K, int LDY, bool X3 = false, class Epi>
 __device__ __forceinline__ void pf_lin_nn(const float* dYs, const float* __restrict__ W, int wave, int lane, Epi epi) {
     static_assert(N % 16 == 0 && K % 16 == 0, "tile multiples");
+    if constexpr (X3) return pf_lin_x3<K / 16, N, LDY>(dYs, W, wave, lane, epi);
     constexpr int NS = N / 16, R = (NS % 8 == 0) ? 8 : (NS % 4 == 0 ? 4 : (NS % 2 == 0 ? 2 : 1)), GP = NS / R, KT = K / 16;
     const int q = lane >> 4, j = lane & 15;
     const int tiles_w = wave < KT ? (KT - 1 - wave) / PF_NW + 1 : 0;
@@ -433,8 +579,8 @@ __device__ __forceinline__ float pf_gelu_grad(float r) {  // d/du of the tanh-ap
     return 0.5f * (1.f + t) + 0.5f * r * (1.f - t * t) * c * (1.f + 3.f * a * r * r);
 }
 
-template <int E, int H>
-static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {
+template <int E, int H, bool X3 = false>
+static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs a) {  // X3: the big linears on (hi, lo) binary16 pairs (pf_lin_x3)
     extern __shared__ __attribute__((aligned(16))) float pf_sm[];
     const int L = a.L, T = a.T, NA = a.NA, heads = a.heads;
     const int hd = E / heads;
@@ -493,7 +639,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         const float* vb = sV + 8 * bi * E;
         pf_ln_fwd(sX, sY, ldE, vb, vb + E, E, k.ln0 + t0 * E, L, wave, lane);
         __syncthreads();
-        pf_lin_nt<3 * E, E, ldE>(sY, k.wqkv_nt, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<3 * E, E, ldE, X3>(sY, k.wqkv_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             const float4 bb = *reinterpret_cast<const float4*>(vb + 2 * E + n);
             v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             *reinterpret_cast<float4*>(sQ + i * ldW + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -503,7 +649,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         // causal attention (layers.py:70-90): scores * scale, masked, softmax, P.V
         pf_attn_fwd_mfma(sQ, sA, ldW, ldE, E, hd, heads, L, scale, k.att + t0 * E, wave, lane, a.alibi);
         __syncthreads();
-        pf_lin_nt<E, E, ldE>(sA, k.wo_nt, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<E, E, ldE, X3>(sA, k.wo_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             const float4 bb = *reinterpret_cast<const float4*>(vb + 5 * E + n);
             const float4 xr = *reinterpret_cast<const float4*>(sX + i * ldE + n);
             v[0] += bb.x + xr.x; v[1] += bb.y + xr.y; v[2] += bb.z + xr.z; v[3] += bb.w + xr.w;
@@ -513,7 +659,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         pf_save_rows(sM, ldE, E, k.hmid + t0 * E, L, tid);
         pf_ln_fwd(sM, sY, ldE, vb + 6 * E, vb + 7 * E, E, k.ln1 + t0 * E, L, wave, lane);
         __syncthreads();
-        pf_lin_nt<H, E, ldE>(sY, k.wfc1_nt, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<H, E, ldE, X3>(sY, k.wfc1_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             f32x4_v gl;
 #pragma unroll
             for (int r = 0; r < 4; ++r) gl[r] = apply_act<ACT_GELU_TANH>(v[r]);
@@ -524,7 +670,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         pf_save_rows(sU, ldW, H, k.u + t0 * H, L, tid);
         pf_save_rows(sG, ldW, H, k.gl + t0 * H, L, tid);
         float* xnext = bi + 1 < a.depth ? a.blk[bi + 1].x : a.xf;
-        pf_lin_nt<E, H, ldW>(sG, k.wfc2_nt, wave, lane, [&](int i, int n, f32x4_v v) {
+        pf_lin_nt<E, H, ldW, X3>(sG, k.wfc2_nt, wave, lane, [&](int i, int n, f32x4_v v) {
             const float4 mr = *reinterpret_cast<const float4*>(sM + i * ldE + n);
             v[0] += mr.x; v[1] += mr.y; v[2] += mr.z; v[3] += mr.w;
             *reinterpret_cast<float4*>(sX + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -552,14 +698,14 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         hR[t * ldE + c] = vr;
     }
     __syncthreads();
-    pf_lin_nt<E, E, ldE>(hA, a.wa0_nt, wave, lane, [&](int i, int n, f32x4_v v) {
+    pf_lin_nt<E, E, ldE, X3>(hA, a.wa0_nt, wave, lane, [&](int i, int n, f32x4_v v) {
         const float4 bb = *reinterpret_cast<const float4*>(sVt + 2 * E + n);
         v[0] = fmaxf(v[0] + bb.x, 0.f); v[1] = fmaxf(v[1] + bb.y, 0.f); v[2] = fmaxf(v[2] + bb.z, 0.f); v[3] = fmaxf(v[3] + bb.w, 0.f);
         if (i >= T) v = f32x4_v{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<float4*>(hHa + i * ldE + n) = make_float4(v[0], v[1], v[2], v[3]);
         if (i < T) store4g(a.ha + (r0 + i) * E + n, v);
     });
-    pf_lin_nt<E, E, ldE>(hR, a.wr0_nt, wave, lane, [&](int i, int n, f32x4_v v) {
+    pf_lin_nt<E, E, ldE, X3>(hR, a.wr0_nt, wave, lane, [&](int i, int n, f32x4_v v) {
         const float4 bb = *reinterpret_cast<const float4*>(sVt + 3 * E + n);
         v[0] = fmaxf(v[0] + bb.x, 0.f); v[1] = fmaxf(v[1] + bb.y, 0.f); v[2] = fmaxf(v[2] + bb.z, 0.f); v[3] = fmaxf(v[3] + bb.w, 0.f);
         if (i >= T) v = f32x4_v{0.f, 0.f, 0.f, 0.f};
@@ -641,10 +787,10 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
     __syncthreads();
     for (int i = tid; i < 16 * ldE; i += PF_THREADS) sA[i] = 0.f;  // sA <- d(hf): rows 3t+1 <- d a_in, rows 3t <- d r_in
     __syncthreads();
-    pf_lin_nn<E, E, ldE>(hDha, a.wa0_nn, wave, lane, [&](int i, int c, f32x4_v v) {
+    pf_lin_nn<E, E, ldE, X3>(hDha, a.wa0_nn, wave, lane, [&](int i, int c, f32x4_v v) {
         if (i < T) *reinterpret_cast<float4*>(sA + (3 * i + 1) * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
     });
-    pf_lin_nn<E, E, ldE>(hDhr, a.wr0_nn, wave, lane, [&](int i, int c, f32x4_v v) {
+    pf_lin_nn<E, E, ldE, X3>(hDhr, a.wr0_nn, wave, lane, [&](int i, int c, f32x4_v v) {
         if (i < T) *reinterpret_cast<float4*>(sA + (3 * i) * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
     });
     __syncthreads();
@@ -664,7 +810,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
             *reinterpret_cast<float4*>(sG + i * ldW + c) = *reinterpret_cast<const float4*>(k.u + (t0 + i) * H + c);
         }
         __syncthreads();
-        pf_lin_nn<E, H, ldE>(sY, k.wfc2_nn, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<E, H, ldE, X3>(sY, k.wfc2_nn, wave, lane, [&](int i, int c, f32x4_v v) {
             if (i < L) {
                 const float4 uu = *reinterpret_cast<const float4*>(sG + i * ldW + c);
                 v[0] *= pf_gelu_grad(uu.x); v[1] *= pf_gelu_grad(uu.y); v[2] *= pf_gelu_grad(uu.z); v[3] *= pf_gelu_grad(uu.w);
@@ -675,7 +821,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         });
         __syncthreads();
         pf_save_rows(sU, ldW, H, k.d_u + t0 * H, L, tid);
-        pf_lin_nn<H, E, ldW>(sU, k.wfc1_nn, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<H, E, ldW, X3>(sU, k.wfc1_nn, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
         });
         __syncthreads();
@@ -691,7 +837,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
             const int i = idx / (3 * E), c = idx - i * 3 * E;
             sQ[i * ldW + c] = k.qkv[(t0 + i) * 3 * E + c];
         }
-        pf_lin_nn<E, E, ldE>(sY, k.wo_nn, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<E, E, ldE, X3>(sY, k.wo_nn, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);  // d att
         });
         __syncthreads();
@@ -700,7 +846,7 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         __syncthreads();
         pf_attn_bwd_mfma_b(sQ, sA, sU, sP, sS, ldW, ldE, E, hd, heads, L, k.d_qkv + t0 * 3 * E, wave, lane);
         __syncthreads();
-        pf_lin_nn<3 * E, E, ldW>(sU, k.wqkv_nn, wave, lane, [&](int i, int c, f32x4_v v) {
+        pf_lin_nn<3 * E, E, ldW, X3>(sU, k.wqkv_nn, wave, lane, [&](int i, int c, f32x4_v v) {
             *reinterpret_cast<float4*>(sA + i * ldE + c) = make_float4(v[0], v[1], v[2], v[3]);
         });
         __syncthreads();

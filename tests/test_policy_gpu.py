@@ -199,6 +199,62 @@ def test_fused_policy_kernel_matches_unfused_path(gpu_lib, kw, B, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("kw,B", [(TINY, 4), (SMALL, 6)])
+def test_fused_kernel_hi_lo_binary16_linears_are_f32_level(gpu_lib, kw, B, monkeypatch):
+    """The 16-bit modes run the fused kernel's big linears on (hi, lo) binary16 operand pairs (policy_fused.h::pf_lin_x3: three 16x16x32 MFMAs per
+    product, per-linear power-of-two scale).  Switched on inside the f32 mode (ARP_PF_X3=1) nothing else rounds to 16 bits, so the comparison with the
+    per-op f32 path isolates them: same bars as the f32-MFMA fused kernel above -- 1e-5 on the outputs, 5e-5 relative on every gradient (backward operands
+    of 1e-3 .. 1e-8 included: that is what the scale is for)."""
+    from arp_amd.train import PolicyTrainer
+    cfg, _, P, (enc, act, rtg), _, _ = _setup(kw, B, 11)
+    res = {}
+    for fused, x3 in (("1", "1"), ("0", "0")):
+        monkeypatch.setenv("ARP_DT_FUSED", fused)
+        monkeypatch.setenv("ARP_PF_X3", x3)
+        tr = PolicyTrainer(cfg, mode="f32")
+        tr.set_params(P)
+        tr.set_batch(enc, act, rtg)
+        out = tr.forward()
+        tr.backward()
+        res[fused] = (out, tr.get_grads())
+        tr.close()
+    (o1, g1), (o0, g0) = res["1"], res["0"]
+    assert np.abs(o1["action_pred"] - o0["action_pred"]).max() < 1e-5
+    assert np.abs(o1["return_pred"] - o0["return_pred"]).max() < 1e-5
+    for k in ("loss", "acc", "trans_loss", "return_loss"):
+        assert abs(o1[k] - o0[k]) < 1e-5, k
+    bad = [(k, float(np.abs(g1[k] - g0[k]).max() / max(np.abs(g0[k]).max(), 1e-6))) for k in P]
+    bad = [b for b in bad if not b[1] < 5e-5]
+    assert not bad, bad
+
+
+def test_fused_kernel_hi_lo_linears_keep_tiny_gradients(gpu_lib, monkeypatch):
+    """Backward operands far below binary16's normal range: with the last action layer zeroed nothing of the cross-entropy reaches the trunk, and with
+    lambda_return_pred = 1e-8 what does is the return loss at 1e-7 .. 1e-12.  Unscaled, the hi halves would be subnormal (or zero) and the gradients
+    garbage; with the per-linear power-of-two scale they match the f32 per-op path to the same RELATIVE bar as at ordinary magnitudes."""
+    from arp_amd.train import PolicyTrainer
+    cfg, _, P, (enc, act, rtg), _, _ = _setup(dict(TINY, lambda_ret=1e-8), 4, 5)
+    P = {k: v.copy() for k, v in P.items()}
+    P["action_outputs_0/layers_2/kernel"] *= 0
+    res = {}
+    for fused, x3 in (("1", "1"), ("0", "0")):
+        monkeypatch.setenv("ARP_DT_FUSED", fused)
+        monkeypatch.setenv("ARP_PF_X3", x3)
+        tr = PolicyTrainer(cfg, mode="f32")
+        tr.set_params(P)
+        tr.set_batch(enc, act, rtg)
+        tr.forward()
+        tr.backward()
+        res[fused] = tr.get_grads()
+        tr.close()
+    g1, g0 = res["1"], res["0"]
+    trunk = [k for k in P if k.startswith("policy/") and np.abs(g0[k]).max() > 0]
+    assert trunk and max(np.abs(g0[k]).max() for k in trunk) < 1e-6, "the setup no longer makes the trunk gradients tiny"
+    bad = [(k, float(np.abs(g1[k] - g0[k]).max() / np.abs(g0[k]).max())) for k in P if np.abs(g0[k]).max() > 0]
+    bad = [b for b in bad if not b[1] < 5e-5]
+    assert not bad, bad
+
+
 def test_long_window_uses_unfused_path(gpu_lib):
     """window 6 -> 18 tokens per sample: beyond the fused kernel's 16-row tile, served by the per-op kernels."""
     from arp_amd.train import PolicyTrainer
