@@ -18,6 +18,9 @@
 #pragma once
 #include "common.h"
 
+#ifndef ARP_ADAMW_PIPE
+#define ARP_ADAMW_PIPE 1
+#endif
 namespace arp {
 
 struct GemmArgs {
@@ -300,6 +303,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                         rres[it] = (m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
+                // Fused AdamW: the weight's p / m / v rows one iteration AHEAD (ARP_ADAMW_PIPE, default on) -- iteration it + 1's three loads are issued
+                // before iteration it's four stores, and iteration 0's before the tile is staged.  A wave's loads and stores retire through one in-order
+                // counter: issued behind the stores (round 3), every iteration's loads also waited for the previous iteration's writes to reach memory.
+                // Addresses of rows / columns past the edge are clamped (finite garbage, never used) so that the loads are unconditional.
+                constexpr bool ADAMW_PIPE = (ARP_ADAMW_PIPE != 0) && SITE == GEMM_SITE_ADAMW && !RESID && sizeof(T) == 2;
+                float4 pq[2], mq[2], vq[2];
+                auto adam_idx = [&](int it) {
+                    const int lr = it * 8 + wave * 2 + (lane >> 5);
+                    const int m = min(m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), g.M - 1), n = min(n0 + (lane & 31) * 4, g.N - 4);
+                    return (size_t)m * g.ldo + n;
+                };
+                auto adam_load = [&](int it) {
+                    const size_t idx = adam_idx(it);
+                    pq[it & 1] = *reinterpret_cast<const float4*>(g.adam_p + idx);
+                    mq[it & 1] = *reinterpret_cast<const float4*>(g.adam_m + idx);
+                    vq[it & 1] = *reinterpret_cast<const float4*>(g.adam_v + idx);
+                };
+                if constexpr (ADAMW_PIPE) adam_load(0);
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -322,6 +343,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     const int m = m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), n = n0 + (lane & 31) * 4;
                     const bool ok = m < g.M && n < g.N;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (ADAMW_PIPE) {
+                        if (it + 1 < 8) adam_load(it + 1);
+                    }
                     if (ok) {
                         v = *reinterpret_cast<const float4*>(smem + lr * RSF + (lane & 31) * 16);
                         if constexpr (RESID) {
@@ -333,8 +357,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                             // (requesting the pass's 24 p / m / v rows ahead of the staging, as the residual epilogue does with its 8, measured
                             //  SLOWER: 4.4 instead of 5.5 TB/s -- 96 more live registers under the staging loop)
                             const size_t idx = (size_t)m * g.ldo + n;
-                            const float4 pv = *reinterpret_cast<const float4*>(g.adam_p + idx), mv = *reinterpret_cast<const float4*>(g.adam_m + idx),
-                                         vv = *reinterpret_cast<const float4*>(g.adam_v + idx);
+                            float4 pv, mv, vv;
+                            if constexpr (ADAMW_PIPE) { pv = pq[it & 1]; mv = mq[it & 1]; vv = vq[it & 1]; }
+                            else {
+                                pv = *reinterpret_cast<const float4*>(g.adam_p + idx);
+                                mv = *reinterpret_cast<const float4*>(g.adam_m + idx);
+                                vv = *reinterpret_cast<const float4*>(g.adam_v + idx);
+                            }
                             float gg[4] = {v.x, v.y, v.z, v.w}, pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w}, nn[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
