@@ -244,7 +244,9 @@ int forward_chunk_x3(arp_enc* c, hipStream_t stream, const float* img_dev, int n
         ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_QKV>(t, "m3ae.qkv", a3, L.w_in, L.b_in, nullptr, qkv, M, 3 * D, 3 * D)));
         {
             ProfScope ps(c->prof, stream, "m3ae.attn");
-            ARP_TRY(launch_attention<float>(stream, k.attn_impl, qkv, ao, nb, N, D, k.heads, 0, 0, 0.f, direct ? a3 : nullptr));
+            // the (hi, lo) binary16 attention (attention.h::attn_x3_kernel) where it exists; ARP_ENC_ATTN_X3=0 keeps the exact-f32 MFMA kernel
+            static const bool attn_x3 = [] { const char* e = getenv("ARP_ENC_ATTN_X3"); return !e || atoi(e) != 0; }();
+            ARP_TRY(launch_attention<float>(stream, direct && attn_x3 ? 3 : k.attn_impl, qkv, ao, nb, N, D, k.heads, 0, 0, 0.f, direct ? a3 : nullptr));
         }
         if (!direct) ARP_TRY(split("m3ae.split", ao, M, D));
         ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, true, 8 + SITE_OUT>(t, "m3ae.out_proj", a3, L.w_out, L.b_out, x, x, M, D, 3 * D)));

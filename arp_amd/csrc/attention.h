@@ -199,6 +199,162 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
     }
 }
 
+// ---- (hi, lo) binary16 MFMA kernel (head_dim 64): the attention of the f16x3 encoder mode ----------------------------------------------------------------
+// Same plan as the f32 kernel above with every product on v_mfma_f32_16x16x32_f16 as hi.hi + lo.hi + hi.lo (2^-22 relative, three instructions of 16
+// cycles per 32-deep step where the f32 form takes eight of 32): K of one (sample, head) in LDS as two binary16 arrays [key][64] (hi, lo), V as two
+// TRANSPOSED arrays [d][key]; Q split in registers (softmax scale and log2 e folded in before the split, so the scores come out in the exp2 domain);
+// the softmax'd accumulators split in registers into the B operand of O^T = V^T.P^T.  A 32-deep contraction step of that product takes the key pair
+// of tiles (2c, 2c+1): slot (g, e) is key 32c + 4g + e for e < 4 and 32c + 16 + 4g + (e - 4) above -- exactly the eight values lane (g, j) holds of
+// S^T tiles 2c and 2c+1, so P never moves between lanes; the matching A operand is two 8-byte reads of a transposed V row.  P is carried times 2^10
+// (exact; its lo halves stay out of binary16's subnormals down to p = 1e-4) and the row sum with it, so the factor cancels in O / l.
+#define ARP_SPLIT1(X, HI, LO)                  \
+    do {                                       \
+        const float _x = pin_f32(X);           \
+        const _Float16 _h = (_Float16)_x;      \
+        HI = _h;                               \
+        LO = (_Float16)(_x - (float)_h);       \
+    } while (0)
+template <int NT>
+__global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int D, int heads, float scale,
+                                                      int causal, int nq, f16_t* __restrict__ out3) {
+    constexpr int HD = 64, NC = (NT + 1) / 2, KROW = 72, VROW = NC * 32 + 4;  // f16 elements per K row (144 B) / per transposed V row
+    extern __shared__ __attribute__((aligned(16))) char attn_smem[];
+    _Float16* Kh = reinterpret_cast<_Float16*>(attn_smem);
+    _Float16* Kl = Kh + NT * 16 * KROW;
+    _Float16* Vh = Kl + NT * 16 * KROW;
+    _Float16* Vl = Vh + HD * VROW;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const size_t ld = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * N * ld + h * HD;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    // K rows (zero beyond N)
+    for (int idx = threadIdx.x; idx < NT * 16 * 16; idx += 512) {
+        const int key = idx >> 4, c4 = idx & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (key < N) v = *reinterpret_cast<const float4*>(base + (size_t)key * ld + D + 4 * c4);
+        h4 hi, lo;
+        ARP_SPLIT1(v.x, hi[0], lo[0]); ARP_SPLIT1(v.y, hi[1], lo[1]); ARP_SPLIT1(v.z, hi[2], lo[2]); ARP_SPLIT1(v.w, hi[3], lo[3]);
+        *reinterpret_cast<h4*>(Kh + key * KROW + 4 * c4) = hi;
+        *reinterpret_cast<h4*>(Kl + key * KROW + 4 * c4) = lo;
+    }
+    // V transposed: one key PAIR per thread and d-quad, so that a store is one dword (two keys of one d)
+    for (int idx = threadIdx.x; idx < NC * 16 * 16; idx += 512) {
+        const int kp = idx >> 4, dq = idx & 15;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (2 * kp < N) v0 = *reinterpret_cast<const float4*>(base + (size_t)(2 * kp) * ld + 2 * D + 4 * dq);
+        if (2 * kp + 1 < N) v1 = *reinterpret_cast<const float4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + 4 * dq);
+        const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h2 hi, lo;
+            ARP_SPLIT1(a0[e], hi[0], lo[0]);
+            ARP_SPLIT1(a1[e], hi[1], lo[1]);
+            *reinterpret_cast<h2*>(Vh + (4 * dq + e) * VROW + 2 * kp) = hi;
+            *reinterpret_cast<h2*>(Vl + (4 * dq + e) * VROW + 2 * kp) = lo;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const float qs = scale * 1.44269504088896340736f;
+    for (int q0 = wave * 16; q0 < nq; q0 += 128) {  // eight waves: two per SIMD, one in its MFMAs while the other is in its softmax / splits
+        asm volatile("" ::: "memory");  // K and V are loop invariant: keep the compiler from hoisting the operand reads of every query block out of the loop
+        const int qi = q0 + j;
+        const float* qrow = base + (size_t)min(qi, N - 1) * ld;
+        f16x8_v qh[2], ql[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + 32 * c + 8 * g), bq = *reinterpret_cast<const float4*>(qrow + 32 * c + 8 * g + 4);
+            const float v[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, bq.x * qs, bq.y * qs, bq.z * qs, bq.w * qs};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ARP_SPLIT1(v[e], qh[c][e], ql[c][e]);
+        }
+        f32x4_v acc[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) acc[kt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f16x8_v kh[NT], kl[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                kh[kt] = *reinterpret_cast<const f16x8_v*>(Kh + (kt * 16 + j) * KROW + 32 * c + 8 * g);
+                kl[kt] = *reinterpret_cast<const f16x8_v*>(Kl + (kt * 16 + j) * KROW + 32 * c + 8 * g);
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[c], acc[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[kt], qh[c], acc[kt], 0, 0, 0);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], ql[c], acc[kt], 0, 0, 0);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * g + r;
+                if (key >= N || (causal && key > qi)) acc[kt][r] = -INFINITY;
+                m = fmaxf(m, acc[kt][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float m10 = m - 10.f;  // P times 2^10
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(acc[kt][r] - m10);  // 2^-inf = 0 for the masked keys; key 0 is never masked, so m is finite
+                acc[kt][r] = pv;
+                l += pv;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        f32x4_v o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f16x8_v ph, pl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ARP_SPLIT1(acc[2 * c][r], ph[r], pl[r]);
+                if (2 * c + 1 < NT) ARP_SPLIT1(acc[2 * c + 1][r], ph[4 + r], pl[4 + r]);
+                else { ph[4 + r] = (_Float16)0.f; pl[4 + r] = (_Float16)0.f; }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const _Float16* vr = Vh + (dt * 16 + j) * VROW + 32 * c + 4 * g;
+                const _Float16* vq = Vl + (dt * 16 + j) * VROW + 32 * c + 4 * g;
+                const h4 a0 = *reinterpret_cast<const h4*>(vr), a1 = *reinterpret_cast<const h4*>(vr + 16);
+                const h4 b0 = *reinterpret_cast<const h4*>(vq), b1 = *reinterpret_cast<const h4*>(vq + 16);
+                const f16x8_v vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const f16x8_v vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[dt], 0, 0, 0);
+            }
+        }
+        if (qi < nq) {
+            const float inv = 1.0f / l;
+            // lane (g, j): query j, d = 16 dt + 4 g + r
+            if (out3) {
+                f16_t* orow3 = out3 + ((size_t)b * N + qi) * 3 * D + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) store_split3(orow3 + 16 * dt, (size_t)D, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            } else {
+                float* orow = out + ((size_t)b * N + qi) * D + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+            }
+        }
+    }
+}
+#undef ARP_SPLIT1
+constexpr int attn_x3_lds_bytes(int nt) { return (2 * nt * 16 * 72 + 2 * 64 * (((nt + 1) / 2) * 32 + 4)) * 2; }
+
 // ---- MFMA kernel (bf16, head_dim 64) -------------------------------------------------------------
 // NT = number of 16-key tiles (keys padded to a multiple of 32, i.e. NT even).
 // LDS: K [NT*16 keys][128 B] and V [NT*16 keys][128 B], both row-major with the 16-byte chunk index XOR-swizzled

@@ -126,7 +126,15 @@ __device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, floa
 }
 // (hi, lo) binary16 pair of four f32 values in the K-concatenated operand layout of ARP_MODE_F16X3: hi at p, lo at p + n, hi again at p + 2 n
 // ([x_hi | x_lo | x_hi] against [W_hi | W_hi | W_lo]: x.W on three 16-bit MFMAs to ~2^-22).  8-byte aligned like store4.
+// A value about to be split into (hi, lo) must be ONE f32 number.  With fp-contract on, hipcc may evaluate `x = m * n` twice: rounded to f32 in front of
+// one use and fused into another (v_fma_mixlo_f16 rounds m * n straight to binary16; `x - hi` becomes fma(m, n, -hi)) -- the two "hi" then differ by one
+// binary16 ulp once in ~2^13 values and that element is off by 2^-11 instead of 2^-22 (found on the x3 attention's prescaled Q: 2 query rows of 514).
+__device__ __forceinline__ float pin_f32(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ void store_split3(f16_t* p, size_t n, float a, float b, float c, float d) {
+    a = pin_f32(a); b = pin_f32(b); c = pin_f32(c); d = pin_f32(d);
     const float ha = h2f(f2h(a)), hb = h2f(f2h(b)), hc = h2f(f2h(c)), hd = h2f(f2h(d));
     const uint2 hi = make_uint2(pack_h2(ha, hb), pack_h2(hc, hd));
     *reinterpret_cast<uint2*>(p) = hi;

@@ -100,7 +100,8 @@ template <int N> __device__ __forceinline__ void pf_wait_vm() {
 // The weights are packed times 2^8: their lo halves (2^-12 of the value) stay binary16 normals down to |w| = 2^-10, and anything smaller is off by less
 // than 2^-33 absolute; |w| >= 256 would overflow the hi half (a LayerNorm'd 128-wide transformer's weights are O(1)).
 constexpr float PF_W_SCALE = 256.f;
-// (hi, lo) of eight consecutive operands: x * s = hi + lo up to 2^-22 relative; s is a power of two
+// (hi, lo) of eight consecutive operands: x * s = hi + lo up to 2^-22 relative; s is a power of two (so x * s is exact and it does not matter whether
+// the compiler rounds it to f32 before a use or fuses it into one -- see common.h::pin_f32 for what happens when it is not)
 __device__ __forceinline__ void pf_split8(const float (&x)[8], float s, f16x8_v& hi, f16x8_v& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {

@@ -252,6 +252,27 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
     }
     if (out8 != 0.f) return fail("attention: the e4m3 output exists on the MFMA kernel only");
     if constexpr (sizeof(T) == 4) {
+        // impl 3: the (hi, lo) binary16 MFMA kernel (attention.h::attn_x3_kernel, the f16x3 encoder mode's attention): head_dim 64, up to 288 keys
+        if (impl == 3 && hd == 64 && N <= 288 && (D & 3) == 0) {
+            const int need = (N + 15) / 16;
+#define ARP_ATTNX3_CASE(nt)                                                                                                        \
+    if (need <= nt) {                                                                                                              \
+        const int ldsx = attn_x3_lds_bytes(nt);                                                                                    \
+        auto kern = attn_x3_kernel<nt>;                                                                                            \
+        ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsx));    \
+        hipLaunchKernelGGL(kern, dim3(B* heads), dim3(512), ldsx, stream, qkv, out, N, D, heads, scale, causal, nq, out3);          \
+        ARP_HIP_OK(hipGetLastError());                                                                                             \
+        return 0;                                                                                                                  \
+    }
+            ARP_ATTNX3_CASE(1)
+            ARP_ATTNX3_CASE(4)
+            ARP_ATTNX3_CASE(5)
+            ARP_ATTNX3_CASE(13)
+            ARP_ATTNX3_CASE(17)
+            ARP_ATTNX3_CASE(18)
+#undef ARP_ATTNX3_CASE
+        }
+        if (impl == 3) impl = 0;  // other shapes: the exact-f32 kernels below
         // exact-f32 attention on the f32-input MFMA (attention.h): head_dim 64, up to 288 keys in LDS
         if (impl == 0 && hd == 64 && N <= 288 && (D & 3) == 0) {
             const int need = (N + 15) / 16;

@@ -177,7 +177,8 @@ ATTN_CASES = [  # B, N, D, heads, causal
 
 
 @pytest.mark.parametrize("case", ATTN_CASES)
-@pytest.mark.parametrize("mode,impl", [(0, 1), (0, 0), (1, 1), (1, 0), (2, 1), (2, 0)])  # (0, 0): the exact-f32 MFMA kernel where head_dim is 64
+# (0, 0): the exact-f32 MFMA kernel where head_dim is 64; (0, 3): the (hi, lo) binary16 MFMA kernel of the f16x3 encoder mode (f32-level: same bar)
+@pytest.mark.parametrize("mode,impl", [(0, 1), (0, 0), (0, 3), (1, 1), (1, 0), (2, 1), (2, 0)])
 def test_attention(gpu_lib, case, mode, impl):
     B, N, D, heads, causal = case
     rng = np.random.default_rng(N * 13 + D)

@@ -230,7 +230,7 @@ def test_fused_kernel_hi_lo_binary16_linears_are_f32_level(gpu_lib, kw, B, monke
 
 def test_fused_kernel_hi_lo_linears_keep_tiny_gradients(gpu_lib, monkeypatch):
     """Backward operands far below binary16's normal range: with both heads' last layers scaled by 1e-7 the gradients that reach the trunk are 1e-8 ..
-    1e-12.  Unscaled, their hi halves would be subnormal (or zero) and the gradients garbage; with the per-linear power-of-two scale they match the
+    1e-12 (measured: 3e-9 .. 2e-8 on the biases and LayerNorm parameters).  Unscaled, their hi halves would be subnormal (or zero) and the gradients garbage; with the per-linear power-of-two scale they match the
     f32 per-op path to the same RELATIVE bar as at ordinary magnitudes."""
     from arp_amd.train import PolicyTrainer
     cfg, _, P, (enc, act, rtg), _, _ = _setup(TINY, 4, 5)
@@ -249,7 +249,9 @@ def test_fused_kernel_hi_lo_linears_keep_tiny_gradients(gpu_lib, monkeypatch):
         res[fused] = tr.get_grads()
         tr.close()
     g1, g0 = res["1"], res["0"]
-    trunk = [k for k in P if k.startswith("policy/Block") and np.abs(g0[k]).max() > 0]
+    # (the kernels' gradients carry the L2 term wd * W of main_procgen.py:114-117, ~2e-5 here whatever the loss does: biases and LayerNorm parameters
+    #  are the ones that see only what came back through the linears)
+    trunk = [k for k in P if k.startswith("policy/Block") and not k.endswith("kernel") and np.abs(g0[k]).max() > 0]
     sizes = {k: float(np.abs(g0[k]).max()) for k in trunk}
     assert trunk and max(sizes.values()) < 1e-6, ("the setup no longer makes the trunk gradients tiny", sizes)
     bad = [(k, float(np.abs(g1[k] - g0[k]).max() / np.abs(g0[k]).max())) for k in P if np.abs(g0[k]).max() > 0]
