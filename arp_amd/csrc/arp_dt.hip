@@ -152,6 +152,7 @@ struct arp_dt {
     // return error goes from max 1.05e-3 (2 seeds of 16 outside north_star's 1e-3) to max 8.7e-4 (none).  Costs the Y32 write and a
     // 1/16-rate GEMM: 0.866 -> 0.926 ms per step at B = 32 (+7 %).  The backward is unchanged.
     bool iti_f32 = false;
+    bool iti_x3 = true;  // ... and that f32-level product on (hi, lo) binary16 MFMA pairs instead of the f32 MFMA (ARP_DT_ITI_X3=0: round 3's f32-MFMA GEMM)
     DevBuf Y32;
     DevBuf colpart;  // column partial sums of mask_copy_colsum_kernel
     DevBuf dres_part;  // per-workgroup d loss / d res partials of adapter_dy_kernel
@@ -319,8 +320,7 @@ int splitk_gemm(arp_dt* c, const char* site, const void* A, int lda, const void*
     if (S == 1) g.ksplit = 1;
     ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_DT + 1>(g, c->stream)));
     const size_t MN = (size_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out,
-                       nullptr, 0, alpha);
+    launch_splitk_reduce<OutT>(c->stream, c->part.as<float>(), S, MN, N, bias, act, out, nullptr, 0, alpha);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -607,7 +607,21 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         ARP_HIP_OK(hipGetLastError());
         Yp = c->Y.as<T>();
     }
-    if (sizeof(T) == 2 && c->iti_f32) {
+    if (sizeof(T) == 2 && c->iti_f32 && c->iti_x3 && Kin % 64 == 0 && E % 4 == 0) {
+        // the same f32-level contraction on (hi, lo) binary16 pairs split in flight (dtops.h::iti_x3_kernel): bound by the 202 MB stream, not by the f32 matrix rate
+        const float* Y32 = k.use_adapter ? c->Y32.as<float>() : c->bt[c->cur].enc32.as<float>();
+        const int tiles = cdiv(R, 128) * cdiv(E, 128);
+        const int nk = (int)(Kin / 64);
+        int S = std::max(1, std::min(nk, 256 / std::max(tiles, 1)));  // one workgroup per CU
+        const int per = (nk + S - 1) / S;
+        S = (nk + per - 1) / per;
+        ARP_TRY(c->part.ensure((size_t)S * R * E * 4));
+        ProfScope ps(c->prof, c->stream, "dt.image_text_input");
+        hipLaunchKernelGGL(iti_x3_kernel, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, c->p("image_text_input/kernel"), Kin, c->part.as<float>(), R, E, (int)Kin, per * 64);
+        ARP_HIP_OK(hipGetLastError());
+        launch_splitk_reduce<float>(c->stream, c->part.as<float>(), S, (size_t)R * E, E, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>());
+        ARP_HIP_OK(hipGetLastError());
+    } else if (sizeof(T) == 2 && c->iti_f32) {
         const float* Y32 = k.use_adapter ? c->Y32.as<float>() : c->bt[c->cur].enc32.as<float>();
         ARP_TRY((splitk_gemm<float, float>(c, "dt.image_text_input", Y32, Kin, c->p("image_text_input/kernel"), Kin, c->p("image_text_input/bias"), ACT_TANH,
                                            c->img.as<float>(), R, E, Kin)));
@@ -688,8 +702,7 @@ int tn_gemm(arp_dt* c, const char* site, const T* A, int lda, const T* B, int ld
     g.out = part.as<float>(); g.ldo = N; g.slice_stride = (size_t)M * N; g.alpha = 1.f;
     ARP_TRY(launch_gemm_tn(tcode, g, st));
     const size_t MN = (size_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(cdiv(MN, 64)), dim3(256), 0, st, part.as<float>(), S, MN, N, nullptr, ACT_NONE, out,
-                       nullptr, 0, alpha);
+    launch_splitk_reduce<float>(st, part.as<float>(), S, MN, N, nullptr, ACT_NONE, out, nullptr, 0, alpha);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -1126,6 +1139,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_PF_X3")) c->pf_x3 = atoi(e) != 0;
     c->iti_f32 = k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_ITI_F32")) c->iti_f32 = atoi(e) != 0 && k.mode != ARP_MODE_F32;
+    if (const char* e = getenv("ARP_DT_ITI_X3")) c->iti_x3 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
     build_layout(c);
@@ -1540,8 +1554,7 @@ template <typename T> int op_gemm_tn(int tile256, int ksplit, const float* A, co
         } else {
             g.out = dP.as<float>(); g.slice_stride = MN; g.alpha = 1.f;
             ARP_TRY(launch_gemm_tn(tcode, g, nullptr));
-            hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(cdiv(MN, 64)), dim3(256), 0, nullptr, dP.as<float>(), ksplit, MN, N, nullptr, ACT_NONE,
-                               dO.as<float>(), nullptr, 0, alpha);
+            launch_splitk_reduce<float>(nullptr, dP.as<float>(), ksplit, MN, N, nullptr, ACT_NONE, dO.as<float>(), nullptr, 0, alpha);
             ARP_HIP_OK(hipGetLastError());
         }
         ARP_HIP_OK(hipMemcpy(out, dO.p, MN * 4, hipMemcpyDeviceToHost));

@@ -225,8 +225,7 @@ int ft_gemm(arp_ft* c, const char* site, const void* A, int lda, const void* W, 
     g.m_fast = (mfast && M <= 4 * GEMM_BM) ? 1 : 0;  // the image tower's 192 rows = two row tiles over the same weight stream
     ARP_TRY((launch_gemm_nt<T, float, ACT_NONE, false, SITE_FT + 1>(g, c->stream)));
     const size_t MN = (size_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, bias, act, out, resid,
-                       ldo == N ? 0 : ldo);
+    launch_splitk_reduce<OutT>(c->stream, c->part.as<float>(), S, MN, N, bias, act, out, resid, ldo == N ? 0 : ldo);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -249,8 +248,7 @@ int ft_gemm_nn(arp_ft* c, const char* site, const void* A, int lda, const void* 
     g.slice_stride = (size_t)M * N; g.alpha = 1.f;
     ARP_TRY(launch_gemm_nn(__is_same(T, bf16_t) ? 1 : 2, g, c->stream));
     const size_t MN = (size_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(cdiv(MN, 64)), dim3(256), 0, c->stream, c->part.as<float>(), S, MN, N, (const float*)nullptr, (int)ACT_NONE, out,
-                       resid, ldo == N ? 0 : ldo);
+    launch_splitk_reduce<OutT>(c->stream, c->part.as<float>(), S, MN, N, (const float*)nullptr, (int)ACT_NONE, out, resid, ldo == N ? 0 : ldo);
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }

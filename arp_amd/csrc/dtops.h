@@ -116,6 +116,163 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* 
     Elem<OutT>::st(out + o, s);
 }
 
+// The same reduction, four outputs per thread and SIXTEEN slice groups per output: 16-byte loads, four of them in flight per thread, 64 slab rows in
+// flight per block where the kernel above keeps 16 -- the 257-slab reduce of image_text_input (16.8 MB) ran at 1.6 TB/s on it.  Fixed order: a thread
+// adds its slabs y, y + 16, ... in four interleaved chains, the sixteen group sums are added as a balanced tree.  Needs MN, N (and ldo) multiples of 4.
+template <typename OutT>
+static __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __restrict__ part, int S, size_t MN, int N, const float* __restrict__ bias,
+                                                             int act, OutT* __restrict__ out, const float* __restrict__ resid, int ldo, float alpha) {
+    __shared__ float4 red[16][16];
+    const int x = threadIdx.x & 15, y = threadIdx.x >> 4;
+    const size_t i = ((size_t)blockIdx.x * 16 + x) * 4;
+    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    auto sum = [](const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < MN) {
+        float4 s0 = s, s1 = s, s2 = s, s3 = s;
+        const float* p = part + i;
+        int k = y;
+        for (; k + 48 < S; k += 64) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (size_t)k * MN), b = *reinterpret_cast<const float4*>(p + (size_t)(k + 16) * MN);
+            const float4 c = *reinterpret_cast<const float4*>(p + (size_t)(k + 32) * MN), d = *reinterpret_cast<const float4*>(p + (size_t)(k + 48) * MN);
+            add(s0, a); add(s1, b); add(s2, c); add(s3, d);
+        }
+        for (; k < S; k += 16) add(s0, *reinterpret_cast<const float4*>(p + (size_t)k * MN));
+        s = sum(sum(s0, s1), sum(s2, s3));
+    }
+    red[y][x] = s;
+    __syncthreads();
+    if (y != 0 || i >= MN) return;
+    float4 t[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t[g] = sum(red[2 * g][x], red[2 * g + 1][x]);
+    s = sum(sum(sum(t[0], t[1]), sum(t[2], t[3])), sum(sum(t[4], t[5]), sum(t[6], t[7])));
+    float v[4] = {alpha * s.x, alpha * s.y, alpha * s.z, alpha * s.w};
+    const int n = (int)(i % N);
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (act == ACT_TANH) v[e] = tanhf(v[e]);
+        else if (act == ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+    }
+    const size_t o = ldo > 0 ? (i / N) * (size_t)ldo + n : i;
+    if (resid) {
+        const float4 r = *reinterpret_cast<const float4*>(resid + o);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    store4(out + o, v[0], v[1], v[2], v[3]);
+}
+// out[m, n] = act(alpha * sum_s part[s, m, n] + bias[n]) (+ resid): the 4-wide kernel where the shape allows it
+template <typename OutT>
+static inline void launch_splitk_reduce(hipStream_t st, const float* part, int S, size_t MN, int N, const float* bias, int act, OutT* out,
+                                        const float* resid = nullptr, int ldo = 0, float alpha = 1.f) {
+    static const bool wide = [] { const char* e = getenv("ARP_SPLITK_REDUCE4"); return !e || atoi(e) != 0; }();
+    // (many-slab reductions only: at S = 8..32, the fine-tune head's, the step measured 3.28 ms on the narrow kernel and 3.35 on this one)
+    if (wide && (MN & 3) == 0 && (N & 3) == 0 && (ldo & 3) == 0 && S >= 64)
+        hipLaunchKernelGGL((splitk_reduce4_kernel<OutT>), dim3((unsigned)((MN / 4 + 15) / 16)), dim3(256), 0, st, part, S, MN, N, bias, act, out, resid, ldo, alpha);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3((unsigned)((MN + 63) / 64)), dim3(256), 0, st, part, S, MN, N, bias, act, out, resid, ldo, alpha);
+}
+
+// ---- image_text_input forward on (hi, lo) binary16 pairs split in flight -----------------------------------------------------------------------------
+// part[s][m][n] = sum over K-slice s of X[m][k] * W[n][k], X and W in f32 (the 16-bit modes keep this one contraction -- K = 197 376 -- at f32
+// level: it is what buys the 1e-3 on 16 of 16 seeds).  On v_mfma_f32_16x16x4_f32 the product is bound by the f32 matrix rate (6.5 GF at 157 TF peak)
+// on top of streaming 202 MB; here every 128 x 64 operand tile is split into (hi, lo) binary16 on its way from registers to LDS (X times 2^4, W
+// times 2^10: W is ~1/sqrt(K), its lo halves would be subnormal unscaled) and the product is hi.hi + lo.hi + hi.lo on three v_mfma_f32_16x16x32_f16,
+// which leaves the kernel bound by the stream alone.  One workgroup per (K slice, 128 x 128 output tile); four waves, each a 64 x 64 block with the W
+// fragment as the MFMA's A operand so that a lane ends up with four consecutive n of one row m.  The next K-tile's sixteen float4 per thread are
+// requested before this tile's MFMAs.  Fixed-order reduction of the slices by launch_splitk_reduce as before.
+static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restrict__ X, size_t ldx, const float* __restrict__ W, size_t ldw, float* __restrict__ part,
+                                                     int M, int N, int K, int kslice) {
+    constexpr int ROW = 72;  // binary16 elements per LDS row (144 B: the 16-byte fragment reads of sixteen rows fall in distinct bank groups)
+    __shared__ __attribute__((aligned(16))) _Float16 sm[4][128 * ROW];  // X hi, X lo, W hi, W lo
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, j = lane & 15, g = lane >> 4;
+    const int n_tiles = (N + 127) / 128;
+    const int m0 = (blockIdx.y / n_tiles) * 128, n0 = (blockIdx.y % n_tiles) * 128;
+    const int k0 = blockIdx.x * kslice, k1 = min(K, k0 + kslice);
+    const int lrow = tid >> 4, lc4 = tid & 15;
+    const float* xp[8];
+    const float* wp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xp[i] = X + (size_t)min(m0 + lrow + 16 * i, M - 1) * ldx + 4 * lc4;
+        wp[i] = W + (size_t)min(n0 + lrow + 16 * i, N - 1) * ldw + 4 * lc4;
+    }
+    float4 xr[8], wreg[8];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xr[i] = *reinterpret_cast<const float4*>(xp[i] + k);
+            wreg[i] = *reinterpret_cast<const float4*>(wp[i] + k);
+        }
+    };
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    auto put = [&](_Float16* hi, _Float16* lo, const float4 v, float sc, int row) {
+        const float a[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};  // power-of-two scales: exact, so the split sees one f32 value whatever gets fused
+        h4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (_Float16)a[e];
+            l[e] = (_Float16)(a[e] - (float)h[e]);
+        }
+        *reinterpret_cast<h4*>(hi + row * ROW + 4 * lc4) = h;
+        *reinterpret_cast<h4*>(lo + row * ROW + 4 * lc4) = l;
+    };
+    f32x4_v acc[4][4];  // [n fragment][m fragment]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    fetch(k0);
+    for (int k = k0; k < k1; k += 64) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            put(sm[0], sm[1], xr[i], 16.f, lrow + 16 * i);
+            put(sm[2], sm[3], wreg[i], 1024.f, lrow + 16 * i);
+        }
+        __syncthreads();
+        if (k + 64 < k1) fetch(k + 64);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f16x8_v xh[4], xl[4];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const int off = (wr * 64 + mf * 16 + j) * ROW + 32 * c + 8 * g;
+                xh[mf] = *reinterpret_cast<const f16x8_v*>(sm[0] + off);
+                xl[mf] = *reinterpret_cast<const f16x8_v*>(sm[1] + off);
+            }
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int off = (wc * 64 + nf * 16 + j) * ROW + 32 * c + 8 * g;
+                const f16x8_v wh = *reinterpret_cast<const f16x8_v*>(sm[2] + off), wl = *reinterpret_cast<const f16x8_v*>(sm[3] + off);
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[mf], acc[nf][mf], 0, 0, 0);
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[mf], acc[nf][mf], 0, 0, 0);
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[mf], acc[nf][mf], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = part + (size_t)blockIdx.x * M * N;
+    constexpr float inv = 1.0f / (16.f * 1024.f);
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int m = m0 + wr * 64 + mf * 16 + j;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = n0 + wc * 64 + nf * 16 + 4 * g;  // N % 4 == 0
+            if (n < N) *reinterpret_cast<float4*>(out + (size_t)m * N + n) = make_float4(acc[nf][mf][0] * inv, acc[nf][mf][1] * inv, acc[nf][mf][2] * inv, acc[nf][mf][3] * inv);
+        }
+    }
+}
+
 // ---- f32 -> T conversion ----------------------------------------------------------------------------
 template <typename T> __global__ __launch_bounds__(256) void convert_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;

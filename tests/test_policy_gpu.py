@@ -259,6 +259,32 @@ def test_fused_kernel_hi_lo_linears_keep_tiny_gradients(gpu_lib, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("kw,B", [(TINY, 4), (SMALL, 6), (FULL, 2)])
+def test_image_text_input_on_hi_lo_binary16_pairs_is_the_f32_product(gpu_lib, kw, B, monkeypatch):
+    """The 16-bit modes keep image_text_input's forward contraction at f32 level (ARP_DT_ITI_F32).  Since round 4 it runs on (hi, lo) binary16 pairs split
+    in flight from the f32 operands (dtops.h::iti_x3_kernel) instead of the f32 MFMA: same operands, products to 2^-22 -- the two must agree far inside
+    what one binary16 rounding of either operand would cost (measured on the f16 ITI path: ~1e-4 on the logits)."""
+    from arp_amd.train import PolicyTrainer
+    cfg, _, P, (enc, act, rtg), _, _ = _setup(kw, B, 21)
+    res = {}
+    for x3 in ("1", "0"):
+        monkeypatch.setenv("ARP_DT_ITI_X3", x3)
+        tr = PolicyTrainer(cfg, mode="f16")
+        tr.set_params(P)
+        tr.set_batch(enc, act, rtg)
+        out = tr.forward()
+        tr.backward()
+        res[x3] = (out, tr.get_grads())
+        tr.close()
+    (o1, g1), (o0, g0) = res["1"], res["0"]
+    e = max(np.abs(o1["action_pred"] - o0["action_pred"]).max(), np.abs(o1["return_pred"] - o0["return_pred"]).max())
+    print(f"x3 vs f32-MFMA image_text_input: outputs differ by {e:.2e}")
+    assert e < 5e-6
+    bad = [(k, float(np.abs(g1[k] - g0[k]).max() / max(np.abs(g0[k]).max(), 1e-6))) for k in P]
+    bad = [b for b in bad if not b[1] < 5e-4]  # (an image embedding that differs by 1e-7 flips a binary16 rounding of the backward activations here and there: measured up to 2.1e-4)
+    assert not bad, bad
+
+
 def test_long_window_uses_unfused_path(gpu_lib):
     """window 6 -> 18 tokens per sample: beyond the fused kernel's 16-row tile, served by the per-op kernels."""
     from arp_amd.train import PolicyTrainer
