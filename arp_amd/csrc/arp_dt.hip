@@ -612,7 +612,8 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         const float* Y32 = k.use_adapter ? c->Y32.as<float>() : c->bt[c->cur].enc32.as<float>();
         const int tiles = cdiv(R, 128) * cdiv(E, 128);
         const int nk = (int)(Kin / 64);
-        int S = std::max(1, std::min(nk, 256 / std::max(tiles, 1)));  // one workgroup per CU
+        static const int iti_wgs = getenv("ARP_DT_ITI_WGS") ? atoi(getenv("ARP_DT_ITI_WGS")) : 256;
+        int S = std::max(1, std::min(nk, iti_wgs / std::max(tiles, 1)));  // workgroups on the chip (74 KB of LDS and 174 registers each: two fit a CU)
         const int per = (nk + S - 1) / S;
         S = (nk + per - 1) / per;
         ARP_TRY(c->part.ensure((size_t)S * R * E * 4));
