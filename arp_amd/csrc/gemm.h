@@ -307,8 +307,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                 // before iteration it's four stores, and iteration 0's before the tile is staged.  A wave's loads and stores retire through one in-order
                 // counter: issued behind the stores (round 3), every iteration's loads also waited for the previous iteration's writes to reach memory.
                 // Addresses of rows / columns past the edge are clamped (finite garbage, never used) so that the loads are unconditional.
+                // (-DARP_ADAMW_PIPE=2 / 3 request two / three iterations ahead: measured the same as one on one box -- 3.47, 3.46, 3.47 ms per step.)
                 constexpr bool ADAMW_PIPE = (ARP_ADAMW_PIPE != 0) && SITE == GEMM_SITE_ADAMW && !RESID && sizeof(T) == 2;
-                float4 pq[2], mq[2], vq[2];
+                constexpr int AD = ARP_ADAMW_PIPE > 1 ? ARP_ADAMW_PIPE : 1, AS = AD + 1;  // iterations ahead, register slots
+                float4 pq[AS], mq[AS], vq[AS];
                 auto adam_idx = [&](int it) {
                     const int lr = it * 8 + wave * 2 + (lane >> 5);
                     const int m = min(m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), g.M - 1), n = min(n0 + (lane & 31) * 4, g.N - 4);
@@ -316,11 +318,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                 };
                 auto adam_load = [&](int it) {
                     const size_t idx = adam_idx(it);
-                    pq[it & 1] = *reinterpret_cast<const float4*>(g.adam_p + idx);
-                    mq[it & 1] = *reinterpret_cast<const float4*>(g.adam_m + idx);
-                    vq[it & 1] = *reinterpret_cast<const float4*>(g.adam_v + idx);
+                    pq[it % AS] = *reinterpret_cast<const float4*>(g.adam_p + idx);
+                    mq[it % AS] = *reinterpret_cast<const float4*>(g.adam_m + idx);
+                    vq[it % AS] = *reinterpret_cast<const float4*>(g.adam_v + idx);
                 };
-                if constexpr (ADAMW_PIPE) adam_load(0);
+                if constexpr (ADAMW_PIPE) {
+#pragma unroll
+                    for (int a = 0; a < AD; ++a) adam_load(a);
+                }
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     const bool ok = m < g.M && n < g.N;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if constexpr (ADAMW_PIPE) {
-                        if (it + 1 < 8) adam_load(it + 1);
+                        if (it + AD < 8) adam_load(it + AD);
                     }
                     if (ok) {
                         v = *reinterpret_cast<const float4*>(smem + lr * RSF + (lane & 31) * 16);
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                             //  SLOWER: 4.4 instead of 5.5 TB/s -- 96 more live registers under the staging loop)
                             const size_t idx = (size_t)m * g.ldo + n;
                             float4 pv, mv, vv;
-                            if constexpr (ADAMW_PIPE) { pv = pq[it & 1]; mv = mq[it & 1]; vv = vq[it & 1]; }
+                            if constexpr (ADAMW_PIPE) { pv = pq[it % AS]; mv = mq[it % AS]; vv = vq[it % AS]; }
                             else {
                                 pv = *reinterpret_cast<const float4*>(g.adam_p + idx);
                                 mv = *reinterpret_cast<const float4*>(g.adam_m + idx);
