@@ -203,10 +203,15 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
 // Same plan as the f32 kernel above with every product on v_mfma_f32_16x16x32_f16 as hi.hi + lo.hi + hi.lo (2^-22 relative, three instructions of 16
 // cycles per 32-deep step where the f32 form takes eight of 32): K of one (sample, head) in LDS as two binary16 arrays [key][64] (hi, lo), V as two
 // TRANSPOSED arrays [d][key]; Q split in registers (softmax scale and log2 e folded in before the split, so the scores come out in the exp2 domain);
-// the softmax'd accumulators split in registers into the B operand of O^T = V^T.P^T.  A 32-deep contraction step of that product takes the key pair
-// of tiles (2c, 2c+1): slot (g, e) is key 32c + 4g + e for e < 4 and 32c + 16 + 4g + (e - 4) above -- exactly the eight values lane (g, j) holds of
-// S^T tiles 2c and 2c+1, so P never moves between lanes; the matching A operand is two 8-byte reads of a transposed V row.  P is carried times 2^10
-// (exact; its lo halves stay out of binary16's subnormals down to p = 1e-4) and the row sum with it, so the factor cancels in O / l.
+// the softmax'd accumulators split in registers into the B operand of O^T = V^T.P^T.  Which keys a 16-row S^T tile holds is free, so tile kt takes
+// keys 32 (kt / 2) + 8 (i / 4) + 4 (kt % 2) + i % 4 for its rows i: lane (g, j) then holds, of tiles 2c and 2c+1 together, the EIGHT CONSECUTIVE keys
+// 32 c + 8 g .. + 7 of query j -- exactly one lane's share of a 32-deep step of O^T = V^T.P^T, whose A operand becomes ONE ds_read_b128 of a transposed
+// V row.  P never moves between lanes.  P is carried times 2^10 (exact; its lo halves stay out of binary16's subnormals down to p = 1e-4) and the row
+// sum with it, so the factor cancels in O / l.
+// LDS images: rows of 128 B (K) / 16 B x ceil8(4 NC) (V^T), 16-byte chunks XOR-swizzled with a key made of the row bits that tell one lane group's
+// sixteen rows apart ((row >> 1 & 1) << 1 | (row >> 4 & 1) << 2 for the permuted K rows, row & 6 for V^T): every fragment read is a conflict-free
+// ds_read_b128.  (First version: padded rows of 144 B / 584 B, two 8-byte reads per V fragment -- SQ_LDS_BANK_CONFLICT 29 % of the LDS cycles and more
+// LDS-array cycles per query block than MFMA cycles, profiles/r4_x3_pmc.json.)
 #define ARP_SPLIT1(X, HI, LO)                  \
     do {                                       \
         const float _x = pin_f32(X);           \
@@ -214,29 +219,33 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
         HI = _h;                               \
         LO = (_Float16)(_x - (float)_h);       \
     } while (0)
+constexpr int attn_x3_vrow_bytes(int nt) { return ((((nt + 1) / 2) * 4 + 7) / 8) * 8 * 16; }
+constexpr int attn_x3_lds_bytes(int nt) { return 2 * ((nt + 1) / 2) * 32 * 128 + 2 * 64 * attn_x3_vrow_bytes(nt); }
 template <int NT>
 __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int D, int heads, float scale,
                                                       int causal, int nq, f16_t* __restrict__ out3) {
-    constexpr int HD = 64, NC = (NT + 1) / 2, KROW = 72, VROW = NC * 32 + 4;  // f16 elements per K row (144 B) / per transposed V row
+    constexpr int HD = 64, NC = (NT + 1) / 2, KROWS = NC * 32, VROWB = attn_x3_vrow_bytes(NT);
     extern __shared__ __attribute__((aligned(16))) char attn_smem[];
-    _Float16* Kh = reinterpret_cast<_Float16*>(attn_smem);
-    _Float16* Kl = Kh + NT * 16 * KROW;
-    _Float16* Vh = Kl + NT * 16 * KROW;
-    _Float16* Vl = Vh + HD * VROW;
+    char* Kh = attn_smem;
+    char* Kl = Kh + KROWS * 128;
+    char* Vh = Kl + KROWS * 128;
+    char* Vl = Vh + HD * VROWB;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const size_t ld = (size_t)3 * D;
     const float* base = qkv + (size_t)b * N * ld + h * HD;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    // K rows (zero beyond N)
-    for (int idx = threadIdx.x; idx < NT * 16 * 16; idx += 512) {
+    auto kkey = [](int row) { return (((row >> 1) & 1) << 1) | (((row >> 4) & 1) << 2); };
+    // K rows (zero beyond N): 8-byte pieces, two per 16-byte chunk
+    for (int idx = threadIdx.x; idx < KROWS * 16; idx += 512) {
         const int key = idx >> 4, c4 = idx & 15;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (key < N) v = *reinterpret_cast<const float4*>(base + (size_t)key * ld + D + 4 * c4);
         h4 hi, lo;
         ARP_SPLIT1(v.x, hi[0], lo[0]); ARP_SPLIT1(v.y, hi[1], lo[1]); ARP_SPLIT1(v.z, hi[2], lo[2]); ARP_SPLIT1(v.w, hi[3], lo[3]);
-        *reinterpret_cast<h4*>(Kh + key * KROW + 4 * c4) = hi;
-        *reinterpret_cast<h4*>(Kl + key * KROW + 4 * c4) = lo;
+        const int off = key * 128 + (((c4 >> 1) ^ kkey(key)) << 4) + (c4 & 1) * 8;
+        *reinterpret_cast<h4*>(Kh + off) = hi;
+        *reinterpret_cast<h4*>(Kl + off) = lo;
     }
     // V transposed: one key PAIR per thread and d-quad, so that a store is one dword (two keys of one d)
     for (int idx = threadIdx.x; idx < NC * 16 * 16; idx += 512) {
@@ -250,14 +259,17 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
             h2 hi, lo;
             ARP_SPLIT1(a0[e], hi[0], lo[0]);
             ARP_SPLIT1(a1[e], hi[1], lo[1]);
-            *reinterpret_cast<h2*>(Vh + (4 * dq + e) * VROW + 2 * kp) = hi;
-            *reinterpret_cast<h2*>(Vl + (4 * dq + e) * VROW + 2 * kp) = lo;
+            const int d = 4 * dq + e;
+            const int off = d * VROWB + (((kp >> 2) ^ (d & 6)) << 4) + (kp & 3) * 4;
+            *reinterpret_cast<h2*>(Vh + off) = hi;
+            *reinterpret_cast<h2*>(Vl + off) = lo;
         }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const float qs = scale * 1.44269504088896340736f;
+    const int krow_j = 8 * (j >> 2) + (j & 3);  // this lane's K row inside a 32-key pair of tiles (+ 4 for the odd tile)
     for (int q0 = wave * 16; q0 < nq; q0 += 128) {  // eight waves: two per SIMD, one in its MFMAs while the other is in its softmax / splits
         asm volatile("" ::: "memory");  // K and V are loop invariant: keep the compiler from hoisting the operand reads of every query block out of the loop
         const int qi = q0 + j;
@@ -278,8 +290,10 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
             f16x8_v kh[NT], kl[NT];
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
-                kh[kt] = *reinterpret_cast<const f16x8_v*>(Kh + (kt * 16 + j) * KROW + 32 * c + 8 * g);
-                kl[kt] = *reinterpret_cast<const f16x8_v*>(Kl + (kt * 16 + j) * KROW + 32 * c + 8 * g);
+                const int row = 32 * (kt >> 1) + 4 * (kt & 1) + krow_j;
+                const int off = row * 128 + (((4 * c + g) ^ kkey(row)) << 4);
+                kh[kt] = *reinterpret_cast<const f16x8_v*>(Kh + off);
+                kl[kt] = *reinterpret_cast<const f16x8_v*>(Kl + off);
             }
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[c], acc[kt], 0, 0, 0);
@@ -288,12 +302,13 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], ql[c], acc[kt], 0, 0, 0);
         }
+        // register r of tile kt, lane (g, j): key 32 (kt / 2) + 8 g + 4 (kt % 2) + r of query j
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + 4 * g + r;
+                const int key = 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
                 if (key >= N || (causal && key > qi)) acc[kt][r] = -INFINITY;
                 m = fmaxf(m, acc[kt][r]);
             }
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            f16x8_v ph, pl;
+            f16x8_v ph, pl;  // keys 32 c + 8 g .. + 7
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ARP_SPLIT1(acc[2 * c][r], ph[r], pl[r]);
@@ -325,12 +340,9 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
             }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const _Float16* vr = Vh + (dt * 16 + j) * VROW + 32 * c + 4 * g;
-                const _Float16* vq = Vl + (dt * 16 + j) * VROW + 32 * c + 4 * g;
-                const h4 a0 = *reinterpret_cast<const h4*>(vr), a1 = *reinterpret_cast<const h4*>(vr + 16);
-                const h4 b0 = *reinterpret_cast<const h4*>(vq), b1 = *reinterpret_cast<const h4*>(vq + 16);
-                const f16x8_v vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                const f16x8_v vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                const int d = dt * 16 + j;
+                const int off = d * VROWB + (((4 * c + g) ^ (d & 6)) << 4);
+                const f16x8_v vh = *reinterpret_cast<const f16x8_v*>(Vh + off), vl = *reinterpret_cast<const f16x8_v*>(Vl + off);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[dt], 0, 0, 0);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[dt], 0, 0, 0);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[dt], 0, 0, 0);
@@ -353,7 +365,6 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
     }
 }
 #undef ARP_SPLIT1
-constexpr int attn_x3_lds_bytes(int nt) { return (2 * nt * 16 * 72 + 2 * 64 * (((nt + 1) / 2) * 32 + 4)) * 2; }
 
 // ---- MFMA kernel (bf16, head_dim 64) -------------------------------------------------------------
 // NT = number of 16-key tiles (keys padded to a multiple of 32, i.e. NT even).

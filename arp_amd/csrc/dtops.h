@@ -187,7 +187,8 @@ static inline void launch_splitk_reduce(hipStream_t st, const float* part, int S
 // requested before this tile's MFMAs.  Fixed-order reduction of the slices by launch_splitk_reduce as before.
 static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restrict__ X, size_t ldx, const float* __restrict__ W, size_t ldw, float* __restrict__ part,
                                                      int M, int N, int K, int kslice) {
-    constexpr int ROW = 72;  // binary16 elements per LDS row (144 B: the 16-byte fragment reads of sixteen rows fall in distinct bank groups)
+    constexpr int ROW = 80;  // binary16 elements per LDS row: 160 B = 40 dwords -- the sixteen lanes of a ds_read_b128 group (rows j, chunks g and g + 1) fall on sixteen
+                             // distinct 4-bank slots; at 144 B seven of them met another's (SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles, profiles/r4_x3_pmc.json)
     __shared__ __attribute__((aligned(16))) _Float16 sm[4][128 * ROW];  // X hi, X lo, W hi, W lo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, j = lane & 15, g = lane >> 4;

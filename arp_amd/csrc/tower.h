@@ -254,7 +254,8 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
     if constexpr (sizeof(T) == 4) {
         // impl 3: the (hi, lo) binary16 MFMA kernel (attention.h::attn_x3_kernel, the f16x3 encoder mode's attention): head_dim 64, up to 288 keys
         if (impl == 3 && hd == 64 && N <= 288 && (D & 3) == 0) {
-            const int need = (N + 15) / 16;
+            // key tiles under the kernel's permuted mapping: tile kt holds keys 32 (kt / 2) + 8 i' + 4 (kt % 2) + r, so the odd tile of the last pair is needed from key 32 c + 4 on
+            const int need = 2 * ((N - 1) / 32) + (((N - 1) % 32) >= 4 ? 2 : 1);
 #define ARP_ATTNX3_CASE(nt)                                                                                                        \
     if (need <= nt) {                                                                                                              \
         const int ldsx = attn_x3_lds_bytes(nt);                                                                                    \
@@ -264,10 +265,10 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
         ARP_HIP_OK(hipGetLastError());                                                                                             \
         return 0;                                                                                                                  \
     }
-            ARP_ATTNX3_CASE(1)
+            ARP_ATTNX3_CASE(2)
             ARP_ATTNX3_CASE(4)
-            ARP_ATTNX3_CASE(5)
-            ARP_ATTNX3_CASE(13)
+            ARP_ATTNX3_CASE(6)
+            ARP_ATTNX3_CASE(14)
             ARP_ATTNX3_CASE(17)
             ARP_ATTNX3_CASE(18)
 #undef ARP_ATTNX3_CASE
