@@ -219,8 +219,19 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
         HI = _h;                               \
         LO = (_Float16)(_x - (float)_h);       \
     } while (0)
+// -DARP_ATTNX3_STAMPS (scripts/attn_x3_stamps.hip only): s_memtime at the phase boundaries of each wave's FIRST query block, 16 slots per wave
+#ifdef ARP_ATTNX3_STAMPS
+__device__ long long* arp_ax3_stamps = nullptr;
+#define ARP_AX3_STAMP(k)                                                                                                              \
+    do {                                                                                                                              \
+        if (arp_ax3_stamps && (threadIdx.x & 63) == 0 && ((k) < 2 || (k) > 7 || ax3_first))                                             \
+            arp_ax3_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime();                  \
+    } while (0)
+#else
+#define ARP_AX3_STAMP(k) do { } while (0)
+#endif
 constexpr int attn_x3_vrow_bytes(int nt) { return ((((nt + 1) / 2) * 4 + 7) / 8) * 8 * 16; }
-constexpr int attn_x3_lds_bytes(int nt) { return 2 * ((nt + 1) / 2) * 32 * 128 + 2 * 64 * attn_x3_vrow_bytes(nt); }
+constexpr int attn_x3_lds_bytes(int nt) { return 2 * ((nt + 1) / 2) * 32 * 128 + 2 * 64 * attn_x3_vrow_bytes(nt) + ((nt + 1) / 2) * 2 * 66 * 4; }  // + the tail block's partials
 template <int NT>
 __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int D, int heads, float scale,
                                                       int causal, int nq, f16_t* __restrict__ out3) {
@@ -233,26 +244,42 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const size_t ld = (size_t)3 * D;
     const float* base = qkv + (size_t)b * N * ld + h * HD;
+    [[maybe_unused]] bool ax3_first = true;
+    ARP_AX3_STAMP(0);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     auto kkey = [](int row) { return (((row >> 1) & 1) << 1) | (((row >> 4) & 1) << 2); };
-    // K rows (zero beyond N): 8-byte pieces, two per 16-byte chunk
-    for (int idx = threadIdx.x; idx < KROWS * 16; idx += 512) {
-        const int key = idx >> 4, c4 = idx & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (key < N) v = *reinterpret_cast<const float4*>(base + (size_t)key * ld + D + 4 * c4);
+    // Staging.  EVERY global load of the workgroup's K and V is requested before the first split (NC + 2 ceil(NC / 2) float4 per thread: 72 registers at
+    // 257 tokens, nothing else is live yet): written as load -> split -> store loops the staging took ~25 us of a 35 us workgroup -- one memory round trip
+    // per iteration, with a single workgroup per CU (153 KB of LDS) and nothing to overlap it with.  Rows beyond N are clamped, then zeroed.
+    constexpr int VI = (NC * 256 + 511) / 512;
+    float4 kreg[NC], v0reg[VI], v1reg[VI];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {  // K rows: 8-byte pieces, two per 16-byte chunk
+        const int idx = threadIdx.x + 512 * i, key = idx >> 4, c4 = idx & 15;
+        kreg[i] = *reinterpret_cast<const float4*>(base + (size_t)min(key, N - 1) * ld + D + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {  // V: one key PAIR per thread and d-quad, so that a transposed store is one dword (two keys of one d)
+        const int idx = min((int)threadIdx.x + 512 * i, NC * 256 - 1), kp = idx >> 4, dq = idx & 15;
+        v0reg[i] = *reinterpret_cast<const float4*>(base + (size_t)min(2 * kp, N - 1) * ld + 2 * D + 4 * dq);
+        v1reg[i] = *reinterpret_cast<const float4*>(base + (size_t)min(2 * kp + 1, N - 1) * ld + 2 * D + 4 * dq);
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int idx = threadIdx.x + 512 * i, key = idx >> 4, c4 = idx & 15;
+        const float4 v = key < N ? kreg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         h4 hi, lo;
         ARP_SPLIT1(v.x, hi[0], lo[0]); ARP_SPLIT1(v.y, hi[1], lo[1]); ARP_SPLIT1(v.z, hi[2], lo[2]); ARP_SPLIT1(v.w, hi[3], lo[3]);
         const int off = key * 128 + (((c4 >> 1) ^ kkey(key)) << 4) + (c4 & 1) * 8;
         *reinterpret_cast<h4*>(Kh + off) = hi;
         *reinterpret_cast<h4*>(Kl + off) = lo;
     }
-    // V transposed: one key PAIR per thread and d-quad, so that a store is one dword (two keys of one d)
-    for (int idx = threadIdx.x; idx < NC * 16 * 16; idx += 512) {
-        const int kp = idx >> 4, dq = idx & 15;
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        if (2 * kp < N) v0 = *reinterpret_cast<const float4*>(base + (size_t)(2 * kp) * ld + 2 * D + 4 * dq);
-        if (2 * kp + 1 < N) v1 = *reinterpret_cast<const float4*>(base + (size_t)(2 * kp + 1) * ld + 2 * D + 4 * dq);
+#pragma unroll
+    for (int i = 0; i < VI; ++i) {
+        const int idx = threadIdx.x + 512 * i, kp = idx >> 4, dq = idx & 15;
+        if (idx >= NC * 256) break;
+        const float4 v0 = 2 * kp < N ? v0reg[i] : make_float4(0.f, 0.f, 0.f, 0.f), v1 = 2 * kp + 1 < N ? v1reg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -266,12 +293,21 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    ARP_AX3_STAMP(1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const float qs = scale * 1.44269504088896340736f;
     const int krow_j = 8 * (j >> 2) + (j & 3);  // this lane's K row inside a 32-key pair of tiles (+ 4 for the odd tile)
-    for (int q0 = wave * 16; q0 < nq; q0 += 128) {  // eight waves: two per SIMD, one in its MFMAs while the other is in its softmax / splits
+    // A last block of one or two queries that would open a round of its own (257 tokens: 16 full blocks on 8 waves, then ONE query) is not given to one
+    // wave while seven idle: every wave takes one 32-key chunk of it (below, after the full blocks) and the partial softmaxes are merged through LDS.
+    const int nfull = nq >> 4, tail = nq & 15;
+    const bool coop = tail >= 1 && tail <= 2 && nfull > 0 && (nfull & 7) == 0;
+    const int nq_blocks = coop ? nfull * 16 : nq;
+    // (Requesting the next block's Q rows ahead of this block's sixteen output stores -- one in-order counter, see gemm.h's AdamW epilogue -- was built and
+    //  measured: no gain, nine spilled registers at NT = 17.  scripts/attn_x3_stamps.hip says where a workgroup's time goes.)
+    for (int q0 = wave * 16; q0 < nq_blocks; q0 += 128) {  // eight waves: two per SIMD, one in its MFMAs while the other is in its softmax / splits
         asm volatile("" ::: "memory");  // K and V are loop invariant: keep the compiler from hoisting the operand reads of every query block out of the loop
+        ARP_AX3_STAMP(2);
         const int qi = q0 + j;
         const float* qrow = base + (size_t)min(qi, N - 1) * ld;
         f16x8_v qh[2], ql[2];
@@ -282,36 +318,52 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 8; ++e) ARP_SPLIT1(v[e], qh[c][e], ql[c][e]);
         }
+        ARP_AX3_STAMP(3);
         f32x4_v acc[NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) acc[kt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+        // K fragments in groups of at most six tiles (48 registers, not the 136 of all seventeen at once: the kernel sits at the 256-register limit of two
+        // waves per SIMD); six independent accumulators between an accumulator's own three MFMAs are 96 issue cycles, more than the instruction's latency
+        constexpr int KG = 6;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            f16x8_v kh[NT], kl[NT];
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                const int row = 32 * (kt >> 1) + 4 * (kt & 1) + krow_j;
-                const int off = row * 128 + (((4 * c + g) ^ kkey(row)) << 4);
-                kh[kt] = *reinterpret_cast<const f16x8_v*>(Kh + off);
-                kl[kt] = *reinterpret_cast<const f16x8_v*>(Kl + off);
+            for (int k0 = 0; k0 < NT; k0 += KG) {
+                f16x8_v kh[KG], kl[KG];
+#pragma unroll
+                for (int u = 0; u < KG; ++u) {
+                    if (k0 + u >= NT) continue;
+                    const int kt = k0 + u, row = 32 * (kt >> 1) + 4 * (kt & 1) + krow_j;
+                    const int off = row * 128 + (((4 * c + g) ^ kkey(row)) << 4);
+                    kh[u] = *reinterpret_cast<const f16x8_v*>(Kh + off);
+                    kl[u] = *reinterpret_cast<const f16x8_v*>(Kl + off);
+                }
+#pragma unroll
+                for (int u = 0; u < KG; ++u)
+                    if (k0 + u < NT) acc[k0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u], qh[c], acc[k0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < KG; ++u)
+                    if (k0 + u < NT) acc[k0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[u], qh[c], acc[k0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < KG; ++u)
+                    if (k0 + u < NT) acc[k0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[u], ql[c], acc[k0 + u], 0, 0, 0);
             }
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], qh[c], acc[kt], 0, 0, 0);
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[kt], qh[c], acc[kt], 0, 0, 0);
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[kt], ql[c], acc[kt], 0, 0, 0);
-        }
+        ARP_AX3_STAMP(4);
         // register r of tile kt, lane (g, j): key 32 (kt / 2) + 8 g + 4 (kt % 2) + r of query j
+        // (masks only in the tiles that can hold a key >= N -- a uniform branch per tile -- or under a causal mask: compare + select + mask bookkeeping
+        //  for every score were 140 vector and 136 scalar instructions of a query block whose last tile alone needs them; scripts/attn_x3_stamps.hip)
         float m = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) {
+            if (causal || 32 * (kt >> 1) + 4 * (kt & 1) + 27 >= N) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
-                if (key >= N || (causal && key > qi)) acc[kt][r] = -INFINITY;
-                m = fmaxf(m, acc[kt][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r;
+                    if (key >= N || (causal && key > qi)) acc[kt][r] = -INFINITY;
+                }
             }
+            m = fmaxf(fmaxf(fmaxf(acc[kt][0], acc[kt][1]), fmaxf(acc[kt][2], acc[kt][3])), m);
+        }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         const float m10 = m - 10.f;  // P times 2^10
@@ -326,6 +378,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
             }
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
+        ARP_AX3_STAMP(5);
         f32x4_v o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
@@ -348,6 +401,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[dt], 0, 0, 0);
             }
         }
+        ARP_AX3_STAMP(6);
         if (qi < nq) {
             const float inv = 1.0f / l;
             // lane (g, j): query j, d = 16 dt + 4 g + r
@@ -362,7 +416,96 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
                     *reinterpret_cast<float4*>(orow + 16 * dt) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
             }
         }
+        ARP_AX3_STAMP(7);
+        ax3_first = false;
     }
+    ARP_AX3_STAMP(8);
+    if (!coop) return;
+    // ---- the short last block, one 32-key chunk per wave: partial (max, sum, O) per chunk and query -> LDS -> fixed-order merge ----------------------
+    float* scr = reinterpret_cast<float*>(Vl + HD * VROWB);  // [NC][2][66]: O (64), max, sum
+    {
+        const int q0 = nfull * 16, qi = q0 + j;
+        const float* qrow = base + (size_t)min(qi, N - 1) * ld;
+        f16x8_v qh[2], ql[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + 32 * c + 8 * g), bq = *reinterpret_cast<const float4*>(qrow + 32 * c + 8 * g + 4);
+            const float v[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, bq.x * qs, bq.y * qs, bq.z * qs, bq.w * qs};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ARP_SPLIT1(v[e], qh[c][e], ql[c][e]);
+        }
+        for (int c = wave; c < NC; c += 8) {
+            f32x4_v a2[2] = {f32x4_v{0.f, 0.f, 0.f, 0.f}, f32x4_v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (2 * c + t >= NT) continue;
+                    const int row = 32 * c + 4 * t + krow_j;
+                    const int off = row * 128 + (((4 * cc + g) ^ kkey(row)) << 4);
+                    const f16x8_v kh = *reinterpret_cast<const f16x8_v*>(Kh + off), kl = *reinterpret_cast<const f16x8_v*>(Kl + off);
+                    a2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[cc], a2[t], 0, 0, 0);
+                    a2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[cc], a2[t], 0, 0, 0);
+                    a2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[cc], a2[t], 0, 0, 0);
+                }
+            float m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 32 * c + 8 * g + 4 * t + r;
+                    if (2 * c + t >= NT || key >= N || (causal && key > qi)) a2[t][r] = -INFINITY;
+                    m = fmaxf(m, a2[t][r]);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float m10 = (m == -INFINITY) ? 0.f : m - 10.f;  // a chunk with no visible key contributes nothing: P = 2^-inf = 0
+            float l = 0.f;
+            f16x8_v ph, pl;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(a2[t][r] - m10);
+                    l += pv;
+                    ARP_SPLIT1(pv, ph[4 * t + r], pl[4 * t + r]);
+                }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            float* dst = scr + (c * 2 + j) * 66;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int d = dt * 16 + j;
+                const int off = d * VROWB + (((4 * c + g) ^ (d & 6)) << 4);
+                const f16x8_v vh = *reinterpret_cast<const f16x8_v*>(Vh + off), vl = *reinterpret_cast<const f16x8_v*>(Vl + off);
+                f32x4_v o = {0.f, 0.f, 0.f, 0.f};
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o, 0, 0, 0);
+                if (j < tail) *reinterpret_cast<float4*>(dst + 16 * dt + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            if (j < tail && g == 0) { dst[64] = m; dst[65] = l; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < tail * 16) {
+        const int jq = threadIdx.x >> 4, d4 = (threadIdx.x & 15) * 4;
+        float M = -INFINITY;
+        for (int c = 0; c < NC; ++c) M = fmaxf(M, scr[(c * 2 + jq) * 66 + 64]);
+        float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NC; ++c) {  // fixed order
+            const float* src = scr + (c * 2 + jq) * 66;
+            const float w = __builtin_amdgcn_exp2f(src[64] - M);  // 0 for an empty chunk (its max is -inf; M is finite: key 0 is visible to every query)
+            L += w * src[65];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) O[e] += w * src[d4 + e];
+        }
+        const float inv = 1.0f / L;
+        const int qi = nfull * 16 + jq;
+        if (out3) store_split3(out3 + ((size_t)b * N + qi) * 3 * D + h * HD + d4, (size_t)D, O[0] * inv, O[1] * inv, O[2] * inv, O[3] * inv);
+        else *reinterpret_cast<float4*>(out + ((size_t)b * N + qi) * D + h * HD + d4) = make_float4(O[0] * inv, O[1] * inv, O[2] * inv, O[3] * inv);
+    }
+    ARP_AX3_STAMP(9);
 }
 #undef ARP_SPLIT1
 

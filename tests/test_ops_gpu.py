@@ -173,6 +173,7 @@ def _attn_ref(qkv, B, N, D, heads, causal):
 ATTN_CASES = [  # B, N, D, heads, causal
     (3, 50, 768, 12, 0), (2, 77, 512, 8, 1), (2, 197, 768, 12, 0), (1, 257, 128, 2, 0), (5, 5, 64, 1, 0), (4, 12, 128, 8, 1),
     (2, 64, 128, 2, 1), (2, 33, 64, 2, 0),
+    (1, 258, 128, 2, 0), (2, 129, 128, 2, 1),  # a last query block of one / two rows behind a multiple of eight full blocks: the x3 kernel's cooperative tail (also causal)
 ]
 
 
