@@ -39,6 +39,21 @@ struct HostTensor {
 
 using namespace arp;
 
+// Experiment (round 4, OFF by default): the part streams of a batch on DISJOINT halves of the chip (hipExtStreamCreateWithCUMask) instead of sharing all
+// 256 CUs -- ARP_CLIP_CUMASK=xcd: stream parity p gets the CUs whose index mod 8 is in [4 p, 4 p + 4) (whole XCDs, if the mask's bit order is the
+// round-robin over XCDs it is documented to be); =half: the low / high 128 mask bits.  Measured in profiles/r4_cumask.txt.
+static hipError_t create_part_stream(hipStream_t* st, int index) {
+    static const char* mode = getenv("ARP_CLIP_CUMASK");
+    if (!mode || !*mode || !strcmp(mode, "0")) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    uint32_t mask[8];
+    const int p = index & 1;
+    for (int w = 0; w < 8; ++w) {
+        if (!strcmp(mode, "xcd")) mask[w] = p ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+        else mask[w] = ((w < 4) == (p == 0)) ? 0xFFFFFFFFu : 0u;
+    }
+    return hipExtStreamCreateWithCUMask(st, 8, mask);
+}
+
 struct arp_clip {
     arp_clip_cfg cfg;
     hipStream_t stream = nullptr;
@@ -633,7 +648,7 @@ static int make_sibling(arp_clip* c) {
     s->copy_stream = nullptr;
     s->ev_copy.clear();
     for (auto& ls : s->lslot) ls = arp_clip::LabelSlot();
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (create_part_stream(&s->stream, (int)c->siblings.size() + 1) != hipSuccess) {
         delete s;
         return fail("hipStreamCreate failed");
     }
@@ -795,7 +810,7 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     if (const char* e = getenv("ARP_CLIP_GRAPH")) c->lat_graph = atoi(e) != 0;
     if (const char* e = getenv("ARP_SKINNY_ROWS")) c->lat_rows = std::min(std::max(atoi(e), 1), SKINNY_MAX_M);
     if (const char* e = getenv("ARP_CLIP_PINNED")) c->lat_pinned = atoi(e) != 0;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (create_part_stream(&c->stream, 0) != hipSuccess) {
         delete c;
         return fail("hipStreamCreate failed");
     }
