@@ -178,7 +178,13 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(PreprocArgs a) {
         const uint4* src = reinterpret_cast<const uint4*>(fbase + (size_t)(a.cy + y_lo) * in_row_bytes);
         uint4* dst = reinterpret_cast<uint4*>(in_s);
         const int nvec = rows * in_row_bytes / 16;
-        for (int i = tid; i < nvec; i += 256) dst[i] = src[i];
+        // four loads in flight per thread (a plain copy loop waits one memory round trip per iteration: six to ten of them per tile)
+        int i = tid;
+        for (; i + 768 < nvec; i += 1024) {
+            const uint4 v0 = src[i], v1 = src[i + 256], v2 = src[i + 512], v3 = src[i + 768];
+            dst[i] = v0; dst[i + 256] = v1; dst[i + 512] = v2; dst[i + 768] = v3;
+        }
+        for (; i < nvec; i += 256) dst[i] = src[i];
     } else {
         for (int i = tid; i < rows * in_row_bytes; i += 256) {
             const int r = i / in_row_bytes, cb = i - r * in_row_bytes;
