@@ -114,6 +114,16 @@ struct arp_dt {
     // the bytes, + everything the transformer produced) launched while the adapter's backward GEMMs still run (step_impl)
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_b1 = nullptr, ev_b2 = nullptr, ev_comm = nullptr;
+    // Experiment (round 4, OFF; ARP_DT_SIDE=1 switches it on): in the single-rank backward of the adapter (16-bit TN path) the weight-gradient GEMMs that
+    // nothing downstream waits for run on a SIDE stream beside the kernels that carry the dependent chain -- dWi beside the fused dY kernel (two streaming
+    // kernels at 3.4 - 3.9 TB/s each), dW2 (216 long workgroups) beside dApre . W2 (387 tiles = one and a half rounds of the chip); forked and joined by
+    // events, inside the captured graph as well.  MEASURED SLOWER (profiles/r4_side.txt, interleaved): step 0.862 -> 0.907 ms -- side by side dW2 takes
+    // 158 us instead of 56 (its K-slices-per-XCD walk wants the chip), dApre . W2 99 instead of 62, the fused dY kernel 94 instead of 72: these kernels
+    // are each sized for 256 CUs and lose more to each other than their tails were worth.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_dapre = nullptr, ev_side = nullptr;
+    bool side_gemms = false;
+    DevBuf part_side;
     bool overlap_comm = true;   // ARP_DT_OVERLAP=0: the serial form (one all-reduce after the whole backward), for A/B and the bit-identity test
     bool force_comm = false;    // ARP_DT_FORCE_COMM=1: run the all-reduce path at world = 1 too (what a 1-GPU box can test)
     bool grads_summed = false;  // the gradient buffer holds the SUM over ranks (set by a data-parallel step)
@@ -673,9 +683,9 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
 // Same math as the tail of backward<T>() below; the operands of the three weight-gradient contractions stay row-major
 // (no transposed K-padded copies): dWi = dz^T Y, dW2 = dApre^T H1, dW1 = dH1^T X.
 template <typename T>
-int tn_gemm(arp_dt* c, const char* site, const T* A, int lda, const T* B, int ldb, float* out, int M, int N, int K, float alpha) {
-    hipStream_t st = c->stream;
-    DevBuf& part = c->part;
+int tn_gemm(arp_dt* c, const char* site, const T* A, int lda, const T* B, int ldb, float* out, int M, int N, int K, float alpha, bool side = false) {
+    hipStream_t st = side ? c->side_stream : c->stream;
+    DevBuf& part = side ? c->part_side : c->part;  // (a side-stream GEMM keeps its split-K slabs to itself)
     const int tcode = __is_same(T, bf16_t) ? 1 : 2;
     GemmTnArgs g;
     int S;
@@ -719,11 +729,17 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
     const int Mxp = (int)((Mx + 63) / 64 * 64), Rp64 = (R + 63) / 64 * 64;
     const float S = c->act_scale(), invS = 1.0f / S;
     const T* Yp = k.use_adapter ? c->Y.as<T>() : c->Xb.as<T>();
+    // the whole backward in one call on one rank, with the adapter and the fused dY kernel: the two weight-gradient GEMMs nothing waits for go to the side stream
+    const bool side = c->side_gemms && stage == 0 && k.use_adapter && c->use_fused_dy() && c->side_stream;
     if (stage != 2) {
         // dz (f32) -> operand type, scaled (rows R..Rp64 of dzb stay zero)
         ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, S, c->dzb.as<T>(), E, nullptr, 0, R, E)));
         // dWi[E, Kin] = dz^T Y: contraction over the R rows, written straight into the gradient buffer
-        ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS)));
+        if (side) {
+            ARP_HIP_OK(hipEventRecord(c->ev_fork, c->stream));
+            ARP_HIP_OK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        }
+        ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS, side)));
     }
     if (!k.use_adapter || stage == 1) return 0;
     const int prow = Mxp / 64, ncb = cdiv(D, 256);
@@ -757,7 +773,11 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
         hipLaunchKernelGGL(dres_to_drw_kernel, dim3(1), dim3(1), 0, c->stream, c->scal.as<float>() + 8, c->p("residual_weight"), c->g("residual_weight"));
         ARP_HIP_OK(hipGetLastError());
     }
-    ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc2_dW", c->dApre.as<T>(), D, c->H1.as<T>(), D, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp, invS)));
+    if (side) {  // dApre is complete on the main stream from here
+        ARP_HIP_OK(hipEventRecord(c->ev_dapre, c->stream));
+        ARP_HIP_OK(hipStreamWaitEvent(c->side_stream, c->ev_dapre, 0));
+    }
+    ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc2_dW", c->dApre.as<T>(), D, c->H1.as<T>(), D, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp, invS, side)));
     const long tiles256 = (long)cdiv((int)Mx, 256) * cdiv(D, 256);
     if (D % 8 == 0 && c->fuse_relu_bwd(tiles256)) {
         // dH1 = (dApre W2) * (H1 > 0) and its column sums (the Dense_0 bias gradient) in the GEMM's own epilogue (gemm256.h)
@@ -783,6 +803,10 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
         ARP_HIP_OK(hipGetLastError());
     }
     ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc1_dW", c->dH1T.as<T>(), D, c->Xb.as<T>(), D, c->g("AdapterMLP_0/Dense_0/kernel"), D, D, Mxp, invS)));
+    if (side) {  // join: everything after the backward (norms, Adam, a later forward) is ordered behind the side stream's two GEMMs
+        ARP_HIP_OK(hipEventRecord(c->ev_side, c->side_stream));
+        ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_side, 0));
+    }
     return 0;
 }
 
@@ -1142,11 +1166,14 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_ITI_F32")) c->iti_f32 = atoi(e) != 0 && k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_ITI_X3")) c->iti_x3 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_SIDE")) c->side_gemms = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
     build_layout(c);
     auto body = [&]() -> int {
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        ARP_HIP_OK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&c->ev_fork, &c->ev_dapre, &c->ev_side}) ARP_HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking));
         for (hipEvent_t* e : {&c->ev_b1, &c->ev_b2, &c->ev_comm, &c->bt[0].up, &c->bt[0].use, &c->bt[1].up, &c->bt[1].use, &c->bt[2].up, &c->bt[2].use})
@@ -1177,12 +1204,15 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
 int arp_dt_destroy(arp_dt* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
-    for (hipStream_t st : {c->stream, c->comm_stream, c->copy_stream[0], c->copy_stream[1]})
+    for (hipStream_t st : {c->stream, c->comm_stream, c->side_stream, c->copy_stream[0], c->copy_stream[1]})
         if (st) (void)hipStreamSynchronize(st);
     for (auto& slot : c->graphs)
         for (auto& gr : slot)
             if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
+    for (hipEvent_t e : {c->ev_fork, c->ev_dapre, c->ev_side})
+        if (e) (void)hipEventDestroy(e);
+    c->part_side.release();
     for (hipEvent_t e : {c->ev_b1, c->ev_b2, c->ev_comm, c->bt[0].up, c->bt[0].use, c->bt[1].up, c->bt[1].use, c->bt[2].up, c->bt[2].use})
         if (e) (void)hipEventDestroy(e);
     c->prof.destroy();
@@ -1195,7 +1225,7 @@ int arp_dt_destroy(arp_dt* c) {
     for (auto* v : {&c->xs, &c->ln0, &c->qkv, &c->att, &c->hmid, &c->ln1, &c->u, &c->gl, &c->d_x1, &c->d_u, &c->d_mid, &c->d_qkv, &c->dws0, &c->dbs0,
                     &c->dws1, &c->dbs1})
         for (auto& b : *v) b.release();
-    for (hipStream_t st : {c->stream, c->comm_stream, c->copy_stream[0], c->copy_stream[1]})
+    for (hipStream_t st : {c->stream, c->comm_stream, c->side_stream, c->copy_stream[0], c->copy_stream[1]})
         if (st) (void)hipStreamDestroy(st);
     delete c;
     return 0;
