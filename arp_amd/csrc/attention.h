@@ -314,9 +314,11 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float4 a = *reinterpret_cast<const float4*>(qrow + 32 * c + 8 * g), bq = *reinterpret_cast<const float4*>(qrow + 32 * c + 8 * g + 4);
-            const float v[8] = {a.x * qs, a.y * qs, a.z * qs, a.w * qs, bq.x * qs, bq.y * qs, bq.z * qs, bq.w * qs};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ARP_SPLIT1(v[e], qh[c][e], ql[c][e]);
+            uint32_t h[4], l[4];
+            split2_f16(a.x, a.y, qs, h[0], l[0]); split2_f16(a.z, a.w, qs, h[1], l[1]);
+            split2_f16(bq.x, bq.y, qs, h[2], l[2]); split2_f16(bq.z, bq.w, qs, h[3], l[3]);
+            qh[c] = __builtin_bit_cast(f16x8_v, u32x4_v{h[0], h[1], h[2], h[3]});
+            ql[c] = __builtin_bit_cast(f16x8_v, u32x4_v{l[0], l[1], l[2], l[3]});
         }
         ARP_AX3_STAMP(3);
         f32x4_v acc[NT];
@@ -384,13 +386,15 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            f16x8_v ph, pl;  // keys 32 c + 8 g .. + 7
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ARP_SPLIT1(acc[2 * c][r], ph[r], pl[r]);
-                if (2 * c + 1 < NT) ARP_SPLIT1(acc[2 * c + 1][r], ph[4 + r], pl[4 + r]);
-                else { ph[4 + r] = (_Float16)0.f; pl[4 + r] = (_Float16)0.f; }
+            uint32_t phu[4] = {0u, 0u, 0u, 0u}, plu[4] = {0u, 0u, 0u, 0u};  // keys 32 c + 8 g .. + 7
+            split2_f16(acc[2 * c][0], acc[2 * c][1], 1.0f, phu[0], plu[0]);
+            split2_f16(acc[2 * c][2], acc[2 * c][3], 1.0f, phu[1], plu[1]);
+            if (2 * c + 1 < NT) {
+                split2_f16(acc[2 * c + 1][0], acc[2 * c + 1][1], 1.0f, phu[2], plu[2]);
+                split2_f16(acc[2 * c + 1][2], acc[2 * c + 1][3], 1.0f, phu[3], plu[3]);
             }
+            const f16x8_v ph = __builtin_bit_cast(f16x8_v, u32x4_v{phu[0], phu[1], phu[2], phu[3]});
+            const f16x8_v pl = __builtin_bit_cast(f16x8_v, u32x4_v{plu[0], plu[1], plu[2], plu[3]});
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d = dt * 16 + j;

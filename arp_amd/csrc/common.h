@@ -133,12 +133,28 @@ __device__ __forceinline__ float pin_f32(float x) {
     asm("" : "+v"(x));
     return x;
 }
+// (hi, lo) binary16 halves of x0 * s and x1 * s, packed pairwise: hi = rn16(x * s) and lo = rn16(x * s - hi), each ONE v_fma_mix instruction that forms the
+// product (and the difference) exactly and rounds once -- four instructions for two values where convert / convert back / subtract / convert take five to six
+// plus the scaling, and there is a single "hi" by construction (pin_f32's hazard cannot arise).  s may be any f32 (1.0f for a plain split).
+__device__ __forceinline__ void split2_f16(float x0, float x1, float s, uint32_t& hi, uint32_t& lo) {
+#ifdef ARP_NO_MIX_SPLIT  // A/B builds: the compiler's own conversion sequence on the pinned products
+    const float a = pin_f32(x0 * s), b = pin_f32(x1 * s);
+    const float ha = h2f(f2h(a)), hb = h2f(f2h(b));
+    hi = pack_h2(ha, hb);
+    lo = pack_h2(a - ha, b - hb);
+    return;
+#endif
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(s), "v"(hi));
+}
 __device__ __forceinline__ void store_split3(f16_t* p, size_t n, float a, float b, float c, float d) {
-    a = pin_f32(a); b = pin_f32(b); c = pin_f32(c); d = pin_f32(d);
-    const float ha = h2f(f2h(a)), hb = h2f(f2h(b)), hc = h2f(f2h(c)), hd = h2f(f2h(d));
-    const uint2 hi = make_uint2(pack_h2(ha, hb), pack_h2(hc, hd));
+    uint2 hi, lo;
+    split2_f16(a, b, 1.0f, hi.x, lo.x);
+    split2_f16(c, d, 1.0f, hi.y, lo.y);
     *reinterpret_cast<uint2*>(p) = hi;
-    *reinterpret_cast<uint2*>(p + n) = make_uint2(pack_h2(a - ha, b - hb), pack_h2(c - hc, d - hd));
+    *reinterpret_cast<uint2*>(p + n) = lo;
     *reinterpret_cast<uint2*>(p + 2 * n) = hi;
 }
 template <typename T> __device__ __forceinline__ void store_split3(T* p, size_t n, float a, float b, float c, float d) { store4(p, a, b, c, d); }  // f16 operands only

@@ -213,15 +213,11 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
     };
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     auto put = [&](_Float16* hi, _Float16* lo, const float4 v, float sc, int row) {
-        const float a[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};  // power-of-two scales: exact, so the split sees one f32 value whatever gets fused
-        h4 h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h[e] = (_Float16)a[e];
-            l[e] = (_Float16)(a[e] - (float)h[e]);
-        }
-        *reinterpret_cast<h4*>(hi + row * ROW + 4 * lc4) = h;
-        *reinterpret_cast<h4*>(lo + row * ROW + 4 * lc4) = l;
+        uint2 h, l;  // common.h::split2_f16: the (power-of-two) scale, hi and lo in four v_fma_mix instructions per pair
+        split2_f16(v.x, v.y, sc, h.x, l.x);
+        split2_f16(v.z, v.w, sc, h.y, l.y);
+        *reinterpret_cast<uint2*>(hi + row * ROW + 4 * lc4) = h;
+        *reinterpret_cast<uint2*>(lo + row * ROW + 4 * lc4) = l;
     };
     f32x4_v acc[4][4];  // [n fragment][m fragment]
 #pragma unroll

@@ -103,13 +103,12 @@ constexpr float PF_W_SCALE = 256.f;
 // (hi, lo) of eight consecutive operands: x * s = hi + lo up to 2^-22 relative; s is a power of two (so x * s is exact and it does not matter whether
 // the compiler rounds it to f32 before a use or fuses it into one -- see common.h::pin_f32 for what happens when it is not)
 __device__ __forceinline__ void pf_split8(const float (&x)[8], float s, f16x8_v& hi, f16x8_v& lo) {
+    // common.h::split2_f16: scale, hi and lo as four v_fma_mix instructions per pair (16 per step; convert / convert back / subtract / convert took 24)
+    uint32_t h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float xs = x[e] * s;
-        const _Float16 h = (_Float16)xs;
-        hi[e] = h;
-        lo[e] = (_Float16)(xs - (float)h);
-    }
+    for (int e = 0; e < 4; ++e) split2_f16(x[2 * e], x[2 * e + 1], s, h[e], l[e]);
+    hi = __builtin_bit_cast(f16x8_v, u32x4_v{h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(f16x8_v, u32x4_v{l[0], l[1], l[2], l[3]});
 }
 
 static __global__ __launch_bounds__(256) void pf_pack_kernel(const PfPackJob* __restrict__ jobs) {
