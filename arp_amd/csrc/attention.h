@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_f32_mfma_kernel(const float* __restr
 // V row.  P never moves between lanes.  P is carried times 2^10 (exact; its lo halves stay out of binary16's subnormals down to p = 1e-4) and the row
 // sum with it, so the factor cancels in O / l.
 // LDS images: rows of 128 B (K) / 16 B x ceil8(4 NC) (V^T), 16-byte chunks XOR-swizzled with a key made of the row bits that tell one lane group's
-// sixteen rows apart ((row >> 1 & 1) << 1 | (row >> 4 & 1) << 2 for the permuted K rows, row & 6 for V^T): every fragment read is a conflict-free
+// sixteen rows apart ((row >> 1 & 1) << 1 | (row >> 4 & 1) << 2 for the permuted K rows, vkey() below for V^T): every fragment read is a conflict-free
 // ds_read_b128.  (First version: padded rows of 144 B / 584 B, two 8-byte reads per V fragment -- SQ_LDS_BANK_CONFLICT 29 % of the LDS cycles and more
 // LDS-array cycles per query block than MFMA cycles, profiles/r4_x3_pmc.json.)
 #define ARP_SPLIT1(X, HI, LO)                  \
@@ -249,6 +249,9 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     auto kkey = [](int row) { return (((row >> 1) & 1) << 1) | (((row >> 4) & 1) << 2); };
+    // V^T rows are 640 B = 0 modulo 32 banks, so the key alone spreads BOTH access patterns: the fragment reads (sixteen rows d = 16 dt + j, chunks g / g + 1 per
+    // lane group) and the transposing 4-byte staging stores (rows d = 4 dq + e of eight consecutive dq, four consecutive key pairs each: 32 distinct banks)
+    auto vkey = [](int d) { return ((d & 6) ^ (((d >> 3) & 3) << 1)) | ((d >> 2) & 1); };
     // Staging.  EVERY global load of the workgroup's K and V is requested before the first split (NC + 2 ceil(NC / 2) float4 per thread: 72 registers at
     // 257 tokens, nothing else is live yet): written as load -> split -> store loops the staging took ~25 us of a 35 us workgroup -- one memory round trip
     // per iteration, with a single workgroup per CU (153 KB of LDS) and nothing to overlap it with.  Rows beyond N are clamped, then zeroed.
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int i = 0; i < VI; ++i) {  // V: one key PAIR per thread and d-quad, so that a transposed store is one dword (two keys of one d)
-        const int idx = min((int)threadIdx.x + 512 * i, NC * 256 - 1), kp = idx >> 4, dq = idx & 15;
+        const int idx = min((int)threadIdx.x + 512 * i, NC * 256 - 1), kp = (idx >> 6) * 4 + (idx & 3), dq = (idx & 63) >> 2;  // a wave: 4 key pairs x 16 d-quads
         v0reg[i] = *reinterpret_cast<const float4*>(base + (size_t)min(2 * kp, N - 1) * ld + 2 * D + 4 * dq);
         v1reg[i] = *reinterpret_cast<const float4*>(base + (size_t)min(2 * kp + 1, N - 1) * ld + 2 * D + 4 * dq);
     }
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int i = 0; i < VI; ++i) {
-        const int idx = threadIdx.x + 512 * i, kp = idx >> 4, dq = idx & 15;
+        const int idx = threadIdx.x + 512 * i, kp = (idx >> 6) * 4 + (idx & 3), dq = (idx & 63) >> 2;
         if (idx >= NC * 256) break;
         const float4 v0 = 2 * kp < N ? v0reg[i] : make_float4(0.f, 0.f, 0.f, 0.f), v1 = 2 * kp + 1 < N ? v1reg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
             ARP_SPLIT1(a0[e], hi[0], lo[0]);
             ARP_SPLIT1(a1[e], hi[1], lo[1]);
             const int d = 4 * dq + e;
-            const int off = d * VROWB + (((kp >> 2) ^ (d & 6)) << 4) + (kp & 3) * 4;
+            const int off = d * VROWB + (((kp >> 2) ^ vkey(d)) << 4) + (kp & 3) * 4;
             *reinterpret_cast<h2*>(Vh + off) = hi;
             *reinterpret_cast<h2*>(Vl + off) = lo;
         }
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d = dt * 16 + j;
-                const int off = d * VROWB + (((4 * c + g) ^ (d & 6)) << 4);
+                const int off = d * VROWB + (((4 * c + g) ^ vkey(d)) << 4);
                 const f16x8_v vh = *reinterpret_cast<const f16x8_v*>(Vh + off), vl = *reinterpret_cast<const f16x8_v*>(Vl + off);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[dt], 0, 0, 0);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[dt], 0, 0, 0);
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d = dt * 16 + j;
-                const int off = d * VROWB + (((4 * c + g) ^ (d & 6)) << 4);
+                const int off = d * VROWB + (((4 * c + g) ^ vkey(d)) << 4);
                 const f16x8_v vh = *reinterpret_cast<const f16x8_v*>(Vh + off), vl = *reinterpret_cast<const f16x8_v*>(Vl + off);
                 f32x4_v o = {0.f, 0.f, 0.f, 0.f};
                 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o, 0, 0, 0);
