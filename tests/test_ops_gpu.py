@@ -195,6 +195,22 @@ def test_attention(gpu_lib, case, mode, impl):
         assert np.abs(out - ref).mean() < 2e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 2, 4, 5, 15, 16, 17, 31, 32, 33, 36, 37, 64, 100, 129, 130, 224, 225, 229, 255, 256, 259, 260, 261, 271, 272, 273, 287, 288])
+@pytest.mark.parametrize("causal", [0, 1])
+def test_attention_x3_every_tile_boundary(gpu_lib, N, causal):
+    """attn_x3_kernel permutes the keys of its 16-row score tiles (tile kt holds keys 32 (kt / 2) + 8 (i / 4) + 4 (kt % 2) + i % 4), so which tiles a sequence
+    length needs, which of them carry masked keys and whether the last query block takes the cooperative path all change at lengths that are not multiples of
+    16: one sequence length on either side of every such boundary up to the 288-key limit, with and without the causal mask, f32-level bar."""
+    B, D, heads = 2, 128, 2
+    rng = np.random.default_rng(N * 7 + causal)
+    qkv = (rng.standard_normal((B * N, 3 * D)) * 1.5).astype(np.float32)
+    out = np.full((B * N, D), np.nan, np.float32)
+    gpu_lib.check(gpu_lib.lib.arp_op_attention(0, 3, _fp(qkv), _fp(out), B, N, D, heads, causal))
+    err = np.abs(out - _attn_ref(qkv, B, N, D, heads, causal)).max()
+    assert err < 1e-5, f"N={N} causal={causal}: max err {err}"
+
+
 PRE_CASES = [(256, 256, False), (256, 256, True), (64, 64, False), (128, 96, False), (200, 300, False), (512, 512, True)]
 
 
