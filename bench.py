@@ -77,6 +77,161 @@ def emit(line):
     os.write(_JSON_FD if _JSON_FD is not None else 1, (line + "\n").encode())
 
 
+# ---- what the driver reads ---------------------------------------------------------------------------------------------------
+# The driver keeps the LAST 8 KB of stdout and parses the LAST line (a 23.6 KB line left BENCH_r04.json.parsed null).
+# So: the last stdout line is the headline object ALONE and at most HEADLINE_LIMIT bytes; every secondary bench is its own compact
+# line (at most SECONDARY_LIMIT bytes) printed BEFORE it; the complete objects go to gpurun_out/bench_full.json.
+HEADLINE_LIMIT = 4096
+SECONDARY_LIMIT = 1024
+FULL_PATH = os.path.join("gpurun_out", "bench_full.json")
+
+
+def sig(o, digits=5):
+    """floats to `digits` significant figures, recursively (a printed 17-digit double is 2-3x the bytes of the number it carries)"""
+    if isinstance(o, bool) or o is None:
+        return o
+    if isinstance(o, float):
+        return float(f"{o:.{digits}g}") if np.isfinite(o) else None
+    if isinstance(o, dict):
+        return {k: sig(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [sig(v, digits) for v in o]
+    return o
+
+
+def pick(d, keys):
+    return None if not isinstance(d, dict) else {k: d[k] for k in keys if k in d and d[k] is not None}
+
+
+def cut(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "~"
+
+
+def compact_secondary(name, d):
+    """One secondary bench's line in at most SECONDARY_LIMIT bytes: the contract keys, the workload, roofline / cpu_baseline / parity
+    numbers.  Prose (sample descriptions, sources, notes) is cut first; the full line is in gpurun_out/bench_full.json."""
+    if not isinstance(d, dict) or "value" not in d:
+        return {"secondary": name, "error": cut(str((d or {}).get("error", "no JSON line")), 300)}
+    out = {"secondary": name}
+    out.update(pick(d, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "dtype"]))
+    out["config"] = {"workload": cut((d.get("config") or {}).get("workload", ""), 150)}
+    par = (d.get("config") or {}).get("parallelism")
+    if par:
+        out["config"]["parallelism"] = cut(par, 40)
+    rf = pick(d.get("roofline"), ["bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "kernel"])
+    if rf:
+        rf["kernel"] = cut(rf.get("kernel", ""), 70)
+        out["roofline"] = rf
+    cb = pick(d.get("cpu_baseline"), ["value", "unit", "cores", "kind"])
+    if cb:
+        out["cpu_baseline"] = cb
+    par = d.get("parity")
+    if isinstance(par, dict):
+        err = par.get("max_logit_err_vs_oracle", par.get("max_cosine_err_vs_oracle"))
+        out["parity"] = {"err": err, "tolerance": par.get("tolerance"), "within_tolerance": par.get("within_tolerance")}
+    ws = d.get("whole_step") or d.get("whole_pass")
+    if isinstance(ws, dict):
+        out["whole"] = pick(ws, ["gflop_per_step", "tflops", "mfma_frac_of_peak", "nominal_mfma_frac_of_peak"])
+    for k in ("rccl", "later_pass_frames_per_s", "rows", "file_rewards_equal_direct_labelling", "more_rewards_ms"):
+        if k in d:
+            out[k] = d[k]
+    if name == "online":
+        out["reward_ms"] = {k: v.get("latency_ms") for k, v in (d.get("reward") or {}).items()}
+        out["greedy_action_ms"] = (d.get("greedy_action") or {}).get("latency_ms")
+    sites = d.get("sites_ms_per_step")
+    if isinstance(sites, dict):
+        out["top_sites_ms"] = dict(list(sites.items())[:4])
+    out = sig(out)
+    for victim in ("top_sites_ms", "more_rewards_ms", "whole", "config"):
+        if len(json.dumps(out)) <= SECONDARY_LIMIT:
+            break
+        out.pop(victim, None)
+    return out
+
+
+def compact_headline(full):
+    """The headline object the driver parses: the contract keys, `config`, `roofline`, `roofline_isolated`, `cpu_baseline`, `whole_pass`,
+    `parity`, `extra_summary`, with prose cut to fit HEADLINE_LIMIT bytes.  Optional blocks are dropped, least important first, until it fits."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in full}
+    cfg = dict(full.get("config") or {})
+    cfg["workload"] = cut(cfg.get("workload", ""), 200)
+    if "operands" in cfg:
+        cfg["operands"] = cut(cfg["operands"], 90)
+    out["config"] = cfg
+    rf = pick(full.get("roofline"), ["bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "mfma_util_pct", "kernel",
+                                     "flops_per_launch", "bytes_per_launch", "avg_launch_ms", "launches", "frames_per_launch", "streams_sharing_chip"])
+    out["roofline"] = rf
+    ri = pick(full.get("roofline_isolated"), ["achieved", "peak", "unit", "frac", "avg_launch_ms", "flops_per_launch"])
+    if ri:
+        out["roofline_isolated"] = ri
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        cb = dict(cb)
+        cb["sample"] = cut(cb.get("sample", ""), 230)
+    out["cpu_baseline"] = cb
+    for k in ("whole_pass", "whole_step", "parity", "rccl", "ranks_seen"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    if full.get("alt_dtype"):
+        out["alt_dtype"] = pick(full["alt_dtype"], ["dtype", "max_cosine_err_vs_oracle", "within_tolerance"])
+    if full.get("seam"):
+        out["seam"] = pick(full["seam"], ["frames_per_s", "pinned_frames_per_s", "pipelined_frames_per_s", "bit_identical_to_hbm_resident",
+                                          "serial_ms_per_step", "prefetched_ms_per_step"])
+    if full.get("per_rank_frames_per_s"):
+        out["per_rank_frames_per_s"] = full["per_rank_frames_per_s"]
+    if full.get("per_rank_samples_per_s"):
+        out["per_rank_samples_per_s"] = full["per_rank_samples_per_s"]
+    if isinstance(full.get("sites_ms_per_step"), dict):
+        out["top_sites_ms"] = dict(list(full["sites_ms_per_step"].items())[:6])
+    for k in ("latency_ms", "later_pass_frames_per_s", "rows", "file_rewards_equal_direct_labelling", "more_rewards_ms", "final_aux"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    if isinstance(full.get("reward"), dict):  # --path online
+        out["reward_ms"] = {k: v.get("latency_ms") for k, v in full["reward"].items()}
+        out["greedy_action_ms"] = (full.get("greedy_action") or {}).get("latency_ms")
+    if full.get("extra_summary"):
+        out["extra_summary"] = full["extra_summary"]
+    out["full"] = FULL_PATH
+    out = sig(out)
+    for victim in ("final_aux", "top_sites_ms", "seam", "alt_dtype", "per_rank_frames_per_s", "per_rank_samples_per_s", "roofline_isolated"):
+        if len(json.dumps(out)) <= HEADLINE_LIMIT:
+            break
+        out.pop(victim, None)
+    if len(json.dumps(out)) > HEADLINE_LIMIT and isinstance(out.get("extra_summary"), dict):  # many ranks / long summaries: keep value + ms only
+        out["extra_summary"] = {k: (pick(v, ["value", "ms_per_step", "parity_err"]) if isinstance(v, dict) else v) for k, v in out["extra_summary"].items()}
+    return out
+
+
+def emit_line(obj):
+    """a bench path's ONE line: the complete object when a parent bench.py collects it (ARP_BENCH_CHILD), the compact form otherwise"""
+    if os.environ.get("ARP_BENCH_CHILD"):
+        emit(json.dumps(obj))
+    else:
+        emit_report(obj)
+
+
+def emit_report(full, secondaries=None):
+    """Writes gpurun_out/bench_full.json, prints the compact secondary lines, then the headline line LAST.  Refuses (exit 3) a headline over
+    HEADLINE_LIMIT: a line the driver cannot parse is an unmeasured round, worse than a failed run that says why."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, FULL_PATH), "w") as f:
+            json.dump(dict(full, extra=secondaries) if secondaries else full, f)
+    except OSError as e:  # a read-only tree must not cost the line
+        print(f"bench: could not write {FULL_PATH}: {e!r}", file=sys.stderr)
+    for name, d in (secondaries or {}).items():
+        line = json.dumps(compact_secondary(name, d))
+        if len(line) > SECONDARY_LIMIT:
+            line = json.dumps({"secondary": name, "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"), "truncated": True})
+        emit(line)
+    line = json.dumps(compact_headline(full))
+    if len(line) > HEADLINE_LIMIT:
+        print(f"bench: headline line is {len(line)} bytes > {HEADLINE_LIMIT}; refusing to print a line the driver cannot parse", file=sys.stderr)
+        sys.exit(3)
+    emit(line)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh copies of this script, one rank per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), BEFORE anything here has
@@ -127,17 +282,18 @@ def spawn_ranks(n):
 def run_secondary(a):
     """--all-secondary: the other benches as child processes (each prints its own ONE JSON line), collected under `extra` so that the
     driver's single run of bench.py carries them.  Called before the parent initialises the GPU."""
+    # least important first: the driver's 8 KB tail holds the headline line (last) and the compact lines printed just before it
     runs = {
-        "policy": ["--path", "policy"],
+        "h5": ["--path", "h5"],
+        "online": ["--path", "online"],
+        "label_vit_b16": ["--model", "ViT-B/16", "--batch", "256"],
         # row N1: the parity-true line runs in f32 (the reference's own arithmetic type; its encoder-inside logits meet 1e-3 on every seed,
         # tests/test_m3ae_gpu.py); the f16 line beside it is a throughput mode whose own parity block says whether it is inside
         "policy_with_encoder": ["--path", "policy", "--with-encoder", "--mode", "f32"],
         "policy_with_encoder_f16x3": ["--path", "policy", "--with-encoder", "--mode", "f32", "--encoder-mode", "f16x3"],  # f32-accurate on the 16-bit MFMA
         "policy_with_encoder_f16": ["--path", "policy", "--with-encoder", "--mode", "f16"],
         "finetune": ["--path", "finetune"],
-        "label_vit_b16": ["--model", "ViT-B/16", "--batch", "256"],
-        "online": ["--path", "online"],
-        "h5": ["--path", "h5"],
+        "policy": ["--path", "policy"],
     }
     # path (2) and row N2 carry their own CPU baseline (a bounded ~5 s sample of the torch-CPU port of the same step, oracle/cpu_baseline_*.py)
     cpu_s = {"policy": 5.0, "finetune": 5.0} if a.cpu_seconds > 0 else {}
@@ -146,7 +302,7 @@ def run_secondary(a):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup), "--cpu-seconds",
                str(cpu_s.get(name, 0)), "--no-secondary"] + args
         try:
-            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, ARP_BENCH_CHILD="1"))
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             extra[name] = json.loads(line[-1]) if line else {"error": (r.stderr or "no output")[-400:], "rc": r.returncode}
         except Exception as e:  # a secondary line must never cost the headline one
@@ -374,7 +530,7 @@ def bench_policy(a):
                 traffic = rec["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             traffic = None
-        emit(json.dumps({
+        emit_line(({
             "metric": "samples/sec ARPDT train_step (frames in, frozen M3AE encoder inside)" if enc is not None else
                       "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -487,7 +643,7 @@ def bench_online(a):
     tr.close()
     ga = {"latency_ms": round(float(np.median(ts)) * 1e3, 4), "mean_ms": round(float(np.mean(ts)) * 1e3, 4), "enc_bytes": int(enc.nbytes), "calls": reps}
     v = lat["ViT-B/32"]["latency_ms"]
-    emit(json.dumps({"metric": "single_frame_reward_latency", "value": v, "unit": "ms", "latency_ms": v, "n_gpus": 1, "steps": reps, "warmup": 8,
+    emit_line(({"metric": "single_frame_reward_latency", "value": v, "unit": "ms", "latency_ms": v, "n_gpus": 1, "steps": reps, "warmup": 8,
                      "ms_per_step": v, "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
                      "config": {"workload": "get_torch_clip_reward: one 256x256x3 uint8 host frame in, one f32 reward out per call (ViT-B/32; the same for "
                                             "ViT-B/16 under reward); greedy_action: one [1,4,257,768] f32 window of encodings in, one action out"},
@@ -543,7 +699,7 @@ def bench_h5(a):
     finally:
         m.close()
         os.remove(path)
-    emit(json.dumps({"metric": "frames/sec label_reward(data_path=HDF5 file) end to end (file -> file)", "value": round(rates[0], 1), "unit": "frames/s",
+    emit_line(({"metric": "frames/sec label_reward(data_path=HDF5 file) end to end (file -> file)", "value": round(rates[0], 1), "unit": "frames/s",
                      "later_pass_frames_per_s": round(max(rates[1:]), 1), "n_gpus": 1, "steps": 3, "warmup": 0, "ms_per_step": rows / rates[0] * 1e3,
                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic", "rows": rows,
                      "config": {"workload": f"recorder-schema file: ob uint8 [{rows},8,256,256,3] in gzip chunks of one row ({size_mb:.0f} MB on disk, "
@@ -659,7 +815,7 @@ def bench_finetune(a):
         tr.close()
         dist.destroy_process_group()
         return
-    emit(json.dumps({
+    emit_line(({
         "metric": "samples/sec CLIP multi-scale adapter fine-tune step (frames in: frozen ViT-B/16 towers + head)" if towers is not None else
                   "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": world * a.finetune_batch * a.steps / elapsed,
         "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
@@ -966,9 +1122,10 @@ def main():
             "sites_total_ms_per_step": total_ms / a.steps,
             "per_rank_frames_per_s": [round(v, 1) for v in per_rank],
         }
-        if extra is not None:
-            out["extra"] = extra
-        emit(json.dumps(out))
+        if os.environ.get("ARP_BENCH_CHILD"):
+            emit(json.dumps(out))
+        else:
+            emit_report(out, extra)
     model.close()
     if dist is not None:
         dist.destroy_process_group()
