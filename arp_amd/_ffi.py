@@ -14,7 +14,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# ARP_LIB: an alternate build of the SAME library (A/B experiments: `make -C arp_amd/csrc ALT=kv0 EXTRA=-DARP_G2_KV=0` writes
+# arp_amd/alt/kv0/libarp_hip.so) -- selected here instead of being copied over the product; relative paths are repo-relative
 LIB_PATH = os.path.join(_HERE, "libarp_hip.so")
+if os.environ.get("ARP_LIB"):
+    LIB_PATH = os.environ["ARP_LIB"] if os.path.isabs(os.environ["ARP_LIB"]) else os.path.join(os.path.dirname(_HERE), os.environ["ARP_LIB"])
 
 MODE_F32, MODE_BF16, MODE_F16, MODE_F16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_QGELU, ACT_RELU, ACT_TANH, ACT_GELU_TANH = 0, 1, 2, 3, 4
@@ -128,6 +132,8 @@ SIGNATURES = {
     "arp_dt_comm_unique_id": (_i, [_vp]),
     "arp_dt_comm_init": (_i, [_vp, _vp, _i, _i]),
     "arp_dt_broadcast_state": (_i, [_vp]),
+    "arp_dt_comm_info": (_i, [_vp, _i32p]),
+    "arp_dt_comm_selfcheck": (_i, [_vp, C.POINTER(C.c_double)]),
     "arp_dt_profile_enable": (_i, [_vp, _i]),
     "arp_dt_profile_reset": (_i, [_vp]),
     "arp_dt_profile_json": (_i, [_vp, C.c_char_p, _i]),
@@ -156,6 +162,8 @@ SIGNATURES = {
     "arp_ft_sync": (_i, [_vp]),
     "arp_ft_comm_init": (_i, [_vp, _vp, _i, _i]),
     "arp_ft_broadcast_state": (_i, [_vp]),
+    "arp_ft_comm_info": (_i, [_vp, _i32p]),
+    "arp_ft_comm_selfcheck": (_i, [_vp, C.POINTER(C.c_double)]),
     "arp_ft_bucket_plan": (_i, [C.POINTER(FtCfg), _i64p, _i64p]),
     "arp_ft_event_record": (_i, [_vp, _vp]),
     "arp_ft_profile_enable": (_i, [_vp, _i]),

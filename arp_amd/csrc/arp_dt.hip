@@ -1520,6 +1520,17 @@ int arp_dt_comm_init(arp_dt* c, const void* id128, int world, int rank) {
     return 0;
 }
 
+int arp_dt_comm_info(arp_dt* c, int32_t* info5) {
+    if (!c || !info5) return fail("null argument");
+    return rccl_comm_info(c->comm, c->has_comm, c->cfg.device, info5);
+}
+int arp_dt_comm_selfcheck(arp_dt* c, double* sum) {
+    if (!c || !sum) return fail("null argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(c->scal.ensure(4096 * 4));
+    return rccl_selfcheck(c->comm, c->has_comm, c->stream, c->scal.as<float>(), c->cfg.rank, sum);
+}
+
 // sync_state_fn (main_procgen.py:94-101): every rank takes rank 0's params and optimizer state
 int arp_dt_broadcast_state(arp_dt* c) {
     if (!c) return fail("null handle");

@@ -897,6 +897,17 @@ int arp_ft_comm_init(arp_ft* c, const void* id128, int world, int rank) {
     return 0;
 }
 
+int arp_ft_comm_info(arp_ft* c, int32_t* info5) {
+    if (!c || !info5) return fail("null argument");
+    return rccl_comm_info(c->comm, c->has_comm, c->cfg.device, info5);
+}
+int arp_ft_comm_selfcheck(arp_ft* c, double* sum) {
+    if (!c || !sum) return fail("null argument");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_TRY(c->scal.ensure(64));
+    return rccl_selfcheck(c->comm, c->has_comm, c->stream, c->scal.as<float>(), c->rank, sum);
+}
+
 // every rank takes rank 0's parameters, AdamW moments and step counter (what loading one checkpoint on every rank gives)
 int arp_ft_broadcast_state(arp_ft* c) {
     if (!c) return fail("null handle");

@@ -294,4 +294,19 @@ static inline fp8_t host_f2fp8(float f) {
     return fp8_t{(uint8_t)(sign | ((E + 7) << 3) | (int)q)};
 }
 
+// K-loop version (round 5).  KV = 1: (i) every LDS-DMA is ONE inline-asm statement in the SADDR form --
+// `s_mov_b32 m0, dst; s_nop 0; global_load_lds_dwordx4 v_off32, s[base:base+1]` -- with the tile's row base + K-tile offset in an SGPR
+// pair bumped by SALU and a 32-bit per-lane offset that never changes (hipcc selects the VGPR-pair form for the builtin: one 64-bit
+// `v_lshl_add_u64` per DMA on the SIMD's vector issue port, the resource section 5d prices the loop by; 16 address VGPRs -> 8);
+// (ii) the steady state (K-tiles whose issues all exist) is peeled from the tails, so the loop body carries no `gi < G` branches and
+// its counted waits are the literal vmcnt(8).  Same MFMA order, same LDS image: results bit-identical to KV = 0.
+#ifndef ARP_G2_KV
+#define ARP_G2_KV 1
+#endif
+// One LDS-DMA of 16 bytes per lane: global address = sbase (wave-uniform, SGPR pair) + voff (per lane, 32-bit), LDS address = lds_dst
+// (wave-uniform byte address) + lane * 16.  M0 is written in the statement that reads it (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void dma16_saddr(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 }  // namespace arp

@@ -116,7 +116,8 @@ template <typename T> __device__ __forceinline__ f32x16_v mfma32(u32x4_v a, u32x
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
 }
-template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0)>
+// K-loop version KV (common.h: ARP_G2_KV, dma16_saddr): 1 = SADDR-form LDS-DMA statements + peeled steady state, bit-identical to 0.
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV>
 __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G2_MAX_VGPR))) void gemm256_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPB = 128 / (int)sizeof(T);
@@ -171,7 +172,16 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     const int srow = lane >> 3;
     const T* src[4][2];
     int dst[4][2];  // byte offset inside a K-tile buffer (wave-uniform)
+    // KV = 1: global address = tile base (SGPR pair: first row of the tile, current K-tile) + off32 (per lane, bytes, fixed for the tile)
+    uint32_t off32[4][2];
+    const char* a_tile = nullptr;
+    const char* w_tile = nullptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto setup_src = [&]() {
+        if constexpr (KV == 1) {
+            a_tile = reinterpret_cast<const char*>(A + (size_t)m0 * g.lda);
+            w_tile = reinterpret_cast<const char*>(W + (size_t)n0 * g.ldw);
+        }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -186,11 +196,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             if (isA) {
                 int am = m0 + row;
                 am = am < g.M ? am : g.M - 1;
-                src[u][i] = A + (size_t)am * g.lda + schunk * EPC;
+                if constexpr (KV == 1) off32[u][i] = (uint32_t)(((size_t)(am - m0) * g.lda + schunk * EPC) * sizeof(T));
+                else src[u][i] = A + (size_t)am * g.lda + schunk * EPC;
             } else {
                 int wn = n0 + row;
                 wn = wn < g.N ? wn : g.N - 1;
-                src[u][i] = W + (size_t)wn * g.ldw + schunk * EPC;
+                if constexpr (KV == 1) off32[u][i] = (uint32_t)(((size_t)(wn - n0) * g.ldw + schunk * EPC) * sizeof(T));
+                else src[u][i] = W + (size_t)wn * g.ldw + schunk * EPC;
             }
         }
     };
@@ -202,12 +214,33 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         if ((ARP_G2_ABL & 2) && gi >= 12) return;
         if (gi < G) {
             const int tt = gi >> 2;
+            if constexpr (KV == 1) {
+                const char* sb = ((u == 0 || u == 3) ? a_tile : w_tile) + (size_t)tt * 128;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dma16_saddr(sb, off32[u][i], lds0 + (tt & 1) * G2_BUF_BYTES + dst[u][i]);
+            } else {
             char* base = smem + (tt & 1) * G2_BUF_BYTES;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[u][i] + (size_t)tt * EPB),
                                                  (__attribute__((address_space(3))) void*)(base + dst[u][i]), 16, 0, 0);
+            }
         }
+    };
+    // KV = 1, steady state: unit U of K-tile tt, no existence test
+    auto issue_ss = [&](int tt, auto U) {
+        constexpr int u = decltype(U)::value;
+        const char* sb = ((u == 0 || u == 3) ? a_tile : w_tile) + (size_t)tt * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16_saddr(sb, off32[u][i], lds0 + (tt & 1) * G2_BUF_BYTES + dst[u][i]);
+    };
+    // the tile's 256 bias values -> LDS (one LDS-DMA of wave 0)
+    auto bias_dma = [&](int n_first) {
+        int n = n_first + lane * 4;
+        n = n + 4 <= g.N ? n : (g.N >= 4 ? g.N - 4 : 0);  // clamped at the ragged edge: those columns are never stored
+        if constexpr (KV == 1) dma16_saddr(g.bias, (uint32_t)n * 4u, lds0 + G2_TILE_BYTES);
+        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + n),
+                                              (__attribute__((address_space(3))) void*)(smem + G2_TILE_BYTES), 16, 0, 0);
     };
     using U0 = std::integral_constant<int, 0>;
     using U1 = std::integral_constant<int, 1>;
@@ -382,12 +415,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     // the tile's bias slice (256 floats) goes to LDS by one LDS-DMA of wave 0, issued ahead of the operand units (so every
     // counted wait covers it): read from global memory in the epilogue it would cost a memory latency with nothing to hide it
     float* bias_s = reinterpret_cast<float*>(smem + G2_TILE_BYTES);
-    if (g.bias && wave == 0 && !pre_issued_bias) {
-        int n = n0 + lane * 4;
-        n = n + 4 <= g.N ? n : (g.N >= 4 ? g.N - 4 : 0);  // clamped at the ragged edge: those columns are never stored
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + n),
-                                         (__attribute__((address_space(3))) void*)bias_s, 16, 0, 0);
-    }
+    if (g.bias && wave == 0 && !pre_issued_bias) bias_dma(n0);
     if constexpr (W32) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -431,7 +459,42 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int kt = 0; kt < nk; ++kt) {
+    int kt_first = 0;
+    if constexpr (KV == 1 && !ARP_G2_OVERLAP_DRAIN) {
+        // ---- steady state: K-tiles 0 .. nk-3 issue steps 2kt+3 (U3 of K-tile kt+1) and 2kt+4 (U0,U1,U2 of K-tile kt+2), both of which
+        // exist, and leave exactly 8 LDS-DMA instructions in flight at each counted wait
+        auto tail_ss = [&]() {
+            wait_vmcnt<8>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as the builtin: hipcc's own wait bookkeeping sees it (behind the asm form it re-waits inside the MFMA segment)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto ktile_ss = [&](int kt, auto BUF) {  // one K-tile out of ring buffer BUF (compile-time: its fragment addresses are loop constants)
+            const char* buf = smem + decltype(BUF)::value * G2_BUF_BYTES;
+            load_a(buf, 0);
+            load_b(buf, I0{});
+            load_b(buf, I1{});
+            issue_ss(kt + 1, U3{});
+            tail_ss();
+            compute2(I0{}, I0{}, I1{});
+            load_a(buf, 1);
+            issue_ss(kt + 2, U0{});
+            issue_ss(kt + 2, U1{});
+            issue_ss(kt + 2, U2{});
+            tail_ss();
+            compute2(I1{}, I1{}, I0{});
+        };
+        for (; kt_first + 3 < nk; kt_first += 2) {
+            ktile_ss(kt_first, I0{});
+            ktile_ss(kt_first + 1, I1{});
+        }
+        if (kt_first + 2 < nk) {
+            ktile_ss(kt_first, I0{});
+            ++kt_first;
+        }
+    }
+    for (int kt = kt_first; kt < nk; ++kt) {
         const char* buf = smem + (kt & 1) * G2_BUF_BYTES;
         const int p = 2 * kt;
         abl_kt = kt;
@@ -640,12 +703,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                 OutT* obase = out + (size_t)(m0 + wave * 2 + (lane >> 5)) * g.ldo + n0 + (lane & 31) * 8;
                 tile_coords(tix + gridDim.x);
                 setup_src();
-                if (g.bias && wave == 0) {
-                    int n = n0 + lane * 4;
-                    n = n + 4 <= g.N ? n : (g.N >= 4 ? g.N - 4 : 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + n),
-                                                     (__attribute__((address_space(3))) void*)(smem + G2_TILE_BYTES), 16, 0, 0);
-                }
+                if (g.bias && wave == 0) bias_dma(n0);
                 issue_step(0);
                 issue_step(1);
                 issue_step(2);
@@ -851,12 +909,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         __syncthreads();  // every wave has finished reading the epilogue tile out of LDS
         tile_coords(tix + gridDim.x);
         setup_src();
-        if (g.bias && wave == 0) {
-            int n = n0 + lane * 4;
-            n = n + 4 <= g.N ? n : (g.N >= 4 ? g.N - 4 : 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g.bias + n),
-                                             (__attribute__((address_space(3))) void*)(smem + G2_TILE_BYTES), 16, 0, 0);
-        }
+        if (g.bias && wave == 0) bias_dma(n0);
         pre_issued_bias = true;
 #if ARP_G2_TWO_PHASE
         issue_step(0);
@@ -880,7 +933,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
 #endif
 }
 
-template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0)>
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV>
 inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     constexpr int EPB = 128 / (int)sizeof(T);
     if (g.M <= 0) return 0;
@@ -889,7 +942,10 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
                     " K=" + std::to_string(g.K));
     if (g.mask && (!G2_MASK_SITE(SITE) || sizeof(OutT) != 2 || ((g.N | g.ldo | g.ldm | g.ldr) & 7) || (g.flags & 3)))
         return fail("gemm256_nt: the masked epilogue needs a 16-bit output and N, ldo, ldm multiples of 8");
-    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE, M32>;
+    // KV = 1 addresses a tile's rows by 32-bit byte offsets from the tile's first row
+    if (KV == 1 && ((size_t)G2_BM * g.lda * sizeof(T) >= (1ull << 32) || (size_t)G2_BN * g.ldw * sizeof(T) >= (1ull << 32)))
+        return fail("gemm256_nt: row stride too large for the 32-bit tile offsets of the KV = 1 K loop");
+    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE, M32, KV>;
     static bool attr_set = false;
     if (!attr_set) {
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

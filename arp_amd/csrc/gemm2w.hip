@@ -44,22 +44,39 @@ __global__ __launch_bounds__(W2_THREADS, 2) __attribute__((amdgpu_num_vgpr(W2_MA
     // ---- LDS-DMA plan: a piece = 8 rows x 128 B; wave w fills A pieces 4w..4w+3 and W pieces 6w..6w+5 ----------------------
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
+    constexpr int KV = ARP_G2_KV;  // 1: every LDS-DMA is a SADDR-form asm statement (common.h::dma16_saddr): tile base + K offset in SGPRs, 32-bit lane offsets
     const T* srcA[4];
     const T* srcW[6];
+    uint32_t offA[4], offW[6];
+    const char* a_tile = reinterpret_cast<const char*>(A + (size_t)m0 * g.lda);
+    const char* w_tile = reinterpret_cast<const char*>(W + (size_t)n0 * g.ldw);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int am = m0 + (wave * 4 + i) * 8 + srow;
         am = am < g.M ? am : g.M - 1;
-        srcA[i] = A + (size_t)am * g.lda + schunk * EPC;
+        if constexpr (KV == 1) offA[i] = (uint32_t)(((size_t)(am - m0) * g.lda + schunk * EPC) * sizeof(T));
+        else srcA[i] = A + (size_t)am * g.lda + schunk * EPC;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         int wn = n0 + (wave * 6 + i) * 8 + srow;
         wn = wn < g.N ? wn : g.N - 1;
-        srcW[i] = W + (size_t)wn * g.ldw + schunk * EPC;
+        if constexpr (KV == 1) offW[i] = (uint32_t)(((size_t)(wn - n0) * g.ldw + schunk * EPC) * sizeof(T));
+        else srcW[i] = W + (size_t)wn * g.ldw + schunk * EPC;
     }
     const int nk = g.K / EPB;
     auto issue = [&](int kt) {
+        if constexpr (KV == 1) {
+            const char* sa = a_tile + (size_t)kt * 128;
+            const char* sw = w_tile + (size_t)kt * 128;
+            const uint32_t b = lds0 + (kt & 1) * W2_BUF_BYTES;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma16_saddr(sa, offA[i], b + (wave * 4 + i) * 1024);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dma16_saddr(sw, offW[i], b + W2_W_REGION + (wave * 6 + i) * 1024);
+            return;
+        }
         char* base = smem + (kt & 1) * W2_BUF_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i)

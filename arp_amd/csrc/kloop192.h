@@ -32,10 +32,15 @@ __device__ __forceinline__ void kloop_256x192(char* smem, const T* __restrict__ 
     // ---- LDS-DMA plan ---------------------------------------------------------------------------------------------------
     const int srow = lane >> 3;
     const int schunk = (lane & 7) ^ srow;
+    constexpr int KV = ARP_G2_KV;  // 1: SADDR-form LDS-DMA statements + peeled steady state (common.h), same bits
     const T* srcA[2][2];  // [q-row][instr]
     int dstA[2][2];
     const T* srcW[3];
     int dstW[3];
+    uint32_t offA[2][2], offW[3];  // KV = 1: byte offsets from the tile's first A / W row
+    const char* a_tile = reinterpret_cast<const char*>(A + (size_t)m0 * lda);
+    const char* w_tile = reinterpret_cast<const char*>(W + (size_t)n0 * ldw);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -44,7 +49,8 @@ __device__ __forceinline__ void kloop_256x192(char* smem, const T* __restrict__ 
             const int row0 = (lr0 >> 6) * 128 + q * 64 + (lr0 & 63);
             int am = m0 + row0 + srow;
             am = am < m_rows ? am : m_rows - 1;  // rows past the tile's frames are computed on valid memory and never consumed
-            srcA[q][i] = A + (size_t)am * lda + schunk * EPC;
+            if constexpr (KV == 1) offA[q][i] = (uint32_t)(((size_t)(am - m0) * lda + schunk * EPC) * sizeof(T));
+            else srcA[q][i] = A + (size_t)am * lda + schunk * EPC;
             dstA[q][i] = row0 * 128;
         }
 #pragma unroll
@@ -53,15 +59,37 @@ __device__ __forceinline__ void kloop_256x192(char* smem, const T* __restrict__ 
         {
             int wn = n0 + row0 + srow;
             wn = wn < n_rows ? wn : n_rows - 1;
-            srcW[i] = W + (size_t)wn * ldw + schunk * EPC;
+            if constexpr (KV == 1) offW[i] = (uint32_t)(((size_t)(wn - n0) * ldw + schunk * EPC) * sizeof(T));
+            else srcW[i] = W + (size_t)wn * ldw + schunk * EPC;
         }
         dstW[i] = K192_W_REGION + row0 * 128;
     }
     const int nk = K / EPB;
     const int S2 = 2 * nk;
+    // KV = 1: one step, no existence test (the caller knows it exists)
+    auto issue_odd_ss = [&](int tt) {
+        const char* sa = a_tile + (size_t)tt * 128;
+        const uint32_t base = lds0 + (tt & 1) * K192_BUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16_saddr(sa, offA[1][i], base + dstA[1][i]);
+    };
+    auto issue_even_ss = [&](int tt) {
+        const char* sa = a_tile + (size_t)tt * 128;
+        const char* sw = w_tile + (size_t)tt * 128;
+        const uint32_t base = lds0 + (tt & 1) * K192_BUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dma16_saddr(sa, offA[0][i], base + dstA[0][i]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma16_saddr(sw, offW[i], base + dstW[i]);
+    };
     auto issue_step = [&](int st) {
         if (st >= S2) return;
         const int tt = st >> 1;
+        if constexpr (KV == 1) {
+            if (st & 1) issue_odd_ss(tt);
+            else issue_even_ss(tt);
+            return;
+        }
         char* base = smem + (tt & 1) * K192_BUF_BYTES;
         if (st & 1) {
 #pragma unroll
@@ -145,9 +173,11 @@ __device__ __forceinline__ void kloop_256x192(char* smem, const T* __restrict__ 
 
     // the head's 192 bias values: one LDS-DMA of wave 0, older than every operand unit (so every counted wait covers it)
     float* bias_s = reinterpret_cast<float*>(smem + K192_RING_BYTES);
-    if (bias && wave == 0 && lane < 48)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + min(n0 + lane * 4, n_rows - 4)),
-                                         (__attribute__((address_space(3))) void*)bias_s, 16, 0, 0);
+    if (bias && wave == 0 && lane < 48) {
+        if constexpr (KV == 1) dma16_saddr(bias, (uint32_t)min(n0 + lane * 4, n_rows - 4) * 4u, lds0 + K192_RING_BYTES);
+        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bias + min(n0 + lane * 4, n_rows - 4)),
+                                              (__attribute__((address_space(3))) void*)bias_s, 16, 0, 0);
+    }
     issue_step(0);
     issue_step(1);
     issue_step(2);
@@ -158,7 +188,38 @@ __device__ __forceinline__ void kloop_256x192(char* smem, const T* __restrict__ 
     if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier behind group 0
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int kt = 0; kt < nk; ++kt) {
+    int kt_first = 0;
+    if constexpr (KV == 1) {
+        // steady state: K-tiles 0 .. nk-3 issue steps 2kt+3 and 2kt+4, both of which exist; 7 LDS-DMA instructions stay in flight at each wait
+        auto tail_ss = [&]() {
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), as the builtin (hipcc's wait bookkeeping sees it)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto ktile_ss = [&](int kt, auto BUF) {
+            const char* buf = smem + decltype(BUF)::value * K192_BUF_BYTES;
+            load_a(buf, 0);
+            load_b(buf);
+            issue_odd_ss(kt + 1);
+            tail_ss();
+            compute(I0{});
+            load_a(buf, 1);
+            issue_even_ss(kt + 2);
+            tail_ss();
+            compute(I1{});
+        };
+        for (; kt_first + 3 < nk; kt_first += 2) {
+            ktile_ss(kt_first, I0{});
+            ktile_ss(kt_first + 1, I1{});
+        }
+        if (kt_first + 2 < nk) {
+            ktile_ss(kt_first, I0{});
+            ++kt_first;
+        }
+    }
+    for (int kt = kt_first; kt < nk; ++kt) {
         const char* buf = smem + (kt & 1) * K192_BUF_BYTES;
         const int p = 2 * kt;
         load_a(buf, 0);

@@ -243,6 +243,16 @@ class FinetuneTrainer:
         """every rank takes rank 0's parameters, AdamW moments and step (= loading one checkpoint everywhere)"""
         check(lib.arp_ft_broadcast_state(self._h))
 
+    def comm_info(self):
+        v = (C.c_int32 * 5)()
+        check(lib.arp_ft_comm_info(self._h, v))
+        return {"nranks": v[0], "rank": v[1], "device": v[2], "rccl_version": v[3], "has_comm": bool(v[4])}
+
+    def comm_selfcheck(self):
+        d = C.c_double()
+        check(lib.arp_ft_comm_selfcheck(self._h, C.byref(d)))
+        return d.value
+
     def record(self, event):
         check(lib.arp_ft_event_record(self._h, event.ptr))
 
@@ -403,6 +413,10 @@ class DataParallel:
             raise ValueError("the control plane did not deliver rank 0's 128-byte RCCL unique id")
         trainer.comm_init(bytes(uid), self.world, self.rank)
         trainer.broadcast_state()
+
+    def certify(self):
+        from .train import certify_collective
+        return certify_collective(self.trainer, self.rank, self.world)
 
     def train_step(self, batch, lr):
         self.trainer.set_batch(*shard_batch(batch, self.rank, self.world))

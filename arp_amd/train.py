@@ -20,6 +20,7 @@ All compute is in libarp_hip.so; there is no CPU fallback.
 """
 import ctypes as C
 import json
+import os
 from dataclasses import asdict, dataclass
 
 import numpy as np
@@ -233,6 +234,18 @@ class PolicyTrainer:
         """sync_state_fn (main_procgen.py:94-101)."""
         check(lib.arp_dt_broadcast_state(self._h))
 
+    def comm_info(self):
+        """what the RCCL communicator says about itself: nranks (ncclCommCount), rank (ncclCommUserRank), device, RCCL version code"""
+        v = (C.c_int32 * 5)()
+        check(lib.arp_dt_comm_info(self._h, v))
+        return {"nranks": v[0], "rank": v[1], "device": v[2], "rccl_version": v[3], "has_comm": bool(v[4])}
+
+    def comm_selfcheck(self):
+        """all-reduce(sum) of ``rank + 1`` through the step's communicator: world (world + 1) / 2 on every rank"""
+        d = C.c_double()
+        check(lib.arp_dt_comm_selfcheck(self._h, C.byref(d)))
+        return d.value
+
     def profile(self, on=True):
         check(lib.arp_dt_profile_enable(self._h, int(on)))
 
@@ -348,6 +361,9 @@ class DataParallel:
         trainer.comm_init(bytes(uid), self.world, self.rank)
         trainer.broadcast_state()
 
+    def certify(self):
+        return certify_collective(self.trainer, self.rank, self.world)
+
     def set_global_batch(self, batch, device_axis=False):
         self.trainer.set_batch(*_batch_arrays(shard_batch(batch, self.rank, self.world, device_axis), self.trainer.cfg.use_symlog))
 
@@ -355,6 +371,18 @@ class DataParallel:
         """aux is the rank-averaged aux of the reference's pmean: identical on every rank."""
         self.set_global_batch(batch, device_axis)
         return self.trainer.train_step(lr)
+
+
+def certify_collective(trainer, rank, world):
+    """What a multi-GPU bench line prints about its communicator: the rank count and user rank RCCL itself reports
+    (``ncclCommCount`` / ``ncclCommUserRank``, not the environment's), and one all-reduce(sum) of ``rank + 1`` through it -- every rank
+    must read world (world + 1) / 2.  ``ok`` is False when any of the three disagrees with (rank, world)."""
+    info = trainer.comm_info()
+    got = trainer.comm_selfcheck()
+    want = world * (world + 1) / 2.0
+    ok = info["nranks"] == world and info["rank"] == rank and got == want and (world == 1 or info["has_comm"])
+    return dict(info, allreduce_selfcheck=got, expected=want, ok=bool(ok),
+                NCCL_ALGO=os.environ.get("NCCL_ALGO"), NCCL_PROTO=os.environ.get("NCCL_PROTO"))
 
 
 def bucket_plan(cfg):

@@ -346,6 +346,36 @@ def gather_rates(dist, world, units, elapsed_local):
     return [units / t for t in out]
 
 
+def gather_cert(dist, world, cert):
+    """The `rccl` block of a multi-GPU line: every rank's own certificate (arp_amd.train.certify_collective: what ncclCommCount /
+    ncclCommUserRank report, and an all-reduce(sum) of rank + 1 through the step's communicator) gathered over the gloo control plane,
+    so that "did RCCL see N ranks" is read off the line, not off the environment."""
+    certs = [cert]
+    if dist is not None:
+        certs = [None] * world
+        dist.all_gather_object(certs, cert)
+    return {"rccl_nranks": sorted({c["nranks"] for c in certs}), "ranks_seen": sorted(c["rank"] for c in certs), "devices": [c["device"] for c in certs],
+            "allreduce_selfcheck": [c["allreduce_selfcheck"] for c in certs], "expected": certs[0]["expected"],
+            "ok": bool(all(c["ok"] for c in certs) and sorted(c["rank"] for c in certs) == list(range(world))),
+            "has_comm": bool(all(c["has_comm"] for c in certs)), "rccl_version": certs[0]["rccl_version"],
+            "NCCL_ALGO": certs[0]["NCCL_ALGO"], "NCCL_PROTO": certs[0]["NCCL_PROTO"]}
+
+
+def label_ranks_seen(dist, rank, world, device):
+    """labelling shards with NO collective: what certifies an N-GPU line is the control plane -- every rank reports itself and a
+    gloo all-reduce of rank + 1 must read N (N + 1) / 2"""
+    if dist is None:
+        return {"ranks_seen": [0], "devices": [device], "control_plane_selfcheck": 1.0, "expected": 1.0, "ok": True}
+    import torch
+    seen = [None] * world
+    dist.all_gather_object(seen, (rank, device, os.getpid()))
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    want = world * (world + 1) / 2.0
+    return {"ranks_seen": sorted(r for r, _, _ in seen), "devices": [d for _, d, _ in sorted(seen)], "distinct_processes": len({p for _, _, p in seen}),
+            "control_plane_selfcheck": float(t), "expected": want, "ok": bool(float(t) == want and sorted(r for r, _, _ in seen) == list(range(world)))}
+
+
 def policy_sites(cfg, B, n_params):
     """Algorithmic work per launch of the policy step's call sites: ("mfma", FLOPs) or ("hbm", bytes)."""
     R = B * cfg.window
@@ -439,6 +469,9 @@ def bench_policy(a):
     tr.set_params(S.policy_params(cfg, seed=0))
     if world > 1:  # RCCL id from rank 0 over gloo, communicator, sync_state_fn
         train.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
+    rccl = gather_cert(dist, world, train.certify_collective(tr, rank, world))  # every rank: the gather is a collective of the control plane
+    if not rccl["ok"]:
+        raise SystemExit(f"--path policy --gpus {world}: the communicator does not span the ranks it should: {rccl}")
     enc = None
     if a.with_encoder:
         from arp_amd import m3ae
@@ -552,7 +585,7 @@ def bench_policy(a):
                            "mfma_frac_of_peak": flops / (elapsed / a.steps) / 1e12 / (PEAK_TFLOPS["f16" if (a.encoder_mode or a.mode) == "f16x3" else (a.encoder_mode or a.mode)] if enc is not None else PEAK_TFLOPS[a.mode])},
             "parity": {"max_logit_err_vs_oracle": parity, "geometry": parity_geometry, "tolerance": 1e-3,
                        "within_tolerance": None if parity is None else bool(parity < 1e-3)},
-            "cpu_baseline": cpu, "seam": seam, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
+            "cpu_baseline": cpu, "seam": seam, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank], "rccl": rccl,
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
     tr.close()
     if dist is not None:
@@ -731,6 +764,9 @@ def bench_finetune(a):
     tr.set_params(FT.synth_params(cfg, seed=0))
     if world > 1:
         FT.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
+    rccl = gather_cert(dist, world, train.certify_collective(tr, rank, world))
+    if not rccl["ok"]:
+        raise SystemExit(f"--path finetune --gpus {world}: the communicator does not span the ranks it should: {rccl}")
     B = a.finetune_batch
     lr = 1e-4
     towers = None
@@ -829,7 +865,7 @@ def bench_finetune(a):
                      "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "kernel": kern,
                      "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms},
         "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12},
-        "cpu_baseline": cpu, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank],
+        "cpu_baseline": cpu, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank], "rccl": rccl,
         "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
     tr.close()
     if dist is not None:
@@ -963,6 +999,7 @@ def main():
     elapsed = t1 - t0
     ev_ms = clip.elapsed_ms(e0, e1)
     per_rank = gather_rates(dist, world, a.batch * a.steps, elapsed)
+    ranks_seen = label_ranks_seen(dist, rank, world, local_rank)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -1121,6 +1158,7 @@ def main():
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
             "sites_total_ms_per_step": total_ms / a.steps,
             "per_rank_frames_per_s": [round(v, 1) for v in per_rank],
+            "ranks_seen": ranks_seen,
         }
         if os.environ.get("ARP_BENCH_CHILD"):
             emit(json.dumps(out))

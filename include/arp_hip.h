@@ -217,6 +217,12 @@ int arp_dt_event_record(arp_dt* h, arp_event* e);
 int arp_dt_comm_unique_id(void* id128);
 int arp_dt_comm_init(arp_dt* h, const void* id128, int world, int rank);
 int arp_dt_broadcast_state(arp_dt* h);
+/* What the communicator says about itself, for a multi-GPU run that certifies itself (the pmean of main_procgen.py:132 needs every
+ * device in it): info5 = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion code, 1 if a communicator exists};
+ * without one (world 1) {1, 0, device, 0, 0}.  arp_dt_comm_selfcheck all-reduces (sum) the scalar rank + 1 through that
+ * communicator on the step's stream: every rank must read world (world + 1) / 2 (without a communicator: 1, nothing reduced). */
+int arp_dt_comm_info(arp_dt* h, int32_t* info5);
+int arp_dt_comm_selfcheck(arp_dt* h, double* sum);
 int arp_dt_profile_enable(arp_dt* h, int on);
 int arp_dt_profile_reset(arp_dt* h);
 int arp_dt_profile_json(arp_dt* h, char* buf, int buf_len);
@@ -305,6 +311,8 @@ int arp_ft_event_record(arp_ft* h, arp_event* e);
  * folded into the AdamW kernel) -- the scheme of the policy step (main_procgen.py:128-139). */
 int arp_ft_comm_init(arp_ft* h, const void* id128, int world, int rank);
 int arp_ft_broadcast_state(arp_ft* h);
+int arp_ft_comm_info(arp_ft* h, int32_t* info5);       /* as arp_dt_comm_info / arp_dt_comm_selfcheck, on the head step's communicator */
+int arp_ft_comm_selfcheck(arp_ft* h, double* sum);
 /* The data-parallel step all-reduces the 1.9 GB gradient in seven buckets in the order the backward produces them (inverse model;
    per tower: second adapter layer, first adapter layer, intermediate linear), each launched on a communication stream as soon as its
    last weight-gradient GEMM is enqueued.  ranges28 = {lo, hi} x 14 in floats (bucket b = ranges 2b, 2b + 1; empty ranges have

@@ -110,7 +110,11 @@ template <typename OutT, int ACT, bool RESID> static void run(const char* name, 
 #endif
     // ---- both MFMA shapes in ONE process, interleaved rounds (cdna_hip_programming.md rule 24), random operands (rule 25) ----
     auto go16 = [&]() { return launch_gemm256_nt<f16_t, OutT, ACT, RESID, 6, false>(g, nullptr); };
+#ifdef G256_AB_KV  // round 5: the second arm is the KV = 1 K loop (SADDR LDS-DMA statements, peeled steady state) on the SAME MFMA shape; columns keep their names
+    auto go32 = [&]() { return launch_gemm256_nt<f16_t, OutT, ACT, RESID, 6, false, 1>(g, nullptr); };
+#else
     auto go32 = [&]() { return launch_gemm256_nt<f16_t, OutT, ACT, RESID, 6, true>(g, nullptr); };
+#endif
     std::vector<uint8_t> out16((size_t)M * N * sizeof(OutT)), out32(out16.size());
     auto h2f = [](f16_t h) { _Float16 x; memcpy(&x, &h, 2); return (float)x; };
     auto as_f = [&](const std::vector<uint8_t>& o, size_t i) { if (sizeof(OutT) == 4) { float f; memcpy(&f, &o[i * 4], 4); return f; } f16_t h; memcpy(&h, &o[i * 2], 2); return h2f(h); };

@@ -83,3 +83,45 @@ def test_emit_report_refuses_an_oversized_headline(tmp_path):
     code = ("import bench; bench.ROOT = %r; bench.compact_headline = lambda full: {'pad': 'x' * 5000}; bench.emit_report({'value': 1})" % str(tmp_path))
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and r.stdout == "" and "refusing" in r.stderr
+
+
+def _cert_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import test_multi_gpu as M
+    from arp_amd import train
+    tr = M._DryTrainer(None, device=rank)
+    tr.comm_init(b"x" * 128, world, rank)
+    rccl = bench.gather_cert(dist, world, train.certify_collective(tr, rank, world))
+    seen = bench.label_ranks_seen(dist, rank, world, rank)
+    # a communicator that spans fewer ranks than the environment says must not certify
+    tr.comm_info = lambda: {"nranks": 1, "rank": 0, "device": rank, "rccl_version": 0, "has_comm": True}
+    bad = bench.gather_cert(dist, world, train.certify_collective(tr, rank, world))
+    q.put((rank, rccl, seen, bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_gpu_lines_certify_their_rank_count_on_gloo():
+    """`bench.py --gpus N` prints what the communicator says about itself (rccl_nranks, ranks_seen, an all-reduce of
+    rank + 1); dry-run on two gloo ranks with the RCCL calls replaced by tests/test_multi_gpu.py's stand-in"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cert_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, rccl, seen, bad in res:
+        assert rccl["ok"] and rccl["rccl_nranks"] == [2] and rccl["ranks_seen"] == [0, 1] and rccl["allreduce_selfcheck"] == [3.0, 3.0] and rccl["expected"] == 3.0
+        assert seen["ok"] and seen["ranks_seen"] == [0, 1] and seen["control_plane_selfcheck"] == 3.0 and seen["distinct_processes"] == 2
+        assert not bad["ok"] and bad["rccl_nranks"] == [1]
+    assert res[0][1] == res[1][1]  # the same block on every rank
+    line = json.dumps(bench.compact_headline({"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 2, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+                                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                                              "config": {"workload": "w"}, "roofline": {}, "cpu_baseline": None, "rccl": res[0][1], "ranks_seen": res[0][2]}))
+    assert '"rccl_nranks": [2]' in line and len(line) < 4096

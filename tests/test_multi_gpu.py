@@ -50,6 +50,17 @@ class _DryTrainer:
             t = torch.from_numpy(self.P[k])
             dist.broadcast(t, src=0)
 
+    def comm_info(self):  # what ncclCommCount / ncclCommUserRank would say: here, what gloo says
+        import torch.distributed as dist
+        return {"nranks": dist.get_world_size(), "rank": dist.get_rank(), "device": self.device, "rccl_version": 0, "has_comm": self.world > 1}
+
+    def comm_selfcheck(self):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(self.rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t)
+
     def set_batch(self, *arrays):
         self.calls.append(("set_batch",) + tuple(np.asarray(a).shape for a in arrays))
         self.batch = arrays
@@ -95,6 +106,8 @@ def _policy_worker(rank, world, port, q, overlap, mode="f32", dry=False):
     tr = (_DryTrainer if dry else PolicyTrainer)(cfg, mode=mode, device=rank)
     tr.set_params(S.policy_params(cfg, seed=1 + rank))  # rank 1 starts elsewhere: sync_state_fn must overwrite it
     dp = train.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
+    cert = dp.certify()  # ncclCommCount / ncclCommUserRank + an all-reduce of rank + 1: the communicator really spans `world` ranks
+    assert cert["ok"] and cert["nranks"] == world and cert["allreduce_selfcheck"] == world * (world + 1) / 2, cert
     enc, act, rtg = S.policy_batch(cfg, 8, seed=5)
     batch = {"image": {"ob": enc}, "action": act, "rtg": {"ob": rtg}}
     auxs = [dp.train_step(batch, 1e-3) for _ in range(4)]
@@ -147,6 +160,8 @@ def _ft_worker(rank, world, port, q, mode, dry=False):
     tr = (_DryTrainer if dry else FT.FinetuneTrainer)(cfg, mode=mode, device=rank)
     tr.set_params(FT.synth_params(cfg, seed=1 + rank))
     dp = FT.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
+    cert = dp.certify()
+    assert cert["ok"] and cert["nranks"] == world and cert["allreduce_selfcheck"] == world * (world + 1) / 2, cert
     b = FT.synth_batch(cfg, 6, seed=2)
     # identical SHARDS on both ranks (the VIP term couples a batch's samples, so shard-mean != full-batch; with equal shards the
     # data-parallel update must equal a single rank's update on that shard)
