@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libarp_hip.so")
 if os.environ.get("ARP_LIB"):
     LIB_PATH = os.environ["ARP_LIB"] if os.path.isabs(os.environ["ARP_LIB"]) else os.path.join(os.path.dirname(_HERE), os.environ["ARP_LIB"])
 
-MODE_F32, MODE_BF16, MODE_F16, MODE_F16X3 = 0, 1, 2, 3
+MODE_F32, MODE_BF16, MODE_F16, MODE_F16X3, MODE_F16C = 0, 1, 2, 3, 4
 ACT_NONE, ACT_QGELU, ACT_RELU, ACT_TANH, ACT_GELU_TANH = 0, 1, 2, 3, 4
 
 
@@ -183,6 +183,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _u8p, _i]),
     "arp_op_gemm_nt": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i]),
     "arp_op_skinny_gemm": (_i, [_i, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp, _fp, _f, _fp]),
+    "arp_op_gemm_f16c": (_i, [_i, _fp, _fp, _fp, _fp, _i, _i, _i, _i32p]),
     "arp_op_gemm_fp8": (_i, [_i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _f]),
     "arp_op_gemm_bench": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "arp_op_gemm_tn": (_i, [_i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _f]),

@@ -99,10 +99,17 @@ struct arp_enc {
     int ws_frames = 0;
     DevBuf patches, pe, x, h, qkv, ao, fc, img_in, out;
     DevBuf a3;  // ARP_MODE_F16X3: the [hi | lo | hi] operand of the current GEMM, binary16 [rows, 3 * (mlp_ratio * width)]
+                // ARP_MODE_F16C: the [hi | x4 | dx4] operand rows (3 bytes per value): [M, D] for LayerNorm / attention outputs, then [M, H] for the hidden activation
+    // ARP_MODE_F16C: per GEMM g in {in_proj, out_proj, fc1, fc2} the correction plan (0 plain, 1 weights, 2 weights + activations) and, per layer, the
+    // power-of-two exponents the e4m3 weight segments were scaled by: dW8 = e4m3(dW * 2^sw_d), W8 = e4m3(W * 2^sw_w)
+    int plan[4] = {2, 2, 2, 1};
+    std::vector<int> sw_d[4], sw_w[4];
+    void* w_emb3 = nullptr;  // ARP_MODE_F16C: the patch embedding's [W_hi | W_hi | W_lo] (its product runs as ARP_MODE_F16X3's K-concatenation)
     Profiler prof;
     int gemm_force = 0;
     int tokens() const { return (cfg.img_res / cfg.patch) * (cfg.img_res / cfg.patch) + 1; }
     size_t esz() const { return (cfg.mode == ARP_MODE_F32 || cfg.mode == ARP_MODE_F16X3) ? 4 : 2; }  // element size of the ACTIVATION buffers
+    size_t wsz() const { return cfg.mode == ARP_MODE_F32 ? 4 : 2; }
 };
 
 namespace {
@@ -115,6 +122,27 @@ int up_f32(arp_enc* c, const float* v, size_t n, float** out) {
     *out = static_cast<float*>(p);
     return 0;
 }
+// [out, 3 in] = [W_hi | W_hi | W_lo] from the transposed kernel t [out, in] (ARP_MODE_F16X3; the patch embedding of ARP_MODE_F16C)
+int up_kernel_x3(arp_enc* c, const std::vector<float>& t, int in, int out_, void** out) {
+    const size_t n = (size_t)in * out_;
+    void* p = nullptr;
+    std::vector<f16_t> hb(3 * n);
+    for (int o = 0; o < out_; ++o)
+        for (int i = 0; i < in; ++i) {
+            const float w = t[(size_t)o * in + i];
+            const f16_t h = host_f2h(w);
+            const float hf = (float)__builtin_bit_cast(_Float16, h.b);
+            f16_t* row = hb.data() + (size_t)o * 3 * in;
+            row[i] = h;
+            row[in + i] = h;
+            row[2 * in + i] = host_f2h(w - hf);
+        }
+    ARP_HIP_OK(hipMalloc(&p, 3 * n * 2));
+    ARP_HIP_OK(hipMemcpy(p, hb.data(), 3 * n * 2, hipMemcpyHostToDevice));
+    c->owned.push_back(p);
+    *out = p;
+    return 0;
+}
 // Flax kernel [in, out] -> device [out, in] in the operand type
 int up_kernel(arp_enc* c, const float* src, int in, int out_, void** out) {
     const size_t n = (size_t)in * out_;
@@ -122,36 +150,61 @@ int up_kernel(arp_enc* c, const float* src, int in, int out_, void** out) {
     for (int i = 0; i < in; ++i)
         for (int o = 0; o < out_; ++o) t[(size_t)o * in + i] = src[(size_t)i * out_ + o];
     void* p = nullptr;
-    if (c->cfg.mode == ARP_MODE_F16X3) {  // [out, 3 in] = [W_hi | W_hi | W_lo]
-        std::vector<f16_t> hb(3 * n);
-        for (int o = 0; o < out_; ++o)
-            for (int i = 0; i < in; ++i) {
-                const float w = t[(size_t)o * in + i];
-                const f16_t h = host_f2h(w);
-                const float hf = (float)__builtin_bit_cast(_Float16, h.b);
-                f16_t* row = hb.data() + (size_t)o * 3 * in;
-                row[i] = h;
-                row[in + i] = h;
-                row[2 * in + i] = host_f2h(w - hf);
-            }
-        ARP_HIP_OK(hipMalloc(&p, 3 * n * 2));
-        ARP_HIP_OK(hipMemcpy(p, hb.data(), 3 * n * 2, hipMemcpyHostToDevice));
-        c->owned.push_back(p);
-        *out = p;
-        return 0;
-    }
-    ARP_HIP_OK(hipMalloc(&p, std::max<size_t>(n * c->esz(), 16)));
+    if (c->cfg.mode == ARP_MODE_F16X3) return up_kernel_x3(c, t, in, out_, out);
+    ARP_HIP_OK(hipMalloc(&p, std::max<size_t>(n * c->wsz(), 16)));
     if (c->cfg.mode == ARP_MODE_BF16) {
         std::vector<bf16_t> hb(n);
         for (size_t i = 0; i < n; ++i) hb[i] = host_f2bf(t[i]);
         ARP_HIP_OK(hipMemcpy(p, hb.data(), n * 2, hipMemcpyHostToDevice));
-    } else if (c->cfg.mode == ARP_MODE_F16) {
+    } else if (c->cfg.mode == ARP_MODE_F16 || c->cfg.mode == ARP_MODE_F16C) {
         std::vector<f16_t> hb(n);
         for (size_t i = 0; i < n; ++i) hb[i] = host_f2h(t[i]);
         ARP_HIP_OK(hipMemcpy(p, hb.data(), n * 2, hipMemcpyHostToDevice));
     } else {
         ARP_HIP_OK(hipMemcpy(p, t.data(), n * 4, hipMemcpyHostToDevice));
     }
+    c->owned.push_back(p);
+    *out = p;
+    return 0;
+}
+// ARP_MODE_F16C: Flax kernel [in, out] -> device rows [W_hi: binary16 x in | dW4: e2m1 x in (| W4: e2m1 x in)] (plan 1 / 2; plan 0: binary16 only)
+// src(i, o) = the weight of input i, output o.  Rows [W_hi: binary16 x in | dW4: e2m1 x in (| W4: e2m1 x in)] for plan 1 (2); two e2m1 values per byte, value 2j in the
+// low nibble (the order common.h::pack_fp4x8 packs activations in).  dW4 = fp4((w - W_hi) 2^*sd), W4 = fp4(w 2^*sw): per-tensor powers of two that put the largest
+// magnitude into (6, 12] (e2m1 saturates at 6: the few values of the top half-binade lose part of their correction, every other value gains a bit).
+template <typename F> void pack_weight_c(F src, int in, int out_, int plan, std::vector<uint8_t>& hb, int* sd, int* sw) {
+    const size_t row_bytes = (size_t)in * 2 + (size_t)plan * (in / 2);
+    hb.assign(row_bytes * out_, 0);
+    float max_d = 0.f, max_w = 0.f;
+    for (int i = 0; i < in; ++i)
+        for (int o = 0; o < out_; ++o) {
+            const float w = src(i, o);
+            const float hf = (float)__builtin_bit_cast(_Float16, host_f2h(w).b);
+            max_d = std::max(max_d, std::fabs(w - hf));
+            max_w = std::max(max_w, std::fabs(w));
+        }
+    auto pick = [](float mx) { return mx > 0.f ? (int)std::floor(std::log2(6.0 / (double)mx)) + 1 : 0; };  // the top binade saturates at 6: measured better than wasting a code on it
+    *sd = std::min(pick(max_d), 100);
+    *sw = std::min(pick(max_w), 100);
+    const float fd = std::ldexp(1.0f, *sd), fw = std::ldexp(1.0f, *sw);
+    for (int o = 0; o < out_; ++o) {
+        uint8_t* row = hb.data() + (size_t)o * row_bytes;
+        for (int i = 0; i < in; ++i) {
+            const float w = src(i, o);
+            const f16_t h = host_f2h(w);
+            const float hf = (float)__builtin_bit_cast(_Float16, h.b);
+            memcpy(row + 2 * (size_t)i, &h.b, 2);
+            const int sh = (i & 1) * 4;
+            if (plan >= 1) row[2 * (size_t)in + i / 2] |= (uint8_t)(host_f2fp4((w - hf) * fd) << sh);
+            if (plan >= 2) row[2 * (size_t)in + in / 2 + i / 2] |= (uint8_t)(host_f2fp4(w * fw) << sh);
+        }
+    }
+}
+int up_kernel_c(arp_enc* c, const float* src, int in, int out_, int plan, void** out, int* sd, int* sw) {
+    std::vector<uint8_t> hb;
+    pack_weight_c([&](int i, int o) { return src[(size_t)i * out_ + o]; }, in, out_, plan, hb, sd, sw);
+    void* p = nullptr;
+    ARP_HIP_OK(hipMalloc(&p, hb.size()));
+    ARP_HIP_OK(hipMemcpy(p, hb.data(), hb.size(), hipMemcpyHostToDevice));
     c->owned.push_back(p);
     *out = p;
     return 0;
@@ -174,6 +227,10 @@ int ensure_ws(arp_enc* c, int frames) {
     ARP_TRY(c->ao.ensure(M * D * e)); ARP_TRY(c->fc.ensure(M * k.mlp_ratio * D * e));
     if (k.mode == ARP_MODE_F16X3)  // [M, 3 D] (a GEMM's A operand) followed by [M, 3 H] (c_fc's own epilogue writes c_proj's operand there)
         ARP_TRY(c->a3.ensure(std::max(M * 3 * (D + k.mlp_ratio * D), B * G * G * 3 * k.patch * k.patch * 3) * 2));
+    if (k.mode == ARP_MODE_F16C) {  // [M, D] and [M, H] operand rows of 3 bytes per value; the patch embedding's (hi, lo, hi) triples share the space
+        ARP_TRY(c->a3.ensure(std::max(M * 3 * (D + k.mlp_ratio * D) + 4096, B * G * G * 3 * k.patch * k.patch * 3 * 2)));
+        ARP_TRY(c->patches.ensure(B * G * G * k.patch * k.patch * 3 * 4));  // f32 patches (split into triples on the device)
+    }
     c->ws_frames = frames;
     return 0;
 }
@@ -262,6 +319,77 @@ int forward_chunk_x3(arp_enc* c, hipStream_t stream, const float* img_dev, int n
     return 0;
 }
 
+// ARP_MODE_F16C: the binary16 encoder with its GEMMs' operand roundings corrected on the scaled fp4 MFMA (include/arp_hip.h).  Per block:
+//   ln_1 -> [hi | x4 (| dx4)] -> in_proj (MIXC) -> qkv binary16 -> MFMA attention -> [hi | x4 | dx4] -> out_proj (MIXC) into the f32 residual stream ->
+//   ln_2 -> [hi | x4 (| dx4)] -> fc1 (MIXC, tanh-GELU; the epilogue stores hi AND the e2m1 segment of fc2's operand) -> fc2 (MIXC) into the residual stream.
+template <int ACT, bool RESID, typename OutT, int SITE>
+int gemm_c(arp_enc* c, TowerCtx& t, const char* site, const void* A, const void* W, int plan, int sd, int sw, const float* bias, const float* resid, void* out,
+           int M, int N, int Kc, int ldo, void* x4_out = nullptr, int ld4 = 0) {
+    // A rows: binary16 x Kc, then e2m1 x Kc (x4), then e2m1 x Kc (dx4): 3 Kc bytes; W rows: binary16 x Kc followed by `plan` e2m1 segments
+    if (Kc % 256) return fail("f16c: widths must be multiples of 256");
+    GemmArgs g;
+    g.A = A; g.W = W; g.bias = bias; g.resid = resid; g.out = out;
+    g.M = M; g.N = N;
+    g.lda = Kc + Kc / 2; g.ldw = Kc + plan * Kc / 4; g.ldr = N; g.ldo = ldo;
+    g.mix_nk16 = Kc / 64;
+    g.mix_nkc_a = plan >= 1 ? Kc / 256 : 0;
+    g.K = Kc + plan * Kc / 4;
+    g.mix_sa = F16C_X_SHIFT + sd;
+    g.mix_sb = F16C_DX_SHIFT + sw;
+    if (x4_out) { g.xb_out = x4_out; g.ldxb = ld4; g.x8_shift = F16C_X_SHIFT; }
+    ProfScope ps(*t.prof, t.stream, site);
+    if (plan == 0) return launch_gemm256_nt<f16_t, OutT, ACT, RESID, SITE>(g, t.stream);  // (no fp4 side output on this instance: plan 0 is for probing only)
+    return launch_gemm256_nt<f16_t, OutT, ACT, RESID, SITE, false, 1, true>(g, t.stream);
+}
+
+int forward_chunk_c(arp_enc* c, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
+    const arp_enc_cfg& k = c->cfg;
+    const int G = k.img_res / k.patch, N = c->tokens(), D = k.width, KP = k.patch * k.patch * 3, H = k.mlp_ratio * D, M = nb * N;
+    if (D / k.heads != 64 || N > 288 || k.attn_impl != 0) return fail("f16c: needs the MFMA attention kernel (head_dim 64, <= 288 tokens)");
+    TowerCtx t;
+    t.stream = stream; t.prof = &c->prof; t.attn_impl = 0; t.gemm_force = c->gemm_force;
+    char* a4 = static_cast<char*>(c->a3.p);                 // [M, D] operand rows, 3 D bytes each: [hi | x4 | dx4]
+    char* a4h = a4 + (((size_t)M * 3 * D + 255) & ~(size_t)255);  // [M, H] operand rows, 3 H bytes each (fc1's epilogue -> fc2)
+    {   // patch embedding on (hi, lo) binary16 pairs (its input rounding alone is a third of the plain f16 encoder's logit error; the product is 0.6 % of the FLOPs)
+        ProfScope ps(c->prof, stream, "m3ae.patchify");
+        const size_t tot = (size_t)nb * G * G * KP;
+        hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, c->patches.as<float>(), nb, k.img_res, k.patch);
+        ARP_HIP_OK(hipGetLastError());
+        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((tot / 8 + 255) / 256)), dim3(256), 0, stream, c->patches.as<float>(), reinterpret_cast<f16_t*>(a4), (size_t)nb * G * G, KP);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", a4, c->w_emb3, c->b_emb, nullptr, c->pe.p, nb * G * G, D, 3 * KP)));
+    {
+        ProfScope ps(c->prof, stream, "m3ae.assemble");
+        const size_t tot = (size_t)nb * N * D;
+        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, c->pe.as<float>(), c->cls, c->pos, c->x.as<float>(), nb * N, N, D);
+        ARP_HIP_OK(hipGetLastError());
+    }
+    float* x = c->x.as<float>();
+    f16_t* qkv = c->qkv.as<f16_t>();
+    auto ln = [&](const char* site, const float* w, const float* b, int plan) -> int {
+        if (plan >= 2) return tower_layernorm<f16c2_t>(t, site, x, D, reinterpret_cast<f16c2_t*>(a4), 3 * D / 2, w, b, M, D, 1e-6f);
+        return tower_layernorm<f16c_t>(t, site, x, D, reinterpret_cast<f16c_t*>(a4), 3 * D / 2, w, b, M, D, 1e-6f);
+    };
+    for (int i = 0; i < k.layers; ++i) {
+        const LayerW& L = c->tower.L[i];
+        ARP_TRY(ln("m3ae.ln_1", L.ln1_w, L.ln1_b, c->plan[0]));
+        ARP_TRY((gemm_c<ACT_NONE, false, f16_t, 8 + SITE_QKV>(c, t, "m3ae.qkv", a4, L.w_in, c->plan[0], c->sw_d[0][i], c->sw_w[0][i], L.b_in, nullptr, qkv, M, 3 * D, D, 3 * D)));
+        {
+            ProfScope ps(c->prof, stream, "m3ae.attn");
+            ARP_TRY(launch_attention<f16_t>(stream, 0, qkv, reinterpret_cast<f16_t*>(a4), nb, N, D, k.heads, 0, 0, 0.f, nullptr, 1));
+        }
+        ARP_TRY((gemm_c<ACT_NONE, true, float, 8 + SITE_OUT>(c, t, "m3ae.out_proj", a4, L.w_out, c->plan[1], c->sw_d[1][i], c->sw_w[1][i], L.b_out, x, x, M, D, D, D)));
+        ARP_TRY(ln("m3ae.ln_2", L.ln2_w, L.ln2_b, c->plan[2]));
+        // fc1's epilogue stores the binary16 hidden activation at the head of fc2's operand rows and its e2m1 copy behind it (row stride 3 H bytes)
+        ARP_TRY((gemm_c<ACT_GELU_TANH, false, f16_t, 8 + SITE_FC1>(c, t, "m3ae.c_fc", a4, L.w_fc, c->plan[2], c->sw_d[2][i], c->sw_w[2][i], L.b_fc, nullptr, a4h, M, H, D, 3 * H / 2,
+                                                                  a4h + 2 * (size_t)H, 3 * H)));
+        ARP_TRY((gemm_c<ACT_NONE, true, float, 8 + SITE_FC2>(c, t, "m3ae.c_proj", a4h, L.w_proj, std::min(c->plan[3], 1), c->sw_d[3][i], c->sw_w[3][i], L.b_proj, x, x, M, D, H, D)));
+    }
+    ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_final", x, (size_t)D, out_dev, D, c->lnf_w, c->lnf_b, M, D, 1e-6f));
+    return 0;
+}
+
 }  // namespace
 
 namespace arp {
@@ -275,6 +403,7 @@ int enc_forward_on(arp_enc* c, hipStream_t stream, const float* images_dev, int 
     for (int off = 0; off < n; off += mb) {
         const int nb = std::min(mb, n - off);
         if (c->cfg.mode == ARP_MODE_F16X3) ARP_TRY(forward_chunk_x3(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
+        else if (c->cfg.mode == ARP_MODE_F16C) ARP_TRY(forward_chunk_c(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
         else if (c->cfg.mode == ARP_MODE_BF16) ARP_TRY(forward_chunk<bf16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
         else if (c->cfg.mode == ARP_MODE_F16) ARP_TRY(forward_chunk<f16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
         else ARP_TRY(forward_chunk<float>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
@@ -294,7 +423,7 @@ extern "C" {
 int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
     if (!cfg || !out) return fail("null argument");
     const arp_enc_cfg& k = *cfg;
-    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16 && k.mode != ARP_MODE_F16 && k.mode != ARP_MODE_F16X3) return fail("bad mode");
+    if (k.mode != ARP_MODE_F32 && k.mode != ARP_MODE_BF16 && k.mode != ARP_MODE_F16 && k.mode != ARP_MODE_F16X3 && k.mode != ARP_MODE_F16C) return fail("bad mode");
     if (k.patch <= 0 || k.img_res % k.patch || k.width % k.heads || k.width % 4) return fail("bad geometry");
     const int kq = k.mode == ARP_MODE_F32 ? 32 : 64;
     if (k.width % kq || (k.patch * k.patch * 3) % kq) return fail("width and 3*patch^2 must be multiples of " + std::to_string(kq));
@@ -306,6 +435,11 @@ int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
     c->cfg = k;
     if (c->cfg.max_frames <= 0) c->cfg.max_frames = 128;
     if (const char* e = getenv("ARP_GEMM")) c->gemm_force = atoi(e);
+    if (const char* e = getenv("ARP_F16C_PLAN")) {  // four digits: in_proj, out_proj, fc1, fc2 (0 plain, 1 weight correction, 2 + activation correction)
+        for (int i = 0; i < 4 && e[i]; ++i)
+            if (e[i] >= '0' && e[i] <= '2') c->plan[i] = e[i] - '0';
+    }
+    c->plan[3] = std::min(c->plan[3], 1);  // fc2's operand comes out of fc1's epilogue, which stores no dx4 segment
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail("hipStreamCreate failed");
@@ -349,6 +483,19 @@ int arp_enc_finalize_weights(arp_enc* c) {
     const int D = k.width, KP = k.patch * k.patch * 3, H = k.mlp_ratio * D, G = k.img_res / k.patch;
     const HostTensor* t;
     ARP_TRY(staged(c, "image_embedding/kernel", {KP, D}, &t)); ARP_TRY(up_kernel(c, t->data.data(), KP, D, &c->w_emb));
+    const bool f16c = k.mode == ARP_MODE_F16C;
+    if (f16c) {
+        std::vector<float> tr((size_t)KP * D);
+        for (int i = 0; i < KP; ++i)
+            for (int o = 0; o < D; ++o) tr[(size_t)o * KP + i] = t->data[(size_t)i * D + o];
+        ARP_TRY(up_kernel_x3(c, tr, KP, D, &c->w_emb3));
+        for (int gi = 0; gi < 4; ++gi) { c->sw_d[gi].assign(k.layers, 0); c->sw_w[gi].assign(k.layers, 0); }
+    }
+    // the block GEMMs' weights: operand type, or ARP_MODE_F16C's [W_hi | dW8 (| W8)] rows with their per-tensor scales
+    auto up_w = [&](const HostTensor* ht, int in, int out_, int gi, int layer, void** dst) -> int {
+        if (f16c) return up_kernel_c(c, ht->data.data(), in, out_, c->plan[gi], dst, &c->sw_d[gi][layer], &c->sw_w[gi][layer]);
+        return up_kernel(c, ht->data.data(), in, out_, dst);
+    };
     ARP_TRY(staged(c, "image_embedding/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->b_emb));
     ARP_TRY(staged(c, "cls_token", {1, 1, D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->cls));
     ARP_TRY(staged(c, "encoder_image_type_embedding", {1, 1, D}, &t));
@@ -379,13 +526,13 @@ int arp_enc_finalize_weights(arp_enc* c) {
         ARP_TRY(staged(c, p + "LayerNorm_0/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln1_b));
         ARP_TRY(staged(c, p + "LayerNorm_1/scale", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln2_w));
         ARP_TRY(staged(c, p + "LayerNorm_1/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln2_b));
-        ARP_TRY(staged(c, p + "Attention_0/Dense_0/kernel", {D, 3 * D}, &t)); ARP_TRY(up_kernel(c, t->data.data(), D, 3 * D, &L.w_in));
+        ARP_TRY(staged(c, p + "Attention_0/Dense_0/kernel", {D, 3 * D}, &t)); ARP_TRY(up_w(t, D, 3 * D, 0, i, &L.w_in));
         ARP_TRY(staged(c, p + "Attention_0/Dense_0/bias", {3 * D}, &t)); ARP_TRY(up_f32(c, t->data.data(), 3 * D, &L.b_in));
-        ARP_TRY(staged(c, p + "Attention_0/Dense_1/kernel", {D, D}, &t)); ARP_TRY(up_kernel(c, t->data.data(), D, D, &L.w_out));
+        ARP_TRY(staged(c, p + "Attention_0/Dense_1/kernel", {D, D}, &t)); ARP_TRY(up_w(t, D, D, 1, i, &L.w_out));
         ARP_TRY(staged(c, p + "Attention_0/Dense_1/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.b_out));
-        ARP_TRY(staged(c, p + "TransformerMLP_0/fc1/kernel", {D, H}, &t)); ARP_TRY(up_kernel(c, t->data.data(), D, H, &L.w_fc));
+        ARP_TRY(staged(c, p + "TransformerMLP_0/fc1/kernel", {D, H}, &t)); ARP_TRY(up_w(t, D, H, 2, i, &L.w_fc));
         ARP_TRY(staged(c, p + "TransformerMLP_0/fc1/bias", {H}, &t)); ARP_TRY(up_f32(c, t->data.data(), H, &L.b_fc));
-        ARP_TRY(staged(c, p + "TransformerMLP_0/fc2/kernel", {H, D}, &t)); ARP_TRY(up_kernel(c, t->data.data(), H, D, &L.w_proj));
+        ARP_TRY(staged(c, p + "TransformerMLP_0/fc2/kernel", {H, D}, &t)); ARP_TRY(up_w(t, H, D, 3, i, &L.w_proj));
         ARP_TRY(staged(c, p + "TransformerMLP_0/fc2/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.b_proj));
     }
     ARP_TRY(staged(c, "encoder/LayerNorm_0/scale", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->lnf_w));
@@ -426,6 +573,53 @@ int arp_enc_profile_json(arp_enc* c, char* buf, int buf_len) {
     if ((int)s.size() + 1 > buf_len) return fail("profile buffer too small");
     memcpy(buf, s.c_str(), s.size() + 1);
     return (int)s.size();
+}
+
+// Test hook for the MIXC instances of gemm256_nt_kernel (ARP_MODE_F16C's products): A [M, K] and W [N, K] f32; the operand rows are built as the
+// encoder builds them -- A: [rn16(a) | fp4(rn16(a) 2^1) | fp4((a - rn16(a)) 2^13)], W: [rn16(w) | fp4(dw 2^sd) (| fp4(w 2^sw))] for plan 1 (2) --
+// and out = A.W^T + bias as f32.  sd_sw (optional, 2 ints) receives the weight scales so that a test can restate the quantisation exactly.
+int arp_op_gemm_f16c(int plan, const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int* sd_sw) {
+    if (!A || !W || !out || M <= 0 || N <= 0 || K < 512 || K % 256 || N % 8 || plan < 0 || plan > 2) return fail("bad argument (K % 256, K >= 512, N % 8, plan 0..2)");
+    DevBuf dA, dW, dB, dO;
+    auto body = [&]() -> int {
+        std::vector<uint8_t> ha((size_t)M * 3 * K, 0), hw;
+        constexpr float sx = (float)(1 << F16C_X_SHIFT), sdx = (float)(1 << F16C_DX_SHIFT);
+        for (int m = 0; m < M; ++m) {
+            uint8_t* row = ha.data() + (size_t)m * 3 * K;
+            for (int k = 0; k < K; ++k) {
+                const float a = A[(size_t)m * K + k];
+                const f16_t h = host_f2h(a);
+                const float hf = (float)__builtin_bit_cast(_Float16, h.b);
+                memcpy(row + 2 * (size_t)k, &h.b, 2);
+                const int sh = (k & 1) * 4;
+                row[2 * (size_t)K + k / 2] |= (uint8_t)(host_f2fp4(hf * sx) << sh);
+                row[2 * (size_t)K + K / 2 + k / 2] |= (uint8_t)(host_f2fp4((a - hf) * sdx) << sh);
+            }
+        }
+        int sd = 0, sw = 0;
+        pack_weight_c([&](int i, int o) { return W[(size_t)o * K + i]; }, K, N, plan, hw, &sd, &sw);
+        if (sd_sw) { sd_sw[0] = sd; sd_sw[1] = sw; }
+        ARP_TRY(dA.ensure(ha.size())); ARP_TRY(dW.ensure(hw.size())); ARP_TRY(dO.ensure((size_t)M * N * 4));
+        ARP_HIP_OK(hipMemcpy(dA.p, ha.data(), ha.size(), hipMemcpyHostToDevice));
+        ARP_HIP_OK(hipMemcpy(dW.p, hw.data(), hw.size(), hipMemcpyHostToDevice));
+        if (bias) {
+            ARP_TRY(dB.ensure((size_t)N * 4));
+            ARP_HIP_OK(hipMemcpy(dB.p, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+        }
+        GemmArgs g;
+        g.A = dA.p; g.W = dW.p; g.bias = bias ? dB.as<float>() : nullptr; g.out = dO.p;
+        g.M = M; g.N = N; g.lda = K + K / 2; g.ldw = K + plan * K / 4; g.ldr = N; g.ldo = N;
+        g.mix_nk16 = K / 64; g.mix_nkc_a = plan >= 1 ? K / 256 : 0; g.K = K + plan * K / 4;
+        g.mix_sa = F16C_X_SHIFT + sd; g.mix_sb = F16C_DX_SHIFT + sw;
+        if (plan == 0) ARP_TRY((launch_gemm256_nt<f16_t, float, ACT_NONE, false, 8 + SITE_OP>(g, nullptr)));
+        else ARP_TRY((launch_gemm256_nt<f16_t, float, ACT_NONE, false, 8 + SITE_OP, false, 1, true>(g, nullptr)));
+        ARP_HIP_OK(hipDeviceSynchronize());
+        ARP_HIP_OK(hipMemcpy(out, dO.p, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+        return 0;
+    };
+    const int rc = body();
+    dA.release(); dW.release(); dB.release(); dO.release();
+    return rc;
 }
 
 }  // extern "C"

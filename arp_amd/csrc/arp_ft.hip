@@ -66,7 +66,8 @@ struct arp_ft {
     int B = 0;
     // operand-type weight shadows: forward layout [out, in] (aliases the f32 parameters in f32 mode) and, where the
     // backward needs dX, the transposed layout [in, out]
-    DevBuf dropped;  // one counter: non-finite gradient elements AdamW treated as missing (f16 mode only), cumulative
+    DevBuf dropped;  // one 32-bit device counter: non-finite gradient elements AdamW treated as missing (f16 mode only) since the last read
+    uint64_t dropped_total = 0;  // ... drained into this 64-bit total at every arp_ft_dropped_gradients (the device word cannot wrap between two reads of a sane run)
     DevBuf mirror;  // bf16 mode: bf16 copy of the flat parameter vector (same offsets) = every forward-layout operand
     DevBuf sW1t[2], sW2t[2], sV1t;
     // 16-bit modes: dX = dY . W on the "NN" kernel (gemm_tn.h: W read AS STORED through the transposing LDS read), every dX ahead of its layer's
@@ -747,7 +748,9 @@ int arp_ft_dropped_gradients(arp_ft* c, uint64_t* count) {
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     unsigned int v = 0;
     ARP_HIP_OK(hipMemcpy(&v, c->dropped.p, 4, hipMemcpyDeviceToHost));
-    *count = v;
+    if (v) ARP_HIP_OK(hipMemset(c->dropped.p, 0, 4));
+    c->dropped_total += v;
+    *count = c->dropped_total;
     return 0;
 }
 int arp_ft_get_step(arp_ft* c, int64_t* step) {

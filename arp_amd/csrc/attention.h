@@ -231,7 +231,9 @@ __device__ long long* arp_ax3_stamps = nullptr;
 #define ARP_AX3_STAMP(k) do { } while (0)
 #endif
 constexpr int attn_x3_vrow_bytes(int nt) { return ((((nt + 1) / 2) * 4 + 7) / 8) * 8 * 16; }
-constexpr int attn_x3_lds_bytes(int nt) { return 2 * ((nt + 1) / 2) * 32 * 128 + 2 * 64 * attn_x3_vrow_bytes(nt) + ((nt + 1) / 2) * 2 * 66 * 4; }  // + the tail block's partials
+// one partial of the cooperative tail: O (64), max, sum + 2 pad floats -- a 68-float stride keeps every row 16-byte aligned for its float4 stores
+constexpr int ATTN_X3_SCR = 68;
+constexpr int attn_x3_lds_bytes(int nt) { return 2 * ((nt + 1) / 2) * 32 * 128 + 2 * 64 * attn_x3_vrow_bytes(nt) + ((nt + 1) / 2) * 2 * ATTN_X3_SCR * 4; }  // + the tail block's partials
 template <int NT>
 __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int D, int heads, float scale,
                                                       int causal, int nq, f16_t* __restrict__ out3) {
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
     ARP_AX3_STAMP(8);
     if (!coop) return;
     // ---- the short last block, one 32-key chunk per wave: partial (max, sum, O) per chunk and query -> LDS -> fixed-order merge ----------------------
-    float* scr = reinterpret_cast<float*>(Vl + HD * VROWB);  // [NC][2][66]: O (64), max, sum
+    float* scr = reinterpret_cast<float*>(Vl + HD * VROWB);  // [NC][2][ATTN_X3_SCR]: O (64), max, sum, pad
     {
         const int q0 = nfull * 16, qi = q0 + j;
         const float* qrow = base + (size_t)min(qi, N - 1) * ld;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
                 }
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
-            float* dst = scr + (c * 2 + j) * 66;
+            float* dst = scr + (c * 2 + j) * ATTN_X3_SCR;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d = dt * 16 + j;
@@ -498,10 +500,10 @@ __global__ __launch_bounds__(512) void attn_x3_kernel(const float* __restrict__ 
     if ((int)threadIdx.x < tail * 16) {
         const int jq = threadIdx.x >> 4, d4 = (threadIdx.x & 15) * 4;
         float M = -INFINITY;
-        for (int c = 0; c < NC; ++c) M = fmaxf(M, scr[(c * 2 + jq) * 66 + 64]);
+        for (int c = 0; c < NC; ++c) M = fmaxf(M, scr[(c * 2 + jq) * ATTN_X3_SCR + 64]);
         float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < NC; ++c) {  // fixed order
-            const float* src = scr + (c * 2 + jq) * 66;
+            const float* src = scr + (c * 2 + jq) * ATTN_X3_SCR;
             const float w = __builtin_amdgcn_exp2f(src[64] - M);  // 0 for an empty chunk (its max is -inf; M is finite: key 0 is visible to every query)
             L += w * src[65];
 #pragma unroll
@@ -534,8 +536,9 @@ __device__ long long* arp_attn_stamps = nullptr;  // scripts/attn_bench.hip: per
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N, int D,
-                                                        int heads, float scale, int causal, int nq, float out8 = 0.f) {
+                                                        int heads, float scale, int causal, int nq, float out8 = 0.f, int outc = 0) {
     // out8 != 0: `out` is an e4m3 buffer [B*N, D] bytes and receives out8 * value (operand of an fp8 out_proj, tower.h)
+    // outc != 0 (T = f16, ARP_MODE_F16C): `out` rows are [hi | x4 | dx4] (3 D bytes each, common.h::store_f16c) -- out_proj's MIXC operand
     constexpr int NP = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -662,6 +665,13 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
                 const float sc = inv * out8;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16 + fg * 4, o[dt][0] * sc, o[dt][1] * sc, o[dt][2] * sc, o[dt][3] * sc);
+            } else if (outc) {
+                if constexpr (__is_same(T, f16_t)) {
+                    f16_t* orow = out + ((size_t)b * N + qidx) * 3 * D / 2;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        store_f16c<true>(orow, h * 64 + dt * 16 + fg * 4, D, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+                }
             } else {
                 T* orow = out + ((size_t)b * N + qidx) * D + h * 64;
 #pragma unroll

@@ -16,6 +16,7 @@ struct f16x3_t { uint16_t b; };
 // raw OCP e4m3fn bits (no infinities, max 448, NaN = 0x7f / 0xff): operand type of the scaled fp8 MFMA (BASELINE configs[4])
 struct fp8_t { uint8_t b; };
 typedef __attribute__((ext_vector_type(8))) int i32x8_v;
+typedef __attribute__((ext_vector_type(4))) int i32x4_v;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_v;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_v;
@@ -88,6 +89,16 @@ __device__ __forceinline__ f32x4_v mfma_fp8(u32x4_v a0, u32x4_v a1, u32x4_v b0, 
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);  // cbsz = blgp = 0: e4m3; scale 2^0
 }
 
+// one v_mfma_scale_f32_16x16x128_f8f6f4 on e2m1 (fp4) operands: 16 bytes = 32 k-values per lane and operand (a 4-register tuple, like the binary16 MFMA's),
+// FOUR times the k per cycle of the 16-bit 16x16x32 form.  scale: byte 0 = the e8m0 block scale of operand A (127 - s multiplies the product by 2^-s),
+// byte 1 = operand B's (127: 2^0) -- one register, picked apart by op_sel.
+__device__ __forceinline__ f32x4_v mfma_fp4_scaled(u32x4_v a, u32x4_v b, f32x4_v c, int scale) {
+    const i32x4_v a4 = __builtin_bit_cast(i32x4_v, a), b4 = __builtin_bit_cast(i32x4_v, b);
+    // the fp4 form reads 4 registers per operand: the upper half of the builtin's 8-wide type is left undefined so that hipcc allocates 4-tuples
+    const i32x8_v a8 = __builtin_shufflevector(a4, a4, 0, 1, 2, 3, -1, -1, -1, -1), b8 = __builtin_shufflevector(b4, b4, 0, 1, 2, 3, -1, -1, -1, -1);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 4, 4, 0, scale, 1, scale);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -158,6 +169,46 @@ __device__ __forceinline__ void store_split3(f16_t* p, size_t n, float a, float 
     *reinterpret_cast<uint2*>(p + 2 * n) = hi;
 }
 template <typename T> __device__ __forceinline__ void store_split3(T* p, size_t n, float a, float b, float c, float d) { store4(p, a, b, c, d); }  // f16 operands only
+
+// ---- ARP_MODE_F16C (row N1): binary16 GEMMs whose operand roundings are corrected on the scaled fp4 MFMA ---------------------------------------
+// An operand row of K values is stored as [hi: binary16 x K | x4: e2m1 x K | dx4: e2m1 x K] (3 K bytes; two values per byte, value 2j in the low nibble):
+// hi = rn16(x), x4 = fp4(hi * 2^F16C_X_SHIFT), dx4 = fp4((x - hi) * 2^F16C_DX_SHIFT), both saturating at +-6 (a clipped outlier only loses part of ITS
+// correction term).  The consumer GEMM (gemm256 MIXC) computes hi.W_hi + 2^-s x4.dW4 (+ 2^-s' dx4.W4): the correction terms are 2^-12 of the product, so
+// the 1-2 significant bits of e2m1 take the binary16 operand roundings out to ~1/4 of their size -- on an MFMA (v_mfma_scale_f32_16x16x128_f8f6f4 with
+// fp4 operands) that moves FOUR times the k per cycle of the binary16 one and takes the same 4-register operand tuples: a K-tile of 128 bytes per row is
+// 256 k-values, so both corrections cost K/256 + K/256 extra K-tiles on top of K/64: 1.5x the binary16 product where (hi, lo) binary16 pairs cost 3x.
+// (An e4m3 variant of the same loop -- 2x the k per cycle, 8-register operand tuples -- was built first: hipcc could not hold its 8-tuples beside 128
+// accumulators without scratch traffic inside the K loop, and a scratch reload is a vmcnt(0), i.e. a drained LDS-DMA ring: 47 ms per step instead of 10.)
+struct f16c_t { uint16_t b; };   // output tag of row kernels: [hi | x4]           (the dx4 segment of the row is left unwritten)
+struct f16c2_t { uint16_t b; };  // [hi | x4 | dx4]
+constexpr int F16C_X_SHIFT = 1, F16C_DX_SHIFT = 13;  // (numpy sweep of the residual error: x 2^1 / dx 2^13 and weight scales one binade into saturation are the flat optimum)
+// eight values -> eight e2m1 nibbles (value 0 in the low nibble of byte 0), round-to-nearest-even, saturating at +-6
+__device__ __forceinline__ uint32_t pack_fp4x8(const float (&v)[8]) {
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v[0], v[1], 1.0f, 0);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v[2], v[3], 1.0f, 1);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v[4], v[5], 1.0f, 2);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v[6], v[7], 1.0f, 3);
+    return w;
+}
+__device__ __forceinline__ uint16_t pack_fp4x4(float a, float b, float c, float d) {
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, a, b, 1.0f, 0);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, c, d, 1.0f, 1);
+    return (uint16_t)w;
+}
+// four consecutive values at column c (a multiple of 4) of a row whose binary16 segment starts at `row` (K = row width)
+template <bool WITH_DX> __device__ __forceinline__ void store_f16c(f16_t* row, int c, int K, float a, float b, float cc, float d) {
+    const float v[4] = {pin_f32(a), pin_f32(b), pin_f32(cc), pin_f32(d)};
+    float h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = h2f(f2h(v[j]));
+    *reinterpret_cast<uint2*>(row + c) = make_uint2(pack_h2(h[0], h[1]), pack_h2(h[2], h[3]));
+    uint8_t* seg = reinterpret_cast<uint8_t*>(row + K);
+    constexpr float sx = (float)(1 << F16C_X_SHIFT), sd = (float)(1 << F16C_DX_SHIFT);
+    *reinterpret_cast<uint16_t*>(seg + (c >> 1)) = pack_fp4x4(h[0] * sx, h[1] * sx, h[2] * sx, h[3] * sx);
+    if constexpr (WITH_DX) *reinterpret_cast<uint16_t*>(seg + (K >> 1) + (c >> 1)) = pack_fp4x4((v[0] - h[0]) * sd, (v[1] - h[1]) * sd, (v[2] - h[2]) * sd, (v[3] - h[3]) * sd);
+}
 
 __device__ __forceinline__ void load4(const f16_t* p, float (&v)[4]) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
@@ -271,6 +322,22 @@ static inline f16_t host_f2h(float f) {
     return f16_t{(uint16_t)(sign | h)};
 }
 
+// host-side f32 -> e2m1 nibble (OCP fp4: 0, 0.5, 1, 1.5, 2, 3, 4, 6 and their negatives; round-to-nearest-even on the 1-bit significand, saturating at +-6)
+static inline uint8_t host_f2fp4(float f) {
+    const uint8_t sign = std::signbit(f) ? 8 : 0;
+    const float a = std::fabs(f);
+    uint8_t m;
+    if (!(a == a)) m = 7;             // NaN -> saturate (never produced by the callers)
+    else if (a <= 0.25f) m = 0;       // tie 0.25 -> 0 (even)
+    else if (a < 0.75f) m = 1;        // 0.5
+    else if (a <= 1.25f) m = 2;       // ties 0.75 -> 1.0, 1.25 -> 1.0
+    else if (a < 1.75f) m = 3;        // 1.5
+    else if (a <= 2.5f) m = 4;        // ties 1.75 -> 2.0, 2.5 -> 2.0
+    else if (a < 3.5f) m = 5;         // 3.0
+    else if (a <= 5.0f) m = 6;        // ties 3.5 -> 4.0, 5.0 -> 4.0
+    else m = 7;                       // 6.0 (saturating)
+    return sign | m;
+}
 // host-side f32 -> e4m3fn (RNE, saturating at +-448, subnormals down to 2^-9)
 static inline fp8_t host_f2fp8(float f) {
     uint32_t u;

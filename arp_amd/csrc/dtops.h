@@ -212,7 +212,13 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
         }
     };
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    auto put = [&](_Float16* hi, _Float16* lo, const float4 v, float sc, int row) {
+    // Range: the fixed scales put |x| >= 4094 or |w| >= 64 beyond binary16 (hi = inf, lo = NaN -> NaN logits with no warning).  The operands
+    // here are LayerNormed encodings mixed with a ReLU'd adapter output (|x| < sqrt(768) = 27.7 for unit gains) and a lecun-normal Dense(197 376 -> 128)
+    // kernel (|w| ~ 1e-2), both far inside; values outside are CLAMPED to the largest magnitude the scale leaves finite (a saturated term, never a NaN).
+    auto put = [&](_Float16* hi, _Float16* lo, float4 v, float sc, int row) {
+        const float lim = 65280.f / sc;
+        v.x = __builtin_amdgcn_fmed3f(v.x, -lim, lim); v.y = __builtin_amdgcn_fmed3f(v.y, -lim, lim);
+        v.z = __builtin_amdgcn_fmed3f(v.z, -lim, lim); v.w = __builtin_amdgcn_fmed3f(v.w, -lim, lim);
         uint2 h, l;  // common.h::split2_f16: the (power-of-two) scale, hi and lo in four v_fma_mix instructions per pair
         split2_f16(v.x, v.y, sc, h.x, l.x);
         split2_f16(v.z, v.w, sc, h.y, l.y);

@@ -249,9 +249,11 @@ static __global__ __launch_bounds__(256) void ft_adamw_kernel(float* __restrict_
         // poison this parameter and both moments for good -- it is treated as a missing (zero) gradient for this step AND COUNTED
         // (arp_ft_dropped_gradients).  In the other modes a non-finite gradient is a diverged step or a bug and stays visible as NaNs,
         // as in torch.
-        if (mask_nonfinite && !(fabsf(gi) < 3.0e38f)) {
-            gi = 0.f;
-            atomicAdd(dropped, 1u);
+        if (mask_nonfinite) {  // counted once per wave instruction (ballot + popcount), not once per element
+            const bool bad = !(fabsf(gi) < 3.0e38f);
+            const unsigned long long bal = __ballot(bad);
+            if (bad) gi = 0.f;
+            if (bal && (int)(threadIdx.x & 63) == __ffsll((long long)bal) - 1) atomicAdd(dropped, (unsigned int)__popcll(bal));
         }
         mm[e] = b1 * mm[e] + (1.f - b1) * gi;
         nn[e] = b2 * nn[e] + (1.f - b2) * gi * gi;

@@ -31,7 +31,8 @@ struct GemmArgs {
     void* out = nullptr;          // [M, ldo] OutT
     int M = 0, N = 0, K = 0;
     int lda = 0, ldw = 0, ldr = 0, ldo = 0;
-    int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only)
+    int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only); bit 5 (32): the caller's promise that A holds
+                        // ceil(M / 256) * 256 readable rows (gemm256 MIXC (ARP_G2_MIX_UNIFORM) reads whole row tiles without a per-lane clamp; the extra rows are never stored)
     int ksplit = 1;     // split-K: gridDim.y slices of K; slice s writes to out + s * slice_stride (bias/resid ignored by callers)
     size_t slice_stride = 0;
     // LayerNorm folding.  Consumer side (a GEMM whose A operand is the UN-normalised row x):
@@ -67,6 +68,14 @@ struct GemmArgs {
     int adam_mask = 0;                     // f16 mode: a non-finite gradient entry counts as missing (and is counted into adam_dropped)
     unsigned int* adam_dropped = nullptr;
     float adam_gscale = 1.f, adam_lr = 0.f, adam_wd = 0.f, adam_b1 = 0.f, adam_b2 = 0.f, adam_eps = 0.f, adam_bc1 = 1.f, adam_bc2 = 1.f;
+    // gemm256 MIXC instances (T = f16; row N1's ARP_MODE_F16C): a row of A / W is [hi: binary16 x Kc | e2m1 x Kc (| e2m1 x Kc)], i.e. its K-tiles
+    // (128 bytes each) are mix_nk16 = Kc / 64 binary16 tiles, then mix_nkc_a = Kc / 256 fp4 tiles whose products are scaled by 2^-mix_sa, then fp4 tiles
+    // scaled by 2^-mix_sb: out = A_hi.W_hi^T + 2^-sa A4.dW4^T (+ 2^-sb dA4.W4^T) -- the operand-rounding corrections of a binary16 GEMM on the scaled
+    // fp4 MFMA, which moves four times the k per cycle.  K (in binary16 units) covers all of them: K = 64 * (nk16 + nkc_a + nkc_b).
+    int mix_nk16 = 0, mix_nkc_a = 0, mix_sa = 0, mix_sb = 0;
+    // gemm256, 16-bit staged epilogue: also store fp4(value * 2^x8_shift) of the same tile at xb_out + row * ldxb (bytes) + column / 2 -- the e2m1
+    // segment of the NEXT GEMM's [hi | x4] operand row (c_fc's epilogue feeding c_proj in ARP_MODE_F16C)
+    int x8_shift = -1;
 };
 constexpr int GEMM_SITE_ADAMW = 26;
 
@@ -373,9 +382,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float gi = gg[e] * g.adam_gscale;
-                                if (g.adam_mask && !(fabsf(gi) < 3.0e38f)) {
-                                    gi = 0.f;
-                                    atomicAdd(g.adam_dropped, 1u);
+                                if (g.adam_mask) {  // one atomic per wave instruction, not per element (a badly overflowing step would serialise millions of same-address atomics here)
+                                    const bool bad = !(fabsf(gi) < 3.0e38f);
+                                    const unsigned long long bal = __ballot(bad);
+                                    if (bad) gi = 0.f;
+                                    if (bal && lane == __ffsll((long long)bal) - 1) atomicAdd(g.adam_dropped, (unsigned int)__popcll(bal));
                                 }
                                 mm[e] = g.adam_b1 * mm[e] + (1.f - g.adam_b1) * gi;
                                 nn[e] = g.adam_b2 * nn[e] + (1.f - g.adam_b2) * gi * gi;

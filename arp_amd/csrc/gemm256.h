@@ -106,6 +106,12 @@ __device__ long long* arp_g2_stamps = nullptr;  // scripts/gemm256_bench.hip: pe
 #ifndef ARP_G2_MFMA32
 #define ARP_G2_MFMA32 0
 #endif
+#ifndef ARP_G2_MIXC_RT
+#define ARP_G2_MIXC_RT 0
+#endif
+#ifndef ARP_G2_MIX_UNIFORM  // MIXC: per-lane DMA offsets collapsed into one register per operand (needs padded operand buffers); measured: MORE scratch traffic, off
+#define ARP_G2_MIX_UNIFORM 0
+#endif
 #ifndef ARP_G2_ABL  // harness ablations: bit 0 = no fragment reads after the first K-tile, bit 1 = no LDS-DMA after the prologue, bit 2 = no residual read in the f32 epilogue (wrong results, timing only)
 #define ARP_G2_ABL 0
 #endif
@@ -117,7 +123,9 @@ template <typename T> __device__ __forceinline__ f32x16_v mfma32(u32x4_v a, u32x
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
 }
 // K-loop version KV (common.h: ARP_G2_KV, dma16_saddr): 1 = SADDR-form LDS-DMA statements + peeled steady state, bit-identical to 0.
-template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV>
+// MIXC (T = f16 only): the trailing K-tiles of every row are e4m3 and run on the scaled fp8 MFMA (GemmArgs::mix_*): same LDS image, same
+// fragment reads, one 16x16x128 MFMA per fragment pair instead of two 16x16x32 ones -- the same 32 matrix-pipe cycles for twice the k.
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV, bool MIXC = false>
 __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G2_MAX_VGPR))) void gemm256_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPB = 128 / (int)sizeof(T);
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     const int total_tiles = m_tiles * n_tiles;
     const int group_m = g.group_m > 0 ? g.group_m : G2_GROUP_M;
     int m0 = 0, n0 = 0;
-    auto tile_coords = [&](int tix) {
+    auto tile_coords = [&](int tix) __attribute__((always_inline)) {
         int t = xcd_remap(tix, total_tiles);
         const int per_group = group_m * n_tiles;
         const int grp = t / per_group;
@@ -177,10 +185,28 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     const char* a_tile = nullptr;
     const char* w_tile = nullptr;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto setup_src = [&]() {
+    // MIXC: no per-lane row clamp -- the caller promises ceil(M / 256) * 256 readable A rows and N % 256 == 0 -- so the eight per-lane offsets collapse
+    // into TWO (one per operand) plus wave-uniform row terms that go into the SGPR base: six VGPRs the e4m3 bodies' 8-register operand tuples need
+    uint32_t off_a = 0, off_w = 0;
+    auto setup_src = [&]() __attribute__((always_inline)) {
         if constexpr (KV == 1) {
             a_tile = reinterpret_cast<const char*>(A + (size_t)m0 * g.lda);
             w_tile = reinterpret_cast<const char*>(W + (size_t)n0 * g.ldw);
+        }
+        if constexpr (MIXC && ARP_G2_MIX_UNIFORM) {
+            off_a = (uint32_t)(((size_t)srow * g.lda + ((lane & 7) ^ srow) * EPC) * sizeof(T));
+            off_w = (uint32_t)(((size_t)srow * g.ldw + ((lane & 7) ^ srow) * EPC) * sizeof(T));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int lr0 = (wave * 2 + i) * 8;
+                    const bool isA = (u == 0 || u == 3);
+                    const int q = (u == 0 || u == 1) ? 0 : 1;
+                    const int row0 = isA ? ((lr0 >> 6) * 128 + q * 64 + (lr0 & 63)) : ((lr0 >> 5) * 64 + q * 32 + (lr0 & 31));
+                    dst[u][i] = (isA ? 0 : G2_B_REGION) + row0 * 128;
+                }
+            return;
         }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -206,15 +232,30 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
         }
     };
+    // MIXC: unit U of K-tile tt; the unit's first row (wave-uniform) goes into the SGPR base, the lane offset is one register per operand
+    auto issue_mix = [&](int tt, auto U) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        constexpr bool isA = (u == 0 || u == 3);
+        constexpr int q = (u == 0 || u == 1) ? 0 : 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr0 = (wave * 2 + i) * 8;
+            const int row0 = isA ? ((lr0 >> 6) * 128 + q * 64 + (lr0 & 63)) : ((lr0 >> 5) * 64 + q * 32 + (lr0 & 31));
+            const char* sb = (isA ? a_tile + (size_t)row0 * g.lda * sizeof(T) : w_tile + (size_t)row0 * g.ldw * sizeof(T)) + (size_t)tt * 128;
+            dma16_saddr(sb, isA ? off_a : off_w, lds0 + (tt & 1) * G2_BUF_BYTES + (isA ? 0 : G2_B_REGION) + row0 * 128);
+        }
+    };
     const int nk = g.K / EPB;
     const int G = 4 * nk;  // total units
     // issue unit index gi (tile gi>>2, unit U) if it exists; U is a compile-time constant per phase
-    auto issue = [&](int gi, auto U) {
+    auto issue = [&](int gi, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         if ((ARP_G2_ABL & 2) && gi >= 12) return;
         if (gi < G) {
             const int tt = gi >> 2;
-            if constexpr (KV == 1) {
+            if constexpr (MIXC && ARP_G2_MIX_UNIFORM) {
+                issue_mix(tt, U);
+            } else if constexpr (KV == 1) {
                 const char* sb = ((u == 0 || u == 3) ? a_tile : w_tile) + (size_t)tt * 128;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) dma16_saddr(sb, off32[u][i], lds0 + (tt & 1) * G2_BUF_BYTES + dst[u][i]);
@@ -228,14 +269,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         }
     };
     // KV = 1, steady state: unit U of K-tile tt, no existence test
-    auto issue_ss = [&](int tt, auto U) {
+    auto issue_ss = [&](int tt, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
+        if constexpr (MIXC && ARP_G2_MIX_UNIFORM) {
+            issue_mix(tt, U);
+            return;
+        }
         const char* sb = ((u == 0 || u == 3) ? a_tile : w_tile) + (size_t)tt * 128;
 #pragma unroll
         for (int i = 0; i < 2; ++i) dma16_saddr(sb, off32[u][i], lds0 + (tt & 1) * G2_BUF_BYTES + dst[u][i]);
     };
     // the tile's 256 bias values -> LDS (one LDS-DMA of wave 0)
-    auto bias_dma = [&](int n_first) {
+    auto bias_dma = [&](int n_first) __attribute__((always_inline)) {
         int n = n_first + lane * 4;
         n = n + 4 <= g.N ? n : (g.N >= 4 ? g.N - 4 : 0);  // clamped at the ragged edge: those columns are never stored
         if constexpr (KV == 1) dma16_saddr(g.bias, (uint32_t)n * 4u, lds0 + G2_TILE_BYTES);
@@ -280,9 +325,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                             // sub-tile 0 without re-reading LDS, so every LDS region is last read >= 3 phases before
                             // the LDS-DMA that overwrites it is issued (WAR margin for the staggered wave groups)
 
+    using F16T = std::false_type;  // K-tile kinds of a MIXC row: binary16 ...
+    using F8T = std::true_type;    // ... or e2m1 (fp4).  Same fragment registers, same LDS reads; compile-time per K-tile BODY (no run-time choice inside the MFMA segments)
     int abl_kt = 0;
-    auto load_a = [&](const char* buf, int mq) {
+    auto load_a = [&](const char* buf, int mq, auto F8) __attribute__((always_inline)) {
         if ((ARP_G2_ABL & 1) && abl_kt > 0) return;
+
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const char* p = buf + a_base + (mq * 64 + mi * RSTEP) * 128;
@@ -294,7 +342,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
         }
     };
-    auto load_b = [&](const char* buf, auto NQ) {
+    auto load_b = [&](const char* buf, auto NQ, auto F8) __attribute__((always_inline)) {
         constexpr int nq = decltype(NQ)::value;
         if ((ARP_G2_ABL & 1) && abl_kt > 0) return;
 #pragma unroll
@@ -308,8 +356,20 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
         }
     };
-    auto mfma_quadrant = [&](auto MQ, auto NQ) {
+    int mix_scale = 0;  // MIXC: the e8m0 scale word of the current e4m3 K-tile (wave-uniform)
+    auto mfma_quadrant = [&](auto MQ, auto NQ, auto F8 = F16T{}) __attribute__((always_inline)) {
         constexpr int mq = decltype(MQ)::value, nq = decltype(NQ)::value;
+        if constexpr (MIXC && sizeof(T) == 2 && !W32) {
+            if constexpr (decltype(F8)::value) {  // an e2m1 K-tile: two 128-deep k-steps, the loop nest of the binary16 tile
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) acc[mq][nq][ni][mi] = mfma_fp4_scaled(breg[nq][ni][ks], areg[mi][ks], acc[mq][nq][ni][mi], mix_scale);
+                return;
+            }
+        }
         if constexpr (W32) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -338,7 +398,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         }
     };
     // one phase = [reads + LDS-DMA issue + counted wait] barrier [MFMAs] barrier
-    auto phase_tail = [&](int ph) {
+    auto phase_tail = [&](int ph) __attribute__((always_inline)) {
         int allow = G - 3 - ph;
         allow = allow > 3 ? 3 : allow;
         wait_units(allow);
@@ -346,7 +406,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto compute = [&](auto MQ, auto NQ) {
+    auto compute = [&](auto MQ, auto NQ) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
         mfma_quadrant(MQ, NQ);
         __builtin_amdgcn_s_setprio(0);
@@ -361,7 +421,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     // earlier by both wave groups -- then waits until step p+1 has landed (steps p+2, p+3 stay in flight: 8 LDS-DMA
     // instructions per thread) so that it is visible, after the barrier, to the reads of phase p+1.
     const int S2 = 2 * nk;
-    auto issue_step = [&](int st) {
+    auto issue_step = [&](int st) __attribute__((always_inline)) {
         const int t4 = (st >> 1) * 4;
         if (st & 1) {
             issue(t4 + 3, U3{});
@@ -371,8 +431,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             issue(t4 + 2, U2{});
         }
     };
-    auto step_cnt = [&](int st) { return st < S2 ? ((st & 1) ? 2 : 6) : 0; };
-    auto wait_instr = [&](int n) {
+    auto step_cnt = [&](int st) __attribute__((always_inline)) { return st < S2 ? ((st & 1) ? 2 : 6) : 0; };
+    auto wait_instr = [&](int n) __attribute__((always_inline)) {
         if (n >= 24) wait_vmcnt<24>();
         else if (n >= 8) wait_vmcnt<8>();
         else if (n >= 6) wait_vmcnt<6>();
@@ -382,17 +442,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     // `young` = the previous tile's epilogue stores, issued AFTER this tile's steps 0..2 (overlapped epilogue, below): they are
     // younger than every step <= 2, so a wait for such a step may leave them in flight too (vmcnt counts in issue order)
     int young = 0;
-    auto phase_tail2 = [&](int p) {
+    auto phase_tail2 = [&](int p) __attribute__((always_inline)) {
         wait_instr(step_cnt(p + 2) + step_cnt(p + 3) + (p + 1 <= 2 ? young : 0));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this phase's fragment reads are done before any wave may overwrite them
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto compute2 = [&](auto MQ, auto NQA, auto NQB) {
+    auto compute2 = [&](auto MQ, auto NQA, auto NQB, auto F8 = F16T{}) __attribute__((always_inline)) {
         __builtin_amdgcn_s_setprio(1);
-        mfma_quadrant(MQ, NQA);
-        mfma_quadrant(MQ, NQB);
+        mfma_quadrant(MQ, NQA, F8);
+        mfma_quadrant(MQ, NQB, F8);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -463,60 +523,83 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     if constexpr (KV == 1 && !ARP_G2_OVERLAP_DRAIN) {
         // ---- steady state: K-tiles 0 .. nk-3 issue steps 2kt+3 (U3 of K-tile kt+1) and 2kt+4 (U0,U1,U2 of K-tile kt+2), both of which
         // exist, and leave exactly 8 LDS-DMA instructions in flight at each counted wait
-        auto tail_ss = [&]() {
+        auto tail_ss = [&]() __attribute__((always_inline)) {
             wait_vmcnt<8>();
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as the builtin: hipcc's own wait bookkeeping sees it (behind the asm form it re-waits inside the MFMA segment)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto ktile_ss = [&](int kt, auto BUF) {  // one K-tile out of ring buffer BUF (compile-time: its fragment addresses are loop constants)
-            const char* buf = smem + decltype(BUF)::value * G2_BUF_BYTES;
-            load_a(buf, 0);
-            load_b(buf, I0{});
-            load_b(buf, I1{});
+        auto ktile_ss = [&](int kt, auto BUF, auto F8) __attribute__((always_inline)) {  // one K-tile out of ring buffer BUF (compile-time: its fragment addresses are loop constants)
+            const char* buf = smem + ((MIXC && RESID && ARP_G2_MIXC_RT) ? (kt & 1) : decltype(BUF)::value) * G2_BUF_BYTES;
+            if constexpr (MIXC && decltype(F8)::value) mix_scale = 0x7f7f7f00 | (127 - (kt < g.mix_nk16 + g.mix_nkc_a ? g.mix_sa : g.mix_sb));
+            load_a(buf, 0, F8);
+            load_b(buf, I0{}, F8);
+            load_b(buf, I1{}, F8);
             issue_ss(kt + 1, U3{});
             tail_ss();
-            compute2(I0{}, I0{}, I1{});
-            load_a(buf, 1);
+            compute2(I0{}, I0{}, I1{}, F8);
+            load_a(buf, 1, F8);
             issue_ss(kt + 2, U0{});
             issue_ss(kt + 2, U1{});
             issue_ss(kt + 2, U2{});
             tail_ss();
-            compute2(I1{}, I1{}, I0{});
+            compute2(I1{}, I1{}, I0{}, F8);
         };
-        for (; kt_first + 3 < nk; kt_first += 2) {
-            ktile_ss(kt_first, I0{});
-            ktile_ss(kt_first + 1, I1{});
-        }
-        if (kt_first + 2 < nk) {
-            ktile_ss(kt_first, I0{});
-            ++kt_first;
+        auto run_ss = [&](int kt_end, auto F8) __attribute__((always_inline)) {  // steady-state K-tiles [kt_first, kt_end), all of one kind
+            if (kt_first < kt_end && (kt_first & 1)) {
+                ktile_ss(kt_first, I1{}, F8);
+                ++kt_first;
+            }
+            for (; kt_first + 1 < kt_end; kt_first += 2) {
+                ktile_ss(kt_first, I0{}, F8);
+                ktile_ss(kt_first + 1, I1{}, F8);
+            }
+            if (kt_first < kt_end) {
+                ktile_ss(kt_first, I0{}, F8);
+                ++kt_first;
+            }
+        };
+        if constexpr (MIXC) {
+            run_ss(g.mix_nk16, F16T{});
+            run_ss(nk - 2, F8T{});
+        } else {
+            run_ss(nk - 2, F16T{});
         }
     }
-    for (int kt = kt_first; kt < nk; ++kt) {
+    // the last two K-tiles (and every K-tile of a KV = 0 build): issues may not exist, the counted waits shrink
+    auto ktile_tail = [&](int kt, auto F8) __attribute__((always_inline)) {
         const char* buf = smem + (kt & 1) * G2_BUF_BYTES;
         const int p = 2 * kt;
         abl_kt = kt;
+        if constexpr (MIXC && decltype(F8)::value) mix_scale = 0x7f7f7f00 | (127 - (kt < g.mix_nk16 + g.mix_nkc_a ? g.mix_sa : g.mix_sb));
         // phase A: quadrants (0,0) and (0,1)
         ARP_FST(0);
-        load_a(buf, 0);
-        load_b(buf, I0{});
-        load_b(buf, I1{});
+        load_a(buf, 0, F8);
+        load_b(buf, I0{}, F8);
+        load_b(buf, I1{}, F8);
         issue_step(p + 3);
         ARP_FST(1);
         phase_tail2(p);
         ARP_FST(2);
-        compute2(I0{}, I0{}, I1{});
+        compute2(I0{}, I0{}, I1{}, F8);
         // phase B: quadrants (1,1) and (1,0) -- the W sub-tiles are still in registers
         ARP_FST(4);
-        load_a(buf, 1);
+        load_a(buf, 1, F8);
         issue_step(p + 4);
         ARP_FST(5);
         phase_tail2(p + 1);
         ARP_FST(6);
-        compute2(I1{}, I1{}, I0{});
+        compute2(I1{}, I1{}, I0{}, F8);
         ARP_FST(8);
+    };
+    if constexpr (MIXC) {
+        // the launcher guarantees >= 2 trailing e4m3 K-tiles: the two tail tiles are of that kind, straight-line (a run-time kind here, or a loop, costs the
+        // allocator the joins it then pays for with scratch traffic -- and a scratch reload is a vmcnt(0), i.e. a drained LDS-DMA ring)
+        ktile_tail(nk - 2, F8T{});
+        ktile_tail(nk - 1, F8T{});
+    } else {
+        for (int kt = kt_first; kt < nk; ++kt) ktile_tail(kt, F16T{});
     }
 #else
     // ---- prologue: units 0..4 in flight, units 0 and 1 landed and visible ---------------------------
@@ -543,18 +626,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         const char* buf = smem + (kt & 1) * G2_BUF_BYTES;
         const int ph = 4 * kt;
         // phase 1: quadrant (0,0)
-        load_a(buf, 0);
-        load_b(buf, I0{});
+        load_a(buf, 0, F16T{});
+        load_b(buf, I0{}, F16T{});
         issue(ph + 5, U1{});
         phase_tail(ph);
         compute(I0{}, I0{});
         // phase 2: quadrant (0,1)
-        load_b(buf, I1{});
+        load_b(buf, I1{}, F16T{});
         issue(ph + 6, U2{});
         phase_tail(ph + 1);
         compute(I0{}, I1{});
         // phase 3: quadrant (1,1)
-        load_a(buf, 1);
+        load_a(buf, 1, F16T{});
         issue(ph + 7, U3{});
         phase_tail(ph + 2);
         compute(I1{}, I1{});
@@ -773,6 +856,20 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                     const u32x4_v v = *reinterpret_cast<const u32x4_v*>(smem + r * RS + (lane & 31) * 16);
                     if (g.flags & 4) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_v*>(out + (size_t)m * g.ldo + n));
                     else *reinterpret_cast<u32x4_v*>(out + (size_t)m * g.ldo + n) = v;
+                    if constexpr (MIXC && __is_same(OutT, f16_t)) {
+                        // ARP_MODE_F16C: the e2m1 segment of the next GEMM's [hi | x4] operand row, from the rounded tile (GemmArgs::x8_shift)
+                        if (g.x8_shift >= 0) {
+                            const float sc = (float)(1 << g.x8_shift);
+                            float f[8];
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) {
+                                const f16x2_v p2 = __builtin_bit_cast(f16x2_v, v[h]);
+                                f[2 * h] = (float)p2[0] * sc;
+                                f[2 * h + 1] = (float)p2[1] * sc;
+                            }
+                            *reinterpret_cast<uint32_t*>(static_cast<char*>(g.xb_out) + (size_t)m * g.ldxb + (n >> 1)) = pack_fp4x8(f);
+                        }
+                    }
                 }
             }
         } else {
@@ -924,6 +1021,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
 #endif
         pre_issued = true;
     }
+    if constexpr (MIXC) break;  // one tile per workgroup (the launcher never makes these instances persistent): nothing of the K loop's state is then live
+                                // across the epilogue, where hipcc would spill it -- and reload it in front of the next tile's loop, behind a vmcnt(0)
     }  // tile loop
 #ifdef ARP_G2_CLOCK
     if (arp_g2_stamps && threadIdx.x == 0) {
@@ -933,7 +1032,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
 #endif
 }
 
-template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV>
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV, bool MIXC = false>
 inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     constexpr int EPB = 128 / (int)sizeof(T);
     if (g.M <= 0) return 0;
@@ -945,7 +1044,9 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     // KV = 1 addresses a tile's rows by 32-bit byte offsets from the tile's first row
     if (KV == 1 && ((size_t)G2_BM * g.lda * sizeof(T) >= (1ull << 32) || (size_t)G2_BN * g.ldw * sizeof(T) >= (1ull << 32)))
         return fail("gemm256_nt: row stride too large for the 32-bit tile offsets of the KV = 1 K loop");
-    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE, M32, KV>;
+    if (MIXC && (sizeof(T) != 2 || g.mix_nk16 <= 0 || 64 * (g.mix_nk16 + g.mix_nkc_a) > g.K || g.K / 64 - g.mix_nk16 < 2 || !KV || (ARP_G2_MIX_UNIFORM && (g.N % G2_BN || !(g.flags & 32))) || g.mix_sa < 0 || g.mix_sa > 120 || g.mix_sb < 0 || g.mix_sb > 120))
+        return fail("gemm256_nt: bad mixed binary16 / e2m1 K-tile plan (needs >= 2 trailing fp4 K-tiles, i.e. Kc >= 512 with one correction segment)");
+    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE, M32, KV, MIXC>;
     static bool attr_set = false;
     if (!attr_set) {
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

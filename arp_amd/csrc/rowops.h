@@ -51,7 +51,10 @@ __device__ __forceinline__ void ln_row_store(float (&v)[NV][4], int D, int lane,
         if (c < D) {
             const float4 ww = *reinterpret_cast<const float4*>(w + c);
             const float4 bb = *reinterpret_cast<const float4*>(b + c);
-            if constexpr (__is_same(OutT, f16x3_t))  // ARP_MODE_F16X3: the next GEMM's K-concatenated operand, written here instead of by a split pass
+            if constexpr (__is_same(OutT, f16c_t) || __is_same(OutT, f16c2_t))  // ARP_MODE_F16C: [hi | x4 (| dx4)] operand row of a gemm256 MIXC product (common.h)
+                store_f16c<__is_same(OutT, f16c2_t)>(reinterpret_cast<f16_t*>(orow), c, D, (v[i][0] - mean) * rstd * ww.x + bb.x, (v[i][1] - mean) * rstd * ww.y + bb.y,
+                                                      (v[i][2] - mean) * rstd * ww.z + bb.z, (v[i][3] - mean) * rstd * ww.w + bb.w);
+            else if constexpr (__is_same(OutT, f16x3_t))  // ARP_MODE_F16X3: the next GEMM's K-concatenated operand, written here instead of by a split pass
                 store_split3(reinterpret_cast<f16_t*>(orow) + c, (size_t)D, (v[i][0] - mean) * rstd * ww.x + bb.x, (v[i][1] - mean) * rstd * ww.y + bb.y,
                              (v[i][2] - mean) * rstd * ww.z + bb.z, (v[i][3] - mean) * rstd * ww.w + bb.w);
             else

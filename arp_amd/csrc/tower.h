@@ -220,7 +220,8 @@ static int tower_layernorm(TowerCtx& c, const char* site, const float* in, size_
 
 template <typename T>
 static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, int B, int N, int D, int heads, int causal, int nq = 0, float out8 = 0.f,
-                            f16_t* out3 = nullptr) {  // out3 (T = float, the f32-MFMA kernel only): (hi, lo, hi) binary16 rows instead of f32
+                            f16_t* out3 = nullptr, int outc = 0) {  // out3 (T = float, the f32-MFMA kernel only): (hi, lo, hi) binary16 rows instead of f32
+                                                                    // outc (T = f16, the MFMA kernel only): [hi | x4 | dx4] rows (ARP_MODE_F16C)
     const int hd = D / heads;
     if (nq <= 0 || nq > N) nq = N;  // query rows produced per sample
     const float scale = 1.0f / sqrtf((float)hd);
@@ -234,7 +235,7 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         const int nqb_ = (nq + 15) / 16;                                                                                    \
         const int qsplit_ = (B * heads < 128 && nqb_ > 4) ? std::min((nqb_ + 3) / 4, 4) : 1;                                   \
-        hipLaunchKernelGGL(kern, dim3(B* heads, qsplit_), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal, nq, out8);  \
+        hipLaunchKernelGGL(kern, dim3(B* heads, qsplit_), dim3(256), lds, stream, qkv, out, N, D, heads, scale, causal, nq, out8, outc);  \
         ARP_HIP_OK(hipGetLastError());                                                                                      \
         return 0;                                                                                                           \
     }
@@ -250,7 +251,7 @@ static int launch_attention(hipStream_t stream, int impl, const T* qkv, T* out, 
 #undef ARP_ATTN_CASE
         }
     }
-    if (out8 != 0.f) return fail("attention: the e4m3 output exists on the MFMA kernel only");
+    if (out8 != 0.f || outc) return fail("attention: the e4m3 / [hi | x4 | dx4] outputs exist on the MFMA kernel only");
     if constexpr (sizeof(T) == 4) {
         // impl 3: the (hi, lo) binary16 MFMA kernel (attention.h::attn_x3_kernel, the f16x3 encoder mode's attention): head_dim 64, up to 288 keys
         if (impl == 3 && hd == 64 && N <= 288 && (D & 3) == 0) {

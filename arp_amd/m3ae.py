@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _ffi
-from ._ffi import MODE_BF16, MODE_F16, MODE_F16X3, MODE_F32, check, lib
+from ._ffi import MODE_BF16, MODE_F16, MODE_F16C, MODE_F16X3, MODE_F32, check, lib
 
 
 @dataclass(frozen=True)
@@ -44,7 +44,7 @@ class M3AEEncoder:
         about twice the f32 mode's speed)."""
         _ffi.require_gpu()
         self.cfg = cfg
-        c = _ffi.EncCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.mlp_ratio, cfg.img_res, {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32, "f16x3": MODE_F16X3}[mode],
+        c = _ffi.EncCfg(cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.mlp_ratio, cfg.img_res, {"bf16": MODE_BF16, "f16": MODE_F16, "f32": MODE_F32, "f16x3": MODE_F16X3, "f16c": MODE_F16C}[mode],
                         device, max_frames, attn_impl)
         h = C.c_void_p()
         check(lib.arp_enc_create(C.byref(c), C.byref(h)))

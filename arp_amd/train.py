@@ -462,16 +462,19 @@ def prefetch_to_device(iterator, size, trainer, *, rank=0, world=1, device_axis=
     batch, and neither iterator can starve the other of slots."""
     import queue
     import threading
+    import warnings
 
+    # Ownership is decided HERE, when the prefetcher is created -- not at the first next() (this used to be a generator function: whichever
+    # iterator was pulled first won, so a validation iterator pulled before the training one silently demoted the training loop; ADVICE r4).
     with _SLOT_OWNER_LOCK:
         owner = getattr(trainer, "_prefetch_owner", None) is None
         if owner:
             token = object()
             trainer._prefetch_owner = token
     if not owner:
-        for batch in iterator:  # no device slots for this one: the host-side preparation only
-            yield batch
-        return
+        warnings.warn("prefetch_to_device: another prefetcher owns this trainer's two device slots; this one yields host batches (staged "
+                      "synchronously by the step functions)", RuntimeWarning, stacklevel=2)
+        return (batch for batch in iterator)  # no device slots for this one: the host-side preparation only
 
     free = queue.Queue()
     for s in range(min(max(int(size), 1), 2)):
@@ -493,22 +496,43 @@ def prefetch_to_device(iterator, size, trainer, *, rank=0, world=1, device_axis=
             ready.put(e)
 
     th = threading.Thread(target=worker, daemon=True)
-    th.start()
-    try:
-        while True:
-            item = ready.get()
-            if item is None:
-                return
-            if isinstance(item, BaseException):
-                raise item
-            yield item
-    finally:
+
+    def release():
         stop.set()
         free.put(0)  # wake a worker blocked on a free slot
-        th.join(timeout=30)  # an upload in flight finishes before the slots change hands
+        if th.is_alive():
+            th.join(timeout=30)  # an upload in flight finishes before the slots change hands
+        if th.is_alive():
+            # the worker is still inside an upload: the slots are NOT free -- keep the ownership (a new prefetcher is demoted to host staging) and say so
+            raise RuntimeError("prefetch_to_device: the upload thread did not stop within 30 s; the device slots stay owned by this prefetcher")
         with _SLOT_OWNER_LOCK:
             if getattr(trainer, "_prefetch_owner", None) is token:
                 trainer._prefetch_owner = None
+
+    def gen():
+        th.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            release()
+
+    g = gen()
+    # a prefetcher that is created and dropped without ever being pulled must give the slots back too
+    import weakref
+    weakref.finalize(g, lambda: (None if th.is_alive() else _release_if_unstarted(trainer, token)))
+    return g
+
+
+def _release_if_unstarted(trainer, token):
+    with _SLOT_OWNER_LOCK:
+        if getattr(trainer, "_prefetch_owner", None) is token:
+            trainer._prefetch_owner = None
 
 
 def _stage(tr, batch, rank, world, device_axis):

@@ -549,7 +549,7 @@ def bench_policy(a):
         avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
         emode = a.encoder_mode or a.mode
         # the matrix pipe a site runs on: the encoder's sites follow the encoder's mode (f16x3: the 16-bit MFMA, three instructions per algorithmic product)
-        peak = (PEAK_TFLOPS["f16" if emode == "f16x3" else emode] if site.startswith("m3ae.") else PEAK_TFLOPS[a.mode]) if kind == "mfma" else 8000.0
+        peak = (PEAK_TFLOPS["f16" if emode in ("f16x3", "f16c") else emode] if site.startswith("m3ae.") else PEAK_TFLOPS[a.mode]) if kind == "mfma" else 8000.0
         achieved = work / (avg_ms * 1e-3) / (1e12 if kind == "mfma" else 1e9)
         flops = policy_step_flops(cfg, a.policy_batch)
         if enc is not None:  # + the frozen encoder's forward: 46.4 GFLOP per frame, 4 frames per sample (193.5 GF per sample in all)
@@ -582,7 +582,7 @@ def bench_policy(a):
                          "traffic_source": None if traffic is None else "profiles/pmc_traffic_policy.json (committed rocprofv3 --pmc passes, not measured in this run)",
                          "note": "the call site with the largest share of the step (sites_ms_per_step)"},
             "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12,
-                           "mfma_frac_of_peak": flops / (elapsed / a.steps) / 1e12 / (PEAK_TFLOPS["f16" if (a.encoder_mode or a.mode) == "f16x3" else (a.encoder_mode or a.mode)] if enc is not None else PEAK_TFLOPS[a.mode])},
+                           "mfma_frac_of_peak": flops / (elapsed / a.steps) / 1e12 / (PEAK_TFLOPS["f16" if (a.encoder_mode or a.mode) in ("f16x3", "f16c") else (a.encoder_mode or a.mode)] if enc is not None else PEAK_TFLOPS[a.mode])},
             "parity": {"max_logit_err_vs_oracle": parity, "geometry": parity_geometry, "tolerance": 1e-3,
                        "within_tolerance": None if parity is None else bool(parity < 1e-3)},
             "cpu_baseline": cpu, "seam": seam, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank], "rccl": rccl,
@@ -901,7 +901,7 @@ def main():
     ap.add_argument("--with-towers", action="store_true", help="finetune path: run the frozen CLIP ViT-B/16 towers inside the timed step "
                     "(uint8 frames + tokens in) instead of feeding pre-computed tower features")
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
-    ap.add_argument("--encoder-mode", default=None, choices=["bf16", "f16", "f32", "f16x3"], help="policy path with --with-encoder: operand mode of the frozen encoder "
+    ap.add_argument("--encoder-mode", default=None, choices=["bf16", "f16", "f32", "f16x3", "f16c"], help="policy path with --with-encoder: operand mode of the frozen encoder "
                     "(default: --mode).  f16x3 = (hi, lo) binary16 operand pairs, three 16-bit MFMAs per product, f32 attention: f32-level error")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")

@@ -31,6 +31,13 @@ extern "C" {
                            product is hi.hi + lo.hi + hi.lo (three MFMAs, ~2^-22 relative; a K-concatenated operand [x_hi | x_lo | x_hi] against
                            [W_hi | W_hi | W_lo] on the ordinary f16 kernels), attention / LayerNorm / residual stream in f32.  The 16-bit mode of row N1
                            that meets north_star's 1e-3 on the policy logits (the plain f16 encoder does not: DESIGN 6b) */
+#define ARP_MODE_F16C 4  /* arp_enc only (round 5): the binary16 encoder with the operand ROUNDINGS of its GEMMs corrected on the scaled fp4 MFMA --
+                           a product is x_hi.W_hi (binary16) + 2^-s x4.dW4 (+ 2^-s' dx4.W4) where dW = W - W_hi, dx = x - x_hi are carried as e2m1
+                           (OCP fp4) with power-of-two block scales: the correction terms are 2^-12 of the product, 1-2 significant bits take the
+                           roundings out to a quarter of their size, and the fp4 MFMA moves four times the k per cycle on the same 4-register operand
+                           tuples, so a product with both corrections costs 1.5x the binary16 one instead of f16x3's 3x.  Patch embedding on (hi, lo)
+                           binary16 pairs; attention, LayerNorm statistics, residual stream as in ARP_MODE_F16.  ARP_F16C_PLAN selects, per GEMM
+                           (in_proj, out_proj, fc1, fc2), 0 = plain / 1 = weight correction / 2 = both */
 
 #define ARP_ACT_NONE 0
 #define ARP_ACT_QGELU 1
@@ -395,6 +402,10 @@ int arp_op_adapter_dy(int mode, const float* dz, const float* Wi, const float* A
                       float* dres, int R, int E, int tokens, int D);
 /* Times `iters` launches of the GEMM on device-resident random operands (HIP events); kernel: 1 = 128x128,
  * 2 = 256x256 pipelined, 0 = auto.  act/resid/out_f32 select the epilogue.  Returns the average ms per launch. */
+/* ARP_MODE_F16C's product alone (gemm256 MIXC): A [M,K], W [N,K] f32 -> operand rows [rn16 | e2m1 segments] built on the host exactly as the encoder's
+   kernels build them, out = A.W^T + bias (f32) with the weight rounding (plan 1) or both operand roundings (plan 2) corrected on the scaled fp4 MFMA;
+   plan 0 = the plain binary16 product.  sd_sw[2] (optional): the power-of-two exponents of the e2m1 weight segments.  K % 256, N % 8. */
+int arp_op_gemm_f16c(int plan, const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int* sd_sw);
 int arp_op_gemm_bench(int mode, int kernel, int act, int resid, int out_f32, int M, int N, int K, int iters, float* avg_ms);
 int arp_op_layernorm(const float* x, const float* w, const float* b, float* out, int rows, int D, float eps);
 /* qkv [B*N, 3*D] -> out [B*N, D]; impl 0 = MFMA (bf16 mode, head_dim 64 only), 1 = VALU. */

@@ -354,15 +354,17 @@ def test_two_prefetchers_on_one_trainer_never_share_device_slots():
 
     tr = Stub()
     train_it = prefetch_to_device(batches(100, 6), 2, tr)
-    val_it = prefetch_to_device(batches(900, 3), 2, tr)
-    seen_train, seen_val = [], []
+    with pytest.warns(RuntimeWarning, match="another prefetcher owns"):  # ownership is decided at CREATION, and the demotion is not silent
+        val_it = prefetch_to_device(batches(900, 3), 2, tr)
+    assert next(val_it)["image"]["ob"].flat[0] == 900.0   # pulling the second one FIRST does not make it the owner
+    seen_train, seen_val = [], [900.0]
     for step in range(6):
         b = next(train_it)
         assert isinstance(b, DeviceBatch)
         with tr.lock:
             seen_train.append(tr.holds.pop(b.slot))  # the step consumes what the slot holds
         b.done()
-        if step % 2 == 1:
+        if step in (1, 3):
             v = next(val_it)
             assert isinstance(v, dict), "the second live prefetcher must not use the trainer's device slots"
             seen_val.append(float(v["image"]["ob"].flat[0]))
@@ -374,6 +376,14 @@ def test_two_prefetchers_on_one_trainer_never_share_device_slots():
     again = prefetch_to_device(batches(500, 1), 2, tr)
     assert isinstance(next(again), DeviceBatch)
     again.close()
+    # ... and a prefetcher that is created but never pulled gives them back when it is dropped
+    unused = prefetch_to_device(batches(600, 1), 2, tr)
+    del unused
+    import gc
+    gc.collect()
+    last = prefetch_to_device(batches(700, 1), 2, tr)
+    assert isinstance(next(last), DeviceBatch)
+    last.close()
 
 
 def test_alibi_slopes_known_answers():

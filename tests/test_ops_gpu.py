@@ -227,6 +227,55 @@ def test_preprocess_bit_exact(gpu_lib, case):
     assert nbad == 0, f"{nbad} of {ref.size} f32 values differ; max abs diff {np.abs(got - ref).max()}"
 
 
+def _quant_fp4(x):
+    """OCP e2m1: 0, 0.5, 1, 1.5, 2, 3, 4, 6 and their negatives; round-to-nearest-even on the one significand bit, saturating at 6 (what
+    v_cvt_scalef32_pk_fp4_f32 and csrc/common.h::host_f2fp4 produce)"""
+    x = np.asarray(x, np.float64)
+    a = np.abs(x)
+    grid = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+    idx = np.clip(np.searchsorted(grid, a, side="left"), 1, 7)       # grid[idx - 1] <= a <= grid[idx] (a > 6: idx = 7 twice over)
+    lo, hi = grid[idx - 1], grid[idx]
+    mid = 0.5 * (lo + hi)
+    q = np.where(a < mid, lo, np.where(a > mid, hi, np.where((idx - 1) % 2 == 0, lo, hi)))   # ties to the even code
+    return np.sign(x) * np.minimum(q, 6.0)
+
+
+@pytest.mark.parametrize("shape", [(300, 512, 512), (257, 768, 768), (1030, 768, 3072), (77, 2304, 512)])
+def test_gemm_f16c_corrects_the_operand_roundings(gpu_lib, shape):
+    """ARP_MODE_F16C's product (gemm256 MIXC: binary16 K-tiles followed by e2m1 K-tiles on the scaled fp4 MFMA, round 5).  Two checks per shape:
+    (i) EXACT restatement -- the same quantised operands multiplied in float64 (hi.W_hi + 2^-(1+sd) x4.dW4 + 2^-(13+sw) dx4.W4) agree with the kernel to
+    f32 summation noise, so a wrong nibble order, k-slot assignment, segment offset or block scale shows at the size of a correction term, not hidden
+    inside it; (ii) the point of it -- against the UNROUNDED product, plan 1 takes most of the weight rounding out and plan 2 most of both."""
+    M, N, K = shape
+    rng = np.random.default_rng(M * 7 + N + K)
+    A = (rng.standard_normal((M, K)) * np.where(rng.random((M, K)) < 0.01, 8.0, 1.0)).astype(np.float32)  # LayerNorm-like rows with a few outliers
+    W = (rng.standard_normal((N, K)) * 0.03).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    A64, W64 = A.astype(np.float64), W.astype(np.float64)
+    ref = A64 @ W64.T + bias
+    terms = np.abs(A64) @ np.abs(W64).T
+    hi, whi = A.astype(np.float16).astype(np.float64), W.astype(np.float16).astype(np.float64)
+    x4, dx4 = _quant_fp4(hi * 2.0), _quant_fp4((A64 - hi) * 2.0 ** 13)
+    errs, rms = {}, {}
+    for plan in (0, 1, 2):
+        out = np.empty((M, N), np.float32)
+        sc = (C.c_int32 * 2)()
+        gpu_lib.check(gpu_lib.lib.arp_op_gemm_f16c(plan, _fp(A), _fp(W), _fp(bias), _fp(out), M, N, K, sc))
+        sd, sw = sc[0], sc[1]
+        assert 6 < np.abs(W64 - whi).max() * 2.0 ** sd <= 12 and 6 < np.abs(W64).max() * 2.0 ** sw <= 12
+        want = hi @ whi.T + bias
+        if plan >= 1:
+            want = want + 2.0 ** -(1 + sd) * (x4 @ _quant_fp4((W64 - whi) * 2.0 ** sd).T)
+        if plan >= 2:
+            want = want + 2.0 ** -(13 + sw) * (dx4 @ _quant_fp4(W64 * 2.0 ** sw).T)
+        tol = 3e-7 * terms + 1e-6 * (np.abs(want) + 1.0)   # f32 accumulation of K (+ K / 2) terms; a misplaced correction term is >= 1e-5 * terms
+        assert (np.abs(out - want) <= tol).all(), (plan, float((np.abs(out - want) / tol).max()))
+        errs[plan] = float((np.abs(out - ref) / terms).max())
+        rms[plan] = float(np.sqrt((((out - ref) / terms) ** 2).mean()))
+    print(f"f16c gemm {shape}: max err / sum|a||w| plan 0 {errs[0]:.2e}, 1 {errs[1]:.2e}, 2 {errs[2]:.2e}; rms {rms[0]:.2e} {rms[1]:.2e} {rms[2]:.2e}")
+    assert rms[1] < 0.85 * rms[0] and rms[2] < 0.45 * rms[0], (errs, rms)
+
+
 @pytest.mark.parametrize("shape", [(300, 512, 256), (256, 256, 128), (1030, 768, 3072), (77, 1024, 384)])
 def test_gemm_fp8_exact_on_representable_operands(gpu_lib, shape):
     """The fp8 instances of the 256x256 kernel (v_mfma_scale_f32_16x16x128_f8f6f4, BASELINE configs[4]).  Operands that are exactly
