@@ -108,6 +108,11 @@ struct arp_dt {
     // 16-bit modes: the fused kernel's big linears on (hi, lo) binary16 operand pairs (policy_fused.h::pf_lin_x3: f32-level products at 5.3x the f32 MFMA
     // rate); the f32 parity mode keeps v_mfma_f32_16x16x4_f32.  ARP_PF_X3=0/1 overrides either way (A/B, tests).
     bool pf_x3 = false;
+    // f16 mode, optional (arp_dt_set_adapter_corrections / ARP_DT_ADAPTER_C=1): the adapter's two FORWARD products with their operand roundings corrected on the
+    // scaled fp4 MFMA (ARP_MODE_F16C's product, gemm256 MIXC) and its output handed to the mix in f32 -- the policy's own share of the encoder-inside logit error
+    // (the comment at fwd_w: X, W1, H1, W2, A) without the f32 MFMA.  The backward reads the same plain binary16 Xb / H1 / A as before.
+    bool adapter_c = false;
+    DevBuf Xc, H1c, A32, W1c, W2c, wc_scal;  // operand rows [hi | x4 | dx4]; packed weights [W_hi | dW4 | W4]; wc_scal: 2 x {absmax pair (2 floats), scale pair (2 ints)}
     ncclComm_t comm = nullptr;
     bool has_comm = false;
     // data-parallel step: gradient all-reduce in two buckets on a communication stream, bucket 1 (image_text_input's kernel, 94 % of
@@ -361,6 +366,21 @@ template <typename T> int refresh_shadows(arp_dt* c) {
     const T* W2 = static_cast<const T*>(c->fwd_w("AdapterMLP_0/Dense_1/kernel"));
     const T* Wi = static_cast<const T*>(c->fwd_w("image_text_input/kernel"));
     if (k.use_adapter) ARP_TRY((transpose_mask<T, T, T>(c, W2, D, nullptr, nullptr, 1.f, nullptr, 0, c->W2t.as<T>(), D, D, D)));
+    if constexpr (__is_same(T, f16_t)) {
+        if (k.use_adapter && c->adapter_c) {  // [W_hi | dW4 | W4] of the adapter's two kernels from the f32 parameters, scales chosen on the device
+            ARP_TRY(c->W1c.ensure((size_t)D * 3 * D + 512)); ARP_TRY(c->W2c.ensure((size_t)D * 3 * D + 512)); ARP_TRY(c->wc_scal.ensure(64));
+            ARP_HIP_OK(hipMemsetAsync(c->wc_scal.p, 0, 64, c->stream));
+            const char* names[2] = {"AdapterMLP_0/Dense_0/kernel", "AdapterMLP_0/Dense_1/kernel"};
+            DevBuf* dst[2] = {&c->W1c, &c->W2c};
+            for (int i = 0; i < 2; ++i) {
+                unsigned int* mx = c->wc_scal.as<unsigned int>() + 8 * i;
+                hipLaunchKernelGGL(wc_absmax_kernel, dim3(64), dim3(256), 0, c->stream, c->p(names[i]), (size_t)D * D, mx);
+                hipLaunchKernelGGL(wc_pack_kernel, dim3(cdiv((size_t)D * D, 1024)), dim3(256), 0, c->stream, c->p(names[i]), D, D, mx, dst[i]->as<f16_t>(),
+                                   reinterpret_cast<int*>(mx) + 4);
+            }
+            ARP_HIP_OK(hipGetLastError());
+        }
+    }
     // the fused dY kernel reads Wi as it lies; only the unfused path wants the [Kin, E] copy
     if (!c->use_fused_dy()) ARP_TRY((transpose_mask<T, T, T>(c, Wi, (int)Kin, nullptr, nullptr, 1.f, nullptr, 0, c->Wit.as<T>(), E, E, (int)Kin)));
     c->shadows_stale = false;
@@ -523,6 +543,7 @@ int ensure_buffers(arp_dt* c, int B) {
     }
     ARP_TRY(c->colpart.ensure((Mxp / 64) * (size_t)D * 4));
     if (c->iti_f32 && k.use_adapter) ARP_TRY(c->Y32.ensure(Mx * D * 4));
+
     DevBuf* tt[] = {&c->XbT, &c->H1T, &c->dApreT, &c->dH1T};
     for (auto* b : tt) {
         ARP_TRY(b->ensure((size_t)D * Mxp * e));
@@ -591,9 +612,12 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     if (c->use_images) {  // frozen M3AE encoder under stop_gradient (arp_dt/ARPDT.py:418-462): frames -> encodings, on this stream
         ARP_TRY(enc_forward_on(c->enc, c->stream, c->bt[c->cur].img32.as<float>(), R, c->bt[c->cur].enc32.as<float>()));
     }
+    const bool adapter_cpath = __is_same(T, f16_t) && k.use_adapter && c->adapter_c && D % 256 == 0 && D >= 512;
     {   // enc f32 -> operand type, both layouts (the transposed one feeds the weight-gradient GEMM)
         ProfScope ps(c->prof, c->stream, "dt.enc_convert");
-        if (k.use_adapter && !c->use_tn()) {
+        if (adapter_cpath && c->use_tn()) {
+            // (convert_f16c_kernel below writes Xb beside the [hi | x4 | dx4] rows in one pass over the encodings)
+        } else if (k.use_adapter && !c->use_tn()) {
             ARP_TRY((transpose_mask<float, float, T>(c, c->bt[c->cur].enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D, c->XbT.as<T>(), Mxp, (int)Mx, D)));
         } else if constexpr (sizeof(T) == 2) {  // no transposed copy wanted: a flat 16-byte-per-lane conversion
             const size_t n = Mx * D;
@@ -605,7 +629,55 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         }
     }
     const T* Yp = c->Xb.as<T>();
-    if (k.use_adapter) {
+    bool adapter_done = false;
+    if constexpr (__is_same(T, f16_t)) {
+        if (adapter_cpath) {
+            ARP_TRY(c->Xc.ensure(Mx * 3 * D + 4096)); ARP_TRY(c->H1c.ensure(Mx * 3 * D + 4096)); ARP_TRY(c->A32.ensure(Mx * D * 4));
+            // relu(relu(x W1 + b1) W2 + b2) with every operand rounding of the two products corrected (gemm256 MIXC): x -> [hi | x4 | dx4] rows, fc1 writes the
+            // hidden rows [hi | x4 | dx4] itself (x4 from the rounded tile, dx4 from the accumulators), fc2 writes the output in f32 for the mix and its binary16
+            // copy for the backward; the plain binary16 Xb / H1 the backward reads come out of the same passes.
+            {
+                ProfScope ps(c->prof, c->stream, "dt.enc_convert");
+                hipLaunchKernelGGL(convert_f16c_kernel, dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<f16_t>(), c->Xc.as<f16_t>(), Mx, D);
+                ARP_HIP_OK(hipGetLastError());
+            }
+            const int* sc = reinterpret_cast<const int*>(c->wc_scal.p);
+            auto mixc = [&](GemmArgs& g, const void* A, const void* W, const float* bias, const int* sptr) {
+                g.A = A; g.W = W; g.bias = bias; g.M = (int)Mx; g.N = D;
+                g.lda = D + D / 2; g.ldw = D + D / 2; g.ldr = D;
+                g.mix_nk16 = D / 64; g.mix_nkc_a = D / 256; g.K = D + D / 2; g.mix_sptr = sptr;
+            };
+            {
+                GemmArgs g;
+                mixc(g, c->Xc.p, c->W1c.p, c->p("AdapterMLP_0/Dense_0/bias"), sc + 4);
+                g.out = c->H1c.p; g.ldo = D + D / 2;
+                g.xb_out = static_cast<char*>(c->H1c.p) + 2 * (size_t)D; g.ldxb = 3 * D; g.x8_shift = F16C_X_SHIFT;
+                g.dx4_out = static_cast<char*>(c->H1c.p) + 2 * (size_t)D + D / 2;
+                ProfScope ps(c->prof, c->stream, "dt.adapter_fc1");
+                ARP_TRY((launch_gemm256_nt<f16_t, f16_t, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
+            }
+            {
+                ProfScope ps(c->prof, c->stream, "dt.adapter_fc1");
+                hipLaunchKernelGGL(extract_hi_kernel, dim3(cdiv(Mx * D, 2048)), dim3(256), 0, c->stream, c->H1c.as<f16_t>(), D + D / 2, c->H1.as<f16_t>(), Mx, D);
+                ARP_HIP_OK(hipGetLastError());
+            }
+            {
+                GemmArgs g;
+                mixc(g, c->H1c.p, c->W2c.p, c->p("AdapterMLP_0/Dense_1/bias"), sc + 12);
+                g.out = c->A32.p; g.ldo = D;
+                g.xb_out = c->A.p; g.ldxb = D;
+                ProfScope ps(c->prof, c->stream, "dt.adapter_fc2");
+                ARP_TRY((launch_gemm256_nt<f16_t, float, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
+            }
+            ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
+            hipLaunchKernelGGL((adapter_mix_kernel<T, float>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A32.as<float>(), c->bt[c->cur].enc32.as<float>(),
+                               c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
+            ARP_HIP_OK(hipGetLastError());
+            Yp = c->Y.as<T>();
+            adapter_done = true;
+        }
+    }
+    if (k.use_adapter && !adapter_done) {
         // AdapterMLP: relu(relu(x W1 + b1) W2 + b2)   (arp_dt/models/adapter/layers.py:19-30)
         ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc1", c->Xb.p, D, c->fwd_w("AdapterMLP_0/Dense_0/kernel"), D, c->p("AdapterMLP_0/Dense_0/bias"), c->H1.p, D, (int)Mx, D, D)));
         ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc2", c->H1.p, D, c->fwd_w("AdapterMLP_0/Dense_1/kernel"), D, c->p("AdapterMLP_0/Dense_1/bias"), c->A.p, D, (int)Mx, D, D)));
@@ -1165,6 +1237,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     c->iti_f32 = k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_ITI_F32")) c->iti_f32 = atoi(e) != 0 && k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_ITI_X3")) c->iti_x3 = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_ADAPTER_C")) c->adapter_c = atoi(e) != 0 && k.mode == ARP_MODE_F16;
     if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_SIDE")) c->side_gemms = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
@@ -1217,7 +1290,7 @@ int arp_dt_destroy(arp_dt* c) {
         if (e) (void)hipEventDestroy(e);
     c->prof.destroy();
     DevBuf* all[] = {&c->params, &c->grads, &c->mu, &c->nu, &c->mirror, &c->W2t, &c->Wit, &c->colpart, &c->Y32, &c->bt[0].enc32, &c->bt[0].img32, &c->bt[0].action, &c->bt[0].rtg, &c->bt[1].enc32, &c->bt[1].img32, &c->bt[1].action, &c->bt[1].rtg, &c->bt[2].enc32, &c->bt[2].img32, &c->bt[2].action, &c->bt[2].rtg, &c->Xb, &c->XbT,
-                     &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
+                     &c->H1, &c->H1T, &c->A, &c->Y, &c->YT, &c->Xc, &c->H1c, &c->A32, &c->W1c, &c->W2c, &c->wc_scal, &c->dY, &c->dApre, &c->dApreT, &c->G, &c->dH1T, &c->dzb, &c->dzT, &c->part, &c->scal, &c->img,
                      &c->hf, &c->a_in, &c->r_in, &c->ha, &c->hr, &c->logits, &c->ret, &c->metrics, &c->dlogits, &c->dret, &c->dha, &c->dhr, &c->da_in,
                      &c->dr_in, &c->dhf, &c->dh, &c->t1, &c->t2, &c->t3, &c->dws, &c->dbs, &c->dimg, &c->dz, &c->dqkv,
                      &c->dwsf, &c->dbsf, &c->dtok, &c->loss_part, &c->gtab, &c->gprefix, &c->ctab, &c->cprefix, &c->pf_pack, &c->pf_jobs};
@@ -1529,6 +1602,15 @@ int arp_dt_comm_selfcheck(arp_dt* c, double* sum) {
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     ARP_TRY(c->scal.ensure(4096 * 4));
     return rccl_selfcheck(c->comm, c->has_comm, c->stream, c->scal.as<float>(), c->cfg.rank, sum);
+}
+
+int arp_dt_set_adapter_corrections(arp_dt* c, int on) {
+    if (!c) return fail("null handle");
+    if (on && c->cfg.mode != ARP_MODE_F16) return fail("adapter corrections exist in ARP_MODE_F16 only (binary16 products corrected on the fp4 MFMA)");
+    if (on && (c->cfg.enc_dim % 256 || c->cfg.enc_dim < 512)) return fail("adapter corrections need enc_dim to be a multiple of 256 and >= 512");
+    c->adapter_c = on != 0;
+    c->shadows_stale = true;  // the packed [W_hi | dW4 | W4] weights are built by refresh_shadows
+    return 0;
 }
 
 // sync_state_fn (main_procgen.py:94-101): every rank takes rank 0's params and optimizer state

@@ -364,8 +364,8 @@ __global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restric
 
 // ---- adapter mix (arp_dt/ARPDT.py:466-472):  y = res*a + (1-res)*x,  res = sigmoid(residual_weight) -----
 // x is the f32 encoder output itself, not its operand-type copy: the skip term then carries no operand rounding.
-template <typename T>
-static __global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __restrict__ a, const float* __restrict__ x, const float* __restrict__ rw,
+template <typename T, typename TA = T>  // TA = float: the adapter output before its rounding to the operand type (arp_dt.hip `adapter_c`)
+static __global__ __launch_bounds__(256) void adapter_mix_kernel(const TA* __restrict__ a, const float* __restrict__ x, const float* __restrict__ rw,
                                                           T* __restrict__ y, size_t n, float* __restrict__ y32 = nullptr) {
     // y32 (optional): the un-rounded mix, for the f32 image_text_input of the precise mode (arp_dt.hip, ARP_DT_ITI_F32)
     const float res = 1.0f / (1.0f + expf(-rw[0]));
@@ -380,11 +380,69 @@ static __global__ __launch_bounds__(256) void adapter_mix_kernel(const T* __rest
         if (y32) store4(y32 + i, yv[0], yv[1], yv[2], yv[3]);
     } else {
         for (size_t j = i; j < n; ++j) {
-            const float v = res * Elem<T>::ld(a + j) + (1.f - res) * x[j];
+            const float v = res * Elem<TA>::ld(a + j) + (1.f - res) * x[j];
             Elem<T>::st(y + j, v);
             if (y32) y32[j] = v;
         }
     }
+}
+
+// ---- the adapter's forward with its operand roundings corrected on the fp4 MFMA (ARP_MODE_F16C's product, common.h; arp_dt.hip `adapter_c`) -------------
+// enc f32 [rows, D] -> xb [rows, D] binary16 (the backward's operand, as convert8_kernel writes it) AND xc [rows][hi | x4 | dx4] (3 D bytes per row)
+static __global__ __launch_bounds__(256) void convert_f16c_kernel(const float* __restrict__ in, f16_t* __restrict__ xb, f16_t* __restrict__ xc, size_t rows, int D) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= rows * (size_t)D) return;
+    const size_t r = i / D;
+    const int c = (int)(i - r * D);
+    float v[4];
+    load4(in + i, v);
+    store4(xb + i, v[0], v[1], v[2], v[3]);
+    store_f16c<true>(xc + r * (size_t)(3 * D / 2), c, D, v[0], v[1], v[2], v[3]);
+}
+// rows [hi | ...] of stride ld (binary16 units) -> contiguous [rows, D] binary16 (the plain copy the backward reads)
+static __global__ __launch_bounds__(256) void extract_hi_kernel(const f16_t* __restrict__ in, int ld, f16_t* __restrict__ out, size_t rows, int D) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= rows * (size_t)D) return;
+    const size_t r = i / D;
+    const int c = (int)(i - r * D);
+    *reinterpret_cast<u32x4_v*>(out + i) = *reinterpret_cast<const u32x4_v*>(in + r * (size_t)ld + c);
+}
+// max |w - rn16(w)| and max |w| of a weight tensor -> mx[0], mx[1] (as non-negative float bits; mx zeroed by the caller)
+static __global__ __launch_bounds__(256) void wc_absmax_kernel(const float* __restrict__ w, size_t n, unsigned int* __restrict__ mx) {
+    float md = 0.f, mw = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = w[i];
+        md = fmaxf(md, fabsf(v - h2f(f2h(v))));
+        mw = fmaxf(mw, fabsf(v));
+    }
+    md = wave_max(md); mw = wave_max(mw);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(mx, __float_as_uint(md));
+        atomicMax(mx + 1, __float_as_uint(mw));
+    }
+}
+// w f32 [N, K] -> rows [W_hi: binary16 x K | dW4: e2m1 x K | W4: e2m1 x K] (3 K bytes), scales 2^sc[0] / 2^sc[1] = the powers of two that put the largest
+// |dW| / |W| into (6, 12] (as arp_enc.hip::pack_weight_c chooses them on the host); thread 0 publishes them for the product (GemmArgs::mix_sptr)
+static __global__ __launch_bounds__(256) void wc_pack_kernel(const float* __restrict__ w, int N, int K, const unsigned int* __restrict__ mx, f16_t* __restrict__ out,
+                                                             int* __restrict__ sc) {
+    const float md = __uint_as_float(mx[0]), mw = __uint_as_float(mx[1]);
+    const int sd = md > 0.f ? (int)floorf(log2f(6.0f / md)) + 1 : 0, sw = mw > 0.f ? (int)floorf(log2f(6.0f / mw)) + 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = sd; sc[1] = sw; }
+    const float fd = ldexpf(1.0f, sd), fw = ldexpf(1.0f, sw);
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (size_t)N * K) return;
+    const size_t r = i / K;
+    const int c = (int)(i - r * K);
+    float v[4];
+    load4(w + i, v);
+    f16_t* row = out + r * (size_t)(3 * K / 2);
+    float h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = h2f(f2h(v[j]));
+    *reinterpret_cast<uint2*>(row + c) = make_uint2(pack_h2(h[0], h[1]), pack_h2(h[2], h[3]));
+    uint8_t* seg = reinterpret_cast<uint8_t*>(row + K);
+    *reinterpret_cast<uint16_t*>(seg + (c >> 1)) = pack_fp4x4((v[0] - h[0]) * fd, (v[1] - h[1]) * fd, (v[2] - h[2]) * fd, (v[3] - h[3]) * fd);
+    *reinterpret_cast<uint16_t*>(seg + (K >> 1) + (c >> 1)) = pack_fp4x4(v[0] * fw, v[1] * fw, v[2] * fw, v[3] * fw);
 }
 
 // partial[b] = sum over the block's slice of dy * (a - x)      (d loss / d res; finished by reduce_sum)

@@ -356,7 +356,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
         }
     };
-    int mix_scale = 0;  // MIXC: the e8m0 scale word of the current e4m3 K-tile (wave-uniform)
+    int mix_scale = 0;  // MIXC: the e8m0 scale word of the current e2m1 K-tile (wave-uniform)
+    int mix_sa = g.mix_sa, mix_sb = g.mix_sb;
+    if constexpr (MIXC) {
+        if (g.mix_sptr) {  // scales chosen on the device (uniform loads)
+            mix_sa = F16C_X_SHIFT + g.mix_sptr[0];
+            mix_sb = F16C_DX_SHIFT + g.mix_sptr[1];
+        }
+    }
     auto mfma_quadrant = [&](auto MQ, auto NQ, auto F8 = F16T{}) __attribute__((always_inline)) {
         constexpr int mq = decltype(MQ)::value, nq = decltype(NQ)::value;
         if constexpr (MIXC && sizeof(T) == 2 && !W32) {
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         };
         auto ktile_ss = [&](int kt, auto BUF, auto F8) __attribute__((always_inline)) {  // one K-tile out of ring buffer BUF (compile-time: its fragment addresses are loop constants)
             const char* buf = smem + ((MIXC && RESID && ARP_G2_MIXC_RT) ? (kt & 1) : decltype(BUF)::value) * G2_BUF_BYTES;
-            if constexpr (MIXC && decltype(F8)::value) mix_scale = 0x7f7f7f00 | (127 - (kt < g.mix_nk16 + g.mix_nkc_a ? g.mix_sa : g.mix_sb));
+            if constexpr (MIXC && decltype(F8)::value) mix_scale = 0x7f7f7f00 | (127 - (kt < g.mix_nk16 + g.mix_nkc_a ? mix_sa : mix_sb));
             load_a(buf, 0, F8);
             load_b(buf, I0{}, F8);
             load_b(buf, I1{}, F8);
@@ -561,8 +568,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
         };
         if constexpr (MIXC) {
+            // ALL K-tiles run in the steady-state bodies: the last two issue the (non-existent) K-tiles nk and nk + 1 -- up to 256 bytes past a row's end, which
+            // the caller keeps readable (GemmArgs::mix_nk16) and nobody consumes -- instead of running a tail whose shrinking waits and existence tests hipcc
+            // compiled into straight-line copies with accumulator spills between the MFMAs (3 of a K = 768 product's 15 K-tiles, each behind a vmcnt(0))
             run_ss(g.mix_nk16, F16T{});
-            run_ss(nk - 2, F8T{});
+            run_ss(nk, F8T{});
+            wait_vmcnt<0>();  // the two over-issued K-tiles land before the epilogue takes the ring over
         } else {
             run_ss(nk - 2, F16T{});
         }
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         const char* buf = smem + (kt & 1) * G2_BUF_BYTES;
         const int p = 2 * kt;
         abl_kt = kt;
-        if constexpr (MIXC && decltype(F8)::value) mix_scale = 0x7f7f7f00 | (127 - (kt < g.mix_nk16 + g.mix_nkc_a ? g.mix_sa : g.mix_sb));
+        if constexpr (MIXC && decltype(F8)::value) mix_scale = 0x7f7f7f00 | (127 - (kt < g.mix_nk16 + g.mix_nkc_a ? mix_sa : mix_sb));
         // phase A: quadrants (0,0) and (0,1)
         ARP_FST(0);
         load_a(buf, 0, F8);
@@ -593,12 +604,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         compute2(I1{}, I1{}, I0{}, F8);
         ARP_FST(8);
     };
-    if constexpr (MIXC) {
-        // the launcher guarantees >= 2 trailing e4m3 K-tiles: the two tail tiles are of that kind, straight-line (a run-time kind here, or a loop, costs the
-        // allocator the joins it then pays for with scratch traffic -- and a scratch reload is a vmcnt(0), i.e. a drained LDS-DMA ring)
-        ktile_tail(nk - 2, F8T{});
-        ktile_tail(nk - 1, F8T{});
-    } else {
+    if constexpr (!MIXC) {
         for (int kt = kt_first; kt < nk; ++kt) ktile_tail(kt, F16T{});
     }
 #else
@@ -757,6 +763,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                                 apply_act4<ACT, sizeof(T) <= 2>(v);
                                 *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
+                                if constexpr (MIXC && __is_same(OutT, f16_t)) {
+                                    if (g.dx4_out && m0 + row < g.M && n0 + col < g.N) {  // the dx4 segment of the next product's operand row (GemmArgs::dx4_out)
+                                        constexpr float sdx = (float)(1 << F16C_DX_SHIFT);
+                                        *reinterpret_cast<uint16_t*>(static_cast<char*>(g.dx4_out) + (size_t)(m0 + row) * g.ldxb + ((n0 + col) >> 1)) =
+                                            pack_fp4x4((v[0] - h2f(f2h(v[0]))) * sdx, (v[1] - h2f(f2h(v[1]))) * sdx, (v[2] - h2f(f2h(v[2]))) * sdx, (v[3] - h2f(f2h(v[3]))) * sdx);
+                                    }
+                                }
                             }
                     }
             };

@@ -56,9 +56,11 @@ class PolicyConfig:
 class PolicyTrainer:
     """Owns one GPU's copy of the policy: parameters, Adam state, activations, RCCL communicator."""
 
-    def __init__(self, cfg, mode="f16", device=0):
+    def __init__(self, cfg, mode="f16", device=0, adapter_corrections=False):
         """mode: GEMM operand type of the adapter path -- "f16" (default: the 16-bit mode that meets north_star's 1e-3 on the
-        logits), "bf16" (8 significand bits: ~1e-2) or "f32" (f32-input MFMA, the parity mode)."""
+        logits), "bf16" (8 significand bits: ~1e-2) or "f32" (f32-input MFMA, the parity mode).
+        adapter_corrections (f16 only): the adapter's forward products with their operand roundings corrected on the fp4 MFMA
+        (arp_dt_set_adapter_corrections) -- what the encoder-inside step (row N1, encoder mode "f16c") pairs with."""
         _ffi.require_gpu()
         self.cfg = cfg
         c = _ffi.DtCfg(cfg.emb, cfg.depth, cfg.heads, cfg.mlp_ratio, cfg.n_actions, cfg.window, cfg.enc_tokens, cfg.enc_dim,
@@ -67,6 +69,8 @@ class PolicyTrainer:
         h = C.c_void_p()
         check(lib.arp_dt_create(C.byref(c), C.byref(h)))
         self._h = h
+        if adapter_corrections:
+            check(lib.arp_dt_set_adapter_corrections(h, 1))
         self.world, self.rank = 1, 0
         self.shapes = {}
         n = C.c_int32()

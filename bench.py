@@ -291,6 +291,8 @@ def run_secondary(a):
         # tests/test_m3ae_gpu.py); the f16 line beside it is a throughput mode whose own parity block says whether it is inside
         "policy_with_encoder": ["--path", "policy", "--with-encoder", "--mode", "f32"],
         "policy_with_encoder_f16x3": ["--path", "policy", "--with-encoder", "--mode", "f32", "--encoder-mode", "f16x3"],  # f32-accurate on the 16-bit MFMA
+        # round 5: binary16 products with their operand roundings corrected on the fp4 MFMA, encoder AND adapter: the 16-bit line that carries the parity claim
+        "policy_with_encoder_f16c": ["--path", "policy", "--with-encoder", "--mode", "f16", "--encoder-mode", "f16c"],
         "policy_with_encoder_f16": ["--path", "policy", "--with-encoder", "--mode", "f16"],
         "finetune": ["--path", "finetune"],
         "policy": ["--path", "policy"],
@@ -430,13 +432,15 @@ def bench_policy(a):
         raise SystemExit(f"--path policy --gpus {world}: {_ffi.device_count()} GPU(s) visible; RCCL needs one GPU per rank")
     _ffi.check(_ffi.lib.arp_set_device(local_rank))
     cfg = PolicyConfig(lambda_ret=0.01)
+    # row N1's 16-bit parity line: the f16c encoder (operand roundings corrected on the fp4 MFMA) goes with the same corrections on the policy's adapter
+    adapter_c = a.mode == "f16" and (a.adapter_c or (a.with_encoder and (a.encoder_mode or a.mode) == "f16c"))
     # parity gate (rank 0): the mode timed below, real geometry (257 x 768 encodings, K = 197 376), B = 2, against the fp64 oracle
     parity = None
     parity_geometry = "B = 2, window 4, 257 x 768 encodings in (K = 197 376)"
     if rank == 0 and a.parity_frames > 0:
         from oracle import arpdt_torch as O
         Pp = S.policy_params(cfg, seed=3)
-        t0 = PolicyTrainer(cfg, mode=a.mode, device=local_rank)
+        t0 = PolicyTrainer(cfg, mode=a.mode, device=local_rank, adapter_corrections=adapter_c)
         t0.set_params(Pp)
         if a.with_encoder:
             # the configuration that is timed: FRAMES in, the frozen encoder in the timed mode in front of the policy in the timed mode, against
@@ -465,7 +469,7 @@ def bench_policy(a):
             out = t0.forward()
             t0.close()
         parity = max(float(np.abs(out["action_pred"] - ref["action_pred"].numpy()).max()), float(np.abs(out["return_pred"] - ref["return_pred"].numpy()).max()))
-    tr = PolicyTrainer(cfg, mode=a.mode, device=local_rank)
+    tr = PolicyTrainer(cfg, mode=a.mode, device=local_rank, adapter_corrections=adapter_c)
     tr.set_params(S.policy_params(cfg, seed=0))
     if world > 1:  # RCCL id from rank 0 over gloo, communicator, sync_state_fn
         train.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
@@ -903,6 +907,7 @@ def main():
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
     ap.add_argument("--encoder-mode", default=None, choices=["bf16", "f16", "f32", "f16x3", "f16c"], help="policy path with --with-encoder: operand mode of the frozen encoder "
                     "(default: --mode).  f16x3 = (hi, lo) binary16 operand pairs, three 16-bit MFMAs per product, f32 attention: f32-level error")
+    ap.add_argument("--adapter-c", action="store_true", help="policy path, f16: the adapter's forward products corrected on the fp4 MFMA (implied by --encoder-mode f16c)")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
     ap.add_argument("--all-secondary", dest="all_secondary", action="store_true", default=True,

@@ -224,6 +224,10 @@ int arp_dt_event_record(arp_dt* h, arp_event* e);
 int arp_dt_comm_unique_id(void* id128);
 int arp_dt_comm_init(arp_dt* h, const void* id128, int world, int rank);
 int arp_dt_broadcast_state(arp_dt* h);
+/* ARP_MODE_F16 only: the adapter's two FORWARD products (models/adapter/layers.py:19-30) with their binary16 operand roundings corrected on the scaled fp4 MFMA
+ * (ARP_MODE_F16C's product) and the adapter output handed to the residual mix in f32: takes the policy's own share out of the encoder-inside logit error
+ * (row N1) for ~0.1 ms per step.  Off by default (ARP_DT_ADAPTER_C=1 turns it on at create); the backward is unchanged. */
+int arp_dt_set_adapter_corrections(arp_dt* h, int on);
 /* What the communicator says about itself, for a multi-GPU run that certifies itself (the pmean of main_procgen.py:132 needs every
  * device in it): info5 = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion code, 1 if a communicator exists};
  * without one (world 1) {1, 0, device, 0, 0}.  arp_dt_comm_selfcheck all-reduces (sum) the scalar rank + 1 through that

@@ -32,7 +32,7 @@ for seed in range(n_seeds):
     t_or = time.perf_counter() - t0
     for em, pm in pairs:
         enc = m3ae.M3AEEncoder(ecfg, EP, mode=em)
-        tr = PolicyTrainer(pcfg, mode=pm)
+        tr = PolicyTrainer(pcfg, mode=pm.replace("+c", ""), adapter_corrections=pm.endswith("+c"))  # "f16+c": adapter products corrected on the fp4 MFMA
         tr.set_params(P)
         tr.attach_encoder(enc)
         tr.set_batch_images(frames, act, rtg)
