@@ -99,6 +99,14 @@ __device__ __forceinline__ f32x4_v mfma_fp4_scaled(u32x4_v a, u32x4_v b, f32x4_v
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, c, 4, 4, 0, scale, 1, scale);
 }
 
+// The same under a lane mask (wave-uniform, SGPR pair): an LDS-DMA that has to be ISSUED -- the counted vmcnt waits of a steady-state loop count it --
+// but whose bytes nobody wants is issued for lane 0 only (mask = 1): 16 bytes through the address path instead of 1 KiB.
+__device__ __forceinline__ void dma16_saddr_masked(const void* sbase, uint32_t voff, uint32_t lds_dst, unsigned long long mask) {
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(mask) : "memory");
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }

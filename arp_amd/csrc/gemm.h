@@ -72,7 +72,6 @@ struct GemmArgs {
     // (128 bytes each) are mix_nk16 = Kc / 64 binary16 tiles, then mix_nkc_a = Kc / 256 fp4 tiles whose products are scaled by 2^-mix_sa, then fp4 tiles
     // scaled by 2^-mix_sb: out = A_hi.W_hi^T + 2^-sa A4.dW4^T (+ 2^-sb dA4.W4^T) -- the operand-rounding corrections of a binary16 GEMM on the scaled
     // fp4 MFMA, which moves four times the k per cycle.  K (in binary16 units) covers all of them: K = 64 * (nk16 + nkc_a + nkc_b).
-    // The kernel reads up to 256 bytes past the end of every A and W row's K range (two over-issued K-tiles, never consumed): both buffers need that slack.
     int mix_nk16 = 0, mix_nkc_a = 0, mix_sa = 0, mix_sb = 0;
     // gemm256, 16-bit staged epilogue: also store fp4(value * 2^x8_shift) of the same tile at xb_out + row * ldxb (bytes) + column / 2 -- the e2m1
     // segment of the NEXT GEMM's [hi | x4] operand row (c_fc's epilogue feeding c_proj in ARP_MODE_F16C)

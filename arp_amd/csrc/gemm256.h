@@ -269,10 +269,22 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         }
     };
     // KV = 1, steady state: unit U of K-tile tt, no existence test
+    // (the last two K-tiles' bodies "issue" K-tiles nk and nk + 1, which do not exist: their source is clamped to the last real K-tile -- re-read, in bounds,
+    //  never consumed -- while the ring slot stays the nominal one, so the steady state needs no existence tests and no tail)
     auto issue_ss = [&](int tt, auto U) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         if constexpr (MIXC && ARP_G2_MIX_UNIFORM) {
             issue_mix(tt, U);
+            return;
+        }
+        if constexpr (MIXC) {
+            // (MIXC runs EVERY K-tile in a steady-state body: the last two "issue" K-tiles nk and nk + 1, which do not exist.  Their LDS-DMAs are issued all the
+            //  same -- the loop's counted waits count them -- but for lane 0 only, from the last real K-tile (in bounds), into the nominal, dead ring slot.
+            //  Issued for all 64 lanes they cost the K = 768 products 2 of 15 K-tiles' worth of address-path time.)
+            const char* sb = ((u == 0 || u == 3) ? a_tile : w_tile) + (size_t)min(tt, nk - 1) * 128;
+            const unsigned long long lanes = tt < nk ? ~0ull : 1ull;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma16_saddr_masked(sb, off32[u][i], lds0 + (tt & 1) * G2_BUF_BYTES + dst[u][i], lanes);
             return;
         }
         const char* sb = ((u == 0 || u == 3) ? a_tile : w_tile) + (size_t)tt * 128;
@@ -568,13 +580,15 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
         };
         if constexpr (MIXC) {
-            // ALL K-tiles run in the steady-state bodies: the last two issue the (non-existent) K-tiles nk and nk + 1 -- up to 256 bytes past a row's end, which
-            // the caller keeps readable (GemmArgs::mix_nk16) and nobody consumes -- instead of running a tail whose shrinking waits and existence tests hipcc
-            // compiled into straight-line copies with accumulator spills between the MFMAs (3 of a K = 768 product's 15 K-tiles, each behind a vmcnt(0))
+            // ALL K-tiles run in the steady-state bodies (issue_ss clamps the two over-issued K-tiles' source) instead of a tail whose shrinking waits and
+            // existence tests hipcc compiled into straight-line copies with accumulator spills between the MFMAs (3 of a K = 768 product's 15 K-tiles, each
+            // behind a vmcnt(0)): 15.2 -> 12.5 ms per encoder-inside step
             run_ss(g.mix_nk16, F16T{});
             run_ss(nk, F8T{});
-            wait_vmcnt<0>();  // the two over-issued K-tiles land before the epilogue takes the ring over
+            kt_first = nk;
         } else {
+            // (every K-tile in a steady-state body here too, the last two with over-issued LDS-DMAs, was measured and NOT kept: the tail of these instances
+            //  compiles clean, and two more K-tiles' worth of LDS-DMA issue cost the K = 768 products the 2-3 % the KV = 1 loop had won: profiles/r5_kv_ab_harness.txt)
             run_ss(nk - 2, F16T{});
         }
     }
@@ -605,8 +619,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         ARP_FST(8);
     };
     if constexpr (!MIXC) {
-        for (int kt = kt_first; kt < nk; ++kt) ktile_tail(kt, F16T{});
+        for (int kt = kt_first; kt < nk; ++kt) ktile_tail(kt, F16T{});  // KV = 0 builds, and products of fewer than three K-tiles
     }
+    if constexpr (MIXC) wait_vmcnt<0>();  // this wave's over-issued LDS-DMAs have landed ...
 #else
     // ---- prologue: units 0..4 in flight, units 0 and 1 landed and visible ---------------------------
     if (!pre_issued) {
@@ -657,6 +672,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MIXC) {
+        // ... and, one barrier later, every wave's: the epilogue stages its tile over the ring, which an LDS-DMA still in flight would overwrite
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #ifdef ARP_G2_FINE
     if (arp_g2_stamps && (threadIdx.x & 63) == 0) {
         long long* d = arp_g2_stamps + ((size_t)tix * 8 + wave) * 16;

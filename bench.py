@@ -1097,11 +1097,14 @@ def main():
         peak = PEAK_TFLOPS[a.mode]
         traffic = None
         mfma_util = None
+        traffic_stale = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch of the dominant kernel from committed rocprofv3 --pmc passes
             try:
                 rec = json.load(open(tpath)).get(dom, {})
                 traffic = rec.get("hbm_bytes_per_launch")
+                from arp_amd._srchash import csrc_sha1
+                traffic_stale = rec.get("csrc_sha1") != csrc_sha1()  # the committed counters were taken on other kernel sources than this tree's
                 mfma_util = rec.get("mfma_util_pct")  # rocprofv3 --pmc MfmaUtil of the same kernel, measured alone (committed run)
                 # the committed PMC run may have used a different launch size: algorithmic and measured bytes scale with the frames
                 if traffic and rec.get("frames_per_launch"):
@@ -1137,7 +1140,7 @@ def main():
                                     "headline configuration; see parity)" if a.fp8_mlp else ""),
                        "parallelism": f"shard{world} (no collective)", "streams_per_gpu": nsplit},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": traffic, "mfma_util_pct": mfma_util,
+                         "traffic": traffic, "traffic_stale": traffic_stale, "mfma_util_pct": mfma_util,
                          "traffic_source": None if traffic is None else "profiles/pmc_traffic.json: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, scaled to this launch's frames; NOT measured in this run",
                          "mfma_util_source": None if mfma_util is None else "profiles/pmc_traffic.json: committed rocprofv3 --pmc MfmaUtil pass (kernel alone on the chip); NOT measured in this run",
                          "kernel": f"{kname} @ {dom}",

@@ -5,6 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r4}
+python3 $R/arp_amd/_srchash.py > $R/gpurun_out/prof_${TAG}_csrc_sha1.txt  # the sources these counters belong to (bench.py: traffic_stale)
 $R/scripts/prof_label.sh $TAG > $R/gpurun_out/prof_${TAG}_label.log 2>&1
 $R/scripts/prof_mfma.sh $TAG > $R/gpurun_out/prof_${TAG}_mfma_summary.txt 2>&1
 cd /tmp && export TMPDIR=/tmp

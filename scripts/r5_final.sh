@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 5 closing evidence: full GPU suite, the driver's command (stdout kept as the driver sees it), rocprofv3 summaries, N1 f16c kernel trace
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out
+(time timeout 2400 python -m pytest tests -q -x -m gpu 2>&1 | grep -E "passed|failed|rror" | head -5) > $O/r5_gpu_suite.txt 2>&1
+(time python bench.py) > $O/r5_bench_default.jsonl 2> $O/r5_bench_default.err
+cp $O/bench_full.json $O/r5_bench_full.json
+./scripts/prof_round.sh r5 > $O/prof_round.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r5_n1_trace -- python3 $R/bench.py --path policy --with-encoder --mode f16 --encoder-mode f16c --steps 10 --warmup 3 --cpu-seconds 0 --parity-frames 0 > $R/gpurun_out/prof_r5_n1_trace.log 2>&1
+find $R/gpurun_out/prof_r5_n1_trace -name "*kernel_trace.csv" -delete
+cp $(find $R/gpurun_out/prof_r5_n1_trace -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r5_n1_f16c_kernel_stats.csv
+cd $R
+cat $O/r5_gpu_suite.txt; tail -n 1 $O/r5_bench_default.jsonl | head -c 1500; echo; wc -l $O/r5_bench_default.jsonl; tail -3 $O/r5_bench_default.err

@@ -86,5 +86,10 @@ if os.path.exists(mf):
         if e and "MfmaUtil_avg" in e:
             rec["mfma_util_pct"] = round(e["MfmaUtil_avg"], 2)
             rec["sq_wait_any_frac"] = round(e.get("SQ_WAIT_ANY_frac_of_wave_cycles", float("nan")), 3)
+sha_file = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_csrc_sha1.txt")
+if os.path.exists(sha_file):  # the kernel sources the passes ran on (arp_amd/_srchash.py); bench.py flags a mismatch as traffic_stale
+    sha = open(sha_file).read().strip()
+    for rec in traffic.values():
+        rec["csrc_sha1"] = sha
 json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic, indent=1))
