@@ -270,9 +270,9 @@ class TrainState:
         self._live = True
 
     @classmethod
-    def create(cls, model, params, mode="f16", device=0):
+    def create(cls, model, params, mode="f16", device=0, adapter_corrections=False):
         cfg = model if isinstance(model, PolicyConfig) else PolicyConfig(**dict(model))
-        tr = PolicyTrainer(cfg, mode=mode, device=device)
+        tr = PolicyTrainer(cfg, mode=mode, device=device, adapter_corrections=adapter_corrections)
         tr.set_params(params)
         return cls(tr)
 

@@ -671,4 +671,5 @@ def test_adapter_corrections_leave_the_backward_alone(gpu_lib):
         if np.linalg.norm(a) < 1e-12:
             continue
         assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))) > 0.999, k
-    assert max(float(np.abs(finals["plain"][k] - finals["corrected"][k]).max()) for k in P) < 5e-3
+    # three Adam steps at lr 1e-3 move a parameter by up to 3e-3, and a ~0 gradient may flip sign between the two modes: compare the MEAN difference
+    assert float(np.mean([np.abs(finals["plain"][k] - finals["corrected"][k]).mean() for k in P])) < 3e-4
