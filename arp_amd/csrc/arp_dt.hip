@@ -128,6 +128,8 @@ struct arp_dt {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_dapre = nullptr, ev_side = nullptr;
     bool side_gemms = false;
+    bool dwi_last = true;   // backward_adapter_tn: image_text_input's weight gradient last (Infinity Cache residency for the norm pass)
+    bool adam_rev = true;   // apply_update: the update walks the flat state from its end (what the norm pass touched last)
     DevBuf part_side;
     bool overlap_comm = true;   // ARP_DT_OVERLAP=0: the serial form (one all-reduce after the whole backward), for A/B and the bit-identity test
     bool force_comm = false;    // ARP_DT_FORCE_COMM=1: run the all-reduce path at world = 1 too (what a 1-GPU box can test)
@@ -167,6 +169,7 @@ struct arp_dt {
     // return error goes from max 1.05e-3 (2 seeds of 16 outside north_star's 1e-3) to max 8.7e-4 (none).  Costs the Y32 write and a
     // 1/16-rate GEMM: 0.866 -> 0.926 ms per step at B = 32 (+7 %).  The backward is unchanged.
     bool iti_f32 = false;
+    bool iti_mix = true;  // ... with the adapter's mix formed inside that kernel's operand load (ARP_DT_ITI_MIX=0: adapter_mix_kernel + a 101 MB f32 copy, rounds 3-5)
     bool iti_x3 = true;  // ... and that f32-level product on (hi, lo) binary16 MFMA pairs instead of the f32 MFMA (ARP_DT_ITI_X3=0: round 3's f32-MFMA GEMM)
     DevBuf Y32;
     DevBuf colpart;  // column partial sums of mask_copy_colsum_kernel
@@ -630,6 +633,10 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     }
     const T* Yp = c->Xb.as<T>();
     bool adapter_done = false;
+    // the adapter's mix inside image_text_input's operand load (16-bit modes with the f32-level (hi, lo) product): no mix launch, no f32 copy of the mix
+    const bool fuse_mix = sizeof(T) == 2 && k.use_adapter && c->iti_f32 && c->iti_x3 && c->iti_mix && Kin % 64 == 0 && E % 4 == 0;
+    const float* mix_a32 = nullptr;
+    const T* mix_a = nullptr;
     if constexpr (__is_same(T, f16_t)) {
         if (adapter_cpath) {
             ARP_TRY(c->Xc.ensure(Mx * 3 * D + 4096)); ARP_TRY(c->H1c.ensure(Mx * 3 * D + 4096)); ARP_TRY(c->A32.ensure(Mx * D * 4));
@@ -669,10 +676,14 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
                 ProfScope ps(c->prof, c->stream, "dt.adapter_fc2");
                 ARP_TRY((launch_gemm256_nt<f16_t, float, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
             }
-            ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
-            hipLaunchKernelGGL((adapter_mix_kernel<T, float>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A32.as<float>(), c->bt[c->cur].enc32.as<float>(),
-                               c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
-            ARP_HIP_OK(hipGetLastError());
+            if (fuse_mix) {
+                mix_a32 = c->A32.as<float>();  // the mix happens inside image_text_input's operand load (dtops.h::iti_x3_kernel)
+            } else {
+                ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
+                hipLaunchKernelGGL((adapter_mix_kernel<T, float>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A32.as<float>(), c->bt[c->cur].enc32.as<float>(),
+                                   c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
+                ARP_HIP_OK(hipGetLastError());
+            }
             Yp = c->Y.as<T>();
             adapter_done = true;
         }
@@ -683,10 +694,14 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         ARP_TRY((big_gemm<T, T, ACT_RELU>(c, "dt.adapter_fc2", c->H1.p, D, c->fwd_w("AdapterMLP_0/Dense_1/kernel"), D, c->p("AdapterMLP_0/Dense_1/bias"), c->A.p, D, (int)Mx, D, D)));
         // (the mix as a second output of fc2's epilogue measured 0.083 ms against 0.050 + 0.035 ms for the two launches: the f32 x rows
         //  arrive behind the tile instead of beside it)
-        ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
-        hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->bt[c->cur].enc32.as<float>(),
-                           c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
-        ARP_HIP_OK(hipGetLastError());
+        if (fuse_mix) {
+            mix_a = c->A.as<T>();
+        } else {
+            ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
+            hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->bt[c->cur].enc32.as<float>(),
+                               c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
+            ARP_HIP_OK(hipGetLastError());
+        }
         Yp = c->Y.as<T>();
     }
     if (sizeof(T) == 2 && c->iti_f32 && c->iti_x3 && Kin % 64 == 0 && E % 4 == 0) {
@@ -700,7 +715,21 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         S = (nk + per - 1) / per;
         ARP_TRY(c->part.ensure((size_t)S * R * E * 4));
         ProfScope ps(c->prof, c->stream, "dt.image_text_input");
-        hipLaunchKernelGGL(iti_x3_kernel, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, c->p("image_text_input/kernel"), Kin, c->part.as<float>(), R, E, (int)Kin, per * 64);
+        static const int ahead = [] { const char* e = getenv("ARP_DT_ITI_AHEAD"); return e && atoi(e) == 2 ? 2 : 1; }();
+        const float* Wi = c->p("image_text_input/kernel");
+        if constexpr (sizeof(T) == 2) {
+            if (mix_a32) {
+                hipLaunchKernelGGL((iti_x3_kernel<1, float, T>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
+                                   per * 64, mix_a32, c->p("residual_weight"), c->Y.as<T>());
+            } else if (mix_a) {
+                hipLaunchKernelGGL((iti_x3_kernel<1, T, T>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
+                                   per * 64, mix_a, c->p("residual_weight"), c->Y.as<T>());
+            } else if (ahead == 2) {
+                hipLaunchKernelGGL(iti_x3_kernel<2>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, per * 64, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr);
+            } else {
+                hipLaunchKernelGGL(iti_x3_kernel<1>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, per * 64, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr);
+            }
+        }
         ARP_HIP_OK(hipGetLastError());
         launch_splitk_reduce<float>(c->stream, c->part.as<float>(), S, (size_t)R * E, E, c->p("image_text_input/bias"), ACT_TANH, c->img.as<float>());
         ARP_HIP_OK(hipGetLastError());
@@ -803,6 +832,10 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
     const T* Yp = k.use_adapter ? c->Y.as<T>() : c->Xb.as<T>();
     // the whole backward in one call on one rank, with the adapter and the fused dY kernel: the two weight-gradient GEMMs nothing waits for go to the side stream
     const bool side = c->side_gemms && stage == 0 && k.use_adapter && c->use_fused_dy() && c->side_stream;
+    // The whole backward in one call: dWi (101 MB of f32 gradient at the real geometry, 95 % of the flat gradient) is produced LAST, so that
+    // the norm pass right behind it finds those bytes in the 256 MiB Infinity Cache instead of HBM (same launches, same arithmetic; a staged
+    // backward needs dWi first for its all-reduce bucket).  ARP_DT_DWI_LAST=0 restores the old order.
+    const bool dwi_last = c->dwi_last && stage == 0 && k.use_adapter && !side;
     if (stage != 2) {
         // dz (f32) -> operand type, scaled (rows R..Rp64 of dzb stay zero)
         ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, S, c->dzb.as<T>(), E, nullptr, 0, R, E)));
@@ -811,7 +844,8 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
             ARP_HIP_OK(hipEventRecord(c->ev_fork, c->stream));
             ARP_HIP_OK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         }
-        ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS, side)));
+        if (!dwi_last)
+            ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS, side)));
     }
     if (!k.use_adapter || stage == 1) return 0;
     const int prow = Mxp / 64, ncb = cdiv(D, 256);
@@ -875,6 +909,7 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
         ARP_HIP_OK(hipGetLastError());
     }
     ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc1_dW", c->dH1T.as<T>(), D, c->Xb.as<T>(), D, c->g("AdapterMLP_0/Dense_0/kernel"), D, D, Mxp, invS)));
+    if (dwi_last) ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS)));
     if (side) {  // join: everything after the backward (norms, Adam, a later forward) is ordered behind the side stream's two GEMMs
         ARP_HIP_OK(hipEventRecord(c->ev_side, c->side_stream));
         ARP_HIP_OK(hipStreamWaitEvent(c->stream, c->ev_side, 0));
@@ -1035,7 +1070,7 @@ int apply_update(arp_dt* c, float lr) {
 #define ARP_ADAM(TM)                                                                                                                    \
     hipLaunchKernelGGL((adam_kernel<TM>), dim3(cdiv(c->P / 4, 256)), dim3(256), 0, c->stream, c->params.as<float>(), c->grads.as<float>(),        \
                        c->mu.as<float>(), c->nu.as<float>(), c->scal.as<float>(), gscale, c->cfg.weight_decay, c->n_decay, c->cfg.clip_norm, lr, \
-                       c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P, c->mirror.as<TM>(), c->mirror_stale ? (size_t)0 : c->n_mirror)
+                       c->cfg.b1, c->cfg.b2, c->cfg.eps, bc1, bc2, c->P, c->mirror.as<TM>(), c->mirror_stale ? (size_t)0 : c->n_mirror, c->adam_rev ? 1 : 0)
     if (c->cfg.mode == ARP_MODE_BF16) ARP_ADAM(bf16_t);
     else if (c->cfg.mode == ARP_MODE_F16) ARP_ADAM(f16_t);
     else ARP_ADAM(float);
@@ -1237,9 +1272,12 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     c->iti_f32 = k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_ITI_F32")) c->iti_f32 = atoi(e) != 0 && k.mode != ARP_MODE_F32;
     if (const char* e = getenv("ARP_DT_ITI_X3")) c->iti_x3 = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_ITI_MIX")) c->iti_mix = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ADAPTER_C")) c->adapter_c = atoi(e) != 0 && k.mode == ARP_MODE_F16;
     if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_SIDE")) c->side_gemms = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_DWI_LAST")) c->dwi_last = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_ADAM_REV")) c->adam_rev = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
     build_layout(c);
     auto body = [&]() -> int {

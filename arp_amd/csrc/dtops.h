@@ -185,8 +185,17 @@ static inline void launch_splitk_reduce(hipStream_t st, const float* part, int S
 // which leaves the kernel bound by the stream alone.  One workgroup per (K slice, 128 x 128 output tile); four waves, each a 64 x 64 block with the W
 // fragment as the MFMA's A operand so that a lane ends up with four consecutive n of one row m.  The next K-tile's sixteen float4 per thread are
 // requested before this tile's MFMAs.  Fixed-order reduction of the slices by launch_splitk_reduce as before.
+// y = res * a + (1 - res) * x, ONE expression for adapter_mix_kernel and for the mix done inside iti_x3_kernel's operand load (the two must agree bit for bit)
+static __device__ __forceinline__ float adapter_mix1(float res, float a, float x) { return __builtin_fmaf(res, a, (1.f - res) * x); }
+struct iti_nomix_t {};
+// TA != iti_nomix_t: the adapter's mix inside the operand load -- X is the f32 encoder output, Amix the adapter's output (operand type, or f32 with the
+// corrected adapter), and the X operand is adapter_mix1(sigmoid(rw), a, x) formed in registers; the rounded mix (what the backward's dWi reads) goes out as
+// y16.  Saves the mix's own pass: it read a + x and wrote y16 + a 101 MB f32 copy that this kernel then read back (303 + 202 MB -> 303 MB at B = 32).
+template <int AHEAD, typename TA = iti_nomix_t, typename TY = f16_t>  // AHEAD: K-tiles of operands in flight per thread
 static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restrict__ X, size_t ldx, const float* __restrict__ W, size_t ldw, float* __restrict__ part,
-                                                     int M, int N, int K, int kslice) {
+                                                     int M, int N, int K, int kslice, const TA* __restrict__ Amix = nullptr, const float* __restrict__ rw = nullptr,
+                                                     TY* __restrict__ y16 = nullptr) {
+    constexpr bool MIX = !__is_same(TA, iti_nomix_t);
     constexpr int ROW = 80;  // binary16 elements per LDS row: 160 B = 40 dwords -- the sixteen lanes of a ds_read_b128 group (rows j, chunks g and g + 1) fall on sixteen
                              // distinct 4-bank slots; at 144 B seven of them met another's (SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles, profiles/r4_x3_pmc.json)
     __shared__ __attribute__((aligned(16))) _Float16 sm[4][128 * ROW];  // X hi, X lo, W hi, W lo
@@ -196,20 +205,47 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
     const int m0 = (blockIdx.y / n_tiles) * 128, n0 = (blockIdx.y % n_tiles) * 128;
     const int k0 = blockIdx.x * kslice, k1 = min(K, k0 + kslice);
     const int lrow = tid >> 4, lc4 = tid & 15;
-    const float* xp[8];
-    const float* wp[8];
+    // 32-bit byte offsets from the (uniform) matrix bases: a scalar base + one address register per load (128 rows of a 197 376-wide f32 matrix are 101 MB)
+    unsigned xo[8], wo[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        xp[i] = X + (size_t)min(m0 + lrow + 16 * i, M - 1) * ldx + 4 * lc4;
-        wp[i] = W + (size_t)min(n0 + lrow + 16 * i, N - 1) * ldw + 4 * lc4;
+        xo[i] = (unsigned)(((size_t)(min(m0 + lrow + 16 * i, M - 1) - m0) * ldx + 4 * lc4) * 4);
+        wo[i] = (unsigned)(((size_t)(min(n0 + lrow + 16 * i, N - 1) - n0) * ldw + 4 * lc4) * 4);
     }
-    float4 xr[8], wreg[8];
-    auto fetch = [&](int k) {
+    X += (size_t)m0 * ldx;  // (offsets stay inside the tile's 128 rows: < 4 GB for rows of up to 8 M floats)
+    W += (size_t)n0 * ldw;
+    float res = 0.f;
+    bool put_y = false;
+    if constexpr (MIX) {
+        Amix += (size_t)m0 * ldx;
+        y16 += (size_t)m0 * ldx;
+        res = 1.0f / (1.0f + expf(-rw[0]));
+        put_y = n0 == 0;  // (every X element belongs to exactly one (row tile, K slice); a second column tile would only repeat the store)
+    }
+    using areg_t = std::conditional_t<sizeof(TA) == 4, float4, uint2>;  // four a values of one lane
+    areg_t ar[AHEAD][MIX ? 8 : 1];
+    // TWO K-tiles of operands in flight per thread (2 x 16 float4; one workgroup per CU, so the registers are there): with one, a tile's loads were
+    // issued behind the previous tile's split and had only its MFMAs (0.7 us) to land in -- 3.75 TB/s of the 202 MB stream
+    float4 xr[AHEAD][8], wreg[AHEAD][8];
+    auto fetch = [&](auto ST, int k) {
+        constexpr int st = decltype(ST)::value;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            xr[i] = *reinterpret_cast<const float4*>(xp[i] + k);
-            wreg[i] = *reinterpret_cast<const float4*>(wp[i] + k);
+            xr[st][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X + k) + xo[i]);
+            if constexpr (MIX) ar[st][i] = *reinterpret_cast<const areg_t*>(reinterpret_cast<const char*>(Amix + k) + (sizeof(TA) == 4 ? xo[i] : xo[i] >> 1));
+            wreg[st][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(W + k) + wo[i]);
         }
+    };
+    // the mix of one lane's four values (adapter_mix_kernel's arithmetic) + its rounded copy to y16
+    auto mixed = [&](float4 x, areg_t a, int k, int i) __attribute__((always_inline)) {
+        if constexpr (MIX) {
+            float av[4];
+            if constexpr (sizeof(TA) == 4) { av[0] = a.x; av[1] = a.y; av[2] = a.z; av[3] = a.w; }
+            else load4(reinterpret_cast<const TA*>(&a), av);
+            x.x = adapter_mix1(res, av[0], x.x); x.y = adapter_mix1(res, av[1], x.y); x.z = adapter_mix1(res, av[2], x.z); x.w = adapter_mix1(res, av[3], x.w);
+            if (put_y && m0 + lrow + 16 * i < M) store4(reinterpret_cast<TY*>(reinterpret_cast<char*>(y16 + k) + (xo[i] >> 1)), x.x, x.y, x.z, x.w);
+        }
+        return x;
     };
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     // Range: the fixed scales put |x| >= 4094 or |w| >= 64 beyond binary16 (hi = inf, lo = NaN -> NaN logits with no warning).  The operands
@@ -230,15 +266,25 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_v{0.f, 0.f, 0.f, 0.f};
-    fetch(k0);
-    for (int k = k0; k < k1; k += 64) {
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto ktile = [&](auto ST, int k) __attribute__((always_inline)) {
+        constexpr int st = decltype(ST)::value;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            put(sm[0], sm[1], xr[i], 16.f, lrow + 16 * i);
-            put(sm[2], sm[3], wreg[i], 1024.f, lrow + 16 * i);
+            put(sm[0], sm[1], mixed(xr[st][i], ar[st][MIX ? i : 0], k, i), 16.f, lrow + 16 * i);
+            put(sm[2], sm[3], wreg[st][i], 1024.f, lrow + 16 * i);
         }
         __syncthreads();
-        if (k + 64 < k1) fetch(k + 64);
+        // unconditional (the slice's last AHEAD tiles re-request its last tile: L2 hits): a conditional fetch makes the staged registers loop-carried
+        // through a merge, and hipcc then waits for the loads right behind their issue (vmcnt(1) at the back edge) -- the prefetch gone
+#ifdef ARP_ITI_R4  // the round-4 form, for same-box A/B builds (make ALT=iti_r4 EXTRA=-DARP_ITI_R4)
+        if (k + 64 * AHEAD < k1) fetch(ST, k + 64 * AHEAD);
+#else
+        __builtin_amdgcn_sched_barrier(0);  // the requests go out HERE, ahead of the MFMAs (left alone, hipcc sinks them to the end of the tile: nothing left to overlap)
+        fetch(ST, min(k + 64 * AHEAD, k1 - 64));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f16x8_v xh[4], xl[4];
@@ -261,6 +307,16 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
             }
         }
         __syncthreads();
+    };
+    fetch(S0{}, k0);
+    if constexpr (AHEAD == 2) {
+        fetch(S1{}, min(k0 + 64, k1 - 64));
+        for (int k = k0; k < k1; k += 128) {
+            ktile(S0{}, k);
+            if (k + 64 < k1) ktile(S1{}, k + 64);
+        }
+    } else {
+        for (int k = k0; k < k1; k += 64) ktile(S0{}, k);
     }
     float* out = part + (size_t)blockIdx.x * M * N;
     constexpr float inv = 1.0f / (16.f * 1024.f);
@@ -375,12 +431,12 @@ static __global__ __launch_bounds__(256) void adapter_mix_kernel(const TA* __res
         load4(a + i, av);
         load4(x + i, xv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) yv[e] = res * av[e] + (1.f - res) * xv[e];
+        for (int e = 0; e < 4; ++e) yv[e] = adapter_mix1(res, av[e], xv[e]);
         store4(y + i, yv[0], yv[1], yv[2], yv[3]);
         if (y32) store4(y32 + i, yv[0], yv[1], yv[2], yv[3]);
     } else {
         for (size_t j = i; j < n; ++j) {
-            const float v = res * Elem<TA>::ld(a + j) + (1.f - res) * x[j];
+            const float v = adapter_mix1(res, Elem<TA>::ld(a + j), x[j]);
             Elem<T>::st(y + j, v);
             if (y32) y32[j] = v;
         }
@@ -923,8 +979,10 @@ template <typename TM>
 static __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mu,
                                                    float* __restrict__ nu, const float* __restrict__ scal, float gscale, float wd, size_t n_decay,
                                                    float clip, float lr, float b1, float b2, float eps, float bc1, float bc2, size_t n,
-                                                   TM* __restrict__ mirror, size_t n_mirror) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float4 per thread; n, n_decay, n_mirror are multiples of 4
+                                                   TM* __restrict__ mirror, size_t n_mirror, int reverse) {
+    // one float4 per thread; n, n_decay, n_mirror are multiples of 4.  reverse: the workgroups walk the state from its end -- the norm pass
+    // just read g and p front to back, so their tails are what the Infinity Cache still holds (element-wise arithmetic: same result)
+    const size_t i = (size_t)(reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * 256 + threadIdx.x;
     if (i >= (n >> 2)) return;
     const float gnorm = sqrtf(scal[0]);
     // A non-finite gradient norm (an f16 backward activation that overflowed its fixed power-of-two scale: a loss spike, huge rtg

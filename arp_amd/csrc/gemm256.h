@@ -1143,9 +1143,31 @@ inline int launch_gemm_auto(const GemmArgs& g, hipStream_t stream, int force = 0
             return launch_gemm2w<T, OutT, ACT, RESID>(g, stream);
     }
     if (g.alpha != 1.f) return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, stream);  // the only kernel with the alpha epilogue
-    if (force == 2) return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);
     if (force == 1) return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, stream);
-    if (tiles256 >= 192) return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);
+    if (force == 2 || tiles256 >= 192) {
+        // Tile rounds (round 5).  A product of a FEW rounds of 256 x 256 tiles whose last round is mostly empty -- c_proj: 600 tiles on 256 CUs = 2.34 rounds,
+        // 300 = 1.17 for a 512-frame part -- runs its full rounds here and the rest of its ROWS on the 128 x 128 kernel (two workgroups per CU, a quarter of
+        // the tile: 180-360 small tiles fill the chip where 44-88 big ones leave two thirds of it idle).  Same MFMA, same k order, same epilogue arithmetic:
+        // the two kernels agree bit for bit (scripts/splitm_bench.hip checks the checksum on every shape), so a row's result does not depend on which one
+        // computed it.  Measured there: c_proj 293 -> 278 us per 1 024 frames, 154.5 -> 134.4 us per 512-frame part (what the two-stream pass launches),
+        // out_proj on this kernel 113 -> 104; products of many rounds (c_fc: 9.4, qkv) LOSE 2-16 % -- the dispatcher already balances them -- hence the gate.
+        static const bool splitm = [] { const char* e = getenv("ARP_GEMM_SPLITM"); return e && atoi(e) != 0; }();
+        const int n_t = (g.N + G2_BN - 1) / G2_BN, m_t = (g.M + G2_BM - 1) / G2_BM;
+        const long rounds = tiles256 / 256, rem_tiles = tiles256 - rounds * 256;
+        const int full_m = (int)(rounds * 256 / n_t);  // tile rows of the full rounds
+        if (splitm && rounds >= 1 && rounds <= 3 && rem_tiles > 8 && rem_tiles <= 128 && full_m < m_t && g.ksplit <= 1 && !g.ln_stats && !g.stats_out && !g.xb_out &&
+            !g.mask && !g.colsum_part && !g.adam_p && !(g.flags & 3) && g.mix_nk16 == 0) {
+            GemmArgs a = g, b = g;
+            a.M = full_m * G2_BM;
+            b.M = g.M - a.M;
+            b.A = static_cast<const T*>(g.A) + (size_t)a.M * g.lda;
+            b.out = static_cast<OutT*>(g.out) + (size_t)a.M * g.ldo;
+            if (g.resid) b.resid = g.resid + (size_t)a.M * g.ldr;
+            if (int rc = launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(a, stream)) return rc;
+            return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(b, stream);
+        }
+        return launch_gemm256_nt<T, OutT, ACT, RESID, SITE>(g, stream);
+    }
     return launch_gemm_nt<T, OutT, ACT, RESID, SITE>(g, stream);
 }
 

@@ -198,7 +198,8 @@ static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* 
     }
     // out_proj (K = N = width, f32 residual epilogue) is the one big GEMM where the two-workgroups-per-CU kernel wins: its tiles
     // are short (12 K-tiles) and epilogue-heavy, so a second resident workgroup pays (measured 57.7 vs 66.8 us at M = 25 600)
-    if (force == 0 && (SITE & 7) == SITE_OUT && M >= 4096) force = 3;
+    static const bool out_g256 = [] { const char* e = getenv("ARP_OUT_G256"); return e && atoi(e) != 0; }();  // A/B: out_proj on gemm256 (+ the tile-round split) instead
+    if (force == 0 && (SITE & 7) == SITE_OUT && M >= 4096) force = out_g256 ? 2 : 3;
     // (c_proj on 256 x 192 tiles -- 400 instead of 300 tiles per 512-frame part, fewer idle slots in the last round -- measured
     //  slower, 5.3 vs 4.5 ms per step: the narrower wave tile's K loop loses more over 48 K-tiles than the rounding wins; removed)
     return launch_gemm_auto<T, OutT, ACT, RESID, SITE>(g, c.stream, force);
