@@ -21,6 +21,7 @@ struct AdapterDyArgs {
     const void* Wi;     // [E, Kin] T: image_text_input/kernel in device layout [out, in], operand-type copy
     const void* A;      // [R, Kin] T: the adapter MLP's output (post-ReLU), = [R * tokens, D]
     const float* x32;   // [R, Kin] f32: the stop-gradient encodings
+    const void* x16 = nullptr;  // ... or their operand-type copy (read instead of x32 when set: half the bytes; arp_dt.hip ARP_DT_DY_X16)
     const float* rw;    // device scalar residual_weight (res = sigmoid(rw) is formed in the kernel)
     void* dApre;        // [R, Kin] T out
     float* colpart;     // [row_blocks * tokens, D] f32 out

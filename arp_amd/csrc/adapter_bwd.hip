@@ -111,11 +111,20 @@ __global__ __launch_bounds__(AD_THREADS) void adapter_dy_kernel(AdapterDyArgs g)
         if (r < g.R) {
             const size_t flat = (size_t)r * g.Kin + n0 + chunk * 8;
             const u32x4_v araw = *reinterpret_cast<const u32x4_v*>(Ap + flat);
-            const float4 x0 = *reinterpret_cast<const float4*>(g.x32 + flat), x1 = *reinterpret_cast<const float4*>(g.x32 + flat + 4);
+            float x[8];
+            if (g.x16) {  // the operand-type copy of the encodings (16 B instead of 32): only d loss / d res reads x, and the dY beside it is a 16-bit product already
+                const u32x4_v xraw = *reinterpret_cast<const u32x4_v*>(static_cast<const T*>(g.x16) + flat);
+                T xt[8];
+                memcpy(xt, &xraw, 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = Elem<T>::ld(&xt[e]);
+            } else {
+                const float4 x0 = *reinterpret_cast<const float4*>(g.x32 + flat), x1 = *reinterpret_cast<const float4*>(g.x32 + flat + 4);
+                x[0] = x0.x; x[1] = x0.y; x[2] = x0.z; x[3] = x0.w; x[4] = x1.x; x[5] = x1.y; x[6] = x1.z; x[7] = x1.w;
+            }
             const float4 v0 = *reinterpret_cast<const float4*>(smem + row * AD_STAGE_STRIDE + chunk * 32);
             const float4 v1 = *reinterpret_cast<const float4*>(smem + row * AD_STAGE_STRIDE + chunk * 32 + 16);
             const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             T a[8], o[8];
             memcpy(a, &araw, 16);
 #pragma unroll

@@ -128,6 +128,9 @@ struct arp_dt {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_dapre = nullptr, ev_side = nullptr;
     bool side_gemms = false;
+    bool dy_x16 = true;       // adapter_dy_kernel reads the encodings' operand-type copy for d loss / d res (ARP_DT_DY_X16=0: the f32 encodings, rounds 2-5)
+    bool merge_small = true;  // the step's small dependent launches merged (ARP_DT_MERGE=0: one launch each, rounds 2-5)
+    bool dzb_from_pf = false;
     bool dwi_last = true;   // backward_adapter_tn: image_text_input's weight gradient last (Infinity Cache residency for the norm pass)
     bool adam_rev = true;   // apply_update: the update walks the flat state from its end (what the norm pass touched last)
     DevBuf part_side;
@@ -173,6 +176,7 @@ struct arp_dt {
     bool iti_x3 = true;  // ... and that f32-level product on (hi, lo) binary16 MFMA pairs instead of the f32 MFMA (ARP_DT_ITI_X3=0: round 3's f32-MFMA GEMM)
     DevBuf Y32;
     DevBuf colpart;  // column partial sums of mask_copy_colsum_kernel
+    DevBuf colpart0;   // the dH1 GEMM's column partials when the small reductions are deferred (backward_adapter_tn)
     DevBuf dres_part;  // per-workgroup d loss / d res partials of adapter_dy_kernel
     int R() const { return B * cfg.window; }
     int L() const { return 3 * cfg.window; }
@@ -591,14 +595,22 @@ int policy_fused(arp_dt* c, bool do_bwd) {
     c->pf.do_bwd = do_bwd ? 1 : 0;
     c->pf.rtg = c->bt[c->cur].rtg.as<float>();  // the CURRENT batch slot's labels (the plan was built when the geometry last changed)
     c->pf.action = c->bt[c->cur].action.as<int>();
+    // the scaled operand-type copy of dz (the TN backward's first operand) straight from the kernel instead of a transpose_mask launch behind it
+    const bool dzb_here = do_bwd && c->merge_small && c->use_tn() && k.mode != ARP_MODE_F32 && c->dzb.p;
+    c->pf.dzb = dzb_here ? c->dzb.p : nullptr;
+    c->pf.dz_scale = c->act_scale();
+    c->pf.dzb_f16 = k.mode == ARP_MODE_F16 ? 1 : 0;
+    c->dzb_from_pf = dzb_here;
     const size_t lds = pf_lds_bytes(k.emb, k.mlp_ratio * k.emb, k.heads, k.depth);
     hipLaunchKernelGGL(pf_pack_kernel, dim3(c->pf_pack_blocks, c->pf_njobs), dim3(256), 0, c->stream, static_cast<const PfPackJob*>(c->pf_jobs.p));
     if (k.emb == 128 && c->pf_x3) hipLaunchKernelGGL((policy_fused_kernel<128, 512, true>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     else if (k.emb == 128) hipLaunchKernelGGL((policy_fused_kernel<128, 512>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     else if (c->pf_x3) hipLaunchKernelGGL((policy_fused_kernel<64, 256, true>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     else hipLaunchKernelGGL((policy_fused_kernel<64, 256>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c->stream, c->loss_part.as<float>(), c->B, c->R(), k.n_actions, k.lambda_ret,
-                       c->metrics.as<float>());
+    // (with the backward behind it and the merged gradient launch on, that launch reduces the losses: backward<T>)
+    if (!(do_bwd && c->merge_small))
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, c->stream, c->loss_part.as<float>(), c->B, c->R(), k.n_actions, k.lambda_ret,
+                           c->metrics.as<float>());
     ARP_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -716,18 +728,21 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         ARP_TRY(c->part.ensure((size_t)S * R * E * 4));
         ProfScope ps(c->prof, c->stream, "dt.image_text_input");
         static const int ahead = [] { const char* e = getenv("ARP_DT_ITI_AHEAD"); return e && atoi(e) == 2 ? 2 : 1; }();
+        // (ARP_DT_ITI_CYCLIC=1: K-tiles dealt round-robin instead of one K range per workgroup -- measured 2 us slower, profiles/r5_policy_ab.txt: the stream is not short of DRAM locality)
+        static const bool cyclic = [] { const char* e = getenv("ARP_DT_ITI_CYCLIC"); return e && atoi(e) != 0; }();
+        const int kslice = cyclic ? 0 : per * 64;
         const float* Wi = c->p("image_text_input/kernel");
         if constexpr (sizeof(T) == 2) {
             if (mix_a32) {
                 hipLaunchKernelGGL((iti_x3_kernel<1, float, T>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
-                                   per * 64, mix_a32, c->p("residual_weight"), c->Y.as<T>());
+                                   kslice, mix_a32, c->p("residual_weight"), c->Y.as<T>());
             } else if (mix_a) {
                 hipLaunchKernelGGL((iti_x3_kernel<1, T, T>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
-                                   per * 64, mix_a, c->p("residual_weight"), c->Y.as<T>());
+                                   kslice, mix_a, c->p("residual_weight"), c->Y.as<T>());
             } else if (ahead == 2) {
-                hipLaunchKernelGGL(iti_x3_kernel<2>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, per * 64, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr);
+                hipLaunchKernelGGL(iti_x3_kernel<2>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, kslice, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr);
             } else {
-                hipLaunchKernelGGL(iti_x3_kernel<1>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, per * 64, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr);
+                hipLaunchKernelGGL(iti_x3_kernel<1>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, kslice, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr);
             }
         }
         ARP_HIP_OK(hipGetLastError());
@@ -836,9 +851,13 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
     // the norm pass right behind it finds those bytes in the 256 MiB Infinity Cache instead of HBM (same launches, same arithmetic; a staged
     // backward needs dWi first for its all-reduce bucket).  ARP_DT_DWI_LAST=0 restores the old order.
     const bool dwi_last = c->dwi_last && stage == 0 && k.use_adapter && !side;
+    // the three small reductions of this backward in one launch behind its last GEMM (both of its fused forms on, nothing on the side stream)
+    const long tiles256_dx = (long)cdiv((int)Mx, 256) * cdiv(D, 256);
+    const bool defer_small = c->merge_small && k.use_adapter && stage != 1 && !side && c->use_fused_dy() && D % 8 == 0 && c->fuse_relu_bwd(tiles256_dx);
+    int fin_rows1 = 0, fin_rows0 = 0, fin_ndres = 0;
     if (stage != 2) {
-        // dz (f32) -> operand type, scaled (rows R..Rp64 of dzb stay zero)
-        ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, S, c->dzb.as<T>(), E, nullptr, 0, R, E)));
+        // dz (f32) -> operand type, scaled (rows R..Rp64 of dzb stay zero); the fused kernel may have written it already (policy_fused)
+        if (!(c->fused && c->dzb_from_pf)) ARP_TRY((transpose_mask<float, float, T>(c, c->dz.as<float>(), E, nullptr, nullptr, S, c->dzb.as<T>(), E, nullptr, 0, R, E)));
         // dWi[E, Kin] = dz^T Y: contraction over the R rows, written straight into the gradient buffer
         if (side) {
             ARP_HIP_OK(hipEventRecord(c->ev_fork, c->stream));
@@ -858,13 +877,19 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
         ARP_TRY(c->dres_part.ensure((size_t)nrb * nct * 4));
         AdapterDyArgs a;
         a.dz = c->dzb.p; a.Wi = c->fwd_w("image_text_input/kernel"); a.A = c->A.p; a.x32 = c->bt[c->cur].enc32.as<float>(); a.rw = c->p("residual_weight");
+        a.x16 = c->dy_x16 ? c->Xb.p : nullptr;
         a.dApre = c->dApre.p; a.colpart = c->colpart.as<float>(); a.dres_part = c->dres_part.as<float>();
         a.R = R; a.E = E; a.Kin = Kin; a.D = D;
         ARP_TRY(launch_adapter_dy(__is_same(T, bf16_t) ? 1 : 2, a, c->stream));
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), nrb * k.enc_tokens, D,
-                           c->g("AdapterMLP_0/Dense_1/bias"), invS);
-        hipLaunchKernelGGL(reduce_dres_to_drw_kernel, dim3(1), dim3(256), 0, c->stream, c->dres_part.as<float>(), nrb * nct, invS, c->p("residual_weight"),
-                           c->g("residual_weight"));
+        if (defer_small) {  // (one launch for these and the Dense_0 bias sums, behind the last adapter GEMM: adapter_grad_finish_kernel)
+            fin_rows1 = nrb * k.enc_tokens;
+            fin_ndres = nrb * nct;
+        } else {
+            hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), nrb * k.enc_tokens, D,
+                               c->g("AdapterMLP_0/Dense_1/bias"), invS);
+            hipLaunchKernelGGL(reduce_dres_to_drw_kernel, dim3(1), dim3(256), 0, c->stream, c->dres_part.as<float>(), nrb * nct, invS, c->p("residual_weight"),
+                               c->g("residual_weight"));
+        }
         ARP_HIP_OK(hipGetLastError());
     } else {
         ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.image_text_input_dX", c->dzb.p, E, c->Wit.p, E, nullptr, c->dY.p, Kin, R, Kin, E)));
@@ -889,15 +914,17 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
         // dH1 = (dApre W2) * (H1 > 0) and its column sums (the Dense_0 bias gradient) in the GEMM's own epilogue (gemm256.h)
         GemmArgs g;
         g.A = c->dApre.p; g.W = c->W2t.p; g.out = c->dH1T.p; g.M = (int)Mx; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldr = D; g.ldo = D;
-        g.mask = c->H1.p; g.ldm = D; g.colsum_part = c->colpart.as<float>();
+        g.mask = c->H1.p; g.ldm = D;
         const int mt = cdiv((int)Mx, 256);
-        ARP_TRY(c->colpart.ensure((size_t)mt * D * 4));
-        g.colsum_part = c->colpart.as<float>();
+        DevBuf& cpart = defer_small ? c->colpart0 : c->colpart;  // (deferred: the dY kernel's partials in colpart are still waiting for their sums)
+        ARP_TRY(cpart.ensure((size_t)mt * D * 4));
+        g.colsum_part = cpart.as<float>();
         {
             ProfScope ps(c->prof, c->stream, "dt.adapter_fc2_dX");
             ARP_TRY((launch_gemm256_nt<T, T, ACT_NONE, false, SITE_DT>(g, c->stream)));
         }
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), mt, D, c->g("AdapterMLP_0/Dense_0/bias"), invS);
+        if (defer_small) fin_rows0 = mt;
+        else hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), mt, D, c->g("AdapterMLP_0/Dense_0/bias"), invS);
         ARP_HIP_OK(hipGetLastError());
     } else {
         ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.adapter_fc2_dX", c->dApre.p, D, c->W2t.p, D, nullptr, c->G.p, D, (int)Mx, D, D)));
@@ -909,6 +936,14 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
         ARP_HIP_OK(hipGetLastError());
     }
     ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc1_dW", c->dH1T.as<T>(), D, c->Xb.as<T>(), D, c->g("AdapterMLP_0/Dense_0/kernel"), D, D, Mxp, invS)));
+    if (defer_small) {
+        if (fin_rows1 <= 0 || fin_rows0 <= 0) return fail("backward_adapter_tn: deferred reductions without their partials");
+        ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
+        hipLaunchKernelGGL(adapter_grad_finish_kernel, dim3(2 * cdiv(D, 64) + 1), dim3(256), 0, c->stream, c->colpart.as<float>(), fin_rows1, c->g("AdapterMLP_0/Dense_1/bias"),
+                           c->colpart0.as<float>(), fin_rows0, c->g("AdapterMLP_0/Dense_0/bias"), D, invS, c->dres_part.as<float>(), fin_ndres, c->p("residual_weight"),
+                           c->g("residual_weight"));
+        ARP_HIP_OK(hipGetLastError());
+    }
     if (dwi_last) ARP_TRY((tn_gemm<T>(c, "dt.image_text_input_dW", c->dzb.as<T>(), E, Yp, Kin, c->g("image_text_input/kernel"), E, Kin, Rp64, invS)));
     if (side) {  // join: everything after the backward (norms, Adam, a later forward) is ordered behind the side stream's two GEMMs
         ARP_HIP_OK(hipEventRecord(c->ev_side, c->side_stream));
@@ -941,11 +976,22 @@ template <typename T> int backward(arp_dt* c, int stage = 0) {
         // so that the step's hipGraph holds them as parallel branches: 1.33 ms per step against 0.99 ms on one stream.)
         hipStream_t st = c->stream;
         ProfScope ps(c->prof, st, "dt.policy_bwd");
+        if (c->merge_small) {
+            PfGradsArgs a;
+            a.gtab = c->gtab.as<SmallGemm>(); a.gprefix = c->gprefix.as<int>(); a.n_gemm = c->n_gemm; a.gemm_tiles = c->gemm_tiles;
+            a.ctab = c->ctab.as<ColSumJob>(); a.cprefix = c->cprefix.as<int>(); a.n_cs = c->n_cs; a.cs_tiles = c->cs_tiles;
+            a.dtok = c->dtok.as<float>(); a.rtg = c->bt[c->cur].rtg.as<float>(); a.action = c->bt[c->cur].action.as<int>();
+            a.dWr = c->g("rtg_input/kernel"); a.demb = c->g("action_input/embedding"); a.R = R; a.E = E; a.NA = NA;
+            a.loss_part = c->loss_part.as<float>(); a.B = c->B; a.lambda = k.lambda_ret; a.metrics = c->metrics.as<float>();
+            hipLaunchKernelGGL(pf_param_grads_kernel, dim3(c->gemm_tiles + c->cs_tiles + NA + 2), dim3(256), 0, st, a);
+            ARP_HIP_OK(hipGetLastError());
+        } else {
         hipLaunchKernelGGL(grouped_small_gemm_kernel, dim3(c->gemm_tiles), dim3(256), 0, st, c->gtab.as<SmallGemm>(), c->gprefix.as<int>(), c->n_gemm);
         hipLaunchKernelGGL(grouped_colsum_kernel, dim3(c->cs_tiles), dim3(256), 0, st, c->ctab.as<ColSumJob>(), c->cprefix.as<int>(), c->n_cs);
         hipLaunchKernelGGL(tokens_bwd_par_kernel, dim3(NA + 1), dim3(TOKB_THREADS), 0, st, c->dtok.as<float>(), c->bt[c->cur].rtg.as<float>(), c->bt[c->cur].action.as<int>(),
                            c->g("rtg_input/kernel"), c->g("action_input/embedding"), R, E, NA);
         ARP_HIP_OK(hipGetLastError());
+        }
     } else {
         ProfScope ps(c->prof, c->stream, "dt.policy_bwd");
         // heads (arp_dt/ARPDT.py:94-99,206-220)
@@ -1063,8 +1109,12 @@ int apply_update(arp_dt* c, float lr) {
     float* pp = pg + nb;
     hipLaunchKernelGGL(norms_partial_kernel, dim3(nb), dim3(256), 0, c->stream, c->grads.as<float>(), c->params.as<float>(), c->P, c->n_decay, gscale,
                        c->cfg.weight_decay, pg, pp);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, pg, nb, 1.0f, c->scal.as<float>() + 0, 0);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, pp, nb, 1.0f, c->scal.as<float>() + 1, 0);
+    if (c->merge_small) {
+        hipLaunchKernelGGL(reduce_sum2_kernel, dim3(2), dim3(256), 0, c->stream, pg, pp, nb, c->scal.as<float>() + 0, c->scal.as<float>() + 1);
+    } else {
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, pg, nb, 1.0f, c->scal.as<float>() + 0, 0);
+        hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, c->stream, pp, nb, 1.0f, c->scal.as<float>() + 1, 0);
+    }
     const double t = (double)(c->step + 1);
     const float bc1 = (float)(1.0 - std::pow((double)c->cfg.b1, t)), bc2 = (float)(1.0 - std::pow((double)c->cfg.b2, t));
 #define ARP_ADAM(TM)                                                                                                                    \
@@ -1277,6 +1327,8 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_SIDE")) c->side_gemms = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_DWI_LAST")) c->dwi_last = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_MERGE")) c->merge_small = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_DY_X16")) c->dy_x16 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ADAM_REV")) c->adam_rev = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
     build_layout(c);

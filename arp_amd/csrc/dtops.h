@@ -203,7 +203,11 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
     const int wr = wave >> 1, wc = wave & 1, j = lane & 15, g = lane >> 4;
     const int n_tiles = (N + 127) / 128;
     const int m0 = (blockIdx.y / n_tiles) * 128, n0 = (blockIdx.y % n_tiles) * 128;
-    const int k0 = blockIdx.x * kslice, k1 = min(K, k0 + kslice);
+    // kslice > 0: workgroup s owns the K range [s * kslice, (s + 1) * kslice); kslice <= 0: the 64-wide K-tiles are dealt round-robin (tile t of workgroup s is
+    // s + t * gridDim.x), so that at any moment the chip reads ONE contiguous stretch of every row (gridDim.x * 256 B) instead of gridDim.x scattered 256-byte pieces
+    const int kstep = kslice > 0 ? 64 : (int)gridDim.x * 64;
+    const int k0 = kslice > 0 ? blockIdx.x * kslice : blockIdx.x * 64;
+    const int klast = kslice > 0 ? min(K, k0 + kslice) - 64 : k0 + (K - 64 - k0) / kstep * kstep;  // this workgroup's last tile (K % 64 == 0; k0 < K: the launcher's grid)
     const int lrow = tid >> 4, lc4 = tid & 15;
     // 32-bit byte offsets from the (uniform) matrix bases: a scalar base + one address register per load (128 rows of a 197 376-wide f32 matrix are 101 MB)
     unsigned xo[8], wo[8];
@@ -279,10 +283,10 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
         // unconditional (the slice's last AHEAD tiles re-request its last tile: L2 hits): a conditional fetch makes the staged registers loop-carried
         // through a merge, and hipcc then waits for the loads right behind their issue (vmcnt(1) at the back edge) -- the prefetch gone
 #ifdef ARP_ITI_R4  // the round-4 form, for same-box A/B builds (make ALT=iti_r4 EXTRA=-DARP_ITI_R4)
-        if (k + 64 * AHEAD < k1) fetch(ST, k + 64 * AHEAD);
+        if (k + kstep * AHEAD <= klast) fetch(ST, k + kstep * AHEAD);
 #else
         __builtin_amdgcn_sched_barrier(0);  // the requests go out HERE, ahead of the MFMAs (left alone, hipcc sinks them to the end of the tile: nothing left to overlap)
-        fetch(ST, min(k + 64 * AHEAD, k1 - 64));
+        fetch(ST, min(k + kstep * AHEAD, klast));
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
@@ -310,13 +314,13 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
     };
     fetch(S0{}, k0);
     if constexpr (AHEAD == 2) {
-        fetch(S1{}, min(k0 + 64, k1 - 64));
-        for (int k = k0; k < k1; k += 128) {
+        fetch(S1{}, min(k0 + kstep, klast));
+        for (int k = k0; k <= klast; k += 2 * kstep) {
             ktile(S0{}, k);
-            if (k + 64 < k1) ktile(S1{}, k + 64);
+            if (k + kstep <= klast) ktile(S1{}, k + kstep);
         }
     } else {
-        for (int k = k0; k < k1; k += 64) ktile(S0{}, k);
+        for (int k = k0; k <= klast; k += kstep) ktile(S0{}, k);
     }
     float* out = part + (size_t)blockIdx.x * M * N;
     constexpr float inv = 1.0f / (16.f * 1024.f);
@@ -540,6 +544,18 @@ static __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __r
     }
 }
 
+// two independent sums in one launch (the two norms of the update: block b sums in_b into out_b, reduce_sum_kernel's order)
+static __global__ __launch_bounds__(256) void reduce_sum2_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int n, float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float red[4];
+    const float* __restrict__ in = blockIdx.x ? in1 : in0;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) (blockIdx.x ? out1 : out0)[0] = 1.0f * ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 // d loss / d residual_weight from the per-workgroup partials of sum dY * (A - x): reduce (fixed order), un-scale, chain through the
 // sigmoid -- reduce_sum_kernel + dres_to_drw_kernel in one launch
 static __global__ __launch_bounds__(256) void reduce_dres_to_drw_kernel(const float* __restrict__ in, int n, float scale, const float* __restrict__ rw,
@@ -624,6 +640,29 @@ __device__ __forceinline__ void colsum_tile(const float* __restrict__ in, int R,
 }
 static __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out, float alpha = 1.f) {
     colsum_tile(in, R, C, out, blockIdx.x, alpha);
+}
+// The adapter backward's three small reductions in one launch, behind its last GEMM (nothing but the norm pass reads their results): the two bias gradients
+// (column sums of the per-row-block partials of adapter_dy_kernel and of the dH1 GEMM's epilogue) and d loss / d residual_weight.  Blocks [0, nb) and
+// [nb, 2 nb) are colsum_kernel's, block 2 nb is reduce_dres_to_drw_kernel's: same arithmetic, same order.
+static __global__ __launch_bounds__(256) void adapter_grad_finish_kernel(const float* __restrict__ cp1, int rows1, float* __restrict__ bias1, const float* __restrict__ cp0, int rows0,
+                                                                  float* __restrict__ bias0, int D, float alpha, const float* __restrict__ dres_part, int n,
+                                                                  const float* __restrict__ rw, float* __restrict__ drw) {
+    const int nb = (D + 63) / 64;
+    int b = (int)blockIdx.x;
+    if (b < nb) { colsum_tile(cp1, rows1, D, bias1, b, alpha); return; }
+    b -= nb;
+    if (b < nb) { colsum_tile(cp0, rows0, D, bias0, b, alpha); return; }
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += dres_part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float dres = alpha * ((red[0] + red[1]) + (red[2] + red[3]));
+        const float res = 1.0f / (1.0f + expf(-rw[0]));
+        drw[0] = dres * res * (1.f - res);
+    }
 }
 
 // ---- masked, scaled ROW-major copy with column partial sums (16-bit modes: operand of the TN weight-gradient GEMM) ----------

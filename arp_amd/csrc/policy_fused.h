@@ -65,6 +65,9 @@ struct PfArgs {
     float *xf, *a_in, *r_in, *ha, *hr, *logits, *ret;           // saved forward (head stage)
     float *dlogits, *dret, *dha, *dhr, *dwsf, *dbsf, *dtok, *dz;  // saved backward
     float* loss_part;                                           // [B][4]: sum CE, hits, sum squared error
+    void* dzb;       // optional: dz * dz_scale in the operand type (dzb_f16: binary16, saturated; else bfloat16) -- what transpose_mask<float, float, T> made of dz
+    float dz_scale;  // in a launch of its own
+    int dzb_f16;
 };
 
 inline size_t pf_lds_bytes(int E, int H, int heads, int depth) {
@@ -861,7 +864,17 @@ static __global__ __launch_bounds__(PF_THREADS) void policy_fused_kernel(PfArgs 
         const int t = i / 3;
         if (i - 3 * t == 0) {
             const float y = a.img[(r0 + t) * E + e];
-            a.dz[(r0 + t) * E + e] = g * (1.f - y * y);
+            const float dzv = pin_f32(g * (1.f - y * y));  // (ONE f32 value for both stores: common.h)
+            a.dz[(r0 + t) * E + e] = dzv;
+            if (a.dzb) {
+                float v = dzv * a.dz_scale;
+                if (a.dzb_f16) {
+                    v = v > 65504.f ? 65504.f : (v < -65504.f ? -65504.f : v);
+                    Elem<f16_t>::st(static_cast<f16_t*>(a.dzb) + (r0 + t) * E + e, v);
+                } else {
+                    Elem<bf16_t>::st(static_cast<bf16_t*>(a.dzb) + (r0 + t) * E + e, v);
+                }
+            }
         }
     }
 }
@@ -923,21 +936,25 @@ __device__ __forceinline__ void small_gemm_tile_tn_mfma(const SmallGemm& g, int 
 
 // which job does this block belong to: the number of job boundaries at or below blockIdx.x, found with ONE load per lane and a ballot
 // (a scan `while (blockIdx.x >= tile_prefix[p + 1]) ++p` is up to n dependent memory round trips in every block; n <= 64)
-__device__ __forceinline__ int grouped_job_index(const int* __restrict__ tile_prefix, int n) {
+__device__ __forceinline__ int grouped_job_index(const int* __restrict__ tile_prefix, int n, int bid) {
     const int lane = threadIdx.x & 63;
     const int bound = lane + 1 < n ? tile_prefix[lane + 1] : 0x7fffffff;
-    return __builtin_amdgcn_readfirstlane(__popcll(__ballot((int)blockIdx.x >= bound)));
+    return __builtin_amdgcn_readfirstlane(__popcll(__ballot(bid >= bound)));
 }
+__device__ __forceinline__ int grouped_job_index(const int* __restrict__ tile_prefix, int n) { return grouped_job_index(tile_prefix, n, (int)blockIdx.x); }
 
-static __global__ __launch_bounds__(256) void grouped_small_gemm_kernel(const SmallGemm* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
-    const int p = grouped_job_index(tile_prefix, n);
+__device__ __forceinline__ void grouped_small_gemm_block(const SmallGemm* __restrict__ tab, const int* __restrict__ tile_prefix, int n, int bid) {
+    const int p = grouped_job_index(tile_prefix, n, bid);
     const SmallGemm g = tab[p];
-    const int local = blockIdx.x - tile_prefix[p];
+    const int local = bid - tile_prefix[p];
     const int nbx = (g.N + 31) / 32;
     if (g.ta && !g.tb && !g.bias && !g.resid && g.act == ACT_NONE && !g.accumulate && !((g.M | g.N) & 15) && !(g.K & 3))
         small_gemm_tile_tn_mfma(g, local % nbx, local / nbx);
     else
         small_gemm_tile(g, local % nbx, local / nbx);
+}
+static __global__ __launch_bounds__(256) void grouped_small_gemm_kernel(const SmallGemm* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
+    grouped_small_gemm_block(tab, tile_prefix, n, (int)blockIdx.x);
 }
 // embedding / rtg-projection gradients from d tokens: block a < NA sums the action-token rows whose action is a, block NA the
 // rtg-token rows weighted by rtg (same sums as tokens_bwd_kernel, no read-modify-write chain).  The rows are split over 1024 / E thread
@@ -945,23 +962,35 @@ static __global__ __launch_bounds__(256) void grouped_small_gemm_kernel(const Sm
 // together: one thread walking all R rows with a load behind each `action[r] == a` test took 31 us of the 0.9 ms step at R = 128.
 // Fixed summation order (group g: rows g, g + G, ...; then groups 0..G-1).
 constexpr int TOKB_THREADS = 1024;
-static __global__ __launch_bounds__(TOKB_THREADS) void tokens_bwd_par_kernel(const float* __restrict__ dtok, const float* __restrict__ rtg, const int* __restrict__ action,
-                                                             float* __restrict__ dWr, float* __restrict__ demb, int R, int E, int n_actions) {
+// NT = 1024: the stand-alone launch; NT = 256: one block of pf_param_grads_kernel (G = 256 / E row groups, deeper unroll: 32 rows' loads in flight per lane)
+template <int NT>
+__device__ __forceinline__ void tokens_bwd_block(int a, const float* __restrict__ dtok, const float* __restrict__ rtg, const int* __restrict__ action,
+                                                 float* __restrict__ dWr, float* __restrict__ demb, int R, int E, int n_actions) {
+    // The summation order is that of TOKB_THREADS threads whatever NT is: G = TOKB_THREADS / E row groups (group g: rows g, g + G, ...), then groups 0..G-1.
+    // A smaller block gives each thread TOKB_THREADS / NT of the groups (their loads all independent), so both launch forms produce the same bits.
     __shared__ float red[TOKB_THREADS];
-    const int a = blockIdx.x;
     const bool is_act = a < n_actions;
     const int tok = is_act ? 2 : 1;
-    if (E <= TOKB_THREADS && TOKB_THREADS % E == 0) {
-        const int G = TOKB_THREADS / E, grp = threadIdx.x / E, e = threadIdx.x % E;
-        float s = 0.f;
+    if (E <= NT && NT % E == 0) {
+        constexpr int PER = TOKB_THREADS / NT;
+        const int G = TOKB_THREADS / E, grp0 = (threadIdx.x / E) * PER, e = threadIdx.x % E;
+        float s[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) s[q] = 0.f;
 #pragma unroll 8
-        for (int r = grp; r < R; r += G) {
-            const float x = dtok[((size_t)r * 3 + tok) * E + e];
-            s += is_act ? (action[r] == a ? x : 0.f) : rtg[r] * x;
+        for (int r = 0; r < R; r += G) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int rr = r + grp0 + q, rc = min(rr, R - 1);  // (loads unconditional: all of an unrolled batch in flight together)
+                const float x = dtok[((size_t)rc * 3 + tok) * E + e];
+                const float v = is_act ? (action[rc] == a ? x : 0.f) : rtg[rc] * x;
+                if (rr < R) s[q] += v;
+            }
         }
-        red[threadIdx.x] = s;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) red[(grp0 + q) * E + e] = s[q];
         __syncthreads();
-        if (grp == 0) {
+        if (grp0 == 0) {
             float t = red[e];
             for (int k = 1; k < G; ++k) t += red[k * E + e];
             if (is_act) demb[(size_t)a * E + e] = t;
@@ -969,7 +998,7 @@ static __global__ __launch_bounds__(TOKB_THREADS) void tokens_bwd_par_kernel(con
         }
         return;
     }
-    for (int e = threadIdx.x; e < E; e += TOKB_THREADS) {
+    for (int e = threadIdx.x; e < E; e += NT) {
         float s = 0.f;
 #pragma unroll 8
         for (int r = 0; r < R; ++r) {
@@ -980,11 +1009,47 @@ static __global__ __launch_bounds__(TOKB_THREADS) void tokens_bwd_par_kernel(con
         else dWr[e] = s;
     }
 }
+static __global__ __launch_bounds__(TOKB_THREADS) void tokens_bwd_par_kernel(const float* __restrict__ dtok, const float* __restrict__ rtg, const int* __restrict__ action,
+                                                             float* __restrict__ dWr, float* __restrict__ demb, int R, int E, int n_actions) {
+    tokens_bwd_block<TOKB_THREADS>((int)blockIdx.x, dtok, rtg, action, dWr, demb, R, E, n_actions);
+}
 struct ColSumJob { const float* in; float* out; int R, C; };
 static __global__ __launch_bounds__(256) void grouped_colsum_kernel(const ColSumJob* __restrict__ tab, const int* __restrict__ tile_prefix, int n) {
     const int p = grouped_job_index(tile_prefix, n);
     const ColSumJob j = tab[p];
     colsum_tile(j.in, j.R, j.C, j.out, blockIdx.x - tile_prefix[p]);
+}
+
+// Everything that turns the fused kernel's saved activation gradients into parameter gradients and metrics, in ONE launch: the grouped weight-gradient
+// tiles, the grouped column sums, the embedding / rtg-projection sums and the loss reduction were four dependent launches (16 + 6 + 8 + 4.5 us and three
+// boundaries on the step's critical path); none of them reads another's output, so their blocks share a grid and the launch lasts as long as its longest part.
+struct PfGradsArgs {
+    const SmallGemm* gtab; const int* gprefix; int n_gemm, gemm_tiles;
+    const ColSumJob* ctab; const int* cprefix; int n_cs, cs_tiles;
+    const float *dtok, *rtg; const int* action; float *dWr, *demb; int R, E, NA;
+    const float* loss_part; int B; float lambda; float* metrics;
+};
+static __global__ __launch_bounds__(256) void pf_param_grads_kernel(PfGradsArgs a) {
+    int b = (int)blockIdx.x;
+    if (b < a.gemm_tiles) { grouped_small_gemm_block(a.gtab, a.gprefix, a.n_gemm, b); return; }
+    b -= a.gemm_tiles;
+    if (b < a.cs_tiles) {
+        const int p = grouped_job_index(a.cprefix, a.n_cs, b);
+        const ColSumJob j = a.ctab[p];
+        colsum_tile(j.in, j.R, j.C, j.out, b - a.cprefix[p]);
+        return;
+    }
+    b -= a.cs_tiles;
+    if (b <= a.NA) { tokens_bwd_block<256>(b, a.dtok, a.rtg, a.action, a.dWr, a.demb, a.R, a.E, a.NA); return; }
+    if (threadIdx.x == 0) {  // loss_finish_kernel's arithmetic
+        float ce = 0.f, hit = 0.f, se = 0.f;
+        for (int i = 0; i < a.B; ++i) { ce += a.loss_part[i * 4]; hit += a.loss_part[i * 4 + 1]; se += a.loss_part[i * 4 + 2]; }
+        const float trans = ce / ((float)a.R * a.NA), rl = se / (float)a.R;
+        a.metrics[0] = trans + a.lambda * rl;
+        a.metrics[1] = hit / (float)a.R;
+        a.metrics[2] = trans;
+        a.metrics[3] = rl;
+    }
 }
 
 }  // namespace arp
