@@ -131,6 +131,8 @@ struct arp_dt {
     bool dy_x16 = true;       // adapter_dy_kernel reads the encodings' operand-type copy for d loss / d res (ARP_DT_DY_X16=0: the f32 encodings, rounds 2-5)
     bool merge_small = true;  // the step's small dependent launches merged (ARP_DT_MERGE=0: one launch each, rounds 2-5)
     bool dzb_from_pf = false;
+    bool pack_early = false;
+    bool defer_w2t = false, w2t_pending = false, packed_in_prologue = false;  // forward<T>'s merged prologue launch (dt_prologue_kernel)
     bool dwi_last = true;   // backward_adapter_tn: image_text_input's weight gradient last (Infinity Cache residency for the norm pass)
     bool adam_rev = true;   // apply_update: the update walks the flat state from its end (what the norm pass touched last)
     DevBuf part_side;
@@ -356,6 +358,27 @@ int transpose_mask(arp_dt* c, const TI* in, int ldi, const TM* mask, const float
     return 0;
 }
 
+// The step's three independent preparations in one launch (16-bit modes, fused transformer): the encodings' f32 -> operand-type conversion (a 151 MB stream),
+// the fused kernel's fragment-major weight copies (pf_pack_kernel's jobs) and the transposed shadow of the adapter's second kernel.  They were three
+// dependent launches; none reads another's output, and the two small ones disappear under the stream.
+struct DtPrologueArgs {
+    const float* enc; void* xb; size_t n8; int conv_blocks;
+    const PfPackJob* jobs; int pack_blocks, njobs;
+    const void* W2; void* W2t; int D;  // W2t == nullptr: no transpose in this launch
+};
+template <typename T> static __global__ __launch_bounds__(256) void dt_prologue_kernel(DtPrologueArgs a) {
+    int b = (int)blockIdx.x;
+    const int npack = a.pack_blocks * a.njobs;
+    if (b < npack) { pf_pack_block(a.jobs, b % a.pack_blocks, a.pack_blocks, b / a.pack_blocks); return; }
+    b -= npack;
+    const int tb = (a.D + 63) / 64, ntr = a.W2t ? tb * tb : 0;
+    if (b < ntr) {
+        transpose_mask_tile<T, T, T>(static_cast<const T*>(a.W2), a.D, nullptr, nullptr, 1.f, nullptr, 0, static_cast<T*>(a.W2t), a.D, a.D, a.D, b % tb, b / tb);
+        return;
+    }
+    convert8_block<T>(a.enc, static_cast<T*>(a.xb), a.n8, b - ntr, a.conv_blocks);
+}
+
 template <typename T> int refresh_shadows(arp_dt* c) {
     if (!c->shadows_stale) return 0;
     const arp_dt_cfg& k = c->cfg;
@@ -372,7 +395,10 @@ template <typename T> int refresh_shadows(arp_dt* c) {
     // device layout of a Dense kernel is [out, in]; the transposed shadows come from the operand-type copy (half the bytes)
     const T* W2 = static_cast<const T*>(c->fwd_w("AdapterMLP_0/Dense_1/kernel"));
     const T* Wi = static_cast<const T*>(c->fwd_w("image_text_input/kernel"));
-    if (k.use_adapter) ARP_TRY((transpose_mask<T, T, T>(c, W2, D, nullptr, nullptr, 1.f, nullptr, 0, c->W2t.as<T>(), D, D, D)));
+    if (k.use_adapter) {
+        if (c->defer_w2t) c->w2t_pending = true;  // forward<T>'s merged prologue launch makes it (the backward is its only reader)
+        else ARP_TRY((transpose_mask<T, T, T>(c, W2, D, nullptr, nullptr, 1.f, nullptr, 0, c->W2t.as<T>(), D, D, D)));
+    }
     if constexpr (__is_same(T, f16_t)) {
         if (k.use_adapter && c->adapter_c) {  // [W_hi | dW4 | W4] of the adapter's two kernels from the f32 parameters, scales chosen on the device
             ARP_TRY(c->W1c.ensure((size_t)D * 3 * D + 512)); ARP_TRY(c->W2c.ensure((size_t)D * 3 * D + 512)); ARP_TRY(c->wc_scal.ensure(64));
@@ -602,7 +628,9 @@ int policy_fused(arp_dt* c, bool do_bwd) {
     c->pf.dzb_f16 = k.mode == ARP_MODE_F16 ? 1 : 0;
     c->dzb_from_pf = dzb_here;
     const size_t lds = pf_lds_bytes(k.emb, k.mlp_ratio * k.emb, k.heads, k.depth);
-    hipLaunchKernelGGL(pf_pack_kernel, dim3(c->pf_pack_blocks, c->pf_njobs), dim3(256), 0, c->stream, static_cast<const PfPackJob*>(c->pf_jobs.p));
+    if (!c->packed_in_prologue)  // (forward<T>'s merged prologue launch packed them already)
+        hipLaunchKernelGGL(pf_pack_kernel, dim3(c->pf_pack_blocks, c->pf_njobs), dim3(256), 0, c->stream, static_cast<const PfPackJob*>(c->pf_jobs.p));
+    c->packed_in_prologue = false;
     if (k.emb == 128 && c->pf_x3) hipLaunchKernelGGL((policy_fused_kernel<128, 512, true>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     else if (k.emb == 128) hipLaunchKernelGGL((policy_fused_kernel<128, 512>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
     else if (c->pf_x3) hipLaunchKernelGGL((policy_fused_kernel<64, 256, true>), dim3(c->B), dim3(PF_THREADS), lds, c->stream, c->pf);
@@ -623,11 +651,15 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     const size_t Mx = (size_t)R * k.enc_tokens;
     const int Kin = k.enc_tokens * D;
     const int Mxp = (int)((Mx + 63) / 64 * 64);
+    const bool adapter_cpath = __is_same(T, f16_t) && k.use_adapter && c->adapter_c && D % 256 == 0 && D >= 512;
+    // 16-bit modes with the fused transformer: conversion + weight packing + W2's transposed shadow in ONE launch (dt_prologue_kernel)
+    const bool prologue = sizeof(T) == 2 && c->merge_small && c->fused && !(adapter_cpath && c->use_tn()) && !(k.use_adapter && !c->use_tn()) && (Mx * D) % 8 == 0;
+    c->defer_w2t = prologue;
     ARP_TRY(refresh_shadows<T>(c));
+    c->defer_w2t = false;
     if (c->use_images) {  // frozen M3AE encoder under stop_gradient (arp_dt/ARPDT.py:418-462): frames -> encodings, on this stream
         ARP_TRY(enc_forward_on(c->enc, c->stream, c->bt[c->cur].img32.as<float>(), R, c->bt[c->cur].enc32.as<float>()));
     }
-    const bool adapter_cpath = __is_same(T, f16_t) && k.use_adapter && c->adapter_c && D % 256 == 0 && D >= 512;
     {   // enc f32 -> operand type, both layouts (the transposed one feeds the weight-gradient GEMM)
         ProfScope ps(c->prof, c->stream, "dt.enc_convert");
         if (adapter_cpath && c->use_tn()) {
@@ -636,12 +668,27 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
             ARP_TRY((transpose_mask<float, float, T>(c, c->bt[c->cur].enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D, c->XbT.as<T>(), Mxp, (int)Mx, D)));
         } else if constexpr (sizeof(T) == 2) {  // no transposed copy wanted: a flat 16-byte-per-lane conversion
             const size_t n = Mx * D;
-            if (n % 8 == 0) hipLaunchKernelGGL((convert8_kernel<T>), dim3((unsigned)std::min<size_t>(cdiv(n / 8, 256), 4096)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<T>(), n / 8);
+            if (prologue) {
+                DtPrologueArgs a;
+                a.enc = c->bt[c->cur].enc32.as<float>(); a.xb = c->Xb.p; a.n8 = n / 8; a.conv_blocks = (int)std::min<size_t>(cdiv(n / 8, 256), 4096);
+                // (the weight packing rides along only on request, ARP_DT_PACK_EARLY=1: packed 200 us ahead of the fused kernel the copies have left L2 by the time
+                //  it streams them -- policy_fused_kernel 113 -> 122 us, more than the launch saved; profiles/r5_policy_ab.txt run 13)
+                a.jobs = static_cast<const PfPackJob*>(c->pf_jobs.p); a.pack_blocks = c->pf_pack_blocks; a.njobs = c->pack_early ? c->pf_njobs : 0;
+                a.W2 = c->fwd_w("AdapterMLP_0/Dense_1/kernel"); a.W2t = c->w2t_pending ? c->W2t.p : nullptr; a.D = D;
+                const int tb = cdiv(D, 64);
+                hipLaunchKernelGGL((dt_prologue_kernel<T>), dim3(a.pack_blocks * a.njobs + (a.W2t ? tb * tb : 0) + a.conv_blocks), dim3(256), 0, c->stream, a);
+                c->w2t_pending = false;
+                c->packed_in_prologue = c->pack_early;
+            } else if (n % 8 == 0) hipLaunchKernelGGL((convert8_kernel<T>), dim3((unsigned)std::min<size_t>(cdiv(n / 8, 256), 4096)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<T>(), n / 8);
             else hipLaunchKernelGGL((convert_kernel<T>), dim3(cdiv(n, 1024)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<T>(), n);
             ARP_HIP_OK(hipGetLastError());
         } else {
             ARP_TRY((transpose_mask<float, float, T>(c, c->bt[c->cur].enc32.as<float>(), D, nullptr, nullptr, 1.f, c->Xb.as<T>(), D, nullptr, Mxp, (int)Mx, D)));
         }
+    }
+    if (c->w2t_pending) {  // (deferred by refresh_shadows, and this call's conversion did not go through the merged launch after all)
+        ARP_TRY((transpose_mask<T, T, T>(c, static_cast<const T*>(c->fwd_w("AdapterMLP_0/Dense_1/kernel")), D, nullptr, nullptr, 1.f, nullptr, 0, c->W2t.as<T>(), D, D, D)));
+        c->w2t_pending = false;
     }
     const T* Yp = c->Xb.as<T>();
     bool adapter_done = false;
@@ -1328,6 +1375,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_SIDE")) c->side_gemms = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_DWI_LAST")) c->dwi_last = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_MERGE")) c->merge_small = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_PACK_EARLY")) c->pack_early = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_DY_X16")) c->dy_x16 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ADAM_REV")) c->adam_rev = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;

@@ -350,13 +350,16 @@ template <typename T> __global__ __launch_bounds__(256) void convert_kernel(cons
 
 // 8 values per lane (two 16-byte loads, one 16-byte store) with a grid-stride loop: the per-step f32 -> operand-type conversion of the
 // encodings is a pure HBM stream (151 MB at B = 32), which 4-value lanes ran at 4.1 TB/s
-template <typename T> __global__ __launch_bounds__(256) void convert8_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n8) {
+template <typename T> __device__ __forceinline__ void convert8_block(const float* __restrict__ in, T* __restrict__ out, size_t n8, int bx, int gx) {
     static_assert(sizeof(T) == 2, "16-bit outputs");
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n8; i += (size_t)gx * 256) {
         const float4 a = *reinterpret_cast<const float4*>(in + i * 8), b = *reinterpret_cast<const float4*>(in + i * 8 + 4);
         const u32x4_v o = {pack2<T>(a.x, a.y), pack2<T>(a.z, a.w), pack2<T>(b.x, b.y), pack2<T>(b.z, b.w)};
         *reinterpret_cast<u32x4_v*>(out + i * 8) = o;
     }
+}
+template <typename T> __global__ __launch_bounds__(256) void convert8_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n8) {
+    convert8_block<T>(in, out, n8, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- tiled transpose with optional mask/scale:  ---------------------------------------------------------
@@ -366,11 +369,10 @@ template <typename T> __global__ __launch_bounds__(256) void convert8_kernel(con
 // and on both writes whenever the leading dimensions are multiples of 4 and the chunk is inside the matrix; ragged
 // edges and odd strides fall back to single elements.
 template <typename TI, typename TM, typename TO>
-__global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restrict__ in, int ldi, const TM* __restrict__ mask,
-                                                             const float* __restrict__ scale_ptr, float scale, TO* __restrict__ outN,
-                                                             int ldn, TO* __restrict__ outT, int ldt, int R, int Ccols) {
+__device__ __forceinline__ void transpose_mask_tile(const TI* __restrict__ in, int ldi, const TM* __restrict__ mask, const float* __restrict__ scale_ptr, float scale,
+                                                    TO* __restrict__ outN, int ldn, TO* __restrict__ outT, int ldt, int R, int Ccols, int bx, int by) {
     __shared__ float tile[64][65];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int r0 = by * 64, c0 = bx * 64;
     const float s = scale_ptr ? scale * scale_ptr[0] : scale;
     const bool vin = (ldi & 3) == 0 && (!outN || (ldn & 3) == 0);
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
@@ -420,6 +422,12 @@ __global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restric
             for (int e = 0; e < 4 && r + e < R; ++e) Elem<TO>::st(outT + (size_t)c * ldt + r + e, tile[lr + e][lc]);
         }
     }
+}
+template <typename TI, typename TM, typename TO>
+__global__ __launch_bounds__(256) void transpose_mask_kernel(const TI* __restrict__ in, int ldi, const TM* __restrict__ mask,
+                                                             const float* __restrict__ scale_ptr, float scale, TO* __restrict__ outN,
+                                                             int ldn, TO* __restrict__ outT, int ldt, int R, int Ccols) {
+    transpose_mask_tile<TI, TM, TO>(in, ldi, mask, scale_ptr, scale, outN, ldn, outT, ldt, R, Ccols, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // ---- adapter mix (arp_dt/ARPDT.py:466-472):  y = res*a + (1-res)*x,  res = sigmoid(residual_weight) -----

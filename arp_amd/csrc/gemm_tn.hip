@@ -107,8 +107,11 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(GemmTnArgs g) {
             __syncthreads();
         }
     }
-    // ---- epilogue: lane holds m = .. + fr, n = .. + 4 fg + {0..3} ---------------------------------------------------------------
+    // ---- epilogue: lane holds m = .. + fr, n = .. + 4 fg + {0..3}: a store instruction straight from the accumulators is sixteen 64-byte pieces in sixteen rows.
+    // Each wave stages its 64 x 64 f32 block through its own 16 KiB of the (now idle) operand ring -- 256-B rows, 16-B chunk c of row r at chunk c ^ (r & 15),
+    // conflict-free both ways -- and writes it back as four whole 256-byte row segments per instruction (dWi: 101 MB of f32 in 1542 tiles).
     float* out = g.out + (size_t)blockIdx.y * g.slice_stride;
+#ifdef ARP_TN_DIRECT_STORE  // the stores straight from the accumulators (rounds 2-5), for A/B builds of scripts/gemm_tn_bench.hip
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -117,6 +120,24 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(GemmTnArgs g) {
             const f32x4_v a4 = acc[ni][mi];
             *reinterpret_cast<float4*>(out + (size_t)m * g.ldo + n) = make_float4(a4[0] * g.alpha, a4[1] * g.alpha, a4[2] * g.alpha, a4[3] * g.alpha);
         }
+    return;
+#endif
+    char* stg = smem + wave * 16384;  // (the K loop's last barrier is behind every wave's last fragment read; a wave reads back only what it wrote)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int row = mi * 16 + fr, chunk = ni * 4 + fg;
+            const f32x4_v a4 = acc[ni][mi];
+            *reinterpret_cast<float4*>(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) = make_float4(a4[0] * g.alpha, a4[1] * g.alpha, a4[2] * g.alpha, a4[3] * g.alpha);
+        }
+    const int rl = lane >> 4, ch = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = 4 * i + rl;
+        const float4 v = *reinterpret_cast<const float4*>(stg + row * 256 + ((ch ^ (row & 15)) << 4));
+        *reinterpret_cast<float4*>(out + (size_t)(m0 + wr * 64 + row) * g.ldo + n0 + wc * 64 + ch * 4) = v;
+    }
 }
 
 // ---- 256 x 256 tile variant (the adapter's 768 x 768 x 32 896 weight gradients) ------------------------------------------------

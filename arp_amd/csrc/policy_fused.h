@@ -114,11 +114,12 @@ __device__ __forceinline__ void pf_split8(const float (&x)[8], float s, f16x8_v&
     lo = __builtin_bit_cast(f16x8_v, u32x4_v{l[0], l[1], l[2], l[3]});
 }
 
-static __global__ __launch_bounds__(256) void pf_pack_kernel(const PfPackJob* __restrict__ jobs) {
-    const PfPackJob jb = jobs[blockIdx.y];
+// block bx of gx of job by (a stand-alone launch's (blockIdx.x, gridDim.x, blockIdx.y), or a slice of a merged launch's grid: arp_dt.hip dt_prologue_kernel)
+__device__ __forceinline__ void pf_pack_block(const PfPackJob* __restrict__ jobs, int bx, int gx, int by) {
+    const PfPackJob jb = jobs[by];
     if (jb.x3) {
         const int total8 = jb.N * jb.K / 8, KS = jb.K / 32, NS = jb.N / 32;
-        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total8; idx += gridDim.x * 256) {
+        for (int idx = bx * 256 + threadIdx.x; idx < total8; idx += gx * 256) {
             const int lane = idx & 63, blk = idx >> 6, q = lane >> 4, j = lane & 15;
             float v[8];
             f16x8_v hi, lo;
@@ -146,7 +147,7 @@ static __global__ __launch_bounds__(256) void pf_pack_kernel(const PfPackJob* __
         return;
     }
     const int total4 = jb.N * jb.K / 4, KS = jb.K / 16, NS = jb.N / 16;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total4; idx += gridDim.x * 256) {
+    for (int idx = bx * 256 + threadIdx.x; idx < total4; idx += gx * 256) {
         const int lane = idx & 63, blk = idx >> 6, q = lane >> 4, j = lane & 15;
         {
             const int t = blk / KS, st = blk - t * KS;
@@ -159,6 +160,7 @@ static __global__ __launch_bounds__(256) void pf_pack_kernel(const PfPackJob* __
         }
     }
 }
+static __global__ __launch_bounds__(256) void pf_pack_kernel(const PfPackJob* __restrict__ jobs) { pf_pack_block(jobs, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y); }
 
 // The same linear on 16-bit MFMA (the 16-bit modes of the step): out[i][tile 16 t + r] = sum_k Xs[i][k] * Wt[r][k] with BOTH operands as (hi, lo)
 // binary16 pairs and the product as hi.hi + lo.hi + hi.lo -- three v_mfma_f32_16x16x32_f16 per 32-deep step (48 matrix-pipe cycles) where the f32
@@ -977,7 +979,7 @@ __device__ __forceinline__ void tokens_bwd_block(int a, const float* __restrict_
         float s[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) s[q] = 0.f;
-#pragma unroll 8
+#pragma unroll(NT == TOKB_THREADS ? 8 : 16)
         for (int r = 0; r < R; r += G) {
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
@@ -1030,18 +1032,19 @@ struct PfGradsArgs {
     const float* loss_part; int B; float lambda; float* metrics;
 };
 static __global__ __launch_bounds__(256) void pf_param_grads_kernel(PfGradsArgs a) {
+    // the blocks with the longest dependent chains first (they are dispatched first): embedding sums, column sums, then the MFMA tiles
     int b = (int)blockIdx.x;
-    if (b < a.gemm_tiles) { grouped_small_gemm_block(a.gtab, a.gprefix, a.n_gemm, b); return; }
-    b -= a.gemm_tiles;
-    if (b < a.cs_tiles) {
+    if (b <= a.NA) { tokens_bwd_block<256>(b, a.dtok, a.rtg, a.action, a.dWr, a.demb, a.R, a.E, a.NA); return; }
+    b -= a.NA + 1;
+    if (b >= 1 && b <= a.cs_tiles) {
+        b -= 1;
         const int p = grouped_job_index(a.cprefix, a.n_cs, b);
         const ColSumJob j = a.ctab[p];
         colsum_tile(j.in, j.R, j.C, j.out, b - a.cprefix[p]);
         return;
     }
-    b -= a.cs_tiles;
-    if (b <= a.NA) { tokens_bwd_block<256>(b, a.dtok, a.rtg, a.action, a.dWr, a.demb, a.R, a.E, a.NA); return; }
-    if (threadIdx.x == 0) {  // loss_finish_kernel's arithmetic
+    if (b > a.cs_tiles) { grouped_small_gemm_block(a.gtab, a.gprefix, a.n_gemm, b - a.cs_tiles - 1); return; }
+    if (threadIdx.x == 0) {  // (b == 0) loss_finish_kernel's arithmetic
         float ce = 0.f, hit = 0.f, se = 0.f;
         for (int i = 0; i < a.B; ++i) { ce += a.loss_part[i * 4]; hit += a.loss_part[i * 4 + 1]; se += a.loss_part[i * 4 + 2]; }
         const float trans = ce / ((float)a.R * a.NA), rl = se / (float)a.R;

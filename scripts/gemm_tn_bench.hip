@@ -103,7 +103,8 @@ static double run(const Case& c, bool check, int iters) {
 int main() {
     // correctness: ragged K-splits, one / many tiles, K-tile counts below the ring depth
     const Case checks[] = {{256, 256, 64, 1, 1, 0},   {256, 256, 128, 1, 1, 0},  {256, 512, 704, 1, 1, 0},  {512, 256, 1344, 5, 1, 0},
-                           {768, 768, 2112, 8, 1, 1}, {768, 768, 2112, 16, 1, 1}, {256, 256, 1344, 5, 0, 0}, {768, 768, 2112, 24, 1, 1}};
+                           {768, 768, 2112, 8, 1, 1}, {768, 768, 2112, 16, 1, 1}, {256, 256, 1344, 5, 0, 0}, {768, 768, 2112, 24, 1, 1},
+                           {128, 1280, 128, 1, 0, 0}};  // (the last: dWi's shape class -- one row of 128 x 128 tiles, two K-tiles, staged f32 epilogue)
     bool ok = true;
 #ifndef TW_ABL
     for (const Case& c : checks) ok &= run(c, true, 2) < 0.05;
@@ -119,5 +120,6 @@ int main() {
                            {768, 768, K, 24, 1, 1, 1}, {768, 768, K, 8, 1, 1, 1}, {768, 768, K, 14, 0, 0, 1}};
 #endif
     for (const Case& c : shapes) run(c, false, 20);
+    run(Case{128, 197376, 128, 1, 0, 0}, false, 20);  // image_text_input's weight gradient at B = 32
     return ok ? 0 : 1;
 }
