@@ -128,6 +128,7 @@ struct arp_dt {
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_dapre = nullptr, ev_side = nullptr;
     bool side_gemms = false;
+    bool mix_x16 = true;      // iti_x3_kernel's mix reads the encodings' operand-type copy, not the f32 encodings (ARP_DT_MIX_X16=0; dtops.h: 16-seed logits 8.73e-4 -> 8.74e-4)
     bool dy_x16 = true;       // adapter_dy_kernel reads the encodings' operand-type copy for d loss / d res (ARP_DT_DY_X16=0: the f32 encodings, rounds 2-5)
     bool merge_small = true;  // the step's small dependent launches merged (ARP_DT_MERGE=0: one launch each, rounds 2-5)
     bool dzb_from_pf = false;
@@ -782,14 +783,17 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
         if constexpr (sizeof(T) == 2) {
             if (mix_a32) {
                 hipLaunchKernelGGL((iti_x3_kernel<1, float, T>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
-                                   kslice, mix_a32, c->p("residual_weight"), c->Y.as<T>());
+                                   kslice, mix_a32, c->p("residual_weight"), c->Y.as<T>(), (const T*)nullptr);
+            } else if (mix_a && c->mix_x16) {
+                hipLaunchKernelGGL((iti_x3_kernel<1, T, T, true>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
+                                   kslice, mix_a, c->p("residual_weight"), c->Y.as<T>(), c->Xb.as<T>());
             } else if (mix_a) {
                 hipLaunchKernelGGL((iti_x3_kernel<1, T, T>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
-                                   kslice, mix_a, c->p("residual_weight"), c->Y.as<T>());
+                                   kslice, mix_a, c->p("residual_weight"), c->Y.as<T>(), (const T*)nullptr);
             } else if (ahead == 2) {
-                hipLaunchKernelGGL(iti_x3_kernel<2>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, kslice, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr);
+                hipLaunchKernelGGL(iti_x3_kernel<2>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, kslice, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr, (const f16_t*)nullptr);
             } else {
-                hipLaunchKernelGGL(iti_x3_kernel<1>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, kslice, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr);
+                hipLaunchKernelGGL(iti_x3_kernel<1>, dim3(S, tiles), dim3(256), 0, c->stream, Y32, Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin, kslice, (const iti_nomix_t*)nullptr, (const float*)nullptr, (f16_t*)nullptr, (const f16_t*)nullptr);
             }
         }
         ARP_HIP_OK(hipGetLastError());
@@ -1377,6 +1381,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_MERGE")) c->merge_small = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_PACK_EARLY")) c->pack_early = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_DY_X16")) c->dy_x16 = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_MIX_X16")) c->mix_x16 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ADAM_REV")) c->adam_rev = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
     build_layout(c);

@@ -191,11 +191,15 @@ struct iti_nomix_t {};
 // TA != iti_nomix_t: the adapter's mix inside the operand load -- X is the f32 encoder output, Amix the adapter's output (operand type, or f32 with the
 // corrected adapter), and the X operand is adapter_mix1(sigmoid(rw), a, x) formed in registers; the rounded mix (what the backward's dWi reads) goes out as
 // y16.  Saves the mix's own pass: it read a + x and wrote y16 + a 101 MB f32 copy that this kernel then read back (303 + 202 MB -> 303 MB at B = 32).
-template <int AHEAD, typename TA = iti_nomix_t, typename TY = f16_t>  // AHEAD: K-tiles of operands in flight per thread
+// X16 (with the mix only): x comes from its operand-type copy x16 (what fc1 and the backward read) instead of the f32 encodings -- 50 MB less per step at B = 32.
+// The mix's value is rounded to the operand type for the backward anyway and its skip term weighs (1 - res) (0.018 at the initial residual_weight = 4), so
+// x's own rounding is at most as large as the adapter output's, which has always been there (arp_dt.hip ARP_DT_MIX_X16).
+template <int AHEAD, typename TA = iti_nomix_t, typename TY = f16_t, bool X16 = false>  // AHEAD: K-tiles of operands in flight per thread
 static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restrict__ X, size_t ldx, const float* __restrict__ W, size_t ldw, float* __restrict__ part,
                                                      int M, int N, int K, int kslice, const TA* __restrict__ Amix = nullptr, const float* __restrict__ rw = nullptr,
-                                                     TY* __restrict__ y16 = nullptr) {
+                                                     TY* __restrict__ y16 = nullptr, const TY* __restrict__ x16 = nullptr) {
     constexpr bool MIX = !__is_same(TA, iti_nomix_t);
+    static_assert(!X16 || MIX, "the operand-type x is the mix's");
     constexpr int ROW = 80;  // binary16 elements per LDS row: 160 B = 40 dwords -- the sixteen lanes of a ds_read_b128 group (rows j, chunks g and g + 1) fall on sixteen
                              // distinct 4-bank slots; at 144 B seven of them met another's (SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles, profiles/r4_x3_pmc.json)
     __shared__ __attribute__((aligned(16))) _Float16 sm[4][128 * ROW];  // X hi, X lo, W hi, W lo
@@ -223,6 +227,7 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
     if constexpr (MIX) {
         Amix += (size_t)m0 * ldx;
         y16 += (size_t)m0 * ldx;
+        if constexpr (X16) x16 += (size_t)m0 * ldx;
         res = 1.0f / (1.0f + expf(-rw[0]));
         put_y = n0 == 0;  // (every X element belongs to exactly one (row tile, K slice); a second column tile would only repeat the store)
     }
@@ -230,18 +235,29 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
     areg_t ar[AHEAD][MIX ? 8 : 1];
     // TWO K-tiles of operands in flight per thread (2 x 16 float4; one workgroup per CU, so the registers are there): with one, a tile's loads were
     // issued behind the previous tile's split and had only its MFMAs (0.7 us) to land in -- 3.75 TB/s of the 202 MB stream
-    float4 xr[AHEAD][8], wreg[AHEAD][8];
+    using xreg_t = std::conditional_t<X16, uint2, float4>;
+    xreg_t xr[AHEAD][8];
+    float4 wreg[AHEAD][8];
     auto fetch = [&](auto ST, int k) {
         constexpr int st = decltype(ST)::value;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            xr[st][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X + k) + xo[i]);
+            if constexpr (X16) xr[st][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(x16 + k) + (xo[i] >> 1));
+            else xr[st][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X + k) + xo[i]);
             if constexpr (MIX) ar[st][i] = *reinterpret_cast<const areg_t*>(reinterpret_cast<const char*>(Amix + k) + (sizeof(TA) == 4 ? xo[i] : xo[i] >> 1));
             wreg[st][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(W + k) + wo[i]);
         }
     };
     // the mix of one lane's four values (adapter_mix_kernel's arithmetic) + its rounded copy to y16
-    auto mixed = [&](float4 x, areg_t a, int k, int i) __attribute__((always_inline)) {
+    auto mixed = [&](xreg_t xin, areg_t a, int k, int i) __attribute__((always_inline)) {
+        float4 x;
+        if constexpr (X16) {
+            float xv[4];
+            load4(reinterpret_cast<const TY*>(&xin), xv);
+            x = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        } else {
+            x = xin;
+        }
         if constexpr (MIX) {
             float av[4];
             if constexpr (sizeof(TA) == 4) { av[0] = a.x; av[1] = a.y; av[2] = a.z; av[3] = a.w; }
