@@ -313,7 +313,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                     for (int it = 0; it < 8; ++it) {
                         const int lr = it * 8 + wave * 2 + (lane >> 5);
                         const int m = m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), n = n0 + (lane & 31) * 4;
-                        rres[it] = (m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        // unconditional, clamped address (gemm256.h: a guarded load is a branch + vmcnt(0) per row; N % 8 == 0 on the staged path)
+                        rres[it] = *reinterpret_cast<const float4*>(g.resid + (size_t)min(m, g.M - 1) * g.ldr + min(n, g.N - 4));
                     }
                 }
                 // Fused AdamW: the weight's p / m / v rows one iteration AHEAD (ARP_ADAMW_PIPE, default on) -- iteration it + 1's three loads are issued

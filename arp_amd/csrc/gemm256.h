@@ -832,20 +832,32 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
 #endif
             ARP_STAMP(2);
+            // the mask's sixteen row segments per thread are requested HERE, unconditionally from clamped addresses and all at once, ahead of the barrier that
+            // publishes the staged tile: inside the `m < M && n < N` branch below each one was a branch + vmcnt(0) of its own (round 5, found in the ISA)
+            u32x4_v mvr[(G2_MASK_SITE(SITE)) ? 16 : 1];
+            if constexpr (G2_MASK_SITE(SITE)) {
+                if (g.mask) {
+                    const OutT* __restrict__ mk = static_cast<const OutT*>(g.mask);
+#pragma unroll
+                    for (int it = 0; it < 16; ++it) {
+                        const int m = min(m0 + it * 16 + wave * 2 + (lane >> 5), g.M - 1), n = min(n0 + (lane & 31) * 8, g.N - 8);
+                        mvr[it] = *reinterpret_cast<const u32x4_v*>(mk + (size_t)m * g.ldm + n);
+                    }
+                }
+            }
             __syncthreads();
             ARP_STAMP(3);
             if (G2_MASK_SITE(SITE) && g.mask) {  // compiled into the policy step's instances only: the ViT kernels keep their register budget
                 // out = (mask > 0) ? value : 0 on whole 16-byte row segments, plus the tile's column sums of what was stored (the bias
                 // gradient of the layer whose ReLU this is): one more 16-byte read per store instead of a separate pass over both tensors
-                const OutT* __restrict__ mk = static_cast<const OutT*>(g.mask);
                 float colacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
                 for (int it = 0; it < 16; ++it) {
                     const int r = it * 16 + wave * 2 + (lane >> 5);
                     const int m = m0 + r, n = n0 + (lane & 31) * 8;
                     if (m < g.M && n < g.N) {
                         u32x4_v v = *reinterpret_cast<const u32x4_v*>(smem + r * RS + (lane & 31) * 16);
-                        const u32x4_v mv = *reinterpret_cast<const u32x4_v*>(mk + (size_t)m * g.ldm + n);
+                        const u32x4_v mv = mvr[G2_MASK_SITE(SITE) ? it : 0];
 #pragma unroll
                         for (int w = 0; w < 4; ++w) {
                             // per 16-bit half: keep = magnitude non-zero and sign clear (bf16 and f16 alike; a NaN mask keeps, as NaN > 0
@@ -922,7 +934,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                     for (int it = 0; it < 16; ++it) {
                         const int lr = it * 8 + wave;
                         const int m = m0 + (lr >> 6) * 128 + p * 64 + (lr & 63), n = n0 + lane * 4;
-                        rres[p][it] = ((ARP_G2_ABL & 4) == 0 && m < g.M && n < g.N) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        // UNCONDITIONAL, from a clamped address (rows / columns outside the matrix re-read its last row / last four columns; their values are never
+                        // stored): behind a `m < M && n < N ? load : 0` hipcc branches around every load and waits vmcnt(0) at each join -- the sixteen "in flight
+                        // together" were sixteen dependent round trips (round 5, found in the ISA; N % 8 == 0 on this path)
+                        if constexpr ((ARP_G2_ABL & 4) == 0) rres[p][it] = *reinterpret_cast<const float4*>(g.resid + (size_t)min(m, g.M - 1) * g.ldr + min(n, g.N - 4));
+                        else rres[p][it] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
             };

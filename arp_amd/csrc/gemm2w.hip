@@ -216,8 +216,8 @@ __global__ __launch_bounds__(W2_THREADS, 2) __attribute__((amdgpu_num_vgpr(W2_MA
                     const int idx = it * W2_THREADS + tid;
                     const int lr = idx / 48, ch = idx - lr * 48;
                     const int m = m0 + (lr >> 5) * 64 + p * 32 + (lr & 31), n = n0 + ch * 4;
-                    rres[p][it] = (m < g.M && (full_n || n + 4 <= g.N)) ? *reinterpret_cast<const float4*>(g.resid + (size_t)m * g.ldr + n)
-                                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                    // unconditional, clamped address (gemm256.h: a guarded load is a branch + vmcnt(0) per row)
+                    rres[p][it] = *reinterpret_cast<const float4*>(g.resid + (size_t)min(m, g.M - 1) * g.ldr + min(n, g.N - 4));
                 }
             }
         };
