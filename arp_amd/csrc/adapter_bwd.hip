@@ -88,6 +88,18 @@ __global__ __launch_bounds__(AD_THREADS) void adapter_dy_kernel(AdapterDyArgs g)
     }
     __syncthreads();  // the operand images are dead: the staging tile overlays them
 
+    // The row pass's operands -- A and (with x16) the encodings, 16 bytes each for four rows per thread -- are requested HERE, all eight at once, from clamped
+    // rows and unconditionally: inside the pass's `r < R` branch each row's loads were followed by a vmcnt(0) of their own (hipcc at the join of a branch
+    // around a load), four dependent memory round trips behind the MFMAs (round 5, found in the ISA).
+    const int chunk_ = (int)threadIdx.x & 15, rowl_ = (int)threadIdx.x >> 4;
+    u32x4_v araw4[4], xraw4[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const size_t flat = (size_t)min(r0 + p * 32 + rowl_, g.R - 1) * g.Kin + n0 + chunk_ * 8;
+        araw4[p] = *reinterpret_cast<const u32x4_v*>(static_cast<const T*>(g.A) + flat);
+        if (g.x16) xraw4[p] = *reinterpret_cast<const u32x4_v*>(static_cast<const T*>(g.x16) + flat);
+    }
+
     // ---- stage the f32 tile (lane holds row .. + fr, columns .. + 4 fg + {0..3}) ------------------------------------------------
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -99,7 +111,6 @@ __global__ __launch_bounds__(AD_THREADS) void adapter_dy_kernel(AdapterDyArgs g)
     __syncthreads();
 
     // ---- row-contiguous pass: 16-byte loads of A, 32-byte loads of x, 16-byte stores of dApre ----------------------------------------
-    const T* __restrict__ Ap = static_cast<const T*>(g.A);
     T* __restrict__ out = static_cast<T*>(g.dApre);
     const float s = 1.0f / (1.0f + expf(-g.rw[0]));  // res = sigmoid(residual_weight), as adapter_mix computes it
     const int chunk = tid & 15, rowl = tid >> 4;
@@ -110,10 +121,10 @@ __global__ __launch_bounds__(AD_THREADS) void adapter_dy_kernel(AdapterDyArgs g)
         const int row = p * 32 + rowl, r = r0 + row;
         if (r < g.R) {
             const size_t flat = (size_t)r * g.Kin + n0 + chunk * 8;
-            const u32x4_v araw = *reinterpret_cast<const u32x4_v*>(Ap + flat);
+            const u32x4_v araw = araw4[p];
             float x[8];
             if (g.x16) {  // the operand-type copy of the encodings (16 B instead of 32): only d loss / d res reads x, and the dY beside it is a 16-bit product already
-                const u32x4_v xraw = *reinterpret_cast<const u32x4_v*>(static_cast<const T*>(g.x16) + flat);
+                const u32x4_v xraw = xraw4[p];
                 T xt[8];
                 memcpy(xt, &xraw, 16);
 #pragma unroll
