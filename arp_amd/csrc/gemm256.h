@@ -757,13 +757,40 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         } else if constexpr (sizeof(OutT) == 2) {
             constexpr int RS = 256 * 2 + 16;  // +16 B pad: fragment rows land on different banks
             auto stage16 = [&](auto LN) {  // LN: the folded-LayerNorm correction is compiled out of the ordinary path
+                // Folded LayerNorm (gemm.h): the tile's 256 (mean, rstd) pairs are formed ONCE, by 256 threads, each from its row's partial sums requested in one
+                // unconditional batch, and handed over in LDS; the column vector c is read once per thread like the bias.  (Rounds 1-4 called ln_row_stats per
+                // fragment row -- a runtime loop of dependent loads, eight times per thread -- and read c behind a per-fragment `n < N` branch: ~100 serialised
+                // loads per thread and tile, the 5.5 ms of site time that made the fold lose 16 % in profiles/r4_lnfold_ab.txt.)
+                float* lnst = reinterpret_cast<float*>(smem + G2_RED_OFF);
+                float4 cq[2][NI];
+                if constexpr (LN.value) {
+                    if (tid < 256) {
+                        const float2* st = reinterpret_cast<const float2*>(g.ln_stats + (size_t)min(m0 + tid, g.M - 1) * g.ln_parts * 2);
+                        float2 pr[8];
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) pr[p] = st[min(p, g.ln_parts - 1)];
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int p = 0; p < 8; ++p)
+                            if (p < g.ln_parts) { s += pr[p].x; q += pr[p].y; }
+                        const float mu = s * g.ln_inv_d;
+                        lnst[2 * tid] = mu;
+                        lnst[2 * tid + 1] = 1.0f / sqrtf(fmaxf(q * g.ln_inv_d - mu * mu, 0.f) + g.ln_eps);
+                    }
+#pragma unroll
+                    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            cq[nq][ni] = *reinterpret_cast<const float4*>(g.ln_c + min(n0 + wc * 64 + nq * 32 + ni * CSTEP + cl, g.N - 4));
+                    __syncthreads();
+                }
 #pragma unroll
                 for (int mq = 0; mq < 2; ++mq)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
                         const int row = wr * 128 + mq * 64 + mi * RSTEP + rl;
                         float mu = 0.f, rs = 1.f;
-                        if constexpr (LN.value) ln_row_stats(g, min(m0 + row, g.M - 1), mu, rs);  // folded LayerNorm (gemm.h)
+                        if constexpr (LN.value) { mu = lnst[2 * row]; rs = lnst[2 * row + 1]; }
 #pragma unroll
                         for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
@@ -773,11 +800,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                                 float v[4] = {a4[0], a4[1], a4[2], a4[3]};
                                 if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
                                 if constexpr (LN.value) {
-                                    if (n0 + col < g.N) {
-                                        const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n0 + col);
-                                        v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
-                                        v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
-                                    }
+                                    const float4 c4 = cq[nq][ni];
+                                    v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
+                                    v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
                                 }
                                 const float4 b = bq[nq][ni];
                                 v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -1088,6 +1113,7 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     if (g.N <= 0 || g.K % EPB != 0 || g.K <= 0 || g.lda % (16 / (int)sizeof(T)) != 0 || g.ldw % (16 / (int)sizeof(T)) != 0)
         return fail("gemm256_nt: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) +
                     " K=" + std::to_string(g.K));
+    if (g.ln_stats && (g.ln_parts < 1 || g.ln_parts > 8)) return fail("gemm256_nt: the folded-LayerNorm epilogue holds at most 8 partial sums per row (width <= 1024)");
     if (g.mask && (!G2_MASK_SITE(SITE) || sizeof(OutT) != 2 || ((g.N | g.ldo | g.ldm | g.ldr) & 7) || (g.flags & 3)))
         return fail("gemm256_nt: the masked epilogue needs a 16-bit output and N, ldo, ldm multiples of 8");
     // KV = 1 addresses a tile's rows by 32-bit byte offsets from the tile's first row
