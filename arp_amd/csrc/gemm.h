@@ -271,6 +271,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
     if (staged) {
         if constexpr (sizeof(OutT) == 2) {
             constexpr int RS = 128 * 2 + 16;
+            // the thread's four bias (and folded-LayerNorm c) fragments once, unconditionally from clamped columns, ahead of the staging loop: behind a per-fragment
+            // `n < N` branch each was a load + vmcnt(0) of its own (gemm256.h; N % 8 == 0 on this path, columns past N are never stored)
+            float4 bq[4], cq[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int nc = min(n0 + wc * 64 + ni * 16 + fg * 4, g.N - 4);
+                // (a pointer select, then an unconditional load: with no bias / no fold the 16 bytes come from the A operand and are not used)
+                bq[ni] = *reinterpret_cast<const float4*>(g.bias ? g.bias + nc : reinterpret_cast<const float*>(g.A));
+                cq[ni] = *reinterpret_cast<const float4*>(g.ln_stats ? g.ln_c + nc : reinterpret_cast<const float*>(g.A));
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 float mu = 0.f, rs = 1.f;
@@ -279,13 +289,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                 for (int ni = 0; ni < 4; ++ni) {
                     const int row = wr * 64 + mi * 16 + fr, col = wc * 64 + ni * 16 + fg * 4;
                     float v[4] = {acc[ni][mi][0] * g.alpha, acc[ni][mi][1] * g.alpha, acc[ni][mi][2] * g.alpha, acc[ni][mi][3] * g.alpha};
-                    if (g.ln_stats && n0 + col < g.N) {
-                        const float4 c4 = *reinterpret_cast<const float4*>(g.ln_c + n0 + col);
+                    if (g.ln_stats) {
+                        const float4 c4 = cq[ni];
                         v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
                         v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
                     }
-                    if (g.bias && n0 + col < g.N) {
-                        const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
+                    if (g.bias) {  // (uniform: no load inside)
+                        const float4 b = bq[ni];
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
 #pragma unroll
@@ -340,6 +350,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                     for (int a = 0; a < AD; ++a) adam_load(a);
                 }
+                float4 bqf[4];  // the four bias fragments once per pass, unconditionally (see the 16-bit path above)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    bqf[ni] = *reinterpret_cast<const float4*>(g.bias ? g.bias + min(n0 + wc * 64 + ni * 16 + fg * 4, g.N - 4) : reinterpret_cast<const float*>(g.A));
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
@@ -347,8 +361,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmArgs g) {
                         const int mi = 2 * p + mh;
                         const int lrow = wr * 32 + mh * 16 + fr, col = wc * 64 + ni * 16 + fg * 4;
                         float v[4] = {acc[ni][mi][0] * g.alpha, acc[ni][mi][1] * g.alpha, acc[ni][mi][2] * g.alpha, acc[ni][mi][3] * g.alpha};
-                        if (g.bias && n0 + col < g.N) {
-                            const float4 b = *reinterpret_cast<const float4*>(g.bias + n0 + col);
+                        if (g.bias) {  // (uniform: no load inside)
+                            const float4 b = bqf[ni];
                             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                         }
 #pragma unroll

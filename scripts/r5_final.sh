@@ -1,11 +1,14 @@
 #!/bin/bash
-# round 5 closing evidence: full GPU suite, the driver's command (stdout kept as the driver sees it), rocprofv3 summaries, N1 f16c kernel trace
+# round 5 closing evidence: full GPU suite, rocprofv3 summaries (kernel stats, PMC passes), THEN the driver's command (stdout kept as the driver sees it) so that
+# its roofline.traffic comes from counters of this very tree (traffic_stale false), N1 f16c kernel trace
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out
 (time timeout 2400 python -m pytest tests -q -x -m gpu 2>&1 | grep -E "passed|failed|rror" | head -5) > $O/r5_gpu_suite.txt 2>&1
+./scripts/prof_round.sh r5 > $O/prof_round.log 2>&1
+python scripts/summarize_round.py r5 > $O/summarize_round.log 2>&1
+mkdir -p $O/box_profiles && cp profiles/pmc_traffic.json profiles/pmc_traffic_finetune.json profiles/r5_pmc_summary.json profiles/r5_mfma_util.json profiles/r5_kernel_stats.csv profiles/r5_policy_kernel_stats.csv profiles/r5_finetune_kernel_stats.csv $O/box_profiles/ 2>/dev/null
 (time python bench.py) > $O/r5_bench_default.jsonl 2> $O/r5_bench_default.err
 cp $O/bench_full.json $O/r5_bench_full.json
-./scripts/prof_round.sh r5 > $O/prof_round.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r5_n1_trace -- python3 $R/bench.py --path policy --with-encoder --mode f16 --encoder-mode f16c --steps 10 --warmup 3 --cpu-seconds 0 --parity-frames 0 > $R/gpurun_out/prof_r5_n1_trace.log 2>&1
