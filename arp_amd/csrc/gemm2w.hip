@@ -168,7 +168,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) __attribute__((amdgpu_num_vgpr(W2_MA
 #pragma unroll
     for (int ni = 0; ni < 6; ++ni) {
         const int n = n0 + wc * 96 + ni * 16 + fg * 4;
-        bias4[ni] = (g.bias && n + 4 <= g.N) ? *reinterpret_cast<const float4*>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // an unconditional load from a selected pointer and a clamped column (a guarded load is a branch + vmcnt(0): six dependent round trips at the head of
+        // every tile's epilogue); without a bias the 16 bytes come from the A operand and are replaced by zeros, columns past N are never stored
+        const float4 bl = *reinterpret_cast<const float4*>(g.bias ? g.bias + min(n, g.N - 4) : reinterpret_cast<const float*>(g.A));
+        bias4[ni] = g.bias ? bl : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (g.flags & 1) {  // ablation: keep the accumulators live, store (almost) nothing
         float sacc = 0.f;

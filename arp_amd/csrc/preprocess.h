@@ -163,12 +163,42 @@ __global__ __launch_bounds__(256) void preprocess_fast_kernel(PreprocArgs a) {
     uint8_t* in_s = reinterpret_cast<uint8_t*>(vT) + ((a.TR * vs * 4 + 15) & ~15);
     uint8_t* mid_s = in_s + ((a.max_rows * in_row_bytes + 15) & ~15);
 
+    // Everything the prologue needs from memory is requested at once -- the two row bounds first, then the tap tables and the normalisation LUT in batches of
+    // eight unconditional loads (clamped indices) per thread.  The three plain copy loops that stood here waited one memory round trip per iteration, and the
+    // row bounds another two behind them: ~11 dependent round trips before the first input row was requested, most of a workgroup's 12-15 us (round 5).
+#ifdef ARP_PRE_OLD_PROLOGUE  // rounds 1-5, for A/B builds of scripts/preprocess_bench.hip
     for (int i = tid; i < a.R * hs; i += 256) hT[i] = a.h_tab[i];
     for (int i = tid; i < 768; i += 256) lut[i] = a.lut[i];
     for (int i = tid; i < (oy1 - oy0) * vs; i += 256) vT[i] = a.v_tab[oy0 * vs + i];
-
+#endif
     const int v_first = a.v_tab[oy0 * vs];
     const int v_last = a.v_tab[(oy1 - 1) * vs];
+#ifndef ARP_PRE_OLD_PROLOGUE
+    {
+        const int nh = a.R * hs, nv = (oy1 - oy0) * vs;
+        for (int base = 0; base < nh; base += 8 * 256) {
+            int hr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hr[q] = a.h_tab[min(base + q * 256 + tid, nh - 1)];
+            float lr[3];
+            int vr = 0;
+            if (base == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) lr[q] = a.lut[q * 256 + tid];
+                vr = a.v_tab[oy0 * vs + min(tid, nv - 1)];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (base + q * 256 + tid < nh) hT[base + q * 256 + tid] = hr[q];
+            if (base == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) lut[q * 256 + tid] = lr[q];
+                if (tid < nv) vT[tid] = vr;
+            }
+        }
+        for (int i = tid + 256; i < nv; i += 256) vT[i] = a.v_tab[oy0 * vs + i];  // (tiles of more than 256 / vs rows: not the shipped plans)
+    }
+#endif
     const int y_lo = v_first & 0xffff;
     const int y_hi = (v_last & 0xffff) + (v_last >> 16);
     const int rows = y_hi - y_lo;
