@@ -762,7 +762,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                 // fragment row -- a runtime loop of dependent loads, eight times per thread -- and read c behind a per-fragment `n < N` branch: ~100 serialised
                 // loads per thread and tile, the 5.5 ms of site time that made the fold lose 16 % in profiles/r4_lnfold_ab.txt.)
                 float* lnst = reinterpret_cast<float*>(smem + G2_RED_OFF);
-                float4 cq[2][NI];
+                float4 cq[LN.value ? 2 : 1][LN.value ? NI : 1];
                 if constexpr (LN.value) {
                     if (tid < 256) {
                         const float2* st = reinterpret_cast<const float2*>(g.ln_stats + (size_t)min(m0 + tid, g.M - 1) * g.ln_parts * 2);
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                                 float v[4] = {a4[0], a4[1], a4[2], a4[3]};
                                 if constexpr (sizeof(T) == 1) { v[0] *= g.alpha; v[1] *= g.alpha; v[2] *= g.alpha; v[3] *= g.alpha; }
                                 if constexpr (LN.value) {
-                                    const float4 c4 = cq[nq][ni];
+                                    const float4 c4 = cq[LN.value ? nq : 0][LN.value ? ni : 0];
                                     v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
                                     v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
                                 }
@@ -818,8 +818,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                             }
                     }
             };
-            if (g.ln_stats) stage16(std::true_type{});
-            else stage16(std::false_type{});
+            if constexpr (G2_MASK_SITE(SITE)) {
+                stage16(std::false_type{});  // (the policy step's instances carry the masked epilogue instead of the folded LayerNorm: the launcher refuses ln_stats there)
+            } else {
+                if (g.ln_stats) stage16(std::true_type{});
+                else stage16(std::false_type{});
+            }
 #if ARP_G2_TWO_PHASE && ARP_G2_OVERLAP_DRAIN
             // ---- overlapped drain (a workgroup that has another tile to do; interior tiles only) --------------------------
             // The tile's bytes move LDS -> registers (64 VGPRs: the accumulators are dead), the barrier releases LDS, the NEXT
@@ -857,32 +861,22 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
             }
 #endif
             ARP_STAMP(2);
-            // the mask's sixteen row segments per thread are requested HERE, unconditionally from clamped addresses and all at once, ahead of the barrier that
-            // publishes the staged tile: inside the `m < M && n < N` branch below each one was a branch + vmcnt(0) of its own (round 5, found in the ISA)
-            u32x4_v mvr[(G2_MASK_SITE(SITE)) ? 16 : 1];
-            if constexpr (G2_MASK_SITE(SITE)) {
-                if (g.mask) {
-                    const OutT* __restrict__ mk = static_cast<const OutT*>(g.mask);
-#pragma unroll
-                    for (int it = 0; it < 16; ++it) {
-                        const int m = min(m0 + it * 16 + wave * 2 + (lane >> 5), g.M - 1), n = min(n0 + (lane & 31) * 8, g.N - 8);
-                        mvr[it] = *reinterpret_cast<const u32x4_v*>(mk + (size_t)m * g.ldm + n);
-                    }
-                }
-            }
             __syncthreads();
             ARP_STAMP(3);
+            // (Round 5 tried the mask's sixteen row segments as one or two unconditional batches -- inside the branch below each load is a branch + vmcnt(0) of its own.
+            //  No gain by wall, and the batch's addresses, formed at the head of the kernel, cost these instances 39 spilled registers: reverted.)
             if (G2_MASK_SITE(SITE) && g.mask) {  // compiled into the policy step's instances only: the ViT kernels keep their register budget
                 // out = (mask > 0) ? value : 0 on whole 16-byte row segments, plus the tile's column sums of what was stored (the bias
                 // gradient of the layer whose ReLU this is): one more 16-byte read per store instead of a separate pass over both tensors
+                const OutT* __restrict__ mk = static_cast<const OutT*>(g.mask);
                 float colacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 4
                 for (int it = 0; it < 16; ++it) {
                     const int r = it * 16 + wave * 2 + (lane >> 5);
                     const int m = m0 + r, n = n0 + (lane & 31) * 8;
                     if (m < g.M && n < g.N) {
                         u32x4_v v = *reinterpret_cast<const u32x4_v*>(smem + r * RS + (lane & 31) * 16);
-                        const u32x4_v mv = mvr[G2_MASK_SITE(SITE) ? it : 0];
+                        const u32x4_v mv = *reinterpret_cast<const u32x4_v*>(mk + (size_t)m * g.ldm + n);
 #pragma unroll
                         for (int w = 0; w < 4; ++w) {
                             // per 16-bit half: keep = magnitude non-zero and sign clear (bf16 and f16 alike; a NaN mask keeps, as NaN > 0
@@ -1113,6 +1107,7 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     if (g.N <= 0 || g.K % EPB != 0 || g.K <= 0 || g.lda % (16 / (int)sizeof(T)) != 0 || g.ldw % (16 / (int)sizeof(T)) != 0)
         return fail("gemm256_nt: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) +
                     " K=" + std::to_string(g.K));
+    if (g.ln_stats && G2_MASK_SITE(SITE)) return fail("gemm256_nt: no folded-LayerNorm epilogue in the masked-epilogue instances");
     if (g.ln_stats && (g.ln_parts < 1 || g.ln_parts > 8)) return fail("gemm256_nt: the folded-LayerNorm epilogue holds at most 8 partial sums per row (width <= 1024)");
     if (g.mask && (!G2_MASK_SITE(SITE) || sizeof(OutT) != 2 || ((g.N | g.ldo | g.ldm | g.ldr) & 7) || (g.flags & 3)))
         return fail("gemm256_nt: the masked epilogue needs a 16-bit output and N, ldo, ldm multiples of 8");

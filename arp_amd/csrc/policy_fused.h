@@ -979,16 +979,37 @@ __device__ __forceinline__ void tokens_bwd_block(int a, const float* __restrict_
         float s[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) s[q] = 0.f;
-#pragma unroll(NT == TOKB_THREADS ? 8 : 16)
-        for (int r = 0; r < R; r += G) {
+        // The block-uniform `is_act` is decided ONCE, outside the loops, and every load is unconditional: written as `is_act ? (action[r] == a ? x : 0) : rtg[r] * x`
+        // per element, each of the two second loads sat in its own branch behind the first and was waited for alone -- ~130 dependent round trips per thread in the
+        // 256-thread form (found in the ISA: it was what made the merged gradient launch 26 us instead of the 16 of its MFMA tiles).  Same sums, same order.
+        auto rows = [&](auto ACT_) __attribute__((always_inline)) {
+            constexpr int UB = 8;  // row steps per batch: 2 * UB * PER loads requested before the first add (hipcc alone keeps one step's in flight)
+            for (int r0 = 0; r0 < R; r0 += G * UB) {
+                float xv[UB][PER], wv[UB][PER];
 #pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                const int rr = r + grp0 + q, rc = min(rr, R - 1);  // (loads unconditional: all of an unrolled batch in flight together)
-                const float x = dtok[((size_t)rc * 3 + tok) * E + e];
-                const float v = is_act ? (action[rc] == a ? x : 0.f) : rtg[rc] * x;
-                if (rr < R) s[q] += v;
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int rc = min(r0 + u * G + grp0 + q, R - 1);
+                        xv[u][q] = dtok[((size_t)rc * 3 + tok) * E + e];
+                        if constexpr (decltype(ACT_)::value) wv[u][q] = __int_as_float(action[rc]);
+                        else wv[u][q] = rtg[rc];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int rr = r0 + u * G + grp0 + q;
+                        float v;
+                        if constexpr (decltype(ACT_)::value) v = __float_as_int(wv[u][q]) == a ? xv[u][q] : 0.f;
+                        else v = wv[u][q] * xv[u][q];
+                        s[q] += rr < R ? v : 0.f;  // (R is a multiple of G in every shipped geometry: nothing is ever added for a row past the end)
+                    }
             }
-        }
+        };
+        if (is_act) rows(std::true_type{});
+        else rows(std::false_type{});
 #pragma unroll
         for (int q = 0; q < PER; ++q) red[(grp0 + q) * E + e] = s[q];
         __syncthreads();
