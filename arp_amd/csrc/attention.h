@@ -583,26 +583,14 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
     //  registers, is what makes this kernel register-bound.)
     // gridDim.y > 1 (the single-frame tower: 12 workgroups would otherwise walk 13 query blocks on 4 waves each): the query blocks are
     // dealt over gridDim.y workgroups, each of which stages the whole K / V image of its head
-    // the NEXT query block's Q fragment is requested at the head of this block's work (unconditionally, from a clamped block index): loaded where it is used,
-    // each of a wave's three or four blocks began with a bare memory round trip in front of its first MFMA
-    u32x4_v qnext[2];
-    {
-        const int q0 = min(wave + 4 * (int)blockIdx.y, nqb - 1) * 16 + fr;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qnext[ks] = *reinterpret_cast<const u32x4_v*>(base + (size_t)min(q0, N - 1) * ld + ks * 32 + fg * 8);
-    }
     for (int qb = wave + 4 * (int)blockIdx.y; qb < nqb; qb += 4 * (int)gridDim.y) {
         int qrow = qb * 16 + fr;
         const int qvalid = qrow < N;
         qrow = qvalid ? qrow : N - 1;
+        // (round 5: the next block's Q fragment requested one block ahead was neutral at N = 197 and costs 8 registers that the N = 257 instance does not have)
         u32x4_v qf[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = qnext[ks];
-        {
-            const int qn = min(qb + 4 * (int)gridDim.y, nqb - 1) * 16 + fr;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) qnext[ks] = *reinterpret_cast<const u32x4_v*>(base + (size_t)min(qn, N - 1) * ld + ks * 32 + fg * 8);
-        }
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const u32x4_v*>(base + qrow * ld + ks * 32 + fg * 8);
 
         // S^T tile kt: rows = keys 16*kt + 4*fg + r, col = query fr
         f32x4_v s[NT];
@@ -614,6 +602,11 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
             for (int ks = 0; ks < 2; ++ks) {
                 const u32x4_v kf = *reinterpret_cast<const u32x4_v*>(Ks + krow * 128 + (((ks * 4 + fg) ^ (krow & 7)) << 4));
                 s[kt] = mfma16<T>(kf, qf[ks], s[kt]);
+            }
+            // at most six key tiles' fragment reads ahead of their MFMAs: left alone, hipcc issues all 2 NT of them first -- 144 registers at NT = 18 (N = 257, the
+            // M3AE encoder), twelve of which went LDS -> scratch -> register on their way to the MFMA (65 spilled registers in that instance; round 5, ISA)
+            if constexpr (NT > 14) {
+                if ((kt % 6) == 5) __builtin_amdgcn_sched_barrier(0);
             }
         }
         AT_ACC(1);
