@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
             }
             // at most six key tiles' fragment reads ahead of their MFMAs: left alone, hipcc issues all 2 NT of them first -- 144 registers at NT = 18 (N = 257, the
             // M3AE encoder), twelve of which went LDS -> scratch -> register on their way to the MFMA (65 spilled registers in that instance; round 5, ISA)
-            if constexpr (NT > 14) {
+            if constexpr (NT >= 14) {
                 if ((kt % 6) == 5) __builtin_amdgcn_sched_barrier(0);
             }
         }
