@@ -122,6 +122,7 @@ struct arp_clip {
     bool ln_fold = false;
     bool fp8_mlp = false;       // vision tower MLP GEMMs on the scaled fp8 MFMA (arp_clip_set_fp8_mlp before finalize; tower.h)
     bool fp8_attn = false;      // ... and in_proj / out_proj as well (arp_clip_set_fp8_mlp(c, 2))
+    bool shared_chip = false;   // this handle's kernels run beside another part stream's (label_dev with two or more parts): tower.h picks out_proj's kernel by it
     bool qkv_fused = true;      // QKV projection + attention in one kernel (qkvattn.h) where the geometry allows; ARP_QKV_FUSED=0 disables
     bool cls_only_last = true;  // vision tower: the last block computes only what ln_post reads (tower.h); ARP_CLS_ONLY=0 disables
     DevBuf stats;
@@ -167,6 +168,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.attn_impl = c->cfg.attn_impl;
     t.gemm_force = c->gemm_force;
     t.qkv_fused = c->qkv_fused;
+    t.shared_chip = c->shared_chip;
     t.fp8_mlp = c->fp8_mlp; t.fp8_attn = c->fp8_attn;
     t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
     t.skinny = c->lat_now; t.h_ready0 = c->lat_now && c->lat_h0; t.lat_stats = c->lat_stats.as<float>(); t.lat_fold0 = c->lat_now && c->lat_f0; t.part = c->part.as<float>(); t.part_floats = c->part.bytes / 4;
@@ -722,7 +724,10 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
             ARP_HIP_OK(hipEventRecord(c->ev_copy[i + 1], c->copy_stream));
             ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_copy[i + 1], 0));
         }
-        ARP_TRY(label_dev_single(s, frames_dev + (size_t)b0 * H * W * 3, nb, H, W, use_crop, rewards_dev + b0));
+        s->shared_chip = true;
+        const int rc = label_dev_single(s, frames_dev + (size_t)b0 * H * W * 3, nb, H, W, use_crop, rewards_dev + b0);
+        s->shared_chip = false;
+        if (rc) return rc;
     }
     for (int i = 1; i < ns; ++i) {  // join: the primary stream continues behind every sibling's last part
         ARP_HIP_OK(hipEventRecord(c->ev_join[i - 1], c->siblings[i - 1]->stream));

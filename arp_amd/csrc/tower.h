@@ -138,6 +138,7 @@ struct TowerCtx {
     // attention writes its output as e4m3 (x 16), out_proj is an fp8 GEMM into the f32 residual stream.
     bool fp8_attn = false;
     bool qkv_fused = true;  // QKV projection + attention in one kernel where qkvattn.h supports the geometry (ARP_QKV_FUSED=0 disables)
+    bool shared_chip = false;  // the pass runs beside another part stream's kernels (arp_clip.hip::label_dev): see out_proj's kernel choice in tower_gemm
     // Latency path (the rollout loop's single-frame reward): with at most SKINNY_MAX_M rows in the residual stream the
     // GEMMs run on the W-tiled skinny kernel (skinny.h), out_proj / c_proj as split-K slabs whose reduction kernel also adds bias +
     // residual and applies the NEXT LayerNorm -- six launches per block, each near the 3 us a dependent launch costs.
@@ -196,9 +197,13 @@ static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* 
             return launch_skinny_gemm(__is_same(T, bf16_t) ? 1 : 2, k, c.stream);
         }
     }
-    // out_proj (K = N = width, f32 residual epilogue) is the one big GEMM where the two-workgroups-per-CU kernel wins: its tiles
-    // are short (12 K-tiles) and epilogue-heavy, so a second resident workgroup pays (measured 57.7 vs 66.8 us at M = 25 600)
-    static const bool out_g256 = [] { const char* e = getenv("ARP_OUT_G256"); return e && atoi(e) != 0; }();  // A/B: out_proj on gemm256 (+ the tile-round split) instead
+    // out_proj (K = N = width, f32 residual epilogue) is the one big GEMM where the two-workgroups-per-CU kernel wins alone on the chip: its tiles
+    // are short (12 K-tiles) and epilogue-heavy, so a second resident workgroup pays (measured 57.7 vs 66.8 us at M = 25 600; row N1's single
+    // stream: 8.84 vs 8.89 ms per step).  Beside a second part stream (the labelling pass) the other stream's kernels are that second workgroup, and since the
+    // residual rows stopped being loaded one at a time (round 5) the 256-tile kernel is the better neighbour: 101.0 -> 101.6 k and 102.8 -> 103.9 k frames/s on
+    // two boxes, ViT-B/16 24.45 -> 24.70 k (profiles/r5_out_g256_ab.txt).  Same MFMA, same k order.  ARP_OUT_G256=0/1 forces either.
+    static const int out_g256_env = [] { const char* e = getenv("ARP_OUT_G256"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    const bool out_g256 = out_g256_env >= 0 ? out_g256_env == 1 : c.shared_chip;
     if (force == 0 && (SITE & 7) == SITE_OUT && M >= 4096) force = out_g256 ? 2 : 3;
     // (c_proj on 256 x 192 tiles -- 400 instead of 300 tiles per 512-frame part, fewer idle slots in the last round -- measured
     //  slower, 5.3 vs 4.5 ms per step: the narrower wave tile's K loop loses more over 48 K-tiles than the rounding wins; removed)
