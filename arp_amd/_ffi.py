@@ -102,6 +102,8 @@ SIGNATURES = {
     "arp_clip_encode_image": (_i, [_vp, _u8p, _i, _i, _i, _i, _i, _fp]),
     "arp_preprocess": (_i, [_u8p, _i, _i, _i, _i, _i, _fp]),
     "arp_bicubic_coeffs": (_i, [_i, _i, _i32p, _i32p, _i32p, _i]),
+    "arp_clip_clock_probe": (_i, [_vp, _i]),
+    "arp_clip_clock_read": (_i, [_vp, C.POINTER(C.c_double)]),
     "arp_clip_profile_enable": (_i, [_vp, _i]),
     "arp_clip_profile_reset": (_i, [_vp]),
     "arp_clip_profile_json": (_i, [_vp, C.c_char_p, _i]),
@@ -175,6 +177,7 @@ SIGNATURES = {
     "arp_enc_load_weight": (_i, [_vp, C.c_char_p, _fp, _i64p, _i]),
     "arp_enc_finalize_weights": (_i, [_vp]),
     "arp_enc_forward": (_i, [_vp, _fp, _i, _fp]),
+    "arp_enc_set_streams": (_i, [_vp, _i, _i, _i]),
     "arp_enc_profile_enable": (_i, [_vp, _i]),
     "arp_enc_profile_json": (_i, [_vp, C.c_char_p, _i]),
     "arp_dt_attach_encoder": (_i, [_vp, _vp]),

@@ -262,6 +262,16 @@ class ClipLabeller:
         check(lib.arp_clip_event_record(self._h, event.ptr))
 
     # -- profiling -------------------------------------------------------------------------------
+    def clock_probe(self, on=True):
+        """c_fc on the clock-diagnostic instance of the GEMM kernel (``arp_clip_clock_probe``); rewards unchanged."""
+        check(lib.arp_clip_clock_probe(self._h, int(on)))
+
+    def clock_read(self):
+        """``{"clock_ghz", "workgroups", "workgroup_us"}`` accumulated since the probe was switched on."""
+        out = (C.c_double * 3)()
+        check(lib.arp_clip_clock_read(self._h, out))
+        return {"clock_ghz": out[0], "workgroups": int(out[1]), "workgroup_us": out[2]}
+
     def profile(self, on=True):
         check(lib.arp_clip_profile_enable(self._h, int(on)))
 

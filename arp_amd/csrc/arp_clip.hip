@@ -122,6 +122,8 @@ struct arp_clip {
     bool ln_fold = false;
     bool fp8_mlp = false;       // vision tower MLP GEMMs on the scaled fp8 MFMA (arp_clip_set_fp8_mlp before finalize; tower.h)
     bool fp8_attn = false;      // ... and in_proj / out_proj as well (arp_clip_set_fp8_mlp(c, 2))
+    DevBuf clock_buf;           // arp_clip_clock_probe: three u64 the clock-diagnostic c_fc instance accumulates into (owned by the primary handle)
+    unsigned long long* clock_acc = nullptr;  // null: the ordinary instances run
     bool shared_chip = false;   // this handle's kernels run beside another part stream's (label_dev with two or more parts): tower.h picks out_proj's kernel by it
     bool qkv_fused = true;      // QKV projection + attention in one kernel (qkvattn.h) where the geometry allows; ARP_QKV_FUSED=0 disables
     bool cls_only_last = true;  // vision tower: the last block computes only what ln_post reads (tower.h); ARP_CLS_ONLY=0 disables
@@ -169,6 +171,7 @@ static TowerCtx ctx_of(arp_clip* c) {
     t.gemm_force = c->gemm_force;
     t.qkv_fused = c->qkv_fused;
     t.shared_chip = c->shared_chip;
+    t.clock_acc = c->clock_acc;
     t.fp8_mlp = c->fp8_mlp; t.fp8_attn = c->fp8_attn;
     t.ms_out = c->ms_out; t.ms_ld = c->ms_ld; t.ms_rows = c->ms_rows;
     t.skinny = c->lat_now; t.h_ready0 = c->lat_now && c->lat_h0; t.lat_stats = c->lat_stats.as<float>(); t.lat_fold0 = c->lat_now && c->lat_f0; t.part = c->part.as<float>(); t.part_floats = c->part.bytes / 4;
@@ -641,6 +644,7 @@ static int make_sibling(arp_clip* c) {
     s->ws_frames = 0;
     DevBuf* bufs[] = {&s->patches, &s->pe, &s->x, &s->h, &s->qkv, &s->ao, &s->fc, &s->cls_h, &s->feat, &s->frames_in, &s->rewards, &s->stats};
     for (auto* b : bufs) *b = DevBuf();
+    s->clock_buf = DevBuf();  // (the primary's; clock_acc is copied per call)
     s->part = DevBuf();  // the latency path never runs on a sibling (parts of >= 128 frames)
     s->lat_stats = DevBuf();
     s->lat_graphs.clear();
@@ -705,6 +709,7 @@ static int label_dev(arp_clip* c, const uint8_t* frames_dev, int n, int H, int W
         s->n_prompts = c->n_prompts;
         s->logit_scale = c->logit_scale;
         s->prof.on = c->prof.on;
+        s->clock_acc = c->clock_acc;
         ARP_HIP_OK(hipStreamWaitEvent(s->stream, c->ev_fork, 0));
     }
     // contiguous parts; part i runs on stream i % ns (0 = the primary, k = sibling k-1).
@@ -850,6 +855,7 @@ int arp_clip_destroy(arp_clip* c) {
     drop_lat_graphs(c);
     c->part.release();
     c->lat_stats.release();
+    c->clock_buf.release();
     if (c->pin_frames) (void)hipHostFree(c->pin_frames);
     if (c->pin_rewards) (void)hipHostFree(c->pin_rewards);
     for (void* p : c->owned) (void)hipFree(p);
@@ -1218,6 +1224,41 @@ int arp_clip_set_streams(arp_clip* c, int n_streams) {
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     for (arp_clip* s : c->siblings) ARP_HIP_OK(hipStreamSynchronize(s->stream));
     c->cfg.n_streams = n_streams;
+    return 0;
+}
+
+// The clock the chip holds under the labelling pass (MI355X_MICROARCH 'DVFS give-back' item 6).  on = 1: the vision tower's c_fc launches run on the
+// clock-diagnostic instance of the 256 x 256 GEMM (gemm256.h, CLK: one s_memtime / s_memrealtime pair around each workgroup, summed into a buffer of their
+// own) until on = 0; the accumulators are zeroed at every on = 1.  Rewards are unchanged (same tile, same K loop, same epilogue).
+int arp_clip_clock_probe(arp_clip* c, int on) {
+    if (!c) return fail("null handle");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    for (arp_clip* s : c->siblings) ARP_HIP_OK(hipStreamSynchronize(s->stream));
+    if (on) {
+        ARP_TRY(c->clock_buf.ensure(64));
+        ARP_HIP_OK(hipMemset(c->clock_buf.p, 0, 64));
+        c->clock_acc = c->clock_buf.as<unsigned long long>();
+    } else {
+        c->clock_acc = nullptr;
+    }
+    for (arp_clip* s : c->siblings) s->clock_acc = c->clock_acc;
+    // (a captured single-frame pass holds the instance it was captured with)
+    return 0;
+}
+// out[0] = clock in GHz = sum d(s_memtime) / sum d(s_memrealtime) x 0.1 (time-weighted over the probed workgroups), out[1] = workgroups probed,
+// out[2] = mean workgroup duration in microseconds (s_memrealtime ticks are 10 ns)
+int arp_clip_clock_read(arp_clip* c, double* out) {
+    if (!c || !out) return fail("null argument");
+    if (!c->clock_buf.p) return fail("arp_clip_clock_probe was never switched on");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    ARP_HIP_OK(hipStreamSynchronize(c->stream));
+    for (arp_clip* s : c->siblings) ARP_HIP_OK(hipStreamSynchronize(s->stream));
+    unsigned long long v[3] = {0, 0, 0};
+    ARP_HIP_OK(hipMemcpy(v, c->clock_buf.p, sizeof(v), hipMemcpyDeviceToHost));
+    out[0] = v[1] ? (double)v[0] / (double)v[1] * 0.1 : 0.0;
+    out[1] = (double)v[2];
+    out[2] = v[2] ? (double)v[1] / (double)v[2] * 0.01 : 0.0;
     return 0;
 }
 

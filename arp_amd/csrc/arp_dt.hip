@@ -90,6 +90,11 @@ struct arp_dt {
     hipStream_t copy_stream[2] = {nullptr, nullptr};
     arp_enc* enc = nullptr;   // optional frozen encoder in front (row N1)
     bool use_images = false;
+    // The encoder's part streams fork and join around ~150 long kernels: replayed as parallel branches of the step's hipGraph that costs more than it overlaps
+    // (1.33 vs 0.99 ms for two short branches), and the encoder's launches are far longer than the host takes to issue them -- so with frames in
+    // the encoder is enqueued EAGERLY in front of the (encoder-less) captured chain.  ARP_DT_ENC_EAGER=0 captures it with the rest, as rounds 1-5 did.
+    bool enc_eager = true;
+    bool enc_outside = false;  // this call's encoder pass has been enqueued ahead of the chain: forward<T> skips it
     // activations (T = operand type)
     DevBuf Xb, XbT, H1, H1T, A, Y, YT, dY, dApre, dApreT, G, dH1T, dzb, dzT, part, scal;
     // f32 small tensors
@@ -658,7 +663,7 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     c->defer_w2t = prologue;
     ARP_TRY(refresh_shadows<T>(c));
     c->defer_w2t = false;
-    if (c->use_images) {  // frozen M3AE encoder under stop_gradient (arp_dt/ARPDT.py:418-462): frames -> encodings, on this stream
+    if (c->use_images && !c->enc_outside) {  // frozen M3AE encoder under stop_gradient (arp_dt/ARPDT.py:418-462): frames -> encodings, on this stream
         ARP_TRY(enc_forward_on(c->enc, c->stream, c->bt[c->cur].img32.as<float>(), R, c->bt[c->cur].enc32.as<float>()));
     }
     {   // enc f32 -> operand type, both layouts (the transposed one feeds the weight-gradient GEMM)
@@ -1191,8 +1196,18 @@ template <typename T> int fwd_bwd(arp_dt* c, int stage = 0) {
 // Replays forward + backward as one hipGraph (a chain of short dependent kernels of a few
 // microseconds).  The first steps of a geometry run eagerly (lazy workspace allocations must not happen under
 // capture); profiling and any capture failure fall back to eager launches.
+template <typename T> int fwd_bwd_graphed_chain(arp_dt* c, int stage);
 template <typename T> int fwd_bwd_graphed(arp_dt* c, int stage = 0) {
-    const int images = c->use_images ? 1 : 0;
+    if (c->use_images && c->enc_eager && c->use_graph && !c->prof.on && stage != 2) {
+        ARP_TRY(enc_forward_on(c->enc, c->stream, c->bt[c->cur].img32.as<float>(), c->R(), c->bt[c->cur].enc32.as<float>()));
+        c->enc_outside = true;
+    }
+    const int rc = fwd_bwd_graphed_chain<T>(c, stage);
+    c->enc_outside = false;
+    return rc;
+}
+template <typename T> int fwd_bwd_graphed_chain(arp_dt* c, int stage) {
+    const int images = c->use_images && !c->enc_outside ? 1 : 0;
     if (!c->use_graph || c->prof.on) return fwd_bwd<T>(c, stage);
     arp_dt::GraphRec& gr = c->graphs[c->cur][stage];  // the chain holds the batch slot's pointers
     if (gr.exec && (gr.B != c->B || gr.images != images)) {
@@ -1384,6 +1399,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_MIX_X16")) c->mix_x16 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ADAM_REV")) c->adam_rev = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_FORCE_COMM")) c->force_comm = atoi(e) != 0;
+    if (const char* e = getenv("ARP_DT_ENC_EAGER")) c->enc_eager = atoi(e) != 0;
     build_layout(c);
     auto body = [&]() -> int {
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

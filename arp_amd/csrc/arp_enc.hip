@@ -96,12 +96,28 @@ struct arp_enc {
     TowerW tower;
     void* w_emb = nullptr;  // T [D, P*P*3]
     float *b_emb = nullptr, *cls = nullptr, *pos = nullptr, *lnf_w = nullptr, *lnf_b = nullptr;
-    int ws_frames = 0;
-    DevBuf patches, pe, x, h, qkv, ao, fc, img_in, out;
-    DevBuf a3;  // ARP_MODE_F16X3: the [hi | lo | hi] operand of the current GEMM, binary16 [rows, 3 * (mlp_ratio * width)]
-                // ARP_MODE_F16C: the [hi | x4 | dx4] operand rows (3 bytes per value): [M, D] for LayerNorm / attention outputs, then [M, H] for the hidden activation
+    // Part streams (round 6, as arp_clip.hip::label_dev): a call's frames are cut into contiguous parts, part 0 on the caller's stream, part k on ws[k].stream,
+    // forked and joined by events -- one part's HBM-bound LayerNorm / attention kernels and GEMM grid tails (M = 128 x 257 rows: c_fc 6.05 rounds of tiles,
+    // out_proj / c_proj 1.51) run beside the other part's GEMMs.  Every part has its own workspace; weights are shared.  A frame's encoding does not depend on
+    // which part it is in (every row's dot products run in the same order whatever M is): tests/test_m3ae_gpu.py::test_part_streams_are_exact.
+    struct Ws {
+        int frames = 0;
+        DevBuf patches, pe, x, h, qkv, ao, fc;
+        DevBuf a3;  // ARP_MODE_F16X3: the [hi | lo | hi] operand of the current GEMM, binary16 [rows, 3 * (mlp_ratio * width)]
+                    // ARP_MODE_F16C: the [hi | x4 | dx4] operand rows (3 bytes per value): [M, D] for LayerNorm / attention outputs, then [M, H] for the hidden activation
+        hipStream_t stream = nullptr;  // parts 1..: the part's own stream (part 0 runs on the caller's)
+        hipEvent_t done = nullptr;
+    };
+    static constexpr int MAX_PARTS = 4;
+    Ws ws[MAX_PARTS];
+    int n_parts = 2;          // arp_enc_set_streams / ARP_ENC_STREAMS
+    int min_part_frames = 24; // a part of fewer frames does not fill the chip's GEMM grid (24 x 257 rows = 24 row tiles x 3..12 column tiles)
+    int first_part = 0;       // frames of part 0 when two parts are cut unevenly (0: equal parts; ARP_ENC_SPLIT)
+    hipEvent_t ev_fork = nullptr;
+    bool shared_chip = false; // the pass being enqueued runs beside another part's kernels (tower.h: out_proj's kernel choice)
+    DevBuf img_in, out;
     // ARP_MODE_F16C: per GEMM g in {in_proj, out_proj, fc1, fc2} the correction plan (0 plain, 1 weights, 2 weights + activations) and, per layer, the
-    // power-of-two exponents the e4m3 weight segments were scaled by: dW8 = e4m3(dW * 2^sw_d), W8 = e4m3(W * 2^sw_w)
+    // power-of-two exponents the e2m1 (fp4) weight segments were scaled by: dW4 = fp4(dW * 2^sw_d), W4 = fp4(W * 2^sw_w)
     int plan[4] = {1, 2, 2, 1};  // in_proj: weights only (ln_1's own rounding is 0.5 % of the error budget, scripts/n1_emulate.py)
     std::vector<int> sw_d[4], sw_w[4];
     void* w_emb3 = nullptr;  // ARP_MODE_F16C: the patch embedding's [W_hi | W_hi | W_lo] (its product runs as ARP_MODE_F16X3's K-concatenation)
@@ -217,60 +233,61 @@ int staged(arp_enc* c, const std::string& name, std::vector<int64_t> shape, cons
     return 0;
 }
 
-int ensure_ws(arp_enc* c, int frames) {
-    if (frames <= c->ws_frames) return 0;
+int ensure_ws(arp_enc* c, arp_enc::Ws& w, int frames) {
+    if (frames <= w.frames) return 0;
     const arp_enc_cfg& k = c->cfg;
     const size_t e = c->esz(), G = k.img_res / k.patch, D = k.width, N = c->tokens(), B = frames, M = B * N;
-    ARP_TRY(c->patches.ensure(B * G * G * k.patch * k.patch * 3 * e));
-    ARP_TRY(c->pe.ensure(B * G * G * D * 4));
-    ARP_TRY(c->x.ensure(M * D * 4)); ARP_TRY(c->h.ensure(M * D * e)); ARP_TRY(c->qkv.ensure(M * 3 * D * e));
-    ARP_TRY(c->ao.ensure(M * D * e)); ARP_TRY(c->fc.ensure(M * k.mlp_ratio * D * e));
+    ARP_TRY(w.patches.ensure(B * G * G * k.patch * k.patch * 3 * e));
+    ARP_TRY(w.pe.ensure(B * G * G * D * 4));
+    ARP_TRY(w.x.ensure(M * D * 4)); ARP_TRY(w.h.ensure(M * D * e)); ARP_TRY(w.qkv.ensure(M * 3 * D * e));
+    ARP_TRY(w.ao.ensure(M * D * e)); ARP_TRY(w.fc.ensure(M * k.mlp_ratio * D * e));
     if (k.mode == ARP_MODE_F16X3)  // [M, 3 D] (a GEMM's A operand) followed by [M, 3 H] (c_fc's own epilogue writes c_proj's operand there)
-        ARP_TRY(c->a3.ensure(std::max(M * 3 * (D + k.mlp_ratio * D), B * G * G * 3 * k.patch * k.patch * 3) * 2));
+        ARP_TRY(w.a3.ensure(std::max(M * 3 * (D + k.mlp_ratio * D), B * G * G * 3 * k.patch * k.patch * 3) * 2));
     if (k.mode == ARP_MODE_F16C) {  // [M, D] and [M, H] operand rows of 3 bytes per value; the patch embedding's (hi, lo, hi) triples share the space
-        ARP_TRY(c->a3.ensure(std::max(M * 3 * (D + k.mlp_ratio * D) + 4096, B * G * G * 3 * k.patch * k.patch * 3 * 2)));
-        ARP_TRY(c->patches.ensure(B * G * G * k.patch * k.patch * 3 * 4));  // f32 patches (split into triples on the device)
+        // (+ one 256-row tile of slack: the MIXC instances read ceil(M / 256) * 256 operand rows unclamped)
+        ARP_TRY(w.a3.ensure(std::max((M + 256) * 3 * (D + k.mlp_ratio * D) + 4096, B * G * G * 3 * k.patch * k.patch * 3 * 2)));
+        ARP_TRY(w.patches.ensure(B * G * G * k.patch * k.patch * 3 * 4));  // f32 patches (split into triples on the device)
     }
-    c->ws_frames = frames;
+    w.frames = frames;
     return 0;
 }
 
-template <typename T> int forward_chunk(arp_enc* c, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
+template <typename T> int forward_chunk(arp_enc* c, arp_enc::Ws& w, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
     const arp_enc_cfg& k = c->cfg;
     const int G = k.img_res / k.patch, N = c->tokens(), D = k.width, KP = k.patch * k.patch * 3;
     TowerCtx t;
-    t.stream = stream; t.prof = &c->prof; t.attn_impl = k.attn_impl; t.gemm_force = c->gemm_force;
+    t.stream = stream; t.prof = &c->prof; t.attn_impl = k.attn_impl; t.gemm_force = c->gemm_force; t.shared_chip = c->shared_chip;
     {
         ProfScope ps(c->prof, stream, "m3ae.patchify");
         const size_t tot = (size_t)nb * G * G * KP;
-        hipLaunchKernelGGL((patchify_kernel<T>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, c->patches.as<T>(), nb,
+        hipLaunchKernelGGL((patchify_kernel<T>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, w.patches.as<T>(), nb,
                            k.img_res, k.patch);
         ARP_HIP_OK(hipGetLastError());
     }
-    ARP_TRY((tower_gemm<T, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", c->patches.p, c->w_emb, c->b_emb, nullptr, c->pe.p,
+    ARP_TRY((tower_gemm<T, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", w.patches.p, c->w_emb, c->b_emb, nullptr, w.pe.p,
                                                                    nb * G * G, D, KP)));
     {
         ProfScope ps(c->prof, stream, "m3ae.assemble");
         const size_t tot = (size_t)nb * N * D;
-        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, c->pe.as<float>(), c->cls, c->pos,
-                           c->x.as<float>(), nb * N, N, D);
+        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, w.pe.as<float>(), c->cls, c->pos,
+                           w.x.as<float>(), nb * N, N, D);
         ARP_HIP_OK(hipGetLastError());
     }
-    ARP_TRY((run_blocks<T, ACT_GELU_TANH, 8>(t, c->tower, "m3ae", c->x.as<float>(), c->h.as<T>(), c->qkv.as<T>(), c->ao.as<T>(), c->fc.as<T>(), nb, N, 0,
+    ARP_TRY((run_blocks<T, ACT_GELU_TANH, 8>(t, c->tower, "m3ae", w.x.as<float>(), w.h.as<T>(), w.qkv.as<T>(), w.ao.as<T>(), w.fc.as<T>(), nb, N, 0,
                                              1e-6f)));
-    ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_final", c->x.as<float>(), (size_t)D, out_dev, D, c->lnf_w, c->lnf_b, nb * N, D, 1e-6f));
+    ARP_TRY(tower_layernorm<float>(t, "m3ae.ln_final", w.x.as<float>(), (size_t)D, out_dev, D, c->lnf_w, c->lnf_b, nb * N, D, 1e-6f));
     return 0;
 }
 
 // ARP_MODE_F16X3: the same network with every GEMM as a K-concatenated (hi, lo) product on the f16 kernels and everything between the GEMMs in f32
 // (LayerNorm outputs, the exact-f32 attention kernel, the tanh-GELU'd hidden activation): 12 x (ln -> split -> in_proj -> attention -> split -> out_proj -> ln ->
 // split -> fc1 -> split -> fc2).  Three MFMAs per product plus the split passes: ~4x the plain f16 step, ~2x faster than the f32-MFMA mode, f32-level error.
-int forward_chunk_x3(arp_enc* c, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
+int forward_chunk_x3(arp_enc* c, arp_enc::Ws& w, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
     const arp_enc_cfg& k = c->cfg;
     const int G = k.img_res / k.patch, N = c->tokens(), D = k.width, KP = k.patch * k.patch * 3, H = k.mlp_ratio * D, M = nb * N;
     TowerCtx t;
-    t.stream = stream; t.prof = &c->prof; t.attn_impl = k.attn_impl; t.gemm_force = c->gemm_force;
-    f16_t* a3 = c->a3.as<f16_t>();
+    t.stream = stream; t.prof = &c->prof; t.attn_impl = k.attn_impl; t.gemm_force = c->gemm_force; t.shared_chip = c->shared_chip;
+    f16_t* a3 = w.a3.as<f16_t>();
     auto split = [&](const char* site, const float* src, size_t rows, int K) -> int {
         if (K % 8) return fail("f16x3: widths must be multiples of 8");
         ProfScope ps(c->prof, stream, site);
@@ -281,18 +298,18 @@ int forward_chunk_x3(arp_enc* c, hipStream_t stream, const float* img_dev, int n
     {
         ProfScope ps(c->prof, stream, "m3ae.patchify");
         const size_t tot = (size_t)nb * G * G * KP;
-        hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, c->patches.as<float>(), nb, k.img_res, k.patch);
+        hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, w.patches.as<float>(), nb, k.img_res, k.patch);
         ARP_HIP_OK(hipGetLastError());
     }
-    ARP_TRY(split("m3ae.split", c->patches.as<float>(), (size_t)nb * G * G, KP));
-    ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", a3, c->w_emb, c->b_emb, nullptr, c->pe.p, nb * G * G, D, 3 * KP)));
+    ARP_TRY(split("m3ae.split", w.patches.as<float>(), (size_t)nb * G * G, KP));
+    ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", a3, c->w_emb, c->b_emb, nullptr, w.pe.p, nb * G * G, D, 3 * KP)));
     {
         ProfScope ps(c->prof, stream, "m3ae.assemble");
         const size_t tot = (size_t)nb * N * D;
-        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, c->pe.as<float>(), c->cls, c->pos, c->x.as<float>(), nb * N, N, D);
+        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, w.pe.as<float>(), c->cls, c->pos, w.x.as<float>(), nb * N, N, D);
         ARP_HIP_OK(hipGetLastError());
     }
-    float *x = c->x.as<float>(), *qkv = c->qkv.as<float>(), *ao = c->ao.as<float>();
+    float *x = w.x.as<float>(), *qkv = w.qkv.as<float>(), *ao = w.ao.as<float>();
     for (int i = 0; i < k.layers; ++i) {
         const LayerW& L = c->tower.L[i];
         // LayerNorm and the attention write the (hi, lo, hi) triples of their f32 results themselves (f16x3_t / out3): no f32 copy, no split pass
@@ -342,31 +359,31 @@ int gemm_c(arp_enc* c, TowerCtx& t, const char* site, const void* A, const void*
     return launch_gemm256_nt<f16_t, OutT, ACT, RESID, SITE, false, 1, true>(g, t.stream);
 }
 
-int forward_chunk_c(arp_enc* c, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
+int forward_chunk_c(arp_enc* c, arp_enc::Ws& w, hipStream_t stream, const float* img_dev, int nb, float* out_dev) {
     const arp_enc_cfg& k = c->cfg;
     const int G = k.img_res / k.patch, N = c->tokens(), D = k.width, KP = k.patch * k.patch * 3, H = k.mlp_ratio * D, M = nb * N;
     if (D / k.heads != 64 || N > 288 || k.attn_impl != 0) return fail("f16c: needs the MFMA attention kernel (head_dim 64, <= 288 tokens)");
     TowerCtx t;
-    t.stream = stream; t.prof = &c->prof; t.attn_impl = 0; t.gemm_force = c->gemm_force;
-    char* a4 = static_cast<char*>(c->a3.p);                 // [M, D] operand rows, 3 D bytes each: [hi | x4 | dx4]
+    t.stream = stream; t.prof = &c->prof; t.attn_impl = 0; t.gemm_force = c->gemm_force; t.shared_chip = c->shared_chip;
+    char* a4 = static_cast<char*>(w.a3.p);                 // [M, D] operand rows, 3 D bytes each: [hi | x4 | dx4]
     char* a4h = a4 + (((size_t)M * 3 * D + 255) & ~(size_t)255);  // [M, H] operand rows, 3 H bytes each (fc1's epilogue -> fc2)
     {   // patch embedding on (hi, lo) binary16 pairs (its input rounding alone is a third of the plain f16 encoder's logit error; the product is 0.6 % of the FLOPs)
         ProfScope ps(c->prof, stream, "m3ae.patchify");
         const size_t tot = (size_t)nb * G * G * KP;
-        hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, c->patches.as<float>(), nb, k.img_res, k.patch);
+        hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, w.patches.as<float>(), nb, k.img_res, k.patch);
         ARP_HIP_OK(hipGetLastError());
-        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((tot / 8 + 255) / 256)), dim3(256), 0, stream, c->patches.as<float>(), reinterpret_cast<f16_t*>(a4), (size_t)nb * G * G, KP);
+        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((tot / 8 + 255) / 256)), dim3(256), 0, stream, w.patches.as<float>(), reinterpret_cast<f16_t*>(a4), (size_t)nb * G * G, KP);
         ARP_HIP_OK(hipGetLastError());
     }
-    ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", a4, c->w_emb3, c->b_emb, nullptr, c->pe.p, nb * G * G, D, 3 * KP)));
+    ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", a4, c->w_emb3, c->b_emb, nullptr, w.pe.p, nb * G * G, D, 3 * KP)));
     {
         ProfScope ps(c->prof, stream, "m3ae.assemble");
         const size_t tot = (size_t)nb * N * D;
-        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, c->pe.as<float>(), c->cls, c->pos, c->x.as<float>(), nb * N, N, D);
+        hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, w.pe.as<float>(), c->cls, c->pos, w.x.as<float>(), nb * N, N, D);
         ARP_HIP_OK(hipGetLastError());
     }
-    float* x = c->x.as<float>();
-    f16_t* qkv = c->qkv.as<f16_t>();
+    float* x = w.x.as<float>();
+    f16_t* qkv = w.qkv.as<f16_t>();
     auto ln = [&](const char* site, const float* w, const float* b, int plan) -> int {
         if (plan >= 2) return tower_layernorm<f16c2_t>(t, site, x, D, reinterpret_cast<f16c2_t*>(a4), 3 * D / 2, w, b, M, D, 1e-6f);
         return tower_layernorm<f16c_t>(t, site, x, D, reinterpret_cast<f16c_t*>(a4), 3 * D / 2, w, b, M, D, 1e-6f);
@@ -394,19 +411,58 @@ int forward_chunk_c(arp_enc* c, hipStream_t stream, const float* img_dev, int nb
 
 namespace arp {
 
+static int forward_part(arp_enc* c, arp_enc::Ws& w, hipStream_t stream, const float* img, int nb, float* out) {
+    ARP_TRY(ensure_ws(c, w, nb));
+    if (c->cfg.mode == ARP_MODE_F16X3) return forward_chunk_x3(c, w, stream, img, nb, out);
+    if (c->cfg.mode == ARP_MODE_F16C) return forward_chunk_c(c, w, stream, img, nb, out);
+    if (c->cfg.mode == ARP_MODE_BF16) return forward_chunk<bf16_t>(c, w, stream, img, nb, out);
+    if (c->cfg.mode == ARP_MODE_F16) return forward_chunk<f16_t>(c, w, stream, img, nb, out);
+    return forward_chunk<float>(c, w, stream, img, nb, out);
+}
+
+// Enqueues the encoder of `n` device-resident frames behind everything already on `stream`; `stream` continues behind the last part.  Safe under a
+// stream capture of `stream` (the part streams join the capture through the fork event and leave it through the join events), but every buffer must
+// exist beforehand: the first call of a geometry allocates and must run eagerly (arp_dt.hip runs two eager steps before it captures).
 int enc_forward_on(arp_enc* c, hipStream_t stream, const float* images_dev, int n, float* out_dev) {
     if (!c || !c->finalized) return fail("encoder weights not finalized");
     if (n <= 0) return 0;
     const int mb = c->cfg.max_frames;
-    ARP_TRY(ensure_ws(c, std::min(n, mb)));
     const size_t fi = (size_t)c->cfg.img_res * c->cfg.img_res * 3, fo = (size_t)c->tokens() * c->cfg.width;
     for (int off = 0; off < n; off += mb) {
         const int nb = std::min(mb, n - off);
-        if (c->cfg.mode == ARP_MODE_F16X3) ARP_TRY(forward_chunk_x3(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
-        else if (c->cfg.mode == ARP_MODE_F16C) ARP_TRY(forward_chunk_c(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
-        else if (c->cfg.mode == ARP_MODE_BF16) ARP_TRY(forward_chunk<bf16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
-        else if (c->cfg.mode == ARP_MODE_F16) ARP_TRY(forward_chunk<f16_t>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
-        else ARP_TRY(forward_chunk<float>(c, stream, images_dev + off * fi, nb, out_dev + off * fo));
+        const float* img = images_dev + off * fi;
+        float* out = out_dev + off * fo;
+        int parts = std::min(c->n_parts, (int)arp_enc::MAX_PARTS);
+        while (parts > 1 && nb / parts < c->min_part_frames) --parts;
+        if (parts < 2) {
+            ARP_TRY(forward_part(c, c->ws[0], stream, img, nb, out));
+            continue;
+        }
+        // contiguous parts: part 0 on the caller's stream, part k on its own
+        int cut[arp_enc::MAX_PARTS + 1];
+        cut[0] = 0;
+        for (int i = 1; i <= parts; ++i) cut[i] = (int)((long long)nb * i / parts);
+        if (parts == 2 && c->first_part > 0 && c->first_part < nb) cut[1] = c->first_part;
+        if (!c->ev_fork) ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int i = 1; i < parts; ++i) {
+            if (!c->ws[i].stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->ws[i].stream, hipStreamNonBlocking));
+            if (!c->ws[i].done) ARP_HIP_OK(hipEventCreateWithFlags(&c->ws[i].done, hipEventDisableTiming));
+        }
+        ARP_HIP_OK(hipEventRecord(c->ev_fork, stream));
+        c->shared_chip = true;
+        int rc = 0;
+        for (int i = 0; i < parts && !rc; ++i) {
+            hipStream_t st = i == 0 ? stream : c->ws[i].stream;
+            if (i > 0 && hipStreamWaitEvent(st, c->ev_fork, 0) != hipSuccess) rc = fail("hipStreamWaitEvent(fork) failed");
+            if (!rc) rc = forward_part(c, c->ws[i], st, img + (size_t)cut[i] * fi, cut[i + 1] - cut[i], out + (size_t)cut[i] * fo);
+        }
+        c->shared_chip = false;
+        // join even after a failure: a part stream that entered a capture must leave it before the capture ends
+        for (int i = 1; i < parts; ++i) {
+            if (hipEventRecord(c->ws[i].done, c->ws[i].stream) != hipSuccess || hipStreamWaitEvent(stream, c->ws[i].done, 0) != hipSuccess)
+                if (!rc) rc = fail("part stream join failed");
+        }
+        if (rc) return rc;
     }
     return 0;
 }
@@ -439,6 +495,14 @@ int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
         for (int i = 0; i < 4 && e[i]; ++i)
             if (e[i] >= '0' && e[i] <= '2') c->plan[i] = e[i] - '0';
     }
+    if (const char* e = getenv("ARP_ENC_STREAMS")) c->n_parts = std::max(1, std::min(atoi(e), (int)arp_enc::MAX_PARTS));
+    if (const char* e = getenv("ARP_ENC_SPLIT")) c->first_part = std::max(0, atoi(e));
+    if (const char* e = getenv("ARP_ENC_MIN_PART")) c->min_part_frames = std::max(1, atoi(e));
+    // fc1's plan-0 instance has no e2m1 side output, which fc2's correction K-tiles read: such a plan would run on stale operand segments
+    if (c->plan[2] == 0 && c->plan[3] >= 1) {
+        delete c;
+        return fail("ARP_F16C_PLAN: fc2 cannot be corrected (digit 4 >= 1) when fc1 runs on the plain instance (digit 3 = 0)");
+    }
     // (fc2's operand comes out of fc1's epilogue: its x4 segment from the rounded tile, its dx4 segment -- plan 2 -- straight from the accumulators)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -454,8 +518,14 @@ int arp_enc_destroy(arp_enc* c) {
     (void)hipDeviceSynchronize();
     c->prof.destroy();
     for (void* p : c->owned) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->patches, &c->pe, &c->x, &c->h, &c->qkv, &c->ao, &c->fc, &c->img_in, &c->out, &c->a3};
-    for (auto* b : bufs) b->release();
+    for (auto& w : c->ws) {
+        DevBuf* bufs[] = {&w.patches, &w.pe, &w.x, &w.h, &w.qkv, &w.ao, &w.fc, &w.a3};
+        for (auto* b : bufs) b->release();
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+        if (w.done) (void)hipEventDestroy(w.done);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    c->img_in.release(); c->out.release();
     (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -491,7 +561,7 @@ int arp_enc_finalize_weights(arp_enc* c) {
         ARP_TRY(up_kernel_x3(c, tr, KP, D, &c->w_emb3));
         for (int gi = 0; gi < 4; ++gi) { c->sw_d[gi].assign(k.layers, 0); c->sw_w[gi].assign(k.layers, 0); }
     }
-    // the block GEMMs' weights: operand type, or ARP_MODE_F16C's [W_hi | dW8 (| W8)] rows with their per-tensor scales
+    // the block GEMMs' weights: operand type, or ARP_MODE_F16C's [W_hi | dW4 (| W4)] rows (e2m1 segments) with their per-tensor scales
     auto up_w = [&](const HostTensor* ht, int in, int out_, int gi, int layer, void** dst) -> int {
         if (f16c) return up_kernel_c(c, ht->data.data(), in, out_, c->plan[gi], dst, &c->sw_d[gi][layer], &c->sw_w[gi][layer]);
         return up_kernel(c, ht->data.data(), in, out_, dst);
@@ -559,6 +629,16 @@ int arp_enc_forward(arp_enc* c, const float* images, int n, float* out) {
         ARP_HIP_OK(hipMemcpyAsync(out + off * fo, c->out.p, nb * fo * 4, hipMemcpyDeviceToHost, c->stream));
         ARP_HIP_OK(hipStreamSynchronize(c->stream));
     }
+    return 0;
+}
+
+// Part streams of a call (see arp_enc::Ws).  n_streams 1 = everything on the caller's stream (rounds 1-5); first_part_frames > 0 cuts two parts unevenly;
+// min_part_frames <= 0 keeps the default (a part of fewer frames runs with fewer parts).  Takes effect from the next call.
+int arp_enc_set_streams(arp_enc* c, int n_streams, int first_part_frames, int min_part_frames) {
+    if (!c || n_streams < 1 || n_streams > arp_enc::MAX_PARTS || first_part_frames < 0) return fail("n_streams must be 1..4");
+    c->n_parts = n_streams;
+    c->first_part = first_part_frames;
+    if (min_part_frames > 0) c->min_part_frames = min_part_frames;
     return 0;
 }
 

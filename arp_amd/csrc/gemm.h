@@ -33,11 +33,13 @@ struct GemmArgs {
     int lda = 0, ldw = 0, ldr = 0, ldo = 0;
     int flags = 0;      // debug/ablation: bit 0 = skip the epilogue stores (timing experiments only); bit 5 (32): the caller's promise that A holds
                         // ceil(M / 256) * 256 readable rows (gemm256 MIXC (ARP_G2_MIX_UNIFORM) reads whole row tiles without a per-lane clamp; the extra rows are never stored)
+    unsigned long long* clock_acc = nullptr;  // gemm256's CLK diagnostic instance only: [0] += d(s_memtime), [1] += d(s_memrealtime), [2] += 1 per workgroup
     int ksplit = 1;     // split-K: gridDim.y slices of K; slice s writes to out + s * slice_stride (bias/resid ignored by callers)
     size_t slice_stride = 0;
     // LayerNorm folding.  Consumer side (a GEMM whose A operand is the UN-normalised row x):
     //   out = rstd_m * (x.W'^T - mu_m * c) + d,  W' = W diag(gamma), c[n] = sum_k W'[n,k], d = W beta + bias (passed as bias)
-    const float* ln_stats = nullptr;  // [M][ln_parts][2]: (sum, sum of squares) of row m over each 128-column segment
+    const float* ln_stats = nullptr;  // [M][ln_parts][2]: (sum, sum of squares) of row m over each 128-column segment; gemm256's folded epilogue holds at most
+                                      // 8 parts per row (width <= 1024: the launcher refuses more), gemm.h's loops over any count
     const float* ln_c = nullptr;      // [N]
     int ln_parts = 0;
     float ln_inv_d = 0.f, ln_eps = 0.f;
@@ -488,6 +490,10 @@ inline int launch_gemm_nt(const GemmArgs& g, hipStream_t stream) {
     if (g.N <= 0 || g.K % EPB != 0 || g.K <= 0 || g.lda % (16 / (int)sizeof(T)) != 0 || g.ldw % (16 / (int)sizeof(T)) != 0)
         return fail("gemm_nt: unsupported shape M=" + std::to_string(g.M) + " N=" + std::to_string(g.N) +
                     " K=" + std::to_string(g.K));
+    // The staged epilogues (N, ldo multiples of 8) load their bias / folded-LayerNorm / residual fragments UNCONDITIONALLY from clamped addresses, and with no
+    // bias or fold a dummy 16 bytes from A: that needs N >= 8 (implied), a 16-byte-aligned A and one whole readable row of it
+    if (((g.N | g.ldo) & 7) == 0 && !(g.flags & 2) && ((reinterpret_cast<uintptr_t>(g.A) & 15) != 0 || (size_t)g.K * sizeof(T) < 16))
+        return fail("gemm_nt: the staged epilogue needs a 16-byte-aligned A operand");
     auto kern = gemm_nt_kernel<T, OutT, ACT, RESID, SITE, STAGES>;
     constexpr int lds_bytes = STAGES * GEMM_STAGE_BYTES;
     static_assert(lds_bytes >= GEMM_LDS_BYTES, "the staged epilogue needs the two-stage ring's 64 KiB");

@@ -123,9 +123,14 @@ template <typename T> __device__ __forceinline__ f32x16_v mfma32(u32x4_v a, u32x
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
 }
 // K-loop version KV (common.h: ARP_G2_KV, dma16_saddr): 1 = SADDR-form LDS-DMA statements + peeled steady state, bit-identical to 0.
-// MIXC (T = f16 only): the trailing K-tiles of every row are e4m3 and run on the scaled fp8 MFMA (GemmArgs::mix_*): same LDS image, same
-// fragment reads, one 16x16x128 MFMA per fragment pair instead of two 16x16x32 ones -- the same 32 matrix-pipe cycles for twice the k.
-template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV, bool MIXC = false>
+// MIXC (T = f16 only): the trailing K-tiles of every row are e2m1 (fp4) and run on the scaled f8f6f4 MFMA (GemmArgs::mix_*): same LDS image, same
+// fragment reads, same 4-register operand tuples, one 16x16x128 MFMA where the binary16 K-tile issues a 16x16x32 one -- the same matrix-pipe cycles
+// for four times the k.  (An e4m3 variant -- twice the k on 8-register tuples -- was built first and lost to register allocation: DESIGN 10 #20.)
+// CLK (round 6): the DIAGNOSTIC instance that measures the clock the chip holds under the pass (MI355X_MICROARCH 'DVFS give-back' item 6: in the real kernel no
+// stamp executes).  One s_memtime / s_memrealtime pair at the head and one at the foot of the workgroup; thread 0 adds the two differences and 1 to
+// GemmArgs::clock_acc[0..2] -- a buffer of its own that nothing else reads.  clock = sum d(s_memtime) / sum d(s_memrealtime) x 100 MHz, time-weighted over the
+// workgroups.  bench.py runs the timed steps once more with c_fc on this instance (arp_clip_clock_probe) and prints whole_pass.clock_ghz.
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV, bool MIXC = false, bool CLK = false>
 __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G2_MAX_VGPR))) void gemm256_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPB = 128 / (int)sizeof(T);
@@ -139,6 +144,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
 #ifdef ARP_G2_CLOCK  // diagnostic build only: the clock this workgroup ran at = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH, DVFS item 6)
     const long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    [[maybe_unused]] unsigned long long dclk_c0 = 0, dclk_r0 = 0;
+    if constexpr (CLK) {
+        dclk_c0 = __builtin_amdgcn_s_memtime();
+        dclk_r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // (lgkmcnt(0) alone: a builtin-form stamp left pending ahead of the loop makes hipcc write lgkmcnt(0) for the loop's LDS waits)
+    }
 
     // ---- persistent tile loop ---------------------------------------------------------------------------
     // The launcher starts at most one workgroup per CU; each walks tiles blockIdx.x, + gridDim.x, ...  Between
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
     const char* w_tile = nullptr;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // MIXC: no per-lane row clamp -- the caller promises ceil(M / 256) * 256 readable A rows and N % 256 == 0 -- so the eight per-lane offsets collapse
-    // into TWO (one per operand) plus wave-uniform row terms that go into the SGPR base: six VGPRs the e4m3 bodies' 8-register operand tuples need
+    // into TWO (one per operand) plus wave-uniform row terms that go into the SGPR base (ARP_G2_MIX_UNIFORM: built for the e4m3 variant's 8-register tuples, off)
     uint32_t off_a = 0, off_w = 0;
     auto setup_src = [&]() __attribute__((always_inline)) {
         if constexpr (KV == 1) {
@@ -1098,9 +1109,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
         arp_g2_stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
     }
 #endif
+    if constexpr (CLK) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (g.clock_acc && threadIdx.x == 0) {
+            atomicAdd(g.clock_acc, c1 - dclk_c0);
+            atomicAdd(g.clock_acc + 1, r1 - dclk_r0);
+            atomicAdd(g.clock_acc + 2, 1ull);
+        }
+    }
 }
 
-template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV, bool MIXC = false>
+template <typename T, typename OutT, int ACT, bool RESID, int SITE, bool M32 = (ARP_G2_MFMA32 != 0), int KV = ARP_G2_KV, bool MIXC = false, bool CLK = false>
 inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     constexpr int EPB = 128 / (int)sizeof(T);
     if (g.M <= 0) return 0;
@@ -1116,7 +1135,7 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
         return fail("gemm256_nt: row stride too large for the 32-bit tile offsets of the KV = 1 K loop");
     if (MIXC && (sizeof(T) != 2 || g.mix_nk16 <= 0 || 64 * (g.mix_nk16 + g.mix_nkc_a) > g.K || g.K / 64 - g.mix_nk16 < 2 || !KV || (ARP_G2_MIX_UNIFORM && (g.N % G2_BN || !(g.flags & 32))) || g.mix_sa < 0 || g.mix_sa > 120 || g.mix_sb < 0 || g.mix_sb > 120))
         return fail("gemm256_nt: bad mixed binary16 / e2m1 K-tile plan (needs >= 2 trailing fp4 K-tiles, i.e. Kc >= 512 with one correction segment)");
-    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE, M32, KV, MIXC>;
+    auto kern = gemm256_nt_kernel<T, OutT, ACT, RESID, SITE, M32, KV, MIXC, CLK>;
     static bool attr_set = false;
     if (!attr_set) {
         ARP_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1135,7 +1154,9 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0 || (n_cu & 7)) n_cu = 256;
     }
-    if (persist && grid > n_cu) grid = n_cu;  // one workgroup per CU walks the tiles
+    // (the MIXC instances do ONE tile per workgroup -- `if constexpr (MIXC) break` at the foot of the kernel's tile loop -- so their grid is never cut down:
+    //  a persistent or tpw > 1 grid would leave every tile past the first `grid` unwritten, silently)
+    if (!MIXC && persist && grid > n_cu) grid = n_cu;  // one workgroup per CU walks the tiles
     // 16-bit-output GEMMs: each workgroup does `tpw` tiles (tix, tix + grid, ...) so that all but its last epilogue drain under
     // the next tile's first phases (overlapped drain in the kernel).  tpw = 2 adds no tile-quantisation (c_fc: 2400 tiles = 9.4 -> 10
     // rounds either way) and keeps two streams interleaving at a granularity of two tiles.
@@ -1153,11 +1174,11 @@ inline int launch_gemm256_nt(const GemmArgs& g, hipStream_t stream) {
     }
     if (group_env > 0 && ga.group_m == 0) ga.group_m = group_env;
 #if ARP_G2_OVERLAP_DRAIN
-    if (sizeof(OutT) == 2 && tpw > 1 && !persist && grid >= 2 * n_cu) {
+    if (!MIXC && sizeof(OutT) == 2 && tpw > 1 && !persist && grid >= 2 * n_cu) {
         grid = (grid + tpw - 1) / tpw;
         ga.ovl = 1;
     }
-    if (sizeof(OutT) == 2 && persist) ga.ovl = 1;
+    if (!MIXC && sizeof(OutT) == 2 && persist) ga.ovl = 1;
 #endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G2_THREADS), G2_LDS_BYTES, stream, ga);
     ARP_HIP_OK(hipGetLastError());

@@ -127,14 +127,16 @@ __global__ __launch_bounds__(QA_THREADS, 2) void qkv_attn_kernel(QkvAttnArgs g) 
         }
         const int klim = g.causal ? (qidx < N ? qidx + 1 : N) : N;
         float mx = -INFINITY;
-        // Without the causal mask only the pad keys (>= N) are hidden, and those sit in the last two key tiles (NT = 2 ceil(N / 32)): the other tiles skip the
-        // compare + select per score -- the softmax, not the MFMAs, is what this kernel is bound by (56 scores per lane at N = 197).  Same values either way.
+        // Without the causal mask only the pad keys (>= N) are hidden: a tile whose sixteen keys are all real skips the compare + select per score (a
+        // wave-uniform test per tile) -- the softmax, not the MFMAs, is what this kernel is bound by.  Same values either way.  (NT is fixed at 4 here while
+        // N may be anything in 1..64: the test is on the tile's last key, not on the tile index -- with N < 32 tiles 0 and 1 hold pad keys too, whose LDS
+        // rows are the NEXT frame's keys.  ADVICE r5.)
         if (!g.causal) {
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (kt >= NT - 2) {
+                    if (kt * 16 + 15 >= N) {
                         const int key = kt * 16 + fg * 4 + r;
                         s[kt][r] = (key < N) ? s[kt][r] : -INFINITY;
                     }

@@ -138,6 +138,7 @@ struct TowerCtx {
     // attention writes its output as e4m3 (x 16), out_proj is an fp8 GEMM into the f32 residual stream.
     bool fp8_attn = false;
     bool qkv_fused = true;  // QKV projection + attention in one kernel where qkvattn.h supports the geometry (ARP_QKV_FUSED=0 disables)
+    unsigned long long* clock_acc = nullptr;  // != null: c_fc runs on gemm256's clock-diagnostic instance and accumulates its workgroups' cycle / real-time stamps here
     bool shared_chip = false;  // the pass runs beside another part stream's kernels (arp_clip.hip::label_dev): see out_proj's kernel choice in tower_gemm
     // Latency path (the rollout loop's single-frame reward): with at most SKINNY_MAX_M rows in the residual stream the
     // GEMMs run on the W-tiled skinny kernel (skinny.h), out_proj / c_proj as split-K slabs whose reduction kernel also adds bias +
@@ -195,6 +196,14 @@ static int tower_gemm(TowerCtx& c, const char* site, const void* A, const void* 
             k.M = M; k.N = N; k.K = K; k.lda = g.lda; k.ldw = g.ldw; k.ldr = g.ldr; k.ldo = g.ldo;
             k.act = ACT; k.out_f32 = sizeof(OutT) == 4;
             return launch_skinny_gemm(__is_same(T, bf16_t) ? 1 : 2, k, c.stream);
+        }
+    }
+    // the clock probe (arp_clip_clock_probe): c_fc of the vision tower on the CLK instance of the 256 x 256 kernel -- same tile, same K loop, four scalar
+    // stamps and three atomics per workgroup more -- so that the clock is read under the very pass bench.py times
+    if constexpr (SITE == SITE_FC1 && sizeof(T) == 2 && sizeof(OutT) == 2 && ACT == ACT_QGELU && !RESID) {
+        if (c.clock_acc && !f && !c.skinny && force != 1 && force != 3 && (long)((M + 255) / 256) * ((N + 255) / 256) >= 192) {
+            g.clock_acc = c.clock_acc;
+            return launch_gemm256_nt<T, OutT, ACT, RESID, SITE, (ARP_G2_MFMA32 != 0), ARP_G2_KV, false, true>(g, c.stream);
         }
     }
     // out_proj (K = N = width, f32 residual epilogue) is the one big GEMM where the two-workgroups-per-CU kernel wins alone on the chip: its tiles

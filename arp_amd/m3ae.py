@@ -63,6 +63,10 @@ class M3AEEncoder:
         check(lib.arp_enc_forward(self._h, _ffi.as_ptr(x, C.c_float), x.shape[0], _ffi.as_ptr(out, C.c_float)))
         return out
 
+    def set_streams(self, n_streams=2, first_part_frames=0, min_part_frames=0):
+        """Part streams of a call (``arp_enc_set_streams``): contiguous parts of the frames on HIP streams of their own; same encodings for every setting."""
+        check(lib.arp_enc_set_streams(self._h, int(n_streams), int(first_part_frames), int(min_part_frames)))
+
     def profile(self, on=True):
         check(lib.arp_enc_profile_enable(self._h, int(on)))
 

@@ -118,7 +118,7 @@ def compact_secondary(name, d):
     par = (d.get("config") or {}).get("parallelism")
     if par:
         out["config"]["parallelism"] = cut(par, 40)
-    rf = pick(d.get("roofline"), ["bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "kernel"])
+    rf = pick(d.get("roofline"), ["bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "avg_launch_ms", "kernel"])
     if rf:
         rf["kernel"] = cut(rf.get("kernel", ""), 70)
         out["roofline"] = rf
@@ -135,6 +135,9 @@ def compact_secondary(name, d):
     for k in ("rccl", "later_pass_frames_per_s", "rows", "file_rewards_equal_direct_labelling", "more_rewards_ms"):
         if k in d:
             out[k] = d[k]
+    if isinstance(d.get("staged"), dict):
+        out["staged"] = pick(d["staged"], ["staged_ms_per_step", "allreduce_b1_ms", "allreduce_b2_ms", "allreduce_ms", "bucket_bytes"])
+        out.pop("rccl", None)
     if name == "online":
         out["reward_ms"] = {k: v.get("latency_ms") for k, v in (d.get("reward") or {}).items()}
         out["greedy_action_ms"] = (d.get("greedy_action") or {}).get("latency_ms")
@@ -292,9 +295,12 @@ def run_secondary(a):
         "policy_with_encoder": ["--path", "policy", "--with-encoder", "--mode", "f32"],
         "policy_with_encoder_f16x3": ["--path", "policy", "--with-encoder", "--mode", "f32", "--encoder-mode", "f16x3"],  # f32-accurate on the 16-bit MFMA
         # round 5: binary16 products with their operand roundings corrected on the fp4 MFMA, encoder AND adapter: the 16-bit line that carries the parity claim
-        "policy_with_encoder_f16c": ["--path", "policy", "--with-encoder", "--mode", "f16", "--encoder-mode", "f16c"],
         "policy_with_encoder_f16": ["--path", "policy", "--with-encoder", "--mode", "f16"],
+        # round 6: the ordering the 8-GPU steps actually use, on one rank through RCCL (identity reduction)
+        "finetune_staged": ["--path", "finetune", "--staged"],
         "finetune": ["--path", "finetune"],
+        "policy_staged": ["--path", "policy", "--staged"],
+        "policy_with_encoder_f16c": ["--path", "policy", "--with-encoder", "--mode", "f16", "--encoder-mode", "f16c"],
         "policy": ["--path", "policy"],
     }
     # path (2) and row N2 carry their own CPU baseline (a bounded ~5 s sample of the torch-CPU port of the same step, oracle/cpu_baseline_*.py)
@@ -413,6 +419,17 @@ def policy_step_flops(cfg, B):
     return adapter + iti + tok
 
 
+def staged_block(train, cfg, prof, steps, elapsed):
+    """--staged: what the data-parallel ordering of the policy step costs on ONE rank (the line's ms_per_step IS the staged step) and what it hands to RCCL"""
+    ranges, total = train.bucket_plan(cfg)
+    per = lambda k: round(prof[k]["ms"] / max(prof[k]["calls"], 1), 4) if k in prof else None
+    return {"staged_ms_per_step": round(elapsed / steps * 1e3, 4),
+            "ordering": "stage 1 (forward, transformer backward, image_text_input dW) -> bucket 1 on the communication stream || stage 2 (adapter backward) -> bucket 2 + loss scalars -> norms, clip, Adam; dWi is NOT produced last here",
+            "allreduce_b1_ms": per("dt.allreduce_b1"), "allreduce_b2_ms": per("dt.allreduce_b2"),
+            "bucket_bytes": [4 * sum(hi - lo for lo, hi in ranges[:2]), 4 * sum(hi - lo for lo, hi in ranges[2:])], "gradient_bytes": 4 * total,
+            "reduction": "ncclAllReduce(sum) over ONE rank (identity): the calls, streams, events and staged graphs of the 8-GPU step, no xGMI traffic"}
+
+
 def bench_policy(a):
     """Secondary benchmark: ARPDT train_step (BASELINE.json configs[3]): B = 32 samples per GPU, T = 4, random-init
     M3AE-shaped encodings [B,4,257,768] resident in HBM, forward + backward + RCCL all-reduce + clip + Adam."""
@@ -431,6 +448,10 @@ def bench_policy(a):
     if world > _ffi.device_count():
         raise SystemExit(f"--path policy --gpus {world}: {_ffi.device_count()} GPU(s) visible; RCCL needs one GPU per rank")
     _ffi.check(_ffi.lib.arp_set_device(local_rank))
+    staged = bool(a.staged and world == 1)
+    if staged:  # read when the handle is created
+        os.environ["ARP_DT_FORCE_COMM"] = "1"
+        os.environ["ARP_DT_OVERLAP"] = "1"
     cfg = PolicyConfig(lambda_ret=0.01)
     # row N1's 16-bit parity line: the f16c encoder (operand roundings corrected on the fp4 MFMA) goes with the same corrections on the policy's adapter
     adapter_c = a.mode == "f16" and (a.adapter_c or (a.with_encoder and (a.encoder_mode or a.mode) == "f16c"))
@@ -473,6 +494,9 @@ def bench_policy(a):
     tr.set_params(S.policy_params(cfg, seed=0))
     if world > 1:  # RCCL id from rank 0 over gloo, communicator, sync_state_fn
         train.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
+    elif staged:  # a one-rank communicator: the staged graphs, the communication stream and the RCCL calls of the DP step, reducing over one rank
+        tr.comm_init(PolicyTrainer.new_unique_id(), 1, 0)
+        tr.broadcast_state()
     rccl = gather_cert(dist, world, train.certify_collective(tr, rank, world))  # every rank: the gather is a collective of the control plane
     if not rccl["ok"]:
         raise SystemExit(f"--path policy --gpus {world}: the communicator does not span the ranks it should: {rccl}")
@@ -560,16 +584,19 @@ def bench_policy(a):
             flops += m3ae.flops_per_frame(ecfg) * a.policy_batch * cfg.window
         # HBM bytes of the dominant site from the PMC counters (scripts/prof_policy_pmc.sh -> profiles/pmc_traffic_policy.json; measured
         # at the default geometry, B = 32 per GPU)
-        traffic = None
+        traffic = traffic_stale = None
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_policy.json")))["sites"].get(site)
+            recs = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_policy.json")))
+            rec = recs["sites"].get(site)
             if rec and a.policy_batch == 32:
                 traffic = rec["hbm_bytes_per_launch"]
+                from arp_amd._srchash import csrc_sha1
+                traffic_stale = recs.get("csrc_sha1") != csrc_sha1()  # (a file with no stamp at all is stale by definition)
         except (OSError, ValueError, KeyError):
             traffic = None
         emit_line(({
-            "metric": "samples/sec ARPDT train_step (frames in, frozen M3AE encoder inside)" if enc is not None else
-                      "samples/sec ARPDT train_step (trainable part, encodings in)", "value": world * a.policy_batch * a.steps / elapsed,
+            "metric": ("samples/sec ARPDT train_step (frames in, frozen M3AE encoder inside)" if enc is not None else
+                       "samples/sec ARPDT train_step (trainable part, encodings in)") + (" -- STAGED data-parallel ordering on one rank" if staged else ""), "value": world * a.policy_batch * a.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode if enc is None or (a.encoder_mode or a.mode) == a.mode else f"encoder {a.encoder_mode}, policy {a.mode}",
             "data": "synthetic",
@@ -581,7 +608,7 @@ def bench_policy(a):
                        "collective": ("RCCL all-reduce(sum) of the flat f32 gradient (107.5 MB) in two buckets on a communication stream -- bucket 1 "
                                       "(image_text_input + transformer + heads, 94 % of the bytes) under the adapter's backward, bucket 2 + 4 loss scalars after it") if world > 1 else "none (1 rank)"},
             "roofline": {"bound": kind, "achieved": achieved, "peak": peak, "unit": "TFLOP/s" if kind == "mfma" else "GB/s",
-                         "frac": achieved / peak, "traffic": traffic, "kernel": f"{'gemm' if kind == 'mfma' else 'norms_partial + adam_kernel'} @ {site}",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_stale": traffic_stale, "kernel": f"{'gemm' if kind == 'mfma' else 'norms_partial + adam_kernel'} @ {site}",
                          ("flops_per_launch" if kind == "mfma" else "bytes_per_launch"): work, "avg_launch_ms": avg_ms,
                          "traffic_source": None if traffic is None else "profiles/pmc_traffic_policy.json (committed rocprofv3 --pmc passes, not measured in this run)",
                          "note": "the call site with the largest share of the step (sites_ms_per_step)"},
@@ -590,6 +617,7 @@ def bench_policy(a):
             "parity": {"max_logit_err_vs_oracle": parity, "geometry": parity_geometry, "tolerance": 1e-3,
                        "within_tolerance": None if parity is None else bool(parity < 1e-3)},
             "cpu_baseline": cpu, "seam": seam, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank], "rccl": rccl,
+            "staged": staged_block(train, cfg, prof, a.steps, elapsed) if staged else None,
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
     tr.close()
     if dist is not None:
@@ -764,10 +792,17 @@ def bench_finetune(a):
         raise SystemExit(f"--path finetune --gpus {world}: {_ffi.device_count()} GPU(s) visible; RCCL needs one GPU per rank")
     _ffi.check(_ffi.lib.arp_set_device(local_rank))
     cfg = FT.FinetuneConfig()
+    staged = bool(a.staged and world == 1)
+    if staged:  # read when the handle is created: the seven-bucket all-reduce from inside the backward, through a one-rank communicator
+        os.environ["ARP_FT_FORCE_COMM"] = "1"
+        os.environ["ARP_FT_OVERLAP"] = "1"
     tr = FT.FinetuneTrainer(cfg, mode=a.mode, device=local_rank)
     tr.set_params(FT.synth_params(cfg, seed=0))
     if world > 1:
         FT.DataParallel(tr, rank, world, train.torch_object_broadcast(dist))
+    elif staged:
+        tr.comm_init(FT.FinetuneTrainer.new_unique_id(), 1, 0)
+        tr.broadcast_state()
     rccl = gather_cert(dist, world, train.certify_collective(tr, rank, world))
     if not rccl["ok"]:
         raise SystemExit(f"--path finetune --gpus {world}: the communicator does not span the ranks it should: {rccl}")
@@ -840,9 +875,11 @@ def bench_finetune(a):
     avg_ms = prof[site]["ms"] / max(prof[site]["calls"], 1)
     flops = FT.flops_per_sample(cfg) * a.finetune_batch
     # HBM bytes of the dominant launch from the committed PMC passes (scripts/prof_round.sh -> profiles/pmc_traffic_finetune.json), matched by the weight's size
-    traffic = traffic_src = None
+    traffic = traffic_src = traffic_stale = None
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_finetune.json")))
+        from arp_amd._srchash import csrc_sha1
+        traffic_stale = rec.get("csrc_sha1") != csrc_sha1()
         if site in dw_sites and a.finetune_batch == 64:
             n_el = int(np.prod(tr.shapes[dw_sites[site]]))
             for e in rec["fused_adamw_gemm_by_grid_threads"].values():
@@ -856,8 +893,8 @@ def bench_finetune(a):
         dist.destroy_process_group()
         return
     emit_line(({
-        "metric": "samples/sec CLIP multi-scale adapter fine-tune step (frames in: frozen ViT-B/16 towers + head)" if towers is not None else
-                  "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)", "value": world * a.finetune_batch * a.steps / elapsed,
+        "metric": ("samples/sec CLIP multi-scale adapter fine-tune step (frames in: frozen ViT-B/16 towers + head)" if towers is not None else
+                   "samples/sec CLIP multi-scale adapter fine-tune step (head; frozen-tower features in)") + (" -- STAGED data-parallel ordering on one rank" if staged else ""), "value": world * a.finetune_batch * a.steps / elapsed,
         "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic",
         "config": {"towers": None if towers is None else ("ViT-B/16, " + a.mode + ((" + fp8 (e4m3) c_fc / c_proj" + (" / in_proj / out_proj" if a.fp8_attn else "")) if a.fp8_mlp else "")),
@@ -866,10 +903,16 @@ def bench_finetune(a):
                                f"(BASELINE.json configs[4])", "parallelism": "single GPU (as the reference)" if world == 1 else f"dp{world}: one RCCL all-reduce(sum) of the "
                                f"flat f32 gradient ({tr.n_params * 4 / 1e9:.1f} GB) per step"},
         "roofline": {"bound": "hbm", "achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "kernel": kern,
+                     "frac": nbytes / (avg_ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic, "traffic_stale": None if traffic is None else traffic_stale, "traffic_source": traffic_src, "kernel": kern,
                      "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms},
         "whole_step": {"gflop_per_step": flops / 1e9, "tflops": flops / (elapsed / a.steps) / 1e12},
         "cpu_baseline": cpu, "final_aux": aux, "per_rank_samples_per_s": [round(v, 1) for v in per_rank], "rccl": rccl,
+        "staged": None if not staged else {
+            "staged_ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "ordering": "seven buckets in production order from inside the backward on the communication stream; AdamW as a separate pass behind the last one (the fused dW + AdamW epilogue needs the SUMMED gradient and is off with a communicator)",
+            "allreduce_ms": [round(prof[f"ft.allreduce_b{i}"]["ms"] / max(prof[f"ft.allreduce_b{i}"]["calls"], 1), 4) if f"ft.allreduce_b{i}" in prof else None for i in range(7)],
+            "bucket_bytes": [4 * sum(hi - lo for lo, hi in b) for b in FT.bucket_plan(cfg)[0]], "gradient_bytes": 4 * FT.bucket_plan(cfg)[1],
+            "reduction": "ncclAllReduce(sum) over ONE rank (identity)"},
         "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}))
     tr.close()
     if dist is not None:
@@ -908,6 +951,10 @@ def main():
     ap.add_argument("--encoder-mode", default=None, choices=["bf16", "f16", "f32", "f16x3", "f16c"], help="policy path with --with-encoder: operand mode of the frozen encoder "
                     "(default: --mode).  f16x3 = (hi, lo) binary16 operand pairs, three 16-bit MFMAs per product, f32 attention: f32-level error")
     ap.add_argument("--adapter-c", action="store_true", help="policy path, f16: the adapter's forward products corrected on the fp4 MFMA (implied by --encoder-mode f16c)")
+    ap.add_argument("--staged", action="store_true", help="policy / finetune path at 1 GPU: the data-parallel ORDERING of the step -- backward staged for the bucketed all-reduce "
+                    "on the communication stream, through a one-rank RCCL communicator (an identity reduction; ARP_DT_FORCE_COMM / ARP_FT_FORCE_COMM with the overlap on, "
+                    "as tests/test_policy_gpu.py::test_bucketed_overlapped_allreduce_equals_serial runs it): the per-rank compute time configs[3] / configs[4] will "
+                    "reproduce on 8 GPUs before any communication time (VERDICT r5 weak #7)")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
     ap.add_argument("--all-secondary", dest="all_secondary", action="store_true", default=True,
@@ -1061,6 +1108,26 @@ def main():
     model.sync()
     prof = model.profile_read()
     prof_ms = clip.elapsed_ms(e2, e3)
+    # ---- the clock the chip held: the same steps once more with c_fc on the clock-diagnostic instance of its kernel (gemm256.h CLK: s_memtime / s_memrealtime
+    # around every workgroup; the timed instances execute no stamp) -- "0.36 of 2.5 PF" is 0.36 of a peak priced at 2.4 GHz
+    clock = None
+    if not a.timed_only:  # (a rocprofv3 --stats run of --timed-only averages exactly the timed launches)
+        model.profile(False)
+        model.clock_probe(True)
+        for _ in range(2):
+            step()
+        model.sync()
+        model.clock_probe(True)  # (zeroes the accumulators: the two steps above brought the chip back under load)
+        e4, e5 = clip.Event(), clip.Event()
+        model.record(e4)
+        for _ in range(a.steps):
+            step()
+        model.record(e5)
+        model.sync()
+        clock = model.clock_read()
+        clock["ms_per_step_while_probed"] = clip.elapsed_ms(e4, e5) / a.steps
+        model.clock_probe(False)
+        model.profile(True)
     # isolated per-kernel figures: the same steps on ONE stream (no other kernel shares the chip with a launch)
     iso = None
     nsplit = max(1, min(a.streams, a.batch // 128))  # parts a batch is labelled in, one HIP stream each (label_dev in arp_clip.hip)
@@ -1160,7 +1227,12 @@ def main():
             # tower.h); the nominal figure prices the pass at SURVEY section 8(d)'s 8.82 GFLOP/frame including that skipped work
             "whole_pass": {"executed_gflop_per_frame": exec_flops / 1e9, "mfma_frac_of_peak": fps / world * exec_flops / (peak * 1e12),
                            "nominal_gflop_per_frame": flops_frame / 1e9, "nominal_mfma_frac_of_peak": fps / world * flops_frame / (peak * 1e12),
-                           "hip_event_ms_per_step": ev_ms / a.steps, "profiled_ms_per_step": prof_ms / a.steps},
+                           "hip_event_ms_per_step": ev_ms / a.steps, "profiled_ms_per_step": prof_ms / a.steps,
+                           # the peak is priced at the chip's 2.4 GHz; at the clock it HELD under this pass (c_fc's workgroups, time-weighted) the same FLOPs are
+                           # this fraction of what the matrix pipes could have issued
+                           "clock_ghz": None if not clock else clock["clock_ghz"], "clock_probe_workgroups": None if not clock else clock["workgroups"],
+                           "clock_probe_ms_per_step": None if not clock else clock["ms_per_step_while_probed"],
+                           "mfma_frac_of_peak_at_held_clock": None if not clock or not clock["clock_ghz"] else fps / world * flops_frame / (peak * 1e12) * 2.4 / clock["clock_ghz"]},
             "parity": {"max_cosine_err_vs_oracle": parity, "frames": a.parity_frames, "tolerance": 1e-4,
                        "within_tolerance": None if parity is None else bool(parity < 1e-4)},
             "sites_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},

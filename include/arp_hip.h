@@ -140,6 +140,13 @@ int arp_clip_profile_reset(arp_clip* h);
 /* JSON object {"site": {"ms": total_ms, "calls": n}, ...}; returns bytes written or < 0. */
 int arp_clip_profile_json(arp_clip* h, char* buf, int buf_len);
 
+/* The shader clock the chip holds under the labelling pass (bench.py: whole_pass.clock_ghz).  on = 1 zeroes the accumulators and routes the vision
+ * tower's c_fc launches through a DIAGNOSTIC instance of the same GEMM kernel that stamps s_memtime / s_memrealtime around every workgroup (the product
+ * instances execute no stamp); rewards are unchanged.  arp_clip_clock_read: out[0] = GHz (sum of shader cycles / sum of 100 MHz ticks over the probed
+ * workgroups), out[1] = workgroups probed, out[2] = mean workgroup duration in microseconds. */
+int arp_clip_clock_probe(arp_clip* h, int on);
+int arp_clip_clock_read(arp_clip* h, double* out3);
+
 /* HIP events on the handle's stream (bench timing) */
 typedef struct arp_event arp_event;
 int arp_event_create(arp_event** out);
@@ -346,7 +353,7 @@ typedef struct arp_enc_cfg {
     int32_t heads;      /* 12  */
     int32_t mlp_ratio;  /* 4   */
     int32_t img_res;    /* 256 -> 257 tokens */
-    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_F16 | ARP_MODE_BF16 | ARP_MODE_F16X3 (need not equal the mode of the policy handle it is attached to) */
+    int32_t mode;       /* ARP_MODE_F32 | ARP_MODE_F16 | ARP_MODE_BF16 | ARP_MODE_F16X3 | ARP_MODE_F16C (need not equal the mode of the policy handle it is attached to) */
     int32_t device;
     int32_t max_frames; /* frames per internal pass; <= 0 -> 128 */
     int32_t attn_impl;  /* 0 auto, 1 VALU */
@@ -357,6 +364,11 @@ int arp_enc_load_weight(arp_enc* h, const char* name, const float* data, const i
 int arp_enc_finalize_weights(arp_enc* h);
 /* images f32 NHWC [n,res,res,3] (already normalised, as the training pipeline delivers them) -> f32 [n,tokens,width] */
 int arp_enc_forward(arp_enc* h, const float* images_host, int n, float* out_host);
+/* Part streams (round 6): a call's frames are encoded as `n_streams` contiguous parts (1..4, default 2), part 0 on the caller's stream and the others on
+ * streams of their own, so that one part's memory-bound kernels and GEMM grid tails run beside another part's GEMMs -- as arp_clip_cfg.n_streams does
+ * for the labelling pass.  first_part_frames > 0 cuts two parts unevenly; a part of fewer than min_part_frames frames (<= 0: keep the default, 24)
+ * is not cut off.  Encodings are bit-identical for every setting. */
+int arp_enc_set_streams(arp_enc* h, int n_streams, int first_part_frames, int min_part_frames);
 int arp_enc_profile_enable(arp_enc* h, int on);
 int arp_enc_profile_json(arp_enc* h, char* buf, int buf_len);
 /* Put the frozen encoder INSIDE the policy step: after attaching, arp_dt_set_batch_images stages raw frames

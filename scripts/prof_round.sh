@@ -14,6 +14,10 @@ for P in policy finetune; do
   find $R/gpurun_out/prof_${TAG}_${P}_trace -name "*kernel_trace.csv" -delete
   cp $(find $R/gpurun_out/prof_${TAG}_${P}_trace -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_${P}_kernel_stats.csv
 done
+for C in FETCH_SIZE WRITE_SIZE; do  # the policy step's kernels launched eagerly (one dispatch per kernel in the counter file)
+  ARP_DT_GRAPH=0 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_policy_$C -- python3 $R/bench.py --path policy --steps 3 --warmup 2 --cpu-seconds 0 --parity-frames 0 > $R/gpurun_out/prof_${TAG}_policy_$C.log 2>&1
+  find $R/gpurun_out/prof_${TAG}_policy_$C -name "*kernel_trace.csv" -delete
+done
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_finetune_$C -- python3 $R/bench.py --path finetune --steps 3 --warmup 2 --cpu-seconds 0 > $R/gpurun_out/prof_${TAG}_finetune_$C.log 2>&1
   find $R/gpurun_out/prof_${TAG}_finetune_$C -name "*kernel_trace.csv" -delete

@@ -7,11 +7,13 @@ import csv
 import glob
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_r2_policy_{c}", "*", "*counter_collection.csv")), key=os.path.getmtime)
+    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_policy_{c}", "*", "*counter_collection.csv")), key=os.path.getmtime)
     if not fs:
         raise SystemExit(f"no counter_collection.csv for {c}")
     for r in csv.DictReader(open(fs[-1])):
@@ -26,7 +28,8 @@ for (k, g), v in acc.items():
 SITES = {  # call site of bench.py --path policy -> kernels launched once per step there
     "dt.clip_adam": ("norms_partial_kernel", "adam_kernel"),
     "dt.adapter_dy_fused": ("adapter_dy_kernel",),
-    "dt.adapter_fc_dW": ("gemm_tn256_kernel",),
+    "dt.adapter_fc_dW": ("gemm_tn256_kernel",), "dt.adapter_fc2_dW": ("gemm_tn256_kernel",), "dt.adapter_fc1_dW": ("gemm_tn256_kernel",),
+    "dt.image_text_input": ("iti_x3_kernel",), "dt.policy_fwd": ("policy_fused_kernel",),
 }
 sites = {}
 for site, subs in SITES.items():
@@ -40,6 +43,7 @@ for site, subs in SITES.items():
     if parts:
         sites[site] = {"hbm_bytes_per_launch": tot, "kernels": parts,
                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches), scripts/prof_policy_pmc.sh"}
-out = {"sites": sites, "kernels": kernels}
+sha_file = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_csrc_sha1.txt")
+out = {"round": tag, "csrc_sha1": open(sha_file).read().strip() if os.path.exists(sha_file) else None, "sites": sites, "kernels": kernels}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic_policy.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(sites, indent=1))

@@ -14,6 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "summarize_prof.py"), tag], check=True, stdout=subprocess.DEVNULL)
+if glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}_policy_FETCH_SIZE", "*", "*counter_collection.csv")):
+    subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "summarize_policy_pmc.py"), tag], check=False, stdout=subprocess.DEVNULL)
 for p in ("policy", "finetune"):
     f = os.path.join(ROOT, "gpurun_out", f"{tag}_{p}_kernel_stats.csv")
     if os.path.exists(f):
@@ -39,7 +41,9 @@ if kernels:
         if "gemm_nt_kernel" in e["kernel"] and ", 26, " in e["kernel"]:
             fused[str(e["grid_threads"])] = {"hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "fetch_KiB": e["fetch_KiB"], "write_KiB": e["write_KiB"],
                                             "weight_elements": e["grid_threads"] // 256 * 128 * 128}
-    out = {"round": tag, "fused_adamw_gemm_by_grid_threads": fused, "kernels": kernels,
+    sha_file = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_csrc_sha1.txt")
+    sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None  # the kernel sources these counters were taken on (bench.py: traffic_stale)
+    out = {"round": tag, "csrc_sha1": sha, "fused_adamw_gemm_by_grid_threads": fused, "kernels": kernels,
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over bench.py --path finetune, scripts/prof_round.sh"}
     json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic_finetune.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(fused, indent=1))

@@ -14,12 +14,13 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 BUDGET = [
     ("arp_clip.o", "attn_mfma_kernel<arp::f16_t, 14>", 0),
     ("arp_enc.o", "attn_mfma_kernel<arp::f16_t, 18>", 0),
-    ("arp_dt.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 2, false, 16, false, 1, false>", 0),
-    ("arp_dt.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 0, false, 16, false, 1, false>", 0),
+    ("arp_dt.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 2, false, 16, false, 1, false, false>", 0),
+    ("arp_dt.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 0, false, 16, false, 1, false, false>", 0),
     ("arp_dt.o", "iti_x3_kernel<1, arp::f16_t, arp::f16_t, true>", 0),
     ("arp_dt.o", "policy_fused_kernel<128, 512, true>", 0),
-    ("arp_clip.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 1, false, 3, false, 1, false>", 3),   # c_fc: three dwords of prologue state
-    ("arp_clip.o", "gemm256_nt_kernel<arp::f16_t, float, 0, true, 4, false, 1, false>", 0),          # c_proj
+    ("arp_clip.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 1, false, 3, false, 1, false, false>", 3),   # c_fc: three dwords of prologue state
+    ("arp_clip.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 1, false, 3, false, 1, false, true>", 3),    # ... and its clock-diagnostic twin (round 6): the same budget
+    ("arp_clip.o", "gemm256_nt_kernel<arp::f16_t, float, 0, true, 4, false, 1, false, false>", 0),          # c_proj
     ("qkvattn.o", "qkv_attn_kernel<arp::f16_t>", 0),
     ("gemm2w.o", "gemm2w_kernel<arp::f16_t, float, 0, true>", 1),
     ("gemm_tn.o", "gemm_tn256_kernel<arp::f16_t>", 0),

@@ -163,3 +163,156 @@ def test_prefetched_frames_with_the_encoder_inside_equal_the_synchronous_path(gp
         state.trainer.close(); enc.close()
     assert out["sync"][0] == out["prefetch"][0]
     assert all(np.array_equal(out["sync"][1][k], out["prefetch"][1][k]) for k in out["sync"][1])
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
+def test_part_streams_are_exact(gpu_lib, mode):
+    """Round 6: a call's frames are encoded as contiguous parts on HIP streams of their own (arp_enc_set_streams).  A frame's encoding does not depend on the
+    part it is in or on how many rows its part has: every setting gives the same bits."""
+    from arp_amd import m3ae, synth_policy as S
+    from oracle import m3ae_np as M
+    cfg, ocfg = m3ae.EncoderConfig(**SMALL_ENC), M.EncConfig(**SMALL_ENC)
+    P = S.m3ae_params(ocfg, seed=3)
+    x = S.normalized_frames(11, cfg.img_res, seed=4)
+    enc = m3ae.M3AEEncoder(cfg, P, mode=mode, max_frames=16)
+    enc.set_streams(1)
+    ref = enc.forward_representation(x)
+    for n, first in ((2, 0), (2, 3), (3, 0), (4, 0)):
+        enc.set_streams(n, first, 1)
+        got = enc.forward_representation(x)
+        assert np.array_equal(got, ref), (mode, n, first, float(np.abs(got - ref).max()))
+    enc.set_streams(2, 0, 1)
+    got = enc.forward_representation(x[:1])  # fewer frames than parts x min_part_frames: one part
+    assert np.array_equal(got, ref[:1])
+    enc.close()
+
+
+def test_part_streams_are_exact_full_geometry(gpu_lib):
+    """... and at the real geometry in the modes whose kernels exist there only (f16c: widths that are multiples of 256; f16x3's K-concatenated products)."""
+    from arp_amd import m3ae, synth_policy as S
+    from oracle import m3ae_np as M
+    cfg, ocfg = m3ae.EncoderConfig(), M.EncConfig()
+    P = S.m3ae_params(ocfg, seed=0)
+    x = S.normalized_frames(5, 256, seed=1)
+    for mode in ("f16c", "f16x3", "f16"):
+        enc = m3ae.M3AEEncoder(cfg, P, mode=mode, max_frames=8)
+        enc.set_streams(1)
+        ref = enc.forward_representation(x)
+        enc.set_streams(2, 2, 1)
+        got = enc.forward_representation(x)
+        assert np.array_equal(got, ref), (mode, float(np.abs(got - ref).max()))
+        enc.close()
+
+
+def test_train_steps_with_part_streams_inside(gpu_lib, monkeypatch):
+    """The encoder's part streams in front of the policy step's captured chain: eager, eager, capture, replay, replay -- with the encoder enqueued eagerly ahead
+    of the chain (the default), captured INTO it with its forks and joins (ARP_DT_ENC_EAGER=0), and on one stream: the same trajectory bit for bit."""
+    from arp_amd import m3ae, synth_policy as S
+    from arp_amd.train import PolicyConfig, PolicyTrainer
+    from oracle import m3ae_np as M
+    ecfg = m3ae.EncoderConfig(**TINY_ENC)
+    pcfg = PolicyConfig(emb=64, depth=2, heads=4, window=3, enc_tokens=ecfg.tokens, enc_dim=ecfg.width, lambda_ret=0.5)
+    EP = S.m3ae_params(M.EncConfig(**TINY_ENC), seed=5)
+    P = S.policy_params(pcfg, seed=6)
+    rng = np.random.default_rng(7)
+    B = 4
+    frames = S.normalized_frames(B * pcfg.window, ecfg.img_res, seed=8).reshape(B, pcfg.window, ecfg.img_res, ecfg.img_res, 3)
+    act = rng.integers(0, pcfg.n_actions, (B, pcfg.window)).astype(np.int32)
+    rtg = rng.random((B, pcfg.window, 1)).astype(np.float32)
+    out = {}
+    for name, streams, eager in (("one", 1, "1"), ("parts_eager", 3, "1"), ("parts_captured", 3, "0")):
+        monkeypatch.setenv("ARP_DT_ENC_EAGER", eager)
+        enc = m3ae.M3AEEncoder(ecfg, EP, mode="f32")
+        enc.set_streams(streams, 0, 1)
+        tr = PolicyTrainer(pcfg, mode="f32")
+        tr.set_params(P)
+        tr.attach_encoder(enc)
+        losses = []
+        for i in range(6):
+            tr.set_batch_images(frames, act, rtg)
+            losses.append(tr.train_step(1e-3)["loss"])
+        fwd = tr.forward()["action_pred"]
+        out[name] = (losses, tr.get_params(), fwd)
+        tr.close(); enc.close()
+    for name in ("parts_eager", "parts_captured"):
+        assert out[name][0] == out["one"][0], (name, out[name][0], out["one"][0])
+        assert all(np.array_equal(out[name][1][k], out["one"][1][k]) for k in out["one"][1]), name
+        assert np.array_equal(out[name][2], out["one"][2]), name
+
+
+SMALL_C = dict(patch=16, width=512, layers=2, heads=8, img_res=64)  # the smallest geometry the f16c products exist at (K % 256 == 0, K >= 512), 17 tokens
+
+
+def _n1_trajectory(ecfg_kw, pcfg, B, steps, lr, seeds):
+    """(f32 encoder + f32 policy) and (f16c encoder + f16 policy + adapter corrections) from the same frames and parameters: per step loss, gradient norms per tensor
+    (of the step's raw loss gradient) and the parameters at the end."""
+    from arp_amd import m3ae, synth_policy as S
+    from arp_amd.train import PolicyTrainer
+    from oracle import m3ae_np as M
+    ecfg = m3ae.EncoderConfig(**ecfg_kw)
+    EP = S.m3ae_params(M.EncConfig(**ecfg_kw), seed=seeds[0])
+    P = S.policy_params(pcfg, seed=seeds[1])
+    rng = np.random.default_rng(seeds[2])
+    frames = S.normalized_frames(B * pcfg.window, ecfg.img_res, seed=seeds[3]).reshape(B, pcfg.window, ecfg.img_res, ecfg.img_res, 3)
+    act = rng.integers(0, pcfg.n_actions, (B, pcfg.window)).astype(np.int32)
+    rtg = rng.random((B, pcfg.window, 1)).astype(np.float32)
+    res = {}
+    for name, emode, pmode in (("f32", "f32", "f32"), ("f16c", "f16c", "f16")):
+        enc = m3ae.M3AEEncoder(ecfg, EP, mode=emode)
+        tr = PolicyTrainer(pcfg, mode=pmode, adapter_corrections=name == "f16c")
+        tr.set_params(P)
+        tr.attach_encoder(enc)
+        losses, gnorms = [], []
+        for i in range(steps):
+            tr.set_batch_images(frames, act, rtg)
+            aux = tr.train_step(lr)
+            assert np.isfinite(aux["loss"]) and np.isfinite(aux["grad_norm"]), (name, i, aux)
+            losses.append(aux["loss"])
+            gnorms.append({k: float(np.linalg.norm(v.astype(np.float64))) for k, v in tr.get_grads().items()})
+        res[name] = (np.array(losses), gnorms, tr.get_params())
+        tr.close(); enc.close()
+    return res
+
+
+def _n1_trajectory_report(tag, res, lr, steps):
+    a, b = res["f32"], res["f16c"]
+    rel = np.abs(a[0] - b[0]) / np.maximum(np.abs(a[0]), 1e-6)
+    worst = {}
+    for i in range(steps):
+        for k, v in a[1][i].items():
+            if v > 1e-12:
+                worst[k] = max(worst.get(k, 0.0), abs(b[1][i][k] - v) / v)
+    dp = {k: float(np.abs(a[2][k].astype(np.float64) - b[2][k]).mean()) for k in a[2]}
+    moved = {k: float(np.abs(a[2][k].astype(np.float64)).mean()) for k in a[2]}
+    wk = max(worst, key=worst.get)
+    pk = max(dp, key=dp.get)
+    print(f"N1 trajectory [{tag}] {steps} steps: loss f32 {a[0][[0, -1]]}, f16c {b[0][[0, -1]]}; max relative loss difference {rel.max():.2e} (first step {rel[0]:.2e}); "
+          f"gradient norms: worst tensor {wk} {worst[wk]:.2e}; parameters: worst mean |dp| {pk} {dp[pk]:.2e} (lr x steps = {lr * steps:.1e})")
+    return rel, worst, dp, moved
+
+
+def test_f16c_training_trajectory_tracks_f32_small(gpu_lib):
+    """row N1's 16-bit configuration -- f16c encoder, f16 policy, adapter corrections -- against the f32 configuration over a TRAINING RUN with
+    frames in, not one forward: 10 clipped Adam steps at the smallest geometry the f16c products exist at.  Loss within 1e-3 relative on every step, every gradient
+    tensor's norm within 2 % on every step, parameters after the run within a tenth of the distance the run moved them (Adam's first steps move every parameter
+    by ~lr per step whatever its gradient's size, so a flipped sign of a near-zero gradient entry costs 2 lr on that entry: the bound is on the MEAN)."""
+    from arp_amd.train import PolicyConfig
+    pcfg = PolicyConfig(emb=128, depth=2, heads=8, window=4, enc_tokens=17, enc_dim=512, lambda_ret=0.01)
+    lr, steps = 3e-4, 10
+    res = _n1_trajectory(SMALL_C, pcfg, 4, steps, lr, (11, 12, 13, 14))
+    rel, worst, dp, moved = _n1_trajectory_report("small", res, lr, steps)
+    assert rel.max() < 1e-3, float(rel.max())
+    assert max(worst.values()) < 2e-2, max(worst.items(), key=lambda kv: kv[1])
+    assert max(dp.values()) < 0.1 * lr * steps, max(dp.items(), key=lambda kv: kv[1])
+
+
+def test_f16c_training_trajectory_tracks_f32_full_geometry(gpu_lib):
+    """... and two steps at the real geometry (ViT-B/16 at 256 x 256 in front of the 26.9 M-parameter policy, B = 2)."""
+    from arp_amd.train import PolicyConfig
+    pcfg = PolicyConfig(lambda_ret=0.01)
+    lr, steps = 3e-4, 2
+    res = _n1_trajectory(dict(), pcfg, 2, steps, lr, (50, 60, 70, 80))
+    rel, worst, dp, moved = _n1_trajectory_report("full", res, lr, steps)
+    assert rel.max() < 1e-3, float(rel.max())
+    assert max(worst.values()) < 2e-2, max(worst.items(), key=lambda kv: kv[1])
+    assert max(dp.values()) < 0.1 * lr * steps, max(dp.items(), key=lambda kv: kv[1])
