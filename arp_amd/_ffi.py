@@ -182,6 +182,7 @@ SIGNATURES = {
     "arp_enc_profile_json": (_i, [_vp, C.c_char_p, _i]),
     "arp_dt_attach_encoder": (_i, [_vp, _vp]),
     "arp_dt_set_batch_images": (_i, [_vp, _fp, _i32p, _fp, _i]),
+    "arp_dt_encode_ahead": (_i, [_vp, _i]),
     "arp_h5_write_rows_deflated": (_i, [_vp, C.c_int64, C.c_int64, _vp, C.c_uint64, C.c_uint64, C.c_uint64, _i, _i]),
     "arp_h5_inflate_last_frames": (_i, [_i, _i, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _u8p, C.c_uint64, C.c_uint64,
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), _u8p, _i]),

@@ -82,6 +82,9 @@ struct arp_dt {
         hipEvent_t up = nullptr;   // recorded on the copy stream behind the slot's upload
         hipEvent_t use = nullptr;  // recorded on the compute stream behind the last step that read the slot
         bool up_pending = false, used = false;
+        hipEvent_t enc_done = nullptr;  // recorded on the encoder stream behind the encoder pass that filled enc32 from img32
+        bool up_recorded = false;       // `up` has been recorded at least once (a slot the prefetcher has used)
+        bool enc_ahead = false;         // enc32 holds (or will hold, behind enc_done) the encodings of the frames now in img32: the step does not encode again
     } bt[3];  // 0 / 1: the prefetcher's slots (arp_dt_upload_batch*_async); 2: the synchronous arp_dt_set_batch* calls -- a validation
               // step or a greedy action in between prefetched train steps must not write into a slot the uploader thread may be filling
     int cur = 2;
@@ -95,6 +98,13 @@ struct arp_dt {
     // the encoder is enqueued EAGERLY in front of the (encoder-less) captured chain.  ARP_DT_ENC_EAGER=0 captures it with the rest, as rounds 1-5 did.
     bool enc_eager = true;
     bool enc_outside = false;  // this call's encoder pass has been enqueued ahead of the chain: forward<T> skips it
+    // Round 6: the encoder is FROZEN (stop_gradient, ARPDT.py:418-462) -- batch i + 1's encodings depend on nothing step i computes.  Every eager encoder pass
+    // runs on a stream of its own (its part streams fork from it), ordered behind the slot's upload and the slot's last reader, and the step waits for the
+    // slot's enc_done event: arp_dt_encode_ahead(slot) lets batch i + 1 be encoded WHILE step i's policy part (19 short, partly HBM-bound launches, one of them
+    // on 32 of 256 CUs) runs -- what prefetch_to_device's uploader thread calls once a batch of frames has landed.  All passes share the encoder's
+    // workspace and are serialised on that one stream.
+    hipStream_t enc_stream = nullptr;
+    hipEvent_t ev_enc_go = nullptr;
     // activations (T = operand type)
     DevBuf Xb, XbT, H1, H1T, A, Y, YT, dY, dApre, dApreT, G, dH1T, dzb, dzT, part, scal;
     // f32 small tensors
@@ -117,6 +127,15 @@ struct arp_dt {
     // scaled fp4 MFMA (ARP_MODE_F16C's product, gemm256 MIXC) and its output handed to the mix in f32 -- the policy's own share of the encoder-inside logit error
     // (the comment at fwd_w: X, W1, H1, W2, A) without the f32 MFMA.  The backward reads the same plain binary16 Xb / H1 / A as before.
     bool adapter_c = false;
+    // Which corrections (round 6; ARP_DT_ADAPTER_PLAN = "<fc1><fc2><e|h>", default below): per product 1 = the WEIGHT rounding corrected (x4 . dW4: +K/256 K-tiles),
+    // 2 = weight and ACTIVATION roundings (+ dx4 . W4: another K/256); e = the adapter output handed to the mix in f32 (fc2 on the f32 read-modify epilogue + a
+    // binary16 copy for the backward), h = as binary16 (the ordinary 16-bit epilogue, no f32 copy).  Chosen with scripts/adapter_plan_emulate.py (fp64 emulation
+    // of every rounding, 8 + 8 seeds) and measured on the GPU: profiles/r6_adapter_plans.txt.
+    int ac_plan1 = 2, ac_plan2 = 2;
+    bool ac_a_exact = true;
+    bool ac_h1_inplace = true;  // the backward reads H1 out of the [hi | x4 | dx4] rows fc1 wrote (row stride 3 D / 2 halves) instead of a copy made by extract_hi_kernel
+    const void* h1_ptr = nullptr;  // what the backward reads as H1 this step, and its row stride
+    int h1_ld = 0;
     DevBuf Xc, H1c, A32, W1c, W2c, wc_scal;  // operand rows [hi | x4 | dx4]; packed weights [W_hi | dW4 | W4]; wc_scal: 2 x {absmax pair (2 floats), scale pair (2 ints)}
     ncclComm_t comm = nullptr;
     bool has_comm = false;
@@ -649,6 +668,40 @@ int policy_fused(arp_dt* c, bool do_bwd) {
     return 0;
 }
 
+// The encoder pass of batch slot `slot` on the encoder stream; after_compute: ordered behind everything on the compute stream (a batch staged synchronously
+// there, and the earlier steps' reads of this slot's enc32); otherwise behind the slot's upload and its last reader.  Caller holds capture_mu.
+int enqueue_encode(arp_dt* c, int slot, bool after_compute) {
+    arp_dt::BatchSlot& b = c->bt[slot];
+    if (!c->enc || !b.images || b.B <= 0) return fail("encode: the slot holds no frames (or no encoder is attached)");
+    if (!c->enc_stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->enc_stream, hipStreamNonBlocking));
+    if (!c->ev_enc_go) ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_enc_go, hipEventDisableTiming));
+    if (!b.enc_done) ARP_HIP_OK(hipEventCreateWithFlags(&b.enc_done, hipEventDisableTiming));
+    if (after_compute) {
+        ARP_HIP_OK(hipEventRecord(c->ev_enc_go, c->stream));
+        ARP_HIP_OK(hipStreamWaitEvent(c->enc_stream, c->ev_enc_go, 0));
+    } else {
+        if (b.up_recorded) ARP_HIP_OK(hipStreamWaitEvent(c->enc_stream, b.up, 0));
+        if (b.used) ARP_HIP_OK(hipStreamWaitEvent(c->enc_stream, b.use, 0));
+    }
+    ARP_TRY(enc_forward_on(c->enc, c->enc_stream, b.img32.as<float>(), b.B * c->cfg.window, b.enc32.as<float>()));
+    ARP_HIP_OK(hipEventRecord(b.enc_done, c->enc_stream));
+    b.enc_ahead = true;
+    return 0;
+}
+// frames -> encodings for the CURRENT slot, ahead of the step's own launches on the compute stream
+int encode_current(arp_dt* c) {
+    if (!c->enc_eager)  // rounds 1-5: on the step's own stream (ARP_DT_ENC_EAGER=0: inside the captured chain)
+        return enc_forward_on(c->enc, c->stream, c->bt[c->cur].img32.as<float>(), c->R(), c->bt[c->cur].enc32.as<float>());
+    arp_dt::BatchSlot& b = c->bt[c->cur];
+    if (!b.enc_ahead) {
+        std::lock_guard<std::mutex> lock(c->capture_mu);
+        ARP_TRY(enqueue_encode(c, c->cur, true));
+    }
+    ARP_HIP_OK(hipStreamWaitEvent(c->stream, b.enc_done, 0));
+    b.enc_ahead = false;
+    return 0;
+}
+
 // ---- forward: everything up to the losses; leaves every activation the backward needs -----------------
 template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     const arp_dt_cfg& k = c->cfg;
@@ -663,8 +716,8 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     c->defer_w2t = prologue;
     ARP_TRY(refresh_shadows<T>(c));
     c->defer_w2t = false;
-    if (c->use_images && !c->enc_outside) {  // frozen M3AE encoder under stop_gradient (arp_dt/ARPDT.py:418-462): frames -> encodings, on this stream
-        ARP_TRY(enc_forward_on(c->enc, c->stream, c->bt[c->cur].img32.as<float>(), R, c->bt[c->cur].enc32.as<float>()));
+    if (c->use_images && !c->enc_outside) {  // frozen M3AE encoder under stop_gradient (arp_dt/ARPDT.py:418-462): frames -> encodings
+        ARP_TRY(encode_current(c));
     }
     {   // enc f32 -> operand type, both layouts (the transposed one feeds the weight-gradient GEMM)
         ProfScope ps(c->prof, c->stream, "dt.enc_convert");
@@ -698,54 +751,81 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     }
     const T* Yp = c->Xb.as<T>();
     bool adapter_done = false;
+    c->h1_ptr = c->H1.p; c->h1_ld = D;
     // the adapter's mix inside image_text_input's operand load (16-bit modes with the f32-level (hi, lo) product): no mix launch, no f32 copy of the mix
     const bool fuse_mix = sizeof(T) == 2 && k.use_adapter && c->iti_f32 && c->iti_x3 && c->iti_mix && Kin % 64 == 0 && E % 4 == 0;
     const float* mix_a32 = nullptr;
     const T* mix_a = nullptr;
     if constexpr (__is_same(T, f16_t)) {
         if (adapter_cpath) {
-            ARP_TRY(c->Xc.ensure(Mx * 3 * D + 4096)); ARP_TRY(c->H1c.ensure(Mx * 3 * D + 4096)); ARP_TRY(c->A32.ensure(Mx * D * 4));
-            // relu(relu(x W1 + b1) W2 + b2) with every operand rounding of the two products corrected (gemm256 MIXC): x -> [hi | x4 | dx4] rows, fc1 writes the
-            // hidden rows [hi | x4 | dx4] itself (x4 from the rounded tile, dx4 from the accumulators), fc2 writes the output in f32 for the mix and its binary16
-            // copy for the backward; the plain binary16 Xb / H1 the backward reads come out of the same passes.
+            ARP_TRY(c->Xc.ensure(Mx * 3 * D + 4096));
+            {   // the hidden rows double as the backward's H1 operand (a TN contraction over the ROWS: rows up to the next multiple of 64 must read as zeros)
+                const void* before = c->H1c.p;
+                ARP_TRY(c->H1c.ensure((size_t)Mxp * 3 * D + 4096));
+                if (c->H1c.p != before) ARP_HIP_OK(hipMemsetAsync(c->H1c.p, 0, (size_t)Mxp * 3 * D + 4096, c->stream));
+            }
+            if (c->ac_a_exact) ARP_TRY(c->A32.ensure(Mx * D * 4));
+            // relu(relu(x W1 + b1) W2 + b2) with the operand roundings of the two products corrected (gemm256 MIXC) as ac_plan1 / ac_plan2 say: x -> [hi | x4 (| dx4)]
+            // rows, fc1 writes the hidden rows [hi | x4 (| dx4)] itself (x4 from the rounded tile, dx4 from the accumulators), fc2 writes the output in f32 for the
+            // mix + its binary16 copy for the backward (ac_a_exact) or in binary16 only; the plain binary16 Xb the backward reads comes out of the conversion pass.
             {
                 ProfScope ps(c->prof, c->stream, "dt.enc_convert");
-                hipLaunchKernelGGL(convert_f16c_kernel, dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<f16_t>(), c->Xc.as<f16_t>(), Mx, D);
+                if (D % 16 == 0) {
+                    if (c->ac_plan1 >= 2) hipLaunchKernelGGL((convert_f16c16_kernel<true>), dim3(cdiv(Mx * D, 4096)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<f16_t>(), c->Xc.as<f16_t>(), Mx, D);
+                    else hipLaunchKernelGGL((convert_f16c16_kernel<false>), dim3(cdiv(Mx * D, 4096)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<f16_t>(), c->Xc.as<f16_t>(), Mx, D);
+                } else {
+                    hipLaunchKernelGGL(convert_f16c_kernel, dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), c->Xb.as<f16_t>(), c->Xc.as<f16_t>(), Mx, D);
+                }
                 ARP_HIP_OK(hipGetLastError());
             }
             const int* sc = reinterpret_cast<const int*>(c->wc_scal.p);
-            auto mixc = [&](GemmArgs& g, const void* A, const void* W, const float* bias, const int* sptr) {
+            auto mixc = [&](GemmArgs& g, const void* A, const void* W, const float* bias, const int* sptr, int plan) {
                 g.A = A; g.W = W; g.bias = bias; g.M = (int)Mx; g.N = D;
                 g.lda = D + D / 2; g.ldw = D + D / 2; g.ldr = D;
-                g.mix_nk16 = D / 64; g.mix_nkc_a = D / 256; g.K = D + D / 2; g.mix_sptr = sptr;
+                g.mix_nk16 = D / 64; g.mix_nkc_a = D / 256; g.K = D + plan * D / 4; g.mix_sptr = sptr;
             };
             {
                 GemmArgs g;
-                mixc(g, c->Xc.p, c->W1c.p, c->p("AdapterMLP_0/Dense_0/bias"), sc + 4);
+                mixc(g, c->Xc.p, c->W1c.p, c->p("AdapterMLP_0/Dense_0/bias"), sc + 4, c->ac_plan1);
                 g.out = c->H1c.p; g.ldo = D + D / 2;
                 g.xb_out = static_cast<char*>(c->H1c.p) + 2 * (size_t)D; g.ldxb = 3 * D; g.x8_shift = F16C_X_SHIFT;
-                g.dx4_out = static_cast<char*>(c->H1c.p) + 2 * (size_t)D + D / 2;
+                g.dx4_out = c->ac_plan2 >= 2 ? static_cast<char*>(c->H1c.p) + 2 * (size_t)D + D / 2 : nullptr;
                 ProfScope ps(c->prof, c->stream, "dt.adapter_fc1");
                 ARP_TRY((launch_gemm256_nt<f16_t, f16_t, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
             }
-            {
+            if (c->ac_h1_inplace && c->use_tn()) {
+                c->h1_ptr = c->H1c.p; c->h1_ld = D + D / 2;
+            } else {
                 ProfScope ps(c->prof, c->stream, "dt.adapter_fc1");
                 hipLaunchKernelGGL(extract_hi_kernel, dim3(cdiv(Mx * D, 2048)), dim3(256), 0, c->stream, c->H1c.as<f16_t>(), D + D / 2, c->H1.as<f16_t>(), Mx, D);
                 ARP_HIP_OK(hipGetLastError());
             }
             {
                 GemmArgs g;
-                mixc(g, c->H1c.p, c->W2c.p, c->p("AdapterMLP_0/Dense_1/bias"), sc + 12);
-                g.out = c->A32.p; g.ldo = D;
-                g.xb_out = c->A.p; g.ldxb = D;
+                mixc(g, c->H1c.p, c->W2c.p, c->p("AdapterMLP_0/Dense_1/bias"), sc + 12, c->ac_plan2);
                 ProfScope ps(c->prof, c->stream, "dt.adapter_fc2");
-                ARP_TRY((launch_gemm256_nt<f16_t, float, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
+                if (c->ac_a_exact) {
+                    g.out = c->A32.p; g.ldo = D;
+                    g.xb_out = c->A.p; g.ldxb = D;
+                    ARP_TRY((launch_gemm256_nt<f16_t, float, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
+                } else {
+                    g.out = c->A.p; g.ldo = D;
+                    g.x8_shift = -1;  // (no e2m1 side output: nothing multiplies the adapter's output on the fp4 MFMA)
+                    ARP_TRY((launch_gemm256_nt<f16_t, f16_t, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
+                }
             }
-            if (fuse_mix) {
+            if (fuse_mix && c->ac_a_exact) {
                 mix_a32 = c->A32.as<float>();  // the mix happens inside image_text_input's operand load (dtops.h::iti_x3_kernel)
-            } else {
+            } else if (fuse_mix) {
+                mix_a = c->A.as<T>();
+            } else if (c->ac_a_exact) {
                 ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
                 hipLaunchKernelGGL((adapter_mix_kernel<T, float>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A32.as<float>(), c->bt[c->cur].enc32.as<float>(),
+                                   c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
+                ARP_HIP_OK(hipGetLastError());
+            } else {
+                ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
+                hipLaunchKernelGGL((adapter_mix_kernel<T>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A.as<T>(), c->bt[c->cur].enc32.as<float>(),
                                    c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
                 ARP_HIP_OK(hipGetLastError());
             }
@@ -964,13 +1044,14 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
         ARP_HIP_OK(hipEventRecord(c->ev_dapre, c->stream));
         ARP_HIP_OK(hipStreamWaitEvent(c->side_stream, c->ev_dapre, 0));
     }
-    ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc2_dW", c->dApre.as<T>(), D, c->H1.as<T>(), D, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp, invS, side)));
+    // (H1 = the hidden rows' binary16 segment: c->H1 itself, or the head of fc1's [hi | x4 | dx4] rows with the adapter corrections on)
+    ARP_TRY((tn_gemm<T>(c, "dt.adapter_fc2_dW", c->dApre.as<T>(), D, static_cast<const T*>(c->h1_ptr), c->h1_ld, c->g("AdapterMLP_0/Dense_1/kernel"), D, D, Mxp, invS, side)));
     const long tiles256 = (long)cdiv((int)Mx, 256) * cdiv(D, 256);
     if (D % 8 == 0 && c->fuse_relu_bwd(tiles256)) {
         // dH1 = (dApre W2) * (H1 > 0) and its column sums (the Dense_0 bias gradient) in the GEMM's own epilogue (gemm256.h)
         GemmArgs g;
         g.A = c->dApre.p; g.W = c->W2t.p; g.out = c->dH1T.p; g.M = (int)Mx; g.N = D; g.K = D; g.lda = D; g.ldw = D; g.ldr = D; g.ldo = D;
-        g.mask = c->H1.p; g.ldm = D;
+        g.mask = c->h1_ptr; g.ldm = c->h1_ld;
         const int mt = cdiv((int)Mx, 256);
         DevBuf& cpart = defer_small ? c->colpart0 : c->colpart;  // (deferred: the dY kernel's partials in colpart are still waiting for their sums)
         ARP_TRY(cpart.ensure((size_t)mt * D * 4));
@@ -986,6 +1067,7 @@ template <typename T> int backward_adapter_tn(arp_dt* c, int stage) {
         ARP_TRY((big_gemm<T, T, ACT_NONE>(c, "dt.adapter_fc2_dX", c->dApre.p, D, c->W2t.p, D, nullptr, c->G.p, D, (int)Mx, D, D)));
         // dH1 = G * (H1 > 0), row-major (in the buffer the other path uses for its transposed copy), + the Dense_0 bias gradient
         ProfScope ps(c->prof, c->stream, "dt.adapter_bwd_masks");
+        if (c->h1_ld != D) return fail("backward_adapter_tn: the unfused ReLU backward reads a contiguous H1 (ARP_DT_ADAPTER_H1_INPLACE=0)");
         hipLaunchKernelGGL((mask_copy_colsum_kernel<T>), dim3(cdiv(D, 256), prow), dim3(256), 0, c->stream, c->G.as<T>(), c->H1.as<T>(), nullptr, 1.f,
                            c->dH1T.as<T>(), c->colpart.as<float>(), (int)Mx, D);
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(D, 64)), dim3(256), 0, c->stream, c->colpart.as<float>(), prow, D, c->g("AdapterMLP_0/Dense_0/bias"), invS);
@@ -1199,7 +1281,7 @@ template <typename T> int fwd_bwd(arp_dt* c, int stage = 0) {
 template <typename T> int fwd_bwd_graphed_chain(arp_dt* c, int stage);
 template <typename T> int fwd_bwd_graphed(arp_dt* c, int stage = 0) {
     if (c->use_images && c->enc_eager && c->use_graph && !c->prof.on && stage != 2) {
-        ARP_TRY(enc_forward_on(c->enc, c->stream, c->bt[c->cur].img32.as<float>(), c->R(), c->bt[c->cur].enc32.as<float>()));
+        ARP_TRY(encode_current(c));
         c->enc_outside = true;
     }
     const int rc = fwd_bwd_graphed_chain<T>(c, stage);
@@ -1390,6 +1472,12 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_ITI_X3")) c->iti_x3 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ITI_MIX")) c->iti_mix = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ADAPTER_C")) c->adapter_c = atoi(e) != 0 && k.mode == ARP_MODE_F16;
+    if (const char* e = getenv("ARP_DT_ADAPTER_PLAN")) {  // "<fc1><fc2><e|h>", e.g. 22e (round 5), 12h
+        if (e[0] >= '1' && e[0] <= '2') c->ac_plan1 = e[0] - '0';
+        if (e[0] && e[1] >= '1' && e[1] <= '2') c->ac_plan2 = e[1] - '0';
+        if (e[0] && e[1] && (e[2] == 'e' || e[2] == 'h')) c->ac_a_exact = e[2] == 'e';
+    }
+    if (const char* e = getenv("ARP_DT_ADAPTER_H1_INPLACE")) c->ac_h1_inplace = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_SIDE")) c->side_gemms = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_DWI_LAST")) c->dwi_last = atoi(e) != 0;
@@ -1442,8 +1530,9 @@ int arp_dt_destroy(arp_dt* c) {
         for (auto& gr : slot)
             if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
-    for (hipEvent_t e : {c->ev_fork, c->ev_dapre, c->ev_side})
+    for (hipEvent_t e : {c->ev_fork, c->ev_dapre, c->ev_side, c->ev_enc_go, c->bt[0].enc_done, c->bt[1].enc_done, c->bt[2].enc_done})
         if (e) (void)hipEventDestroy(e);
+    if (c->enc_stream) { (void)hipStreamSynchronize(c->enc_stream); (void)hipStreamDestroy(c->enc_stream); }
     c->part_side.release();
     for (hipEvent_t e : {c->ev_b1, c->ev_b2, c->ev_comm, c->bt[0].up, c->bt[0].use, c->bt[1].up, c->bt[1].use, c->bt[2].up, c->bt[2].use})
         if (e) (void)hipEventDestroy(e);
@@ -1562,6 +1651,8 @@ int arp_dt_set_batch(arp_dt* c, const float* enc, const int32_t* action, const f
     if (!c || !enc || !action || !rtg || B <= 0) return fail("bad argument");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     c->cur = 2;  // the synchronous slot
+    if (c->bt[2].enc_ahead && c->enc_stream) ARP_HIP_OK(hipStreamSynchronize(c->enc_stream));  // (an encode-ahead pass still writing the buffer about to be filled)
+    c->bt[2].enc_ahead = false;
     ARP_TRY(stage_slot(c, 2, c->stream, enc, nullptr, action, rtg, B));
     ARP_TRY(ensure_buffers(c, B));
     c->use_images = false;
@@ -1590,6 +1681,8 @@ static int upload_async(arp_dt* c, int slot, const float* enc, const float* fram
     ARP_TRY(stage_slot(c, slot, c->copy_stream[slot], enc, frames, action, rtg, B));
     ARP_HIP_OK(hipEventRecord(b.up, c->copy_stream[slot]));
     b.up_pending = true;
+    b.up_recorded = true;
+    b.enc_ahead = false;  // (new frames: whatever enc32 holds belongs to the batch before)
     return 0;
 }
 int arp_dt_upload_batch_async(arp_dt* c, int slot, const float* enc, const int32_t* action, const float* rtg, int B) {
@@ -1630,11 +1723,27 @@ int arp_dt_set_batch_images(arp_dt* c, const float* images, const int32_t* actio
     if (!c->enc) return fail("no encoder attached: call arp_dt_attach_encoder first");
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     c->cur = 2;  // the synchronous slot
+    if (c->bt[2].enc_ahead && c->enc_stream) ARP_HIP_OK(hipStreamSynchronize(c->enc_stream));  // (an encode-ahead pass still reading the frames about to be replaced)
+    c->bt[2].enc_ahead = false;
     ARP_TRY(stage_slot(c, 2, c->stream, nullptr, images, action, rtg, B));
     ARP_TRY(ensure_buffers(c, B));
     ARP_HIP_OK(hipStreamSynchronize(c->stream));
     c->use_images = true;
     return 0;
+}
+
+// Encode batch slot `slot` (0 / 1: a batch of frames uploaded with arp_dt_upload_batch_images_async; 2: the batch staged by arp_dt_set_batch_images) NOW, on the
+// encoder's own stream, instead of at the head of the step that will read it: the frozen encoder's pass for batch i + 1 then runs beside step i's policy
+// part.  Ordered on the GPU behind the slot's upload and behind the last step that read the slot; the step that selects the slot waits for the pass.  May be
+// called from the uploader thread (it takes the capture lock, like the uploads).  A slot that is re-selected without a new upload and without another call
+// of this function is encoded again by its step: no step ever reads encodings it did not pay for.
+int arp_dt_encode_ahead(arp_dt* c, int slot) {
+    if (!c || slot < 0 || slot > 2) return fail("bad argument");
+    if (!c->enc) return fail("no encoder attached: call arp_dt_attach_encoder first");
+    if (!c->enc_eager) return fail("arp_dt_encode_ahead needs the eager encoder path (ARP_DT_ENC_EAGER=0 captures the encoder inside the step's graph)");
+    ARP_HIP_OK(hipSetDevice(c->cfg.device));
+    std::lock_guard<std::mutex> lock(c->capture_mu);
+    return enqueue_encode(c, slot, slot == 2);
 }
 
 int arp_dt_forward(arp_dt* c, float* action_logits, float* return_pred, float* metrics) {

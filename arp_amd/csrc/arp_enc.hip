@@ -80,6 +80,32 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     *reinterpret_cast<uint4*>(o + 2 * (size_t)K) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
+// patchify_kernel<float> + split3_kernel in one pass (round 6; f16x3 and f16c modes): the f32 patch matrix is never written (100 MB per 128 frames written and
+// read back).  Same values: each element is loaded once, hi = rn16(v), lo = rn16(v - hi) as split3_kernel forms them.
+__global__ __launch_bounds__(256) void patchify_split3_kernel(const float* __restrict__ img, f16_t* __restrict__ out, int n, int res, int P) {
+    const int G = res / P, K = P * P * 3;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (size_t)n * G * G * K) return;
+    const int k = (int)(i % K);
+    const size_t row = i / K;
+    const int px = (int)(row % G), py = (int)((row / G) % G);
+    const size_t b = row / ((size_t)G * G);
+    const int p1 = k / (P * 3), rem = k - p1 * P * 3;
+    const float* src = img + ((b * res + (size_t)py * P + p1) * res + (size_t)px * P) * 3 + rem;
+    const float v[4] = {src[0], src[1], src[2], src[3]};
+    uint32_t hi[2], lo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float h0 = h2f(f2h(v[2 * j])), h1 = h2f(f2h(v[2 * j + 1]));
+        hi[j] = pack_h2(h0, h1);
+        lo[j] = pack_h2(v[2 * j] - h0, v[2 * j + 1] - h1);
+    }
+    f16_t* o = out + row * 3 * (size_t)K + k;
+    *reinterpret_cast<uint2*>(o) = make_uint2(hi[0], hi[1]);
+    *reinterpret_cast<uint2*>(o + K) = make_uint2(lo[0], lo[1]);
+    *reinterpret_cast<uint2*>(o + 2 * (size_t)K) = make_uint2(hi[0], hi[1]);
+}
+
 struct HostTensor {
     std::vector<float> data;
     std::vector<int64_t> shape;
@@ -118,6 +144,7 @@ struct arp_enc {
     DevBuf img_in, out;
     // ARP_MODE_F16C: per GEMM g in {in_proj, out_proj, fc1, fc2} the correction plan (0 plain, 1 weights, 2 weights + activations) and, per layer, the
     // power-of-two exponents the e2m1 (fp4) weight segments were scaled by: dW4 = fp4(dW * 2^sw_d), W4 = fp4(W * 2^sw_w)
+    bool vperm = true;  // ARP_MODE_F16C: V's columns permuted inside every head so that the attention's [hi | x4 | dx4] rows leave in whole pieces (attention.h, outc == 2); ARP_F16C_VPERM=0: round 5's stores
     int plan[4] = {1, 2, 2, 1};  // in_proj: weights only (ln_1's own rounding is 0.5 % of the error budget, scripts/n1_emulate.py)
     std::vector<int> sw_d[4], sw_w[4];
     void* w_emb3 = nullptr;  // ARP_MODE_F16C: the patch embedding's [W_hi | W_hi | W_lo] (its product runs as ARP_MODE_F16X3's K-concatenation)
@@ -295,13 +322,12 @@ int forward_chunk_x3(arp_enc* c, arp_enc::Ws& w, hipStream_t stream, const float
         ARP_HIP_OK(hipGetLastError());
         return 0;
     };
-    {
+    {   // frames -> (hi, lo, hi) patch triples in one pass
         ProfScope ps(c->prof, stream, "m3ae.patchify");
         const size_t tot = (size_t)nb * G * G * KP;
-        hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, w.patches.as<float>(), nb, k.img_res, k.patch);
+        hipLaunchKernelGGL(patchify_split3_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, a3, nb, k.img_res, k.patch);
         ARP_HIP_OK(hipGetLastError());
     }
-    ARP_TRY(split("m3ae.split", w.patches.as<float>(), (size_t)nb * G * G, KP));
     ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", a3, c->w_emb, c->b_emb, nullptr, w.pe.p, nb * G * G, D, 3 * KP)));
     {
         ProfScope ps(c->prof, stream, "m3ae.assemble");
@@ -370,9 +396,7 @@ int forward_chunk_c(arp_enc* c, arp_enc::Ws& w, hipStream_t stream, const float*
     {   // patch embedding on (hi, lo) binary16 pairs (its input rounding alone is a third of the plain f16 encoder's logit error; the product is 0.6 % of the FLOPs)
         ProfScope ps(c->prof, stream, "m3ae.patchify");
         const size_t tot = (size_t)nb * G * G * KP;
-        hipLaunchKernelGGL((patchify_kernel<float>), dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, w.patches.as<float>(), nb, k.img_res, k.patch);
-        ARP_HIP_OK(hipGetLastError());
-        hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((tot / 8 + 255) / 256)), dim3(256), 0, stream, w.patches.as<float>(), reinterpret_cast<f16_t*>(a4), (size_t)nb * G * G, KP);
+        hipLaunchKernelGGL(patchify_split3_kernel, dim3((unsigned)((tot / 4 + 255) / 256)), dim3(256), 0, stream, img_dev, reinterpret_cast<f16_t*>(a4), nb, k.img_res, k.patch);
         ARP_HIP_OK(hipGetLastError());
     }
     ARP_TRY((tower_gemm<f16_t, float, ACT_NONE, false, 8 + SITE_PATCH>(t, "m3ae.image_embedding", a4, c->w_emb3, c->b_emb, nullptr, w.pe.p, nb * G * G, D, 3 * KP)));
@@ -394,7 +418,7 @@ int forward_chunk_c(arp_enc* c, arp_enc::Ws& w, hipStream_t stream, const float*
         ARP_TRY((gemm_c<ACT_NONE, false, f16_t, 8 + SITE_QKV>(c, t, "m3ae.qkv", a4, L.w_in, c->plan[0], c->sw_d[0][i], c->sw_w[0][i], L.b_in, nullptr, qkv, M, 3 * D, D, 3 * D)));
         {
             ProfScope ps(c->prof, stream, "m3ae.attn");
-            ARP_TRY(launch_attention<f16_t>(stream, 0, qkv, reinterpret_cast<f16_t*>(a4), nb, N, D, k.heads, 0, 0, 0.f, nullptr, 1));
+            ARP_TRY(launch_attention<f16_t>(stream, 0, qkv, reinterpret_cast<f16_t*>(a4), nb, N, D, k.heads, 0, 0, 0.f, nullptr, c->vperm ? 2 : 1));
         }
         ARP_TRY((gemm_c<ACT_NONE, true, float, 8 + SITE_OUT>(c, t, "m3ae.out_proj", a4, L.w_out, c->plan[1], c->sw_d[1][i], c->sw_w[1][i], L.b_out, x, x, M, D, D, D)));
         ARP_TRY(ln("m3ae.ln_2", L.ln2_w, L.ln2_b, c->plan[2]));
@@ -495,6 +519,7 @@ int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
         for (int i = 0; i < 4 && e[i]; ++i)
             if (e[i] >= '0' && e[i] <= '2') c->plan[i] = e[i] - '0';
     }
+    if (const char* e = getenv("ARP_F16C_VPERM")) c->vperm = atoi(e) != 0;
     if (const char* e = getenv("ARP_ENC_STREAMS")) c->n_parts = std::max(1, std::min(atoi(e), (int)arp_enc::MAX_PARTS));
     if (const char* e = getenv("ARP_ENC_SPLIT")) c->first_part = std::max(0, atoi(e));
     if (const char* e = getenv("ARP_ENC_MIN_PART")) c->min_part_frames = std::max(1, atoi(e));
@@ -562,9 +587,22 @@ int arp_enc_finalize_weights(arp_enc* c) {
         for (int gi = 0; gi < 4; ++gi) { c->sw_d[gi].assign(k.layers, 0); c->sw_w[gi].assign(k.layers, 0); }
     }
     // the block GEMMs' weights: operand type, or ARP_MODE_F16C's [W_hi | dW4 (| W4)] rows (e2m1 segments) with their per-tensor scales
+    // f16c with vperm: output column o of in_proj's V third (o = 2 D + head * 64 + d') carries the ORIGINAL column 2 D + head * 64 + pi(d'), pi = the swap of
+    // bits [5:4] and [3:2] (an involution): the MFMA attention then holds sixteen consecutive original columns per lane (attention.h, outc == 2)
+    const bool vp = f16c && c->vperm && D / k.heads == 64 && c->tokens() > 64;  // (the attention instances of <= 64 tokens keep round 5's stores: attention.h)
+    c->vperm = vp;
+    auto vperm_col = [&](int o) { return o < 2 * D ? o : (o & ~63) | ((o >> 2) & 3) << 4 | ((o >> 4) & 3) << 2 | (o & 3); };
+    std::vector<float> permuted;
     auto up_w = [&](const HostTensor* ht, int in, int out_, int gi, int layer, void** dst) -> int {
-        if (f16c) return up_kernel_c(c, ht->data.data(), in, out_, c->plan[gi], dst, &c->sw_d[gi][layer], &c->sw_w[gi][layer]);
-        return up_kernel(c, ht->data.data(), in, out_, dst);
+        const float* src = ht->data.data();
+        if (vp && gi == 0) {
+            permuted.resize((size_t)in * out_);
+            for (int i = 0; i < in; ++i)
+                for (int o = 0; o < out_; ++o) permuted[(size_t)i * out_ + o] = src[(size_t)i * out_ + vperm_col(o)];
+            src = permuted.data();
+        }
+        if (f16c) return up_kernel_c(c, src, in, out_, c->plan[gi], dst, &c->sw_d[gi][layer], &c->sw_w[gi][layer]);
+        return up_kernel(c, src, in, out_, dst);
     };
     ARP_TRY(staged(c, "image_embedding/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->b_emb));
     ARP_TRY(staged(c, "cls_token", {1, 1, D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &c->cls));
@@ -597,7 +635,14 @@ int arp_enc_finalize_weights(arp_enc* c) {
         ARP_TRY(staged(c, p + "LayerNorm_1/scale", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln2_w));
         ARP_TRY(staged(c, p + "LayerNorm_1/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.ln2_b));
         ARP_TRY(staged(c, p + "Attention_0/Dense_0/kernel", {D, 3 * D}, &t)); ARP_TRY(up_w(t, D, 3 * D, 0, i, &L.w_in));
-        ARP_TRY(staged(c, p + "Attention_0/Dense_0/bias", {3 * D}, &t)); ARP_TRY(up_f32(c, t->data.data(), 3 * D, &L.b_in));
+        ARP_TRY(staged(c, p + "Attention_0/Dense_0/bias", {3 * D}, &t));
+        if (vp) {
+            std::vector<float> pb(3 * D);
+            for (int o = 0; o < 3 * D; ++o) pb[o] = t->data[vperm_col(o)];
+            ARP_TRY(up_f32(c, pb.data(), 3 * D, &L.b_in));
+        } else {
+            ARP_TRY(up_f32(c, t->data.data(), 3 * D, &L.b_in));
+        }
         ARP_TRY(staged(c, p + "Attention_0/Dense_1/kernel", {D, D}, &t)); ARP_TRY(up_w(t, D, D, 1, i, &L.w_out));
         ARP_TRY(staged(c, p + "Attention_0/Dense_1/bias", {D}, &t)); ARP_TRY(up_f32(c, t->data.data(), D, &L.b_out));
         ARP_TRY(staged(c, p + "TransformerMLP_0/fc1/kernel", {D, H}, &t)); ARP_TRY(up_w(t, D, H, 2, i, &L.w_fc));

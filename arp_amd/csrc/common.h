@@ -217,6 +217,29 @@ template <bool WITH_DX> __device__ __forceinline__ void store_f16c(f16_t* row, i
     *reinterpret_cast<uint16_t*>(seg + (c >> 1)) = pack_fp4x4(h[0] * sx, h[1] * sx, h[2] * sx, h[3] * sx);
     if constexpr (WITH_DX) *reinterpret_cast<uint16_t*>(seg + (K >> 1) + (c >> 1)) = pack_fp4x4((v[0] - h[0]) * sd, (v[1] - h[1]) * sd, (v[2] - h[2]) * sd, (v[3] - h[3]) * sd);
 }
+// sixteen consecutive values at column c (a multiple of 16): the same three segments as whole 32- / 8- / 8-byte pieces (two 16-byte stores and two 8-byte
+// stores per lane where four calls of the form above issue twelve stores of 8, 2 and 2 bytes)
+__device__ __forceinline__ void store_f16c16(f16_t* row, int c, int K, const float (&a)[16]) {
+    float v[16], h[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        v[j] = pin_f32(a[j]);
+        h[j] = h2f(f2h(v[j]));
+    }
+    uint4* hi = reinterpret_cast<uint4*>(row + c);
+    hi[0] = make_uint4(pack_h2(h[0], h[1]), pack_h2(h[2], h[3]), pack_h2(h[4], h[5]), pack_h2(h[6], h[7]));
+    hi[1] = make_uint4(pack_h2(h[8], h[9]), pack_h2(h[10], h[11]), pack_h2(h[12], h[13]), pack_h2(h[14], h[15]));
+    uint8_t* seg = reinterpret_cast<uint8_t*>(row + K);
+    constexpr float sx = (float)(1 << F16C_X_SHIFT), sd = (float)(1 << F16C_DX_SHIFT);
+    float x0[8], x1[8], d0[8], d1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        x0[j] = h[j] * sx; x1[j] = h[8 + j] * sx;
+        d0[j] = (v[j] - h[j]) * sd; d1[j] = (v[8 + j] - h[8 + j]) * sd;
+    }
+    *reinterpret_cast<uint2*>(seg + (c >> 1)) = make_uint2(pack_fp4x8(x0), pack_fp4x8(x1));
+    *reinterpret_cast<uint2*>(seg + (K >> 1) + (c >> 1)) = make_uint2(pack_fp4x8(d0), pack_fp4x8(d1));
+}
 
 __device__ __forceinline__ void load4(const f16_t* p, float (&v)[4]) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);

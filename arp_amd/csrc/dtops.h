@@ -483,6 +483,40 @@ static __global__ __launch_bounds__(256) void convert_f16c_kernel(const float* _
     store4(xb + i, v[0], v[1], v[2], v[3]);
     store_f16c<true>(xc + r * (size_t)(3 * D / 2), c, D, v[0], v[1], v[2], v[3]);
 }
+// the same with SIXTEEN values per lane (D % 16 == 0): two 16-byte loads ahead of 32 + 32 + 8 (+ 8) bytes of stores, where the four-value form stores 8 + 8 + 2 + 2
+template <bool WITH_DX>
+static __global__ __launch_bounds__(256) void convert_f16c16_kernel(const float* __restrict__ in, f16_t* __restrict__ xb, f16_t* __restrict__ xc, size_t rows, int D) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i >= rows * (size_t)D) return;
+    const size_t r = i / D;
+    const int c = (int)(i - r * D);
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(in + i + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    f16_t* row = xc + r * (size_t)(3 * D / 2);
+    float h[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h[j] = h2f(f2h(v[j]));
+    const uint4 h0 = make_uint4(pack_h2(h[0], h[1]), pack_h2(h[2], h[3]), pack_h2(h[4], h[5]), pack_h2(h[6], h[7]));
+    const uint4 h1 = make_uint4(pack_h2(h[8], h[9]), pack_h2(h[10], h[11]), pack_h2(h[12], h[13]), pack_h2(h[14], h[15]));
+    reinterpret_cast<uint4*>(xb + i)[0] = h0; reinterpret_cast<uint4*>(xb + i)[1] = h1;
+    reinterpret_cast<uint4*>(row + c)[0] = h0; reinterpret_cast<uint4*>(row + c)[1] = h1;
+    uint8_t* seg = reinterpret_cast<uint8_t*>(row + D);
+    constexpr float sx = (float)(1 << F16C_X_SHIFT), sd = (float)(1 << F16C_DX_SHIFT);
+    float x0[8], x1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x0[j] = h[j] * sx; x1[j] = h[8 + j] * sx; }
+    *reinterpret_cast<uint2*>(seg + (c >> 1)) = make_uint2(pack_fp4x8(x0), pack_fp4x8(x1));
+    if constexpr (WITH_DX) {
+        float d0[8], d1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { d0[j] = (v[j] - h[j]) * sd; d1[j] = (v[8 + j] - h[8 + j]) * sd; }
+        *reinterpret_cast<uint2*>(seg + (D >> 1) + (c >> 1)) = make_uint2(pack_fp4x8(d0), pack_fp4x8(d1));
+    }
+}
 // rows [hi | ...] of stride ld (binary16 units) -> contiguous [rows, D] binary16 (the plain copy the backward reads)
 static __global__ __launch_bounds__(256) void extract_hi_kernel(const f16_t* __restrict__ in, int ld, f16_t* __restrict__ out, size_t rows, int D) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;

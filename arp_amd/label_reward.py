@@ -312,17 +312,24 @@ class RowSink:
 
     def _run(self):
         cache = {}
+        t_create = t_write = 0.0
         while True:
             item = self.q.get()
             if item is None:
+                if os.environ.get("ARP_LABEL_TIMING") == "1":
+                    print(f"[RowSink] dataset create / grow {1e3 * t_create:.1f} ms, row writes {1e3 * t_write:.1f} ms", flush=True)
                 return
             if self.err is not None:
                 continue  # drain: the error surfaces in close()
             try:
                 key, first, rows = item
+                t = time.perf_counter()
                 if key not in cache:
                     cache[key] = self._dataset(key)
+                t1 = time.perf_counter()
                 cache[key][first : first + rows.shape[0]] = rows.astype(self.dtype, copy=False)
+                t_create += t1 - t
+                t_write += time.perf_counter() - t1
             except BaseException as e:  # noqa: BLE001 -- re-raised by close()
                 self.err = e
 
@@ -586,6 +593,8 @@ def label_reward(
         raise ValueError("world > 1 needs gather=<callable returning every rank's results>: rank 0 alone would write a file "
                          "shorter than len_data (the reference always labels the whole file)")
     is_hdf5 = False
+    timing = os.environ.get("ARP_LABEL_TIMING") == "1"
+    tm = [("start", time.perf_counter())]
     if store is None:
         if data_path is None:
             dirname = f"{env_name}_{distribution_mode}_level{start_level}to{num_levels}_num{num_demonstrations}_frame{num_frames}"
@@ -595,7 +604,9 @@ def label_reward(
         # one process: "a" as the reference (label_reward.py:69).  Sharded (one process per GPU): every rank READS through its own
         # read-only handle -- HDF5 locks a file that is open for writing -- and rank 0 reopens it "a" for the single-writer step
         store, is_hdf5 = _open_store(data_path, "a" if world == 1 else "r")
+    tm.append(("open", time.perf_counter()))
     _, num_frames, _ = trajectory_bounds(store)  # quirk Q2: the argument is overwritten from the file
+    tm.append(("bounds", time.perf_counter()))
 
     compute_reward = make_compute_reward(model_type)
     own_model = clip_model is None
@@ -616,6 +627,7 @@ def label_reward(
                     raise ValueError("no BPE vocabulary offline: pass tokens=<int32 [1,77]> or tokenizer=<callable>")
                 tokens = tokenizer([text] if not isinstance(text, list) else text)
             clip_model.set_text(np.asarray(tokens, dtype=np.int32))
+        tm.append(("model+text", time.perf_counter()))
 
         # one process on a real file: rows are written while the next batch is labelled (RowSink)
         sink = None
@@ -628,8 +640,10 @@ def label_reward(
             if sink is not None:
                 sink.abort()  # no half-labelled datasets stay behind (the reference writes nothing before the labelling is complete)
             raise
+        tm.append(("label_store", time.perf_counter()))
         if sink is not None:
             sink.close()
+        tm.append(("sink.close", time.perf_counter()))
         if is_hdf5 and world > 1:
             store.close()  # before the gather: it is the barrier after which no rank holds the file
             file_open = False
@@ -640,9 +654,13 @@ def label_reward(
                 file_open = True
             for res in per_rank:
                 write_results(store, res, is_hdf5, num_frames)
+        tm.append(("write", time.perf_counter()))
     finally:  # an error on the way (weights, a failed GPU call, the gather) still releases the GPU handle and the file
         if file_open:
             store.close()
+        if timing:
+            tm.append(("close", time.perf_counter()))
+            print("[label_reward] " + ", ".join(f"{n} {1e3 * (t - tm[i][1]):.1f} ms" for i, (n, t) in enumerate(tm[1:])) + f"; total {1e3 * (tm[-1][1] - tm[0][1]):.1f} ms", flush=True)
         if own_model and clip_model is not None:
             clip_model.close()
     return None

@@ -155,6 +155,11 @@ class PolicyTrainer:
         self._inflight = getattr(self, "_inflight", {})
         self._inflight[int(slot)] = (enc, action, rtg, B)
 
+    def encode_ahead(self, slot):
+        """Enqueue the frozen encoder's pass for the frames in batch slot ``slot`` now, on the encoder's own stream, so that it runs beside the current step's
+        policy part (``arp_dt_encode_ahead``); the step that reads the slot then waits for it instead of encoding at its head."""
+        check(lib.arp_dt_encode_ahead(self._h, int(slot)))
+
     def select(self, slot):
         """The next forward / val_step / train_step reads batch slot ``slot`` (ordered behind its upload on the GPU)."""
         check(lib.arp_dt_select_batch(self._h, int(slot)))
@@ -493,7 +498,10 @@ def prefetch_to_device(iterator, size, trainer, *, rank=0, world=1, device_axis=
                 if stop.is_set():
                     return
                 enc, act, rtg = _batch_arrays(shard_batch(batch, rank, world, device_axis), trainer.cfg.use_symlog)
-                trainer.upload_async(slot, enc, act, rtg, images=getattr(trainer, "_encoder", None) is not None and enc.ndim == 5 and enc.shape[-1] == 3)
+                images = getattr(trainer, "_encoder", None) is not None and enc.ndim == 5 and enc.shape[-1] == 3
+                trainer.upload_async(slot, enc, act, rtg, images=images)
+                if images and os.environ.get("ARP_DT_ENCODE_AHEAD", "1") != "0" and os.environ.get("ARP_DT_ENC_EAGER", "1") != "0":
+                    trainer.encode_ahead(slot)  # the frozen encoder's pass for this batch runs beside the step that is reading the OTHER slot
                 ready.put(DeviceBatch(trainer, slot, lambda s=slot: free.put(s)))
             ready.put(None)
         except BaseException as e:  # surfaces in the consumer

@@ -506,21 +506,43 @@ def bench_policy(a):
         ecfg = m3ae.EncoderConfig()
         enc = m3ae.M3AEEncoder(ecfg, S.m3ae_params(ecfg, seed=0), mode=a.encoder_mode or a.mode, device=local_rank, max_frames=a.policy_batch * cfg.window)
         tr.attach_encoder(enc)
-        _, act_, rtg_ = S.policy_batch(PolicyConfig(enc_tokens=1, enc_dim=4), a.policy_batch, seed=100 + rank)
-        frames = S.normalized_frames(a.policy_batch * cfg.window, 256, seed=100 + rank).reshape(a.policy_batch, cfg.window, 256, 256, 3)
-        tr.set_batch_images(frames, act_, rtg_)
+        # Frames in, as the training loop feeds them: prefetch_to_device keeps TWO batches of frames on the device (main_procgen.py:703) and the step alternates
+        # between the slots.  The encoder is frozen, so batch i + 1 is encoded on the encoder's own stream while step i's policy part runs
+        # (arp_dt_encode_ahead -- what prefetch_to_device's uploader thread calls once a batch has landed): every step still pays for exactly one encoder
+        # pass over its own 128 frames, inside the timed region (--no-encode-ahead: each step encodes at its own head, as in rounds 1-5).
+        ahead = not a.no_encode_ahead and os.environ.get("ARP_DT_ENC_EAGER", "1") != "0"
+        for k in (0, 1):
+            _, act_, rtg_ = S.policy_batch(PolicyConfig(enc_tokens=1, enc_dim=4), a.policy_batch, seed=100 + rank + 17 * k)
+            frames = S.normalized_frames(a.policy_batch * cfg.window, 256, seed=100 + rank + 17 * k).reshape(a.policy_batch, cfg.window, 256, 256, 3)
+            tr.upload_async(k, frames, act_, rtg_, images=True)
+        step_no = [0]
+        if ahead:
+            tr.encode_ahead(0)
+        settle = 6  # set-up, not warm-up: each slot's chain runs eagerly twice before it is captured (arp_dt.hip::fwd_bwd_graphed) -- three steps per slot
+
+        def step():
+            k = step_no[0]
+            step_no[0] += 1
+            tr.select(k & 1)
+            tr.train_step_async(lr)
+            if ahead:
+                tr.encode_ahead((k + 1) & 1)
     else:
         tr.set_batch(*S.policy_batch(cfg, a.policy_batch, seed=100 + rank))
+        settle = 0
+
+        def step():
+            tr.train_step_async(lr)
     lr = 5e-4
-    for _ in range(a.warmup):
-        tr.train_step_async(lr)
+    for _ in range(settle + a.warmup):
+        step()
     tr.sync()
     if dist is not None:
         dist.barrier()
     _ffi.check(_ffi.lib.arp_dev_synchronize())
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tr.train_step_async(lr)
+        step()
     tr.sync()
     _ffi.check(_ffi.lib.arp_dev_synchronize())
     elapsed = time.perf_counter() - t0
@@ -533,14 +555,17 @@ def bench_policy(a):
     tr.profile(True)
     tr.profile_reset()
     for _ in range(a.steps):
-        tr.train_step_async(lr)
+        step()
     tr.sync()
+    _ffi.check(_ffi.lib.arp_dev_synchronize())
     prof = tr.profile_read()
     if enc is not None:
         enc.profile(True)
-        tr.train_step_async(lr)
+        step()
         tr.sync()
+        _ffi.check(_ffi.lib.arp_dev_synchronize())
         prof.update({k: {"ms": v["ms"] * a.steps, "calls": v["calls"] * a.steps} for k, v in enc.profile_read().items()})
+        enc.profile(False)
     aux = tr.train_step(lr)
     # ---- the S4 seam as the reference calls it: train_step_fn(state, HOST batch, rng) (main_procgen.py:718), outside the timed region.
     # serial = the 101 MB batch uploaded synchronously in front of every step; prefetched = prefetch_to_device(.., 2): batch i+1 goes up
@@ -955,6 +980,8 @@ def main():
                     "on the communication stream, through a one-rank RCCL communicator (an identity reduction; ARP_DT_FORCE_COMM / ARP_FT_FORCE_COMM with the overlap on, "
                     "as tests/test_policy_gpu.py::test_bucketed_overlapped_allreduce_equals_serial runs it): the per-rank compute time configs[3] / configs[4] will "
                     "reproduce on 8 GPUs before any communication time (VERDICT r5 weak #7)")
+    ap.add_argument("--no-encode-ahead", action="store_true", help="policy path with --with-encoder: every step encodes its own batch at its head (rounds 1-5) instead of the "
+                    "frozen encoder's pass for batch i + 1 running beside step i's policy part")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
                     "(frames in, the reference's own boundary; SURVEY row N1) instead of feeding pre-computed encodings")
     ap.add_argument("--all-secondary", dest="all_secondary", action="store_true", default=True,

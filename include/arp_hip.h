@@ -375,6 +375,11 @@ int arp_enc_profile_json(arp_enc* h, char* buf, int buf_len);
  * [B,T,res,res,3] f32 and every forward / train step runs the encoder first (on the step's stream). */
 int arp_dt_attach_encoder(arp_dt* h, arp_enc* enc);
 int arp_dt_set_batch_images(arp_dt* h, const float* images, const int32_t* action, const float* rtg, int B);
+/* The encoder is frozen: batch i + 1's encodings depend on nothing step i computes.  arp_dt_encode_ahead(slot) enqueues the encoder pass of the frames in
+ * batch slot `slot` (0 / 1: uploaded with arp_dt_upload_batch_images_async; 2: staged by arp_dt_set_batch_images) on the encoder's own stream NOW -- behind the
+ * slot's upload and the last step that read the slot -- so that it runs beside the current step's policy part; the step that then reads the slot waits for it
+ * instead of encoding.  Callable from the uploader thread.  Without it a step encodes its own batch at its head (same stream of work, same encodings). */
+int arp_dt_encode_ahead(arp_dt* h, int slot);
 
 /* ---- host I/O of path (1) (no GPU involved) -------------------------------
  * Reads n stored chunks of a gzip-chunked dataset (`ob` of data/PPG/trajectory_recorder.py:148-176: one chunk = one row =

@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Which of the adapter's operand-rounding corrections does the policy's 1e-3 bar need?  CPU emulation (fp64 arithmetic, IEEE half and OCP e2m1 roundings
+inserted where the f16 policy step rounds) at the real geometry, B = 2, on N(0,1) encodings (tests/test_policy_gpu.py's 16 seeds) and behind REAL encoder
+outputs (oracle/m3ae_np in fp64: the case that reads 1.18e-3 on seed 3 in profiles/r5_n1_probe.txt).  Test infrastructure: uses the oracle; no GPU.
+
+    python scripts/adapter_plan_emulate.py [n_seeds_normal] [n_seeds_encoder]
+
+A product with plan (pw, px):  x.W ~ x_hi.W_hi + [pw] 2^-s x4.dW4 + [px] 2^-s' dx4.W4   (arp_enc.hip / gemm256.h MIXC; hi = rn16, x4 = fp4(x_hi 2^1),
+dW4 = fp4((W - W_hi) 2^sd), dx4 = fp4((x - x_hi) 2^13), W4 = fp4(W 2^sw), per-tensor sd / sw: largest magnitude in (6, 12]).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from arp_amd import synth_policy as S  # noqa: E402
+from arp_amd.train import PolicyConfig  # noqa: E402
+from oracle import arpdt_torch as O  # noqa: E402
+
+torch.set_num_threads(8)
+FP4 = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], dtype=torch.float64)
+
+
+def h(t):
+    return t.to(torch.float16).double()
+
+
+def fp4(t):
+    """round to nearest e2m1 value (ties to even mantissa), saturating at 6"""
+    a = t.abs().clamp(max=6.0)
+    idx = torch.bucketize(a, FP4)  # first grid value >= a
+    idx = idx.clamp(1, 7)
+    lo, hi = FP4[idx - 1], FP4[idx]
+    mid = 0.5 * (lo + hi)
+    up = (a > mid) | ((a == mid) & ((idx % 2) == 0))  # tie: the even code (codes 0..7: even index = even mantissa)
+    return torch.sign(t) * torch.where(up, hi, lo)
+
+
+def pick(mx):
+    return int(np.floor(np.log2(6.0 / mx))) + 1 if mx > 0 else 0
+
+
+def prod(x, W, pw, px, x_is_exact_hi=False):
+    """x [M,K] (unrounded), W [K,N] (Flax layout): the product as the f16 step computes it with weight / activation corrections"""
+    xh, Wh = h(x), h(W)
+    out = xh @ Wh
+    if pw:
+        dW = W - Wh
+        sd = pick(float(dW.abs().max()))
+        out = out + (fp4(xh * 2.0) @ fp4(dW * 2.0 ** sd)) * 2.0 ** (-1 - sd)
+    if px:
+        dx = x - xh
+        sw = pick(float(W.abs().max()))
+        out = out + (fp4(dx * 2.0 ** 13) @ fp4(W * 2.0 ** sw)) * 2.0 ** (-13 - sw)
+    return out
+
+
+def run(P, pcfg, ocfg, enc, act, rtg, ref, plan1, plan2, a_exact, x_skip16):
+    B, T = act.shape
+    D = pcfg.enc_dim
+    x = enc.reshape(-1, D)
+    h1 = torch.relu(prod(x, P["AdapterMLP_0/Dense_0/kernel"], *plan1) + P["AdapterMLP_0/Dense_0/bias"])
+    # fc1's output reaches fc2 as f32-level (hi + correction segments) only when fc2 corrects its activations; its hi part is rn16 either way
+    a = torch.relu(prod(h1, P["AdapterMLP_0/Dense_1/kernel"], *plan2) + P["AdapterMLP_0/Dense_1/bias"])
+    if not a_exact:
+        a = h(a)
+    res = torch.sigmoid(P["residual_weight"])
+    y = res * a + (1 - res) * (h(x) if x_skip16 else x)
+    P2 = dict(P)
+    P2["residual_weight"] = torch.tensor([-1e4], dtype=torch.float64)  # identity adapter: feed y through the rest of the oracle (f32-level there)
+    out = O.forward(P2, ocfg, y.reshape(enc.shape), act, rtg)
+    return max(float((out["action_pred"] - ref["action_pred"]).abs().max()), float((out["return_pred"] - ref["return_pred"]).abs().max()))
+
+
+CONFIGS = {  # name: (plan fc1 (pw, px), plan fc2 (pw, px), A handed to the mix unrounded, skip term from the binary16 encodings)
+    "f16 (default today)": ((0, 0), (0, 0), False, True),
+    "f16, A exact": ((0, 0), (0, 0), True, True),
+    "full corrections (r5 adapter_c)": ((1, 1), (1, 1), True, False),
+    "full, A f16": ((1, 1), (1, 1), False, True),
+    "weights only, A exact": ((1, 0), (1, 0), True, True),
+    "weights only, A f16": ((1, 0), (1, 0), False, True),
+    "activations only, A exact": ((0, 1), (0, 1), True, True),
+    "fc1 w, fc2 w+x, A exact": ((1, 0), (1, 1), True, True),
+    "fc1 w+x, fc2 w, A exact": ((1, 1), (1, 0), True, True),
+    "fc1 none, fc2 w+x, A exact": ((0, 0), (1, 1), True, True),
+    "fc1 none, fc2 w, A exact": ((0, 0), (1, 0), True, True),
+    "fc1 w+x, fc2 w, A f16": ((1, 1), (1, 0), False, True),
+    "fc1 w, fc2 w+x, A f16": ((1, 0), (1, 1), False, True),
+    "fc1 w+x, fc2 none, A f16": ((1, 1), (0, 0), False, True),
+}
+
+
+def main():
+    n_norm = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    n_enc = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    pcfg, ocfg = PolicyConfig(lambda_ret=0.01), O.PolicyConfig(lambda_ret=0.01)
+    cases = []
+    for seed in range(n_norm):  # tests/test_policy_gpu.py::_setup(FULL, 2, 100 + 7 seed)
+        s = 100 + 7 * seed
+        P = S.policy_params(pcfg, seed=s)
+        enc, act, rtg = S.policy_batch(pcfg, 2, seed=s + 1)
+        cases.append(("N(0,1)", seed, P, enc, act, rtg))
+    if n_enc:
+        from oracle import m3ae_np as M
+        eocfg = M.EncConfig()
+        for seed in range(n_enc):  # scripts/n1_parity_probe.py / tests/test_m3ae_gpu.py seeds
+            EP = S.m3ae_params(eocfg, seed=50 + seed)
+            P = S.policy_params(pcfg, seed=60 + seed)
+            rng = np.random.default_rng(70 + seed)
+            frames = S.normalized_frames(2 * pcfg.window, 256, seed=80 + seed).reshape(2, pcfg.window, 256, 256, 3)
+            act = rng.integers(0, pcfg.n_actions, (2, pcfg.window)).astype(np.int32)
+            rtg = rng.random((2, pcfg.window, 1)).astype(np.float32)
+            t = time.time()
+            cache = f"/tmp/arp_emul_codes_{seed}.npy"
+            if os.path.exists(cache):
+                codes = np.load(cache)
+            else:
+                codes = M.forward_representation(EP, eocfg, frames.reshape(-1, 256, 256, 3)).reshape(2, pcfg.window, 257, 768)
+                np.save(cache, np.asarray(codes, np.float32))
+            print(f"# encoder oracle seed {seed}: {time.time() - t:.1f} s", flush=True)
+            cases.append(("encoder", seed, P, np.asarray(codes, np.float32), act, rtg))  # the f32 encoder hands f32 encodings over
+    errs = {k: {"N(0,1)": [], "encoder": []} for k in CONFIGS}
+    for kind, seed, P, enc, act, rtg in cases:
+        Pt = {k: torch.from_numpy(np.asarray(v)).double() for k, v in P.items()}
+        e, a, r = torch.from_numpy(np.asarray(enc)).double(), torch.from_numpy(act).long(), torch.from_numpy(rtg).double()
+        ref = O.forward(Pt, ocfg, e, a, r)
+        row = []
+        for name, (p1, p2, ax, xs) in CONFIGS.items():
+            v = run(Pt, pcfg, ocfg, e, a, r, ref, p1, p2, ax, xs)
+            errs[name][kind].append(v)
+            row.append(f"{v:.2e}")
+        print(f"{kind} seed {seed}: " + "  ".join(row), flush=True)
+    print()
+    for name in CONFIGS:
+        parts = []
+        for kind in ("N(0,1)", "encoder"):
+            v = errs[name][kind]
+            if v:
+                parts.append(f"{kind}: max {max(v):.2e} median {float(np.median(v)):.2e} outside 1e-3: {sum(x >= 1e-3 for x in v)}/{len(v)}")
+        print(f"{name:34s} " + " | ".join(parts))
+
+
+if __name__ == "__main__":
+    main()
