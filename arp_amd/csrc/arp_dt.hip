@@ -1391,6 +1391,7 @@ template <typename T> int step_impl(arp_dt* c, float lr, float* aux) {
         // 2 (the adapter's backward: the fused dY pass and three 768 x 768 x 32 896 GEMMs, ~0.25 ms) still runs -> bucket 2 + the
         // loss scalars -> the update waits for both.
         const BucketPlan b = bucket_plan(c);
+        if (!c->comm_stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
         ARP_TRY(fwd_bwd_graphed<T>(c, 1));
         ARP_HIP_OK(hipEventRecord(c->ev_b1, c->stream));
         ARP_HIP_OK(hipStreamWaitEvent(c->comm_stream, c->ev_b1, 0));
@@ -1490,12 +1491,13 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_ENC_EAGER")) c->enc_eager = atoi(e) != 0;
     build_layout(c);
     auto body = [&]() -> int {
+        // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (8 here, arp_amd/_ffi.py): two streams that land on ONE queue run
+        // one after the other.  Round 6 measured what that costs: with the encoder's stream added this handle + its encoder held nine streams, the encoder's two
+        // part streams shared a queue, and the step went 10.6 -> 12.4 ms (profiles/r6_n1_ab_queues.txt).  Only the compute stream exists from the start; the
+        // communication, side and copy streams are created by the first call that needs them (stream_or_create).
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-        ARP_HIP_OK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        if (c->side_gemms) ARP_HIP_OK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
         for (hipEvent_t* e : {&c->ev_fork, &c->ev_dapre, &c->ev_side}) ARP_HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking));
-        ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking));
         for (hipEvent_t* e : {&c->ev_b1, &c->ev_b2, &c->ev_comm, &c->bt[0].up, &c->bt[0].use, &c->bt[1].up, &c->bt[1].use, &c->bt[2].up, &c->bt[2].use})
             ARP_HIP_OK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         DevBuf* fb[] = {&c->params, &c->grads, &c->mu, &c->nu};
@@ -1678,6 +1680,7 @@ static int upload_async(arp_dt* c, int slot, const float* enc, const float* fram
     std::lock_guard<std::mutex> capture_lock(c->capture_mu);
     if (b.used) ARP_HIP_OK(hipEventSynchronize(b.use));
     // a slot that has to GROW frees its old buffers (hipFree synchronises the device): size them once, with the largest batch
+    if (!c->copy_stream[slot]) ARP_HIP_OK(hipStreamCreateWithFlags(&c->copy_stream[slot], hipStreamNonBlocking));
     ARP_TRY(stage_slot(c, slot, c->copy_stream[slot], enc, frames, action, rtg, B));
     ARP_HIP_OK(hipEventRecord(b.up, c->copy_stream[slot]));
     b.up_pending = true;

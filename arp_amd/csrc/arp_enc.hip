@@ -529,10 +529,8 @@ int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
         return fail("ARP_F16C_PLAN: fc2 cannot be corrected (digit 4 >= 1) when fc1 runs on the plain instance (digit 3 = 0)");
     }
     // (fc2's operand comes out of fc1's epilogue: its x4 segment from the rounded tile, its dx4 segment -- plan 2 -- straight from the accumulators)
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
-        return fail("hipStreamCreate failed");
-    }
+    // (the handle's own stream serves arp_enc_forward only and is created by its first call: inside a policy step the encoder runs on the step's streams, and a
+    //  process's streams share GPU_MAX_HW_QUEUES hardware queues -- arp_dt.hip)
     *out = c;
     return 0;
 }
@@ -551,7 +549,7 @@ int arp_enc_destroy(arp_enc* c) {
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     c->img_in.release(); c->out.release();
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }
@@ -665,6 +663,7 @@ int arp_enc_forward(arp_enc* c, const float* images, int n, float* out) {
     ARP_HIP_OK(hipSetDevice(c->cfg.device));
     const size_t fi = (size_t)c->cfg.img_res * c->cfg.img_res * 3, fo = (size_t)c->tokens() * c->cfg.width;
     const int mb = c->cfg.max_frames;
+    if (!c->stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     ARP_TRY(c->img_in.ensure((size_t)std::min(n, mb) * fi * 4));
     ARP_TRY(c->out.ensure((size_t)std::min(n, mb) * fo * 4));
     for (int off = 0; off < n; off += mb) {

@@ -629,7 +629,7 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
     build_layout(c);
     auto body = [&]() -> int {
         ARP_HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        // (the communication stream is created with the communicator: a process's streams share GPU_MAX_HW_QUEUES hardware queues, arp_dt.hip)
         for (auto& e : c->ev_bucket) ARP_HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
         if (const char* e = getenv("ARP_FT_OVERLAP")) c->overlap_comm = atoi(e) != 0;
@@ -894,6 +894,7 @@ int arp_ft_comm_init(arp_ft* c, const void* id128, int world, int rank) {
     memcpy(&id, id128, 128);
     if (!rccl_api()) return fail("librccl.so.1 could not be loaded");
     if (ncclResult_t r = rccl_api()->CommInitRank(&c->comm, world, id, rank); r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
+    if (!c->comm_stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     c->has_comm = true;
     c->world = world;
     c->rank = rank;

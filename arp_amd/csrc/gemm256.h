@@ -112,7 +112,8 @@ __device__ long long* arp_g2_stamps = nullptr;  // scripts/gemm256_bench.hip: pe
 #ifndef ARP_G2_MIX_UNIFORM  // MIXC: per-lane DMA offsets collapsed into one register per operand (needs padded operand buffers); measured: MORE scratch traffic, off
 #define ARP_G2_MIX_UNIFORM 0
 #endif
-#ifndef ARP_G2_ABL  // harness ablations: bit 0 = no fragment reads after the first K-tile, bit 1 = no LDS-DMA after the prologue, bit 2 = no residual read in the f32 epilogue (wrong results, timing only)
+#ifndef ARP_G2_ABL  // harness ablations: bit 0 = no fragment reads after the first K-tile, bit 1 = no LDS-DMA after the prologue, bit 2 = no residual read in the f32 epilogue,
+                    // bit 3 = no bias / activation arithmetic in the 16-bit staged epilogue (conversion, staging and stores stay) (wrong results, timing only)
 #define ARP_G2_ABL 0
 #endif
 typedef __attribute__((ext_vector_type(16))) float f32x16_v;
@@ -815,9 +816,11 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                                     v[0] = rs * (v[0] - mu * c4.x); v[1] = rs * (v[1] - mu * c4.y);
                                     v[2] = rs * (v[2] - mu * c4.z); v[3] = rs * (v[3] - mu * c4.w);
                                 }
-                                const float4 b = bq[nq][ni];
-                                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                                apply_act4<ACT, sizeof(T) <= 2>(v);
+                                if constexpr ((ARP_G2_ABL & 8) == 0) {
+                                    const float4 b = bq[nq][ni];
+                                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                                    apply_act4<ACT, sizeof(T) <= 2>(v);
+                                }
                                 *reinterpret_cast<uint2*>(smem + row * RS + col * 2) = make_uint2(pack2<OutT>(v[0], v[1]), pack2<OutT>(v[2], v[3]));
                                 if constexpr (MIXC && __is_same(OutT, f16_t)) {
                                     if (g.dx4_out && m0 + row < g.M && n0 + col < g.N) {  // the dx4 segment of the next product's operand row (GemmArgs::dx4_out)
@@ -934,15 +937,16 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                     if constexpr (MIXC && __is_same(OutT, f16_t)) {
                         // ARP_MODE_F16C: the e2m1 segment of the next GEMM's [hi | x4] operand row, from the rounded tile (GemmArgs::x8_shift)
                         if (g.x8_shift >= 0) {
-                            const float sc = (float)(1 << g.x8_shift);
-                            float f[8];
-#pragma unroll
-                            for (int h = 0; h < 4; ++h) {
-                                const f16x2_v p2 = __builtin_bit_cast(f16x2_v, v[h]);
-                                f[2 * h] = (float)p2[0] * sc;
-                                f[2 * h + 1] = (float)p2[1] * sc;
-                            }
-                            *reinterpret_cast<uint32_t*>(static_cast<char*>(g.xb_out) + (size_t)m * g.ldxb + (n >> 1)) = pack_fp4x8(f);
+                            // v_cvt_scalef32_pk_fp4_f16 converts a PAIR of binary16 values divided by its scale operand (scripts/fp4_cvt_probe.hip: scale 0.5 doubles)
+                            // straight from the staged tile's packed words: four instructions per eight values where unpack + multiply + the f32 form took twenty
+                            // (same nibbles: a power-of-two scale is exact, the value is rounded once either way)
+                            const float inv = 1.0f / (float)(1 << g.x8_shift);
+                            uint32_t w4 = 0;
+                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, v[0]), inv, 0);
+                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, v[1]), inv, 1);
+                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, v[2]), inv, 2);
+                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, v[3]), inv, 3);
+                            *reinterpret_cast<uint32_t*>(static_cast<char*>(g.xb_out) + (size_t)m * g.ldxb + (n >> 1)) = w4;
                         }
                     }
                 }

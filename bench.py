@@ -132,7 +132,7 @@ def compact_secondary(name, d):
     ws = d.get("whole_step") or d.get("whole_pass")
     if isinstance(ws, dict):
         out["whole"] = pick(ws, ["gflop_per_step", "tflops", "mfma_frac_of_peak", "nominal_mfma_frac_of_peak"])
-    for k in ("rccl", "later_pass_frames_per_s", "rows", "file_rewards_equal_direct_labelling", "more_rewards_ms"):
+    for k in ("rccl", "later_pass_frames_per_s", "cold_process_first_call_frames_per_s", "rows", "file_rewards_equal_direct_labelling", "more_rewards_ms"):
         if k in d:
             out[k] = d[k]
     if isinstance(d.get("staged"), dict):
@@ -779,22 +779,32 @@ def bench_h5(a):
     m = clip.ClipLabeller(cfg, synth.clip_weights(cfg, seed=0), mode=a.mode, device=0)
     tok = synth.prompt_tokens(1, 8, seed=2)
     rates = []
+    keys = ("ob_clip_reward", "ob_clip_pos_rtg")
     try:
-        for _ in range(3):
+        # pass 0: the first labelling call of this PROCESS -- it also pays the GPU runtime's lazy work (code objects loaded at the first launch of every kernel, the
+        # labeller's device / pinned buffers, the text tower's first run): a cost per process, not per file.  Its two datasets are then deleted, so that pass 1 is
+        # again a FIRST pass over the file (both label datasets created and filled) by a process that has labelled before -- `value`.  Passes 2, 3 overwrite.
+        for k in range(4):
             t = time.perf_counter()
             L.label_reward("coinrun", "hard", 500, 0, "x", ".", data_path=path, clip_model=m, tokens=tok)
             rates.append(rows / (time.perf_counter() - t))
+            if k == 0:
+                with h5store.H5Store(path, "a") as f:
+                    for key in keys:
+                        del f[key]
         with h5store.H5Store(path, "r") as f:
             same = bool(np.array_equal(f["ob_clip_reward"][0:64, -1], m.label(f["ob"][0:64, -1])))
     finally:
         m.close()
         os.remove(path)
-    emit_line(({"metric": "frames/sec label_reward(data_path=HDF5 file) end to end (file -> file)", "value": round(rates[0], 1), "unit": "frames/s",
-                     "later_pass_frames_per_s": round(max(rates[1:]), 1), "n_gpus": 1, "steps": 3, "warmup": 0, "ms_per_step": rows / rates[0] * 1e3,
+    emit_line(({"metric": "frames/sec label_reward(data_path=HDF5 file) end to end (file -> file), first pass over the file", "value": round(rates[1], 1), "unit": "frames/s",
+                     "later_pass_frames_per_s": round(max(rates[2:]), 1), "cold_process_first_call_frames_per_s": round(rates[0], 1),
+                     "n_gpus": 1, "steps": 3, "warmup": 1, "ms_per_step": rows / rates[1] * 1e3,
                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.mode, "data": "synthetic", "rows": rows,
                      "config": {"workload": f"recorder-schema file: ob uint8 [{rows},8,256,256,3] in gzip chunks of one row ({size_mb:.0f} MB on disk, "
                                             f"{rows * F * 196608 / 1e9:.1f} GB raw; written here in {t_write:.1f} s, page-cache resident), trajectories of {tlen} rows; "
-                                            "first pass creates ob_clip_reward / ob_clip_pos_rtg, later passes overwrite them"},
+                                            "`value` = a pass that CREATES ob_clip_reward / ob_clip_pos_rtg (the datasets of the process's very first call -- "
+                                            "cold_process_first_call_frames_per_s: code-object loads, first allocations -- are deleted before it); later passes overwrite them"},
                      "file_rewards_equal_direct_labelling": same}))
 
 
