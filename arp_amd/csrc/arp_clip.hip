@@ -808,6 +808,7 @@ int arp_clip_create(const arp_clip_cfg* cfg, arp_clip** out) {
     ARP_HIP_OK(hipGetDeviceCount(&ndev));
     if (k.device < 0 || k.device >= ndev) return fail("no such HIP device: " + std::to_string(k.device));
     ARP_HIP_OK(hipSetDevice(k.device));
+    ARP_TRY(prime_runtime(k.device));  // (runtime.h: one null-stream copy before the process's first stream exists)
     arp_clip* c = new arp_clip();
     c->cfg = k;
     if (c->cfg.max_batch <= 0) c->cfg.max_batch = 1024;

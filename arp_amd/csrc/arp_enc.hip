@@ -511,6 +511,7 @@ int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
     ARP_HIP_OK(hipGetDeviceCount(&ndev));
     if (k.device < 0 || k.device >= ndev) return fail("no such HIP device");
     ARP_HIP_OK(hipSetDevice(k.device));
+    ARP_TRY(prime_runtime(k.device));  // (runtime.h: one null-stream copy before the process's first stream exists)
     arp_enc* c = new arp_enc();
     c->cfg = k;
     if (c->cfg.max_frames <= 0) c->cfg.max_frames = 128;

@@ -624,6 +624,7 @@ int arp_ft_create(const arp_ft_cfg* cfg, arp_ft** out) {
     ARP_HIP_OK(hipGetDeviceCount(&ndev));
     if (k.device < 0 || k.device >= ndev) return fail("no such HIP device: " + std::to_string(k.device));
     ARP_HIP_OK(hipSetDevice(k.device));
+    ARP_TRY(prime_runtime(k.device));  // (runtime.h: one null-stream copy before the process's first stream exists)
     arp_ft* c = new arp_ft();
     c->cfg = k;
     build_layout(c);

@@ -562,6 +562,63 @@ static __global__ __launch_bounds__(256) void wc_pack_kernel(const float* __rest
     *reinterpret_cast<uint16_t*>(seg + (c >> 1)) = pack_fp4x4((v[0] - h[0]) * fd, (v[1] - h[1]) * fd, (v[2] - h[2]) * fd, (v[3] - h[3]) * fd);
     *reinterpret_cast<uint16_t*>(seg + (K >> 1) + (c >> 1)) = pack_fp4x4(v[0] * fw, v[1] * fw, v[2] * fw, v[3] * fw);
 }
+// Both adapter kernels in TWO launches per step instead of four and a memset (round 6): blockIdx.y = the tensor.  mx: per tensor 8 words -- [0] max |w - rn16(w)|,
+// [1] max |w| (float bits, accumulated with atomicMax: they must read 0 when the absmax launch starts), [2] a ticket counter, [4] / [5] the two scale exponents the
+// product reads (GemmArgs::mix_sptr).  The pack launch's LAST block -- by ticket, after every block has read the maxima -- puts [0], [1], [2] back to zero for the
+// next step: no memset node, and the same captured graph works every step.
+static __global__ __launch_bounds__(256) void wc_absmax2_kernel(const float* __restrict__ w0, const float* __restrict__ w1, size_t n, unsigned int* __restrict__ mx) {
+    const float* __restrict__ w = blockIdx.y ? w1 : w0;
+    unsigned int* m = mx + 8 * blockIdx.y;
+    float md = 0.f, mw = 0.f;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        float v[4];
+        load4(w + i, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            md = fmaxf(md, fabsf(v[j] - h2f(f2h(v[j]))));
+            mw = fmaxf(mw, fabsf(v[j]));
+        }
+    }
+    md = wave_max(md); mw = wave_max(mw);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(m, __float_as_uint(md));
+        atomicMax(m + 1, __float_as_uint(mw));
+    }
+}
+static __global__ __launch_bounds__(256) void wc_pack2_kernel(const float* __restrict__ w0, const float* __restrict__ w1, int N, int K, unsigned int* __restrict__ mx,
+                                                              f16_t* __restrict__ out0, f16_t* __restrict__ out1) {
+    const float* __restrict__ w = blockIdx.y ? w1 : w0;
+    f16_t* __restrict__ out = blockIdx.y ? out1 : out0;
+    unsigned int* m = mx + 8 * blockIdx.y;
+    const float md = __uint_as_float(__hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), mw = __uint_as_float(__hip_atomic_load(m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int sd = md > 0.f ? (int)floorf(log2f(6.0f / md)) + 1 : 0, sw = mw > 0.f ? (int)floorf(log2f(6.0f / mw)) + 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { reinterpret_cast<int*>(m)[4] = sd; reinterpret_cast<int*>(m)[5] = sw; }
+    const float fd = ldexpf(1.0f, sd), fw = ldexpf(1.0f, sw);
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i < (size_t)N * K) {
+        const size_t r = i / K;
+        const int c = (int)(i - r * K);
+        float v[4];
+        load4(w + i, v);
+        f16_t* row = out + r * (size_t)(3 * K / 2);
+        float h[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[j] = h2f(f2h(v[j]));
+        *reinterpret_cast<uint2*>(row + c) = make_uint2(pack_h2(h[0], h[1]), pack_h2(h[2], h[3]));
+        uint8_t* seg = reinterpret_cast<uint8_t*>(row + K);
+        *reinterpret_cast<uint16_t*>(seg + (c >> 1)) = pack_fp4x4((v[0] - h[0]) * fd, (v[1] - h[1]) * fd, (v[2] - h[2]) * fd, (v[3] - h[3]) * fd);
+        *reinterpret_cast<uint16_t*>(seg + (K >> 1) + (c >> 1)) = pack_fp4x4(v[0] * fw, v[1] * fw, v[2] * fw, v[3] * fw);
+    }
+    __syncthreads();  // every thread of this block has read the maxima
+    if (threadIdx.x == 0) {
+        const unsigned int t = atomicAdd(m + 2, 1u);
+        if (t == gridDim.x - 1) {  // the tensor's last block: the accumulators read 0 again when the next step's absmax launch starts
+            __hip_atomic_store(m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(m + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(m + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 // partial[b] = sum over the block's slice of dy * (a - x)      (d loss / d res; finished by reduce_sum)
 template <typename T>

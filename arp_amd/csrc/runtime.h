@@ -36,6 +36,27 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// One synchronous host -> device copy on the NULL stream before the process creates its first stream (round 6, profiles/r6_n1_flow.txt / r6_n1_flow3.txt).
+// Measured on one box, same binary, same kernels: the encoder-inside policy step with two encoder part streams + the encode-ahead stream runs 11.7 ms per
+// step when the handle's hipStreamCreate is the process's FIRST HIP work after device selection, and 10.05 ms when any hipMemcpy(H2D) came before it -- an encoder
+// created first (its weight uploads), the bench's parity gate, or just this copy; a hipMalloc / hipFree alone does not do it, GPU_MAX_HW_QUEUES 4 / 8 / 16 does
+// not explain it.  The runtime sets up the null stream's hardware queue (and its copy machinery) at that first copy; which hardware queue the handle's own streams
+// then land on relative to it is what differs.  Every *_create calls this once per device before it creates a stream, so the fast arrangement is the only one.
+inline int prime_runtime(int device) {
+    static bool done[64] = {false};
+    if (device < 0 || device >= 64 || done[device]) return 0;
+    void* d = nullptr;
+    const size_t n = 16u << 20;
+    std::vector<char> h(n, 0);
+    ARP_HIP_OK(hipMalloc(&d, n));
+    const hipError_t e = hipMemcpy(d, h.data(), n, hipMemcpyHostToDevice);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(std::string("prime_runtime: hipMemcpy failed: ") + hipGetErrorString(e));
+    done[device] = true;
+    return 0;
+}
+
 // Brackets every launch of a call site with two HIP events on the launch stream; durations are
 // summed per site name when read.  Off by default (the event packets cost a few microseconds of
 // stream time per launch).

@@ -56,7 +56,7 @@ class PolicyConfig:
 class PolicyTrainer:
     """Owns one GPU's copy of the policy: parameters, Adam state, activations, RCCL communicator."""
 
-    def __init__(self, cfg, mode="f16", device=0, adapter_corrections=False):
+    def __init__(self, cfg, mode="f16", device=0, adapter_corrections=None):
         """mode: GEMM operand type of the adapter path -- "f16" (default: the 16-bit mode that meets north_star's 1e-3 on the
         logits), "bf16" (8 significand bits: ~1e-2) or "f32" (f32-input MFMA, the parity mode).
         adapter_corrections (f16 only): the adapter's forward products with their operand roundings corrected on the fp4 MFMA
@@ -69,8 +69,9 @@ class PolicyTrainer:
         h = C.c_void_p()
         check(lib.arp_dt_create(C.byref(c), C.byref(h)))
         self._h = h
-        if adapter_corrections:
-            check(lib.arp_dt_set_adapter_corrections(h, 1))
+        # None: the library's default -- ON in f16 mode where the corrected products exist (enc_dim a multiple of 256, >= 512), since round 6
+        if adapter_corrections is not None:
+            check(lib.arp_dt_set_adapter_corrections(h, int(bool(adapter_corrections))))
         self.world, self.rank = 1, 0
         self.shapes = {}
         n = C.c_int32()
@@ -275,7 +276,7 @@ class TrainState:
         self._live = True
 
     @classmethod
-    def create(cls, model, params, mode="f16", device=0, adapter_corrections=False):
+    def create(cls, model, params, mode="f16", device=0, adapter_corrections=None):
         cfg = model if isinstance(model, PolicyConfig) else PolicyConfig(**dict(model))
         tr = PolicyTrainer(cfg, mode=mode, device=device, adapter_corrections=adapter_corrections)
         tr.set_params(params)

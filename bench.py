@@ -442,6 +442,7 @@ def bench_policy(a):
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C_
     from arp_amd import _ffi, clip, synth_policy as S, train
     from arp_amd.train import PolicyConfig, PolicyTrainer
     _ffi.require_gpu()
@@ -454,7 +455,9 @@ def bench_policy(a):
         os.environ["ARP_DT_OVERLAP"] = "1"
     cfg = PolicyConfig(lambda_ret=0.01)
     # row N1's 16-bit parity line: the f16c encoder (operand roundings corrected on the fp4 MFMA) goes with the same corrections on the policy's adapter
-    adapter_c = a.mode == "f16" and (a.adapter_c or (a.with_encoder and (a.encoder_mode or a.mode) == "f16c"))
+    # (round 6: the corrected adapter is the f16 policy's default; the plain-f16-encoder line stays the all-plain throughput mode it has been since round 2)
+    emode_ = (a.encoder_mode or a.mode) if a.with_encoder else None
+    adapter_c = a.mode == "f16" and not a.no_adapter_c and (a.adapter_c or emode_ not in ("f16", "bf16"))
     # parity gate (rank 0): the mode timed below, real geometry (257 x 768 encodings, K = 197 376), B = 2, against the fp64 oracle
     parity = None
     parity_geometry = "B = 2, window 4, 257 x 768 encodings in (K = 197 376)"
@@ -490,6 +493,43 @@ def bench_policy(a):
             out = t0.forward()
             t0.close()
         parity = max(float(np.abs(out["action_pred"] - ref["action_pred"].numpy()).max()), float(np.abs(out["return_pred"] - ref["return_pred"].numpy()).max()))
+    if a.churn and a.with_encoder:  # diagnostic (scripts/r6_n1_flow3.sh): which part of the parity gate's throw-away work changes the timed objects' speed?
+        from arp_amd import m3ae
+        kinds = a.churn.split(",")
+        if "malloc" in kinds:
+            ps = []
+            for _ in range(8):
+                p_ = C_.c_void_p()
+                _ffi.check(_ffi.lib.arp_dev_malloc(C_.byref(p_), 512 << 20))
+                ps.append(p_)
+            for p_ in ps:
+                _ffi.check(_ffi.lib.arp_dev_free(p_))
+        if "h2d" in kinds:
+            p_ = C_.c_void_p()
+            _ffi.check(_ffi.lib.arp_dev_malloc(C_.byref(p_), 128 << 20))
+            hb = np.zeros(128 << 20, np.uint8)
+            _ffi.check(_ffi.lib.arp_memcpy_h2d(p_, hb.ctypes.data_as(C_.c_void_p), hb.nbytes))
+            _ffi.check(_ffi.lib.arp_dev_free(p_))
+        t9 = e9 = None
+        if "trainer" in kinds or "full" in kinds or "fwd_enc" in kinds:
+            t9 = PolicyTrainer(cfg, mode=a.mode, device=local_rank, adapter_corrections=adapter_c)
+            t9.set_params(S.policy_params(cfg, seed=3))
+        if "encoder" in kinds or "full" in kinds:
+            e9 = m3ae.M3AEEncoder(m3ae.EncoderConfig(), S.m3ae_params(m3ae.EncoderConfig(), seed=50), mode=a.encoder_mode or a.mode, device=local_rank, max_frames=2 * cfg.window)
+        if "fwd_enc" in kinds:  # the trainer's forward on ENCODINGS (no encoder involved)
+            t9.set_batch(*S.policy_batch(cfg, 2, seed=4))
+            t9.forward()
+        if "encfwd" in kinds and e9 is not None:  # the encoder alone
+            e9.forward_representation(S.normalized_frames(2 * cfg.window, 256, seed=80))
+        if "full" in kinds:
+            t9.attach_encoder(e9)
+            _, act9, rtg9 = S.policy_batch(PolicyConfig(enc_tokens=1, enc_dim=4), 2, seed=4)
+            t9.set_batch_images(S.normalized_frames(2 * cfg.window, 256, seed=80).reshape(2, cfg.window, 256, 256, 3), act9, rtg9)
+            t9.forward()
+        if t9 is not None:
+            t9.close()
+        if e9 is not None:
+            e9.close()
     tr = PolicyTrainer(cfg, mode=a.mode, device=local_rank, adapter_corrections=adapter_c)
     tr.set_params(S.policy_params(cfg, seed=0))
     if world > 1:  # RCCL id from rank 0 over gloo, communicator, sync_state_fn
@@ -510,11 +550,15 @@ def bench_policy(a):
         # between the slots.  The encoder is frozen, so batch i + 1 is encoded on the encoder's own stream while step i's policy part runs
         # (arp_dt_encode_ahead -- what prefetch_to_device's uploader thread calls once a batch has landed): every step still pays for exactly one encoder
         # pass over its own 128 frames, inside the timed region (--no-encode-ahead: each step encodes at its own head, as in rounds 1-5).
-        ahead = not a.no_encode_ahead and os.environ.get("ARP_DT_ENC_EAGER", "1") != "0"
-        for k in (0, 1):
+        ahead = not a.no_encode_ahead and os.environ.get("ARP_DT_ENC_EAGER", "1") != "0" and not a.single_slot
+        for k in (() if a.single_slot else (0, 1)):
             _, act_, rtg_ = S.policy_batch(PolicyConfig(enc_tokens=1, enc_dim=4), a.policy_batch, seed=100 + rank + 17 * k)
             frames = S.normalized_frames(a.policy_batch * cfg.window, 256, seed=100 + rank + 17 * k).reshape(a.policy_batch, cfg.window, 256, 256, 3)
             tr.upload_async(k, frames, act_, rtg_, images=True)
+        if a.single_slot:  # rounds 1-5: ONE batch staged synchronously, every step encodes it at its head
+            _, act_, rtg_ = S.policy_batch(PolicyConfig(enc_tokens=1, enc_dim=4), a.policy_batch, seed=100 + rank)
+            frames = S.normalized_frames(a.policy_batch * cfg.window, 256, seed=100 + rank).reshape(a.policy_batch, cfg.window, 256, 256, 3)
+            tr.set_batch_images(frames, act_, rtg_)
         step_no = [0]
         if ahead:
             tr.encode_ahead(0)
@@ -523,7 +567,8 @@ def bench_policy(a):
         def step():
             k = step_no[0]
             step_no[0] += 1
-            tr.select(k & 1)
+            if not a.single_slot:
+                tr.select(k & 1)
             tr.train_step_async(lr)
             if ahead:
                 tr.encode_ahead((k + 1) & 1)
@@ -985,11 +1030,14 @@ def main():
     ap.add_argument("--policy-batch", type=int, default=32, help="samples per GPU per step (256 / 8 in configs[3])")
     ap.add_argument("--encoder-mode", default=None, choices=["bf16", "f16", "f32", "f16x3", "f16c"], help="policy path with --with-encoder: operand mode of the frozen encoder "
                     "(default: --mode).  f16x3 = (hi, lo) binary16 operand pairs, three 16-bit MFMAs per product, f32 attention: f32-level error")
-    ap.add_argument("--adapter-c", action="store_true", help="policy path, f16: the adapter's forward products corrected on the fp4 MFMA (implied by --encoder-mode f16c)")
+    ap.add_argument("--adapter-c", action="store_true", help="policy path, f16: the adapter's forward products corrected on the fp4 MFMA (the default since round 6, except behind a plain 16-bit encoder)")
+    ap.add_argument("--no-adapter-c", action="store_true", help="policy path, f16: the plain binary16 adapter products (rounds 2-5's default: 0.76 ms per step, logits 8.7e-4 over 16 seeds, 1.18e-3 behind encoder outputs)")
     ap.add_argument("--staged", action="store_true", help="policy / finetune path at 1 GPU: the data-parallel ORDERING of the step -- backward staged for the bucketed all-reduce "
                     "on the communication stream, through a one-rank RCCL communicator (an identity reduction; ARP_DT_FORCE_COMM / ARP_FT_FORCE_COMM with the overlap on, "
                     "as tests/test_policy_gpu.py::test_bucketed_overlapped_allreduce_equals_serial runs it): the per-rank compute time configs[3] / configs[4] will "
                     "reproduce on 8 GPUs before any communication time (VERDICT r5 weak #7)")
+    ap.add_argument("--single-slot", action="store_true", help="policy path with --with-encoder: rounds 1-5's flow -- one batch of frames staged once, every step encodes at its head")
+    ap.add_argument("--churn", default="", help="diagnostic: throw-away work before the timed objects are created, comma-separated: malloc, h2d, trainer, encoder, fwd_enc, encfwd, full")
     ap.add_argument("--no-encode-ahead", action="store_true", help="policy path with --with-encoder: every step encodes its own batch at its head (rounds 1-5) instead of the "
                     "frozen encoder's pass for batch i + 1 running beside step i's policy part")
     ap.add_argument("--with-encoder", action="store_true", help="policy path: run the frozen M3AE ViT-B/16 encoder inside the step "
