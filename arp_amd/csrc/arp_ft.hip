@@ -894,8 +894,8 @@ int arp_ft_comm_init(arp_ft* c, const void* id128, int world, int rank) {
     static_assert(sizeof(ncclUniqueId) == 128, "unexpected ncclUniqueId size");
     memcpy(&id, id128, 128);
     if (!rccl_api()) return fail("librccl.so.1 could not be loaded");
+    if (!c->comm_stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));  // (before RCCL's own queues: arp_dt.hip::arp_dt_comm_init)
     if (ncclResult_t r = rccl_api()->CommInitRank(&c->comm, world, id, rank); r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
-    if (!c->comm_stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     c->has_comm = true;
     c->world = world;
     c->rank = rank;

@@ -194,12 +194,16 @@ struct iti_nomix_t {};
 // X16 (with the mix only): x comes from its operand-type copy x16 (what fc1 and the backward read) instead of the f32 encodings -- 50 MB less per step at B = 32.
 // The mix's value is rounded to the operand type for the backward anyway and its skip term weighs (1 - res) (0.018 at the initial residual_weight = 4), so
 // x's own rounding is at most as large as the adapter output's, which has always been there (arp_dt.hip ARP_DT_MIX_X16).
-template <int AHEAD, typename TA = iti_nomix_t, typename TY = f16_t, bool X16 = false>  // AHEAD: K-tiles of operands in flight per thread
+// ADX (round 6, with a binary16 Amix): adx holds, per adapter output value, the e2m1 code of its binary16 ROUNDING ERROR times 2^F16C_DX_SHIFT (two per byte, the layout
+// fc2's epilogue writes as GemmArgs::dx4_out) -- the mix is formed on a_hi + 2^-13 fp4: the adapter output to ~2^-14 instead of 2^-12 for 12.6 MB more than the binary16
+// hand-off, where the f32 hand-off costs 50 MB more here and the f32 read-modify epilogue in fc2 (arp_dt.hip, ARP_DT_ADAPTER_PLAN "d").
+template <int AHEAD, typename TA = iti_nomix_t, typename TY = f16_t, bool X16 = false, bool ADX = false>  // AHEAD: K-tiles of operands in flight per thread
 static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restrict__ X, size_t ldx, const float* __restrict__ W, size_t ldw, float* __restrict__ part,
                                                      int M, int N, int K, int kslice, const TA* __restrict__ Amix = nullptr, const float* __restrict__ rw = nullptr,
-                                                     TY* __restrict__ y16 = nullptr, const TY* __restrict__ x16 = nullptr) {
+                                                     TY* __restrict__ y16 = nullptr, const TY* __restrict__ x16 = nullptr, const uint8_t* __restrict__ adx = nullptr) {
     constexpr bool MIX = !__is_same(TA, iti_nomix_t);
     static_assert(!X16 || MIX, "the operand-type x is the mix's");
+    static_assert(!ADX || (MIX && sizeof(TA) == 2), "the e2m1 correction belongs to a binary16 adapter output");
     constexpr int ROW = 80;  // binary16 elements per LDS row: 160 B = 40 dwords -- the sixteen lanes of a ds_read_b128 group (rows j, chunks g and g + 1) fall on sixteen
                              // distinct 4-bank slots; at 144 B seven of them met another's (SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles, profiles/r4_x3_pmc.json)
     __shared__ __attribute__((aligned(16))) _Float16 sm[4][128 * ROW];  // X hi, X lo, W hi, W lo
@@ -228,6 +232,7 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
         Amix += (size_t)m0 * ldx;
         y16 += (size_t)m0 * ldx;
         if constexpr (X16) x16 += (size_t)m0 * ldx;
+        if constexpr (ADX) adx += (size_t)m0 * ldx / 2;
         res = 1.0f / (1.0f + expf(-rw[0]));
         put_y = n0 == 0;  // (every X element belongs to exactly one (row tile, K slice); a second column tile would only repeat the store)
     }
@@ -238,6 +243,7 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
     using xreg_t = std::conditional_t<X16, uint2, float4>;
     xreg_t xr[AHEAD][8];
     float4 wreg[AHEAD][8];
+    uint16_t dxr[AHEAD][ADX ? 8 : 1];  // four e2m1 codes per lane and row
     auto fetch = [&](auto ST, int k) {
         constexpr int st = decltype(ST)::value;
 #pragma unroll
@@ -245,11 +251,12 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
             if constexpr (X16) xr[st][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(x16 + k) + (xo[i] >> 1));
             else xr[st][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X + k) + xo[i]);
             if constexpr (MIX) ar[st][i] = *reinterpret_cast<const areg_t*>(reinterpret_cast<const char*>(Amix + k) + (sizeof(TA) == 4 ? xo[i] : xo[i] >> 1));
+            if constexpr (ADX) dxr[st][i] = *reinterpret_cast<const uint16_t*>(adx + (k >> 1) + (xo[i] >> 3));
             wreg[st][i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(W + k) + wo[i]);
         }
     };
     // the mix of one lane's four values (adapter_mix_kernel's arithmetic) + its rounded copy to y16
-    auto mixed = [&](xreg_t xin, areg_t a, int k, int i) __attribute__((always_inline)) {
+    auto mixed = [&](xreg_t xin, areg_t a, int k, int i, uint32_t dx = 0) __attribute__((always_inline)) {
         float4 x;
         if constexpr (X16) {
             float xv[4];
@@ -262,6 +269,12 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
             float av[4];
             if constexpr (sizeof(TA) == 4) { av[0] = a.x; av[1] = a.y; av[2] = a.z; av[3] = a.w; }
             else load4(reinterpret_cast<const TA*>(&a), av);
+            if constexpr (ADX) {  // v_cvt_scalef32_pk_f32_fp4 multiplies by its scale operand on the way up (scripts/fp4_cvt_probe2.hip)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                constexpr float isd = 1.0f / (float)(1 << F16C_DX_SHIFT);
+                const f2 d01 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(dx, isd, 0), d23 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(dx, isd, 1);
+                av[0] += d01[0]; av[1] += d01[1]; av[2] += d23[0]; av[3] += d23[1];
+            }
             x.x = adapter_mix1(res, av[0], x.x); x.y = adapter_mix1(res, av[1], x.y); x.z = adapter_mix1(res, av[2], x.z); x.w = adapter_mix1(res, av[3], x.w);
             if (put_y && m0 + lrow + 16 * i < M) store4(reinterpret_cast<TY*>(reinterpret_cast<char*>(y16 + k) + (xo[i] >> 1)), x.x, x.y, x.z, x.w);
         }
@@ -292,7 +305,7 @@ static __global__ __launch_bounds__(256) void iti_x3_kernel(const float* __restr
         constexpr int st = decltype(ST)::value;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            put(sm[0], sm[1], mixed(xr[st][i], ar[st][MIX ? i : 0], k, i), 16.f, lrow + 16 * i);
+            put(sm[0], sm[1], mixed(xr[st][i], ar[st][MIX ? i : 0], k, i, ADX ? dxr[st][ADX ? i : 0] : 0), 16.f, lrow + 16 * i);
             put(sm[2], sm[3], wreg[st][i], 1024.f, lrow + 16 * i);
         }
         __syncthreads();

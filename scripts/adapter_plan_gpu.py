@@ -59,6 +59,9 @@ for plan in plans:
             el.append(float(np.abs(out["action_pred"] - rl).max()))
             er.append(float(np.abs(out["return_pred"] - rr).max()))
         both = [max(a, b) for a, b in zip(el, er)]
+        if os.environ.get("PER_SEED"):
+            print(f"  plan {plan} {kind} logits per seed: " + " ".join(f"{v:.2e}" for v in el), flush=True)
+            print(f"  plan {plan} {kind} return per seed: " + " ".join(f"{v:.2e}" for v in er), flush=True)
         line.append(f"{kind}: logits max {max(el):.2e} return max {max(er):.2e} | per-seed max {max(both):.2e} median {np.median(both):.2e} outside 1e-3: {sum(v >= 1e-3 for v in both)}/{len(both)}")
     tr.close()
     print(f"plan {plan:4s} " + "  ||  ".join(line), flush=True)
