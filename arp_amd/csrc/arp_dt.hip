@@ -127,16 +127,19 @@ struct arp_dt {
     // scaled fp4 MFMA (ARP_MODE_F16C's product, gemm256 MIXC) and its output handed to the mix in f32 -- the policy's own share of the encoder-inside logit error
     // (the comment at fwd_w: X, W1, H1, W2, A) without the f32 MFMA.  The backward reads the same plain binary16 Xb / H1 / A as before.
     bool adapter_c = false;
-    // Which corrections (round 6; ARP_DT_ADAPTER_PLAN = "<fc1><fc2><e|h>", default below): per product 1 = the WEIGHT rounding corrected (x4 . dW4: +K/256 K-tiles),
-    // 2 = weight and ACTIVATION roundings (+ dx4 . W4: another K/256); e = the adapter output handed to the mix in f32 (fc2 on the f32 read-modify epilogue + a
-    // binary16 copy for the backward), h = as binary16 (the ordinary 16-bit epilogue, no f32 copy).  Chosen with scripts/adapter_plan_emulate.py (fp64 emulation
-    // of every rounding, 8 + 8 seeds) and measured on the GPU: profiles/r6_adapter_plans.txt.
+    // Which corrections (round 6; ARP_DT_ADAPTER_PLAN = "<fc1><fc2><e|h|d>", default below): per product 1 = the WEIGHT rounding corrected (x4 . dW4: +K/256 K-tiles),
+    // 2 = weight and ACTIVATION roundings (+ dx4 . W4: another K/256); the adapter output reaches the mix as e = f32 (fc2 on the f32 read-modify epilogue + a
+    // binary16 copy for the backward), h = binary16 (the ordinary 16-bit epilogue, no f32 copy), d = binary16 + the e2m1 code of its rounding error (fc2's dx4 side
+    // output into Adx, decoded by iti_x3_kernel's mix).  Chosen with scripts/adapter_plan_emulate.py (fp64 emulation of every rounding, 8 + 8 seeds) and measured on
+    // the GPU: profiles/r6_adapter_plans.txt.
     int ac_plan1 = 2, ac_plan2 = 2;
-    bool ac_a_dx = false;  // "d": the adapter output as binary16 + the e2m1 code of its rounding error (fc2's dx4 side output, read by iti_x3_kernel's mix)
-    DevBuf Adx;            //      [Mx, D / 2] bytes
-    bool ac_a_exact = true;  // 22e.  22h is 0.075 ms per step cheaper and holds the 16- and 8-seed bars too (7.1e-4 / 6.4e-4 against 6.6e-4 / 4.8e-4), but reads 9.0e-4 on
-                             // the seed of bench.py's own parity gate, where 22e reads 7.0e-4 and the plain products 8.3e-4: the hand-off's rounding is the one term left that
-                             // can land on the wrong side of a seed
+    // 22d.  Per-seed maxima over 16 seeds of N(0,1) encodings / 8 seeds behind f32 encoder outputs / the seed of bench.py's own gate, and the policy step alone:
+    //   plain 8.7e-4 / 1.18e-3 / 8.3e-4, 0.77 ms;  22h 7.1e-4 / 6.4e-4 / 9.0e-4, 0.87;  22d 7.3e-4 / 4.6e-4 / 6.5e-4, 0.90;  22e 6.6e-4 / 4.8e-4 / 7.0e-4, 0.93
+    // (one box).  h leaves the hand-off's rounding as the one term that can land on the wrong side of a seed (the gate's); d takes it out to 2^-14 for 12.6 MB where
+    // e moves 50 MB more and puts fc2 on the f32 epilogue.
+    bool ac_a_dx = true;
+    DevBuf Adx;            // d: [Mx, D / 2] bytes
+    bool ac_a_exact = false;
     bool ac_h1_inplace = true;  // the backward reads H1 out of the [hi | x4 | dx4] rows fc1 wrote (row stride 3 D / 2 halves) instead of a copy made by extract_hi_kernel
     const void* h1_ptr = nullptr;  // what the backward reads as H1 this step, and its row stride
     int h1_ld = 0;
@@ -760,6 +763,7 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
     const bool fuse_mix = sizeof(T) == 2 && k.use_adapter && c->iti_f32 && c->iti_x3 && c->iti_mix && Kin % 64 == 0 && E % 4 == 0;
     const float* mix_a32 = nullptr;
     const T* mix_a = nullptr;
+    const bool a_exact = c->ac_a_exact || (c->ac_a_dx && !fuse_mix);  // (the e2m1 hand-off exists inside image_text_input's operand load only)
     if constexpr (__is_same(T, f16_t)) {
         if (adapter_cpath) {
             ARP_TRY(c->Xc.ensure(Mx * 3 * D + 4096));
@@ -768,7 +772,7 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
                 ARP_TRY(c->H1c.ensure((size_t)Mxp * 3 * D + 4096));
                 if (c->H1c.p != before) ARP_HIP_OK(hipMemsetAsync(c->H1c.p, 0, (size_t)Mxp * 3 * D + 4096, c->stream));
             }
-            if (c->ac_a_exact) ARP_TRY(c->A32.ensure(Mx * D * 4));
+            if (a_exact) ARP_TRY(c->A32.ensure(Mx * D * 4));
             // relu(relu(x W1 + b1) W2 + b2) with the operand roundings of the two products corrected (gemm256 MIXC) as ac_plan1 / ac_plan2 say: x -> [hi | x4 (| dx4)]
             // rows, fc1 writes the hidden rows [hi | x4 (| dx4)] itself (x4 from the rounded tile, dx4 from the accumulators), fc2 writes the output in f32 for the
             // mix + its binary16 copy for the backward (ac_a_exact) or in binary16 only; the plain binary16 Xb the backward reads comes out of the conversion pass.
@@ -810,7 +814,7 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
                 GemmArgs g;
                 mixc(g, c->H1c.p, c->W2c.p, c->p("AdapterMLP_0/Dense_1/bias"), sc + 12, c->ac_plan2);
                 ProfScope ps(c->prof, c->stream, "dt.adapter_fc2");
-                if (c->ac_a_exact) {
+                if (a_exact) {
                     g.out = c->A32.p; g.ldo = D;
                     g.xb_out = c->A.p; g.ldxb = D;
                     ARP_TRY((launch_gemm256_nt<f16_t, float, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
@@ -824,11 +828,11 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
                     ARP_TRY((launch_gemm256_nt<f16_t, f16_t, ACT_RELU, false, SITE_DT, false, 1, true>(g, c->stream)));
                 }
             }
-            if (fuse_mix && c->ac_a_exact) {
+            if (fuse_mix && a_exact) {
                 mix_a32 = c->A32.as<float>();  // the mix happens inside image_text_input's operand load (dtops.h::iti_x3_kernel)
             } else if (fuse_mix) {
                 mix_a = c->A.as<T>();
-            } else if (c->ac_a_exact) {
+            } else if (a_exact) {
                 ProfScope ps(c->prof, c->stream, "dt.adapter_mix");
                 hipLaunchKernelGGL((adapter_mix_kernel<T, float>), dim3(cdiv(Mx * D, 1024)), dim3(256), 0, c->stream, c->A32.as<float>(), c->bt[c->cur].enc32.as<float>(),
                                    c->p("residual_weight"), c->Y.as<T>(), Mx * D, c->iti_f32 ? c->Y32.as<float>() : nullptr);
@@ -879,7 +883,10 @@ template <typename T> int forward(arp_dt* c, bool with_bwd = false) {
             if (mix_a32) {
                 hipLaunchKernelGGL((iti_x3_kernel<1, float, T>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
                                    kslice, mix_a32, c->p("residual_weight"), c->Y.as<T>(), (const T*)nullptr);
-            } else if (mix_a && adapter_cpath && c->ac_a_dx) {  // binary16 adapter output + the e2m1 code of its rounding error; x from the f32 encodings
+            } else if (mix_a && adapter_cpath && c->ac_a_dx && c->mix_x16) {  // binary16 adapter output + the e2m1 code of its rounding error
+                hipLaunchKernelGGL((iti_x3_kernel<1, T, T, true, true>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
+                                   kslice, mix_a, c->p("residual_weight"), c->Y.as<T>(), c->Xb.as<T>(), c->Adx.as<uint8_t>());
+            } else if (mix_a && adapter_cpath && c->ac_a_dx) {
                 hipLaunchKernelGGL((iti_x3_kernel<1, T, T, false, true>), dim3(S, tiles), dim3(256), 0, c->stream, c->bt[c->cur].enc32.as<float>(), Kin, Wi, Kin, c->part.as<float>(), R, E, (int)Kin,
                                    kslice, mix_a, c->p("residual_weight"), c->Y.as<T>(), (const T*)nullptr, c->Adx.as<uint8_t>());
             } else if (mix_a && c->mix_x16) {
@@ -1487,11 +1494,11 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_ITI_X3")) c->iti_x3 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ITI_MIX")) c->iti_mix = atoi(e) != 0;
     // Round 6: ON by default where the corrected products exist (f16, adapter widths that are multiples of 256): the plain f16 adapter reads 8.7e-4 on the logits over
-    // 16 seeds of N(0,1) encodings and 1.18e-3 behind real encoder outputs (one seed of eight outside north_star's 1e-3); corrected (plan 22e) 6.6e-4 / 4.8e-4,
-    // for +0.16 ms per 32-sample step (profiles/r6_adapter_plans.txt).  ARP_DT_ADAPTER_C=0 / arp_dt_set_adapter_corrections(h, 0): the plain products.
+    // 16 seeds of N(0,1) encodings and 1.18e-3 behind real encoder outputs (one seed of eight outside north_star's 1e-3); corrected (plan 22d) 7.3e-4 / 4.6e-4,
+    // for +0.13 ms per 32-sample step (profiles/r6_adapter_plans.txt).  ARP_DT_ADAPTER_C=0 / arp_dt_set_adapter_corrections(h, 0): the plain products.
     c->adapter_c = k.mode == ARP_MODE_F16 && k.use_adapter && k.enc_dim % 256 == 0 && k.enc_dim >= 512;
     if (const char* e = getenv("ARP_DT_ADAPTER_C")) c->adapter_c = c->adapter_c && atoi(e) != 0;
-    if (const char* e = getenv("ARP_DT_ADAPTER_PLAN")) {  // "<fc1><fc2><e|h>", e.g. 22e (round 5), 12h
+    if (const char* e = getenv("ARP_DT_ADAPTER_PLAN")) {  // "<fc1><fc2><e|h|d>", e.g. 22e (round 5), 12h
         if (e[0] >= '1' && e[0] <= '2') c->ac_plan1 = e[0] - '0';
         if (e[0] && e[1] >= '1' && e[1] <= '2') c->ac_plan2 = e[1] - '0';
         if (e[0] && e[1] && (e[2] == 'e' || e[2] == 'h' || e[2] == 'd')) { c->ac_a_exact = e[2] == 'e'; c->ac_a_dx = e[2] == 'd'; }
