@@ -135,6 +135,7 @@ SIGNATURES = {
     "arp_dt_comm_init": (_i, [_vp, _vp, _i, _i]),
     "arp_dt_broadcast_state": (_i, [_vp]),
     "arp_dt_set_adapter_corrections": (_i, [_vp, _i]),
+    "arp_dt_debug_read": (C.c_int64, [_vp, C.c_char_p, _vp, C.c_int64]),
     "arp_dt_comm_info": (_i, [_vp, _i32p]),
     "arp_dt_comm_selfcheck": (_i, [_vp, C.POINTER(C.c_double)]),
     "arp_dt_profile_enable": (_i, [_vp, _i]),

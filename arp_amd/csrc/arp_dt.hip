@@ -1906,6 +1906,22 @@ int arp_dt_comm_selfcheck(arp_dt* c, double* sum) {
     return rccl_selfcheck(c->comm, c->has_comm, c->stream, c->scal.as<float>(), c->cfg.rank, sum);
 }
 
+// Test hook (scripts/adapter_chain_probe.py, tests): the bytes of one of the step's intermediate device buffers after a forward, by name -- "Xc" / "H1c" the adapter's
+// [hi | x4 | dx4] operand rows, "W1c" / "W2c" its packed weights, "wc_scal" their scales (16 ints), "A32" / "A" / "Adx" its output as the mix reads it, "Y" the mix,
+// "img" the image embedding.  Copies min(bytes, the buffer's size) bytes; returns the buffer's size.
+int64_t arp_dt_debug_read(arp_dt* c, const char* name, void* out, int64_t bytes) {
+    if (!c || !name) { fail("null argument"); return -1; }
+    const std::string n = name;
+    const DevBuf* b = n == "Xc" ? &c->Xc : n == "H1c" ? &c->H1c : n == "W1c" ? &c->W1c : n == "W2c" ? &c->W2c : n == "wc_scal" ? &c->wc_scal : n == "A32" ? &c->A32 : n == "A" ? &c->A
+                      : n == "Adx" ? &c->Adx : n == "Y" ? &c->Y : n == "img" ? &c->img : n == "H1" ? &c->H1 : n == "Xb" ? &c->Xb : nullptr;
+    if (!b) { fail("unknown buffer name"); return -1; }
+    if (hipSetDevice(c->cfg.device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { fail("device"); return -1; }
+    if (out && bytes > 0 && b->p) {
+        if (hipMemcpy(out, b->p, (size_t)std::min<int64_t>(bytes, (int64_t)b->bytes), hipMemcpyDeviceToHost) != hipSuccess) { fail("copy"); return -1; }
+    }
+    return (int64_t)b->bytes;
+}
+
 int arp_dt_set_adapter_corrections(arp_dt* c, int on) {
     if (!c) return fail("null handle");
     if (on && c->cfg.mode != ARP_MODE_F16) return fail("adapter corrections exist in ARP_MODE_F16 only (binary16 products corrected on the fp4 MFMA)");

@@ -941,11 +941,17 @@ __global__ __launch_bounds__(G2_THREADS, 2) __attribute__((amdgpu_num_vgpr(ARP_G
                             // straight from the staged tile's packed words: four instructions per eight values where unpack + multiply + the f32 form took twenty
                             // (same nibbles: a power-of-two scale is exact, the value is rounded once either way)
                             const float inv = 1.0f / (float)(1 << g.x8_shift);
+                            // The four words go through SCALARS first: __builtin_bit_cast(f16x2_v, v[i]) on an ELEMENT of an ext-vector compiles (hipcc 7.0, -O3) to
+                            // a read of element 0 whatever i is -- rounds 5 and 6 stored the first pair's two codes four times over (every x4 segment written by an
+                            // epilogue: c_fc -> c_proj in the f16c encoder, fc1 -> fc2 in the corrected adapter), so the x4 . dW4 correction of the product behind it
+                            // added noise of the size it was meant to remove.  Found with scripts/adapter_chain_probe.py (arp_dt_debug_read), pinned by
+                            // tests/test_policy_gpu.py::test_adapter_operand_rows_hold_what_the_products_assume.
+                            const uint32_t e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
                             uint32_t w4 = 0;
-                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, v[0]), inv, 0);
-                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, v[1]), inv, 1);
-                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, v[2]), inv, 2);
-                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, v[3]), inv, 3);
+                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, e0), inv, 0);
+                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, e1), inv, 1);
+                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, e2), inv, 2);
+                            w4 = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(w4, __builtin_bit_cast(f16x2_v, e3), inv, 3);
                             *reinterpret_cast<uint32_t*>(static_cast<char*>(g.xb_out) + (size_t)m * g.ldxb + (n >> 1)) = w4;
                         }
                     }

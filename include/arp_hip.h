@@ -235,6 +235,9 @@ int arp_dt_broadcast_state(arp_dt* h);
  * (ARP_MODE_F16C's product) and the adapter output handed to the residual mix in f32: takes the policy's own share out of the encoder-inside logit error
  * (row N1) for ~0.1 ms per step.  Off by default (ARP_DT_ADAPTER_C=1 turns it on at create); the backward is unchanged. */
 int arp_dt_set_adapter_corrections(arp_dt* h, int on);
+/* test hook: the bytes of a named intermediate device buffer of the last forward ("Xc", "H1c", "W1c", "W2c", "wc_scal", "A32", "A", "Adx", "Y", "img", "H1", "Xb");
+   copies min(bytes, size), returns the buffer's size or -1 */
+int64_t arp_dt_debug_read(arp_dt* h, const char* name, void* out, int64_t bytes);
 /* What the communicator says about itself, for a multi-GPU run that certifies itself (the pmean of main_procgen.py:132 needs every
  * device in it): info5 = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion code, 1 if a communicator exists};
  * without one (world 1) {1, 0, device, 0, 0}.  arp_dt_comm_selfcheck all-reduces (sum) the scalar rank + 1 through that

@@ -268,6 +268,7 @@ def test_image_text_input_on_hi_lo_binary16_pairs_is_the_f32_product(gpu_lib, kw
     cfg, _, P, (enc, act, rtg), _, _ = _setup(kw, B, 21)
     res = {}
     monkeypatch.setenv("ARP_DT_MIX_X16", "0")  # the same operands on both sides: the x3 kernel's mix from the f32 encodings, as the f32-MFMA path's mix launch forms it
+    monkeypatch.setenv("ARP_DT_ADAPTER_PLAN", "22e")  # ... and from the f32 adapter output (the default e2m1 hand-off exists inside the x3 kernel's operand load only)
     for x3 in ("1", "0"):
         monkeypatch.setenv("ARP_DT_ITI_X3", x3)
         tr = PolicyTrainer(cfg, mode="f16")
@@ -432,6 +433,87 @@ def test_f16_training_tracks_f32_over_many_steps(gpu_lib):
         print(f"loss f32: {a[[0, 9, 49, 99, 149]]}  {name}: {b[[0, 9, 49, 99, 149]]}  rel first 20 {rel[:20].max():.2e} all {rel.max():.2e}")
         assert a[-1] < 0.5 * a[0] and b[-1] < 0.5 * b[0], "both modes must learn the fixed batch"
         assert rel[:20].max() < 1e-2 and rel.max() < 5e-2, (name, float(rel[:20].max()), float(rel.max()))
+
+
+def _fp4_grid_round(x):
+    """OCP e2m1, round to nearest even, saturating at 6 (tests/test_ops_gpu.py::_quant_fp4)"""
+    grid = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+    x = np.asarray(x, np.float64)
+    a = np.minimum(np.abs(x), 6.0)
+    idx = np.clip(np.searchsorted(grid, a, side="left"), 1, 7)
+    lo, hi = grid[idx - 1], grid[idx]
+    mid = 0.5 * (lo + hi)
+    return np.sign(x) * np.where((a > mid) | ((a == mid) & (idx % 2 == 0)), hi, lo)
+
+
+def test_adapter_operand_rows_hold_what_the_products_assume(gpu_lib, monkeypatch):
+    """The corrected adapter INSIDE the step, segment by segment (round 6).  Rounds 5 and 6 ran with every x4 segment an EPILOGUE wrote (fc1 -> fc2 here, c_fc -> c_proj
+    in the f16c encoder) holding its first pair of codes four times over -- `__builtin_bit_cast(f16x2_v, v[i])` on an ext-vector element compiles to a read of element 0
+    (gemm256.h) -- so the x4 . dW4 term of the product behind it added noise of the size it was meant to remove, and no test saw it: the unit test of the product builds
+    its operand rows on the host, and the logits stayed inside 1e-3.  This reads the step's buffers back (arp_dt_debug_read) and restates each from the layer before:
+    Xc / W1c / W2c / the hidden rows' x4 EXACTLY, the hidden rows' hi and dx4 up to f32 summation noise of the restated product, the output against the float64
+    product of the segments as read back."""
+    import ctypes as C
+    from arp_amd.train import PolicyTrainer
+    monkeypatch.setenv("ARP_DT_ADAPTER_PLAN", "22e")
+    cfg, _, P, (enc, act, rtg), _, _ = _setup(FULL, 2, 100)
+    D = cfg.enc_dim
+    M = enc.size // D
+    tr = PolicyTrainer(cfg, mode="f16", adapter_corrections=True)
+    tr.set_params(P)
+    tr.set_batch(enc, act, rtg)
+    tr.forward()
+    dec = np.concatenate([np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]), -np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])])
+
+    def read(name, nbytes):
+        buf = np.empty(nbytes, np.uint8)
+        assert gpu_lib.lib.arp_dt_debug_read(tr._h, name.encode(), buf.ctypes.data_as(C.c_void_p), nbytes) >= nbytes, name
+        return buf
+
+    def rows(buf, R):
+        b = buf.reshape(R, 3 * D)
+
+        def seg(x):
+            out = np.empty((R, D), np.float64)
+            out[:, 0::2] = dec[x & 15]
+            out[:, 1::2] = dec[x >> 4]
+            return out
+        return b[:, : 2 * D].copy().view(np.float16).astype(np.float64), seg(b[:, 2 * D: 2 * D + D // 2]), seg(b[:, 2 * D + D // 2:])
+
+    h16 = lambda a: a.astype(np.float16).astype(np.float64)  # noqa: E731
+    sc = read("wc_scal", 64).view(np.int32)
+    x = enc.reshape(M, D).astype(np.float64)
+    Xc, H1c = rows(read("Xc", M * 3 * D), M), rows(read("H1c", M * 3 * D), M)
+    A32 = read("A32", M * D * 4).view(np.float32).reshape(M, D).astype(np.float64)
+    W1c, W2c = rows(read("W1c", D * 3 * D), D), rows(read("W2c", D * 3 * D), D)
+    tr.close()
+    assert np.array_equal(Xc[0], h16(x)) and np.array_equal(Xc[1], _fp4_grid_round(2.0 * h16(x))) and np.array_equal(Xc[2], _fp4_grid_round((x - h16(x)) * 2.0 ** 13))
+    b1 = np.asarray(P["AdapterMLP_0/Dense_0/bias"]).astype(np.float64)
+    b2 = np.asarray(P["AdapterMLP_0/Dense_1/bias"]).astype(np.float64)
+
+    def wrows(name, sd, sw):
+        Wt = np.asarray(P[name]).astype(np.float64).T
+        return h16(Wt), _fp4_grid_round((Wt - h16(Wt)) * 2.0 ** sd), _fp4_grid_round(Wt * 2.0 ** sw)
+
+    def product(Ac, Wr, sd, sw):
+        return Ac[0] @ Wr[0].T + 2.0 ** -(1 + sd) * (Ac[1] @ Wr[1].T) + 2.0 ** -(13 + sw) * (Ac[2] @ Wr[2].T)
+
+    W1r, W2r = wrows("AdapterMLP_0/Dense_0/kernel", sc[4], sc[5]), wrows("AdapterMLP_0/Dense_1/kernel", sc[12], sc[13])
+    for nm, name, got, want, sd, sw in (("W1c", "AdapterMLP_0/Dense_0/kernel", W1c, W1r, sc[4], sc[5]), ("W2c", "AdapterMLP_0/Dense_1/kernel", W2c, W2r, sc[12], sc[13])):
+        Wt = np.asarray(P[name]).astype(np.float64).T  # the product's rows are the kernel's output columns
+        assert 6 < np.abs(Wt - h16(Wt)).max() * 2.0 ** sd <= 12 and 6 < np.abs(Wt).max() * 2.0 ** sw <= 12, (nm, sd, sw)  # one binade into saturation, as designed
+        assert all(np.array_equal(g, w) for g, w in zip(got, want)), nm
+    v1 = np.maximum(product(Xc, W1r, sc[4], sc[5]) + b1, 0.0)
+    assert (np.abs(H1c[0] - h16(v1)) > 2.0 ** -10 * np.maximum(np.abs(v1), 2.0 ** -14)).mean() < 1e-3   # a binary16 tie moved by f32 summation noise: measured 3e-5
+    assert np.array_equal(H1c[1], _fp4_grid_round(2.0 * H1c[0])), float((H1c[1] != _fp4_grid_round(2.0 * H1c[0])).mean())
+    assert (H1c[2] != _fp4_grid_round((v1 - H1c[0]) * 2.0 ** 13)).mean() < 1e-2                              # measured 8e-4
+    v2 = np.maximum(product(H1c, W2r, sc[12], sc[13]) + b2, 0.0)
+    assert np.abs(A32 - v2).max() < 1e-5, float(np.abs(A32 - v2).max())                                     # measured 1.3e-6
+    exact = np.maximum(np.maximum(x @ np.asarray(P["AdapterMLP_0/Dense_0/kernel"], np.float64) + b1, 0.0) @ np.asarray(P["AdapterMLP_0/Dense_1/kernel"], np.float64) + b2, 0.0)
+    plain = np.maximum(h16(np.maximum(h16(x) @ W1r[0].T + b1, 0.0)) @ W2r[0].T + b2, 0.0)
+    r_c, r_p = float(np.sqrt(((A32 - exact) ** 2).mean())), float(np.sqrt(((plain - exact) ** 2).mean()))
+    print(f"adapter output, rms error against float64: corrected products {r_c:.2e}, plain binary16 products {r_p:.2e} ({r_c / r_p:.2f}x)")
+    assert r_c < 0.35 * r_p, (r_c, r_p)
 
 
 def test_f16_full_geometry_logits_over_sixteen_seeds(gpu_lib, monkeypatch):
@@ -707,6 +789,9 @@ def test_round5_launch_forms_give_the_same_step(gpu_lib, monkeypatch):
     (image_text_input's K-tiles dealt round-robin regroup its f32 partial sums, so that switch is held fixed here.)"""
     from arp_amd.train import PolicyTrainer
     cfg, ocfg, P, (enc, act, rtg), Pt, tb = _setup(FULL, 2, 37)
+    # (round 6: the adapter output reaches the mix in f32 in every arm -- the default binary16 + e2m1 hand-off lives inside image_text_input's operand load, which
+    #  the ARP_DT_ITI_MIX=0 arm does not have; what this test pins is where the work runs, not that hand-off)
+    monkeypatch.setenv("ARP_DT_ADAPTER_PLAN", "22e")
     old = {"ARP_DT_ITI_MIX": "0", "ARP_DT_MERGE": "0", "ARP_DT_DWI_LAST": "0", "ARP_DT_ADAM_REV": "0", "ARP_DT_DY_X16": "0", "ARP_DT_MIX_X16": "0"}
 
     def run(env):
