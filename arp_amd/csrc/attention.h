@@ -539,7 +539,8 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
                                                         int heads, float scale, int causal, int nq, float out8 = 0.f, int outc = 0) {
     // out8 != 0: `out` is an e4m3 buffer [B*N, D] bytes and receives out8 * value (operand of an fp8 out_proj, tower.h)
     // outc != 0 (T = f16, ARP_MODE_F16C): `out` rows are [hi | x4 | dx4] (3 D bytes each, common.h::store_f16c) -- out_proj's MIXC operand
-    // outc == 2 (round 6): the caller has permuted V's columns inside every head, column d' of the V block = original column pi(d'), pi = the swap of bits [5:4]
+    // outc & 4 (round 6): no dx4 segment (the consumer corrects its weight rounding only -- ARP_F16C_PLAN digit 2 < 2 -- and never reads it)
+    // (outc & 3) == 2 (round 6): the caller has permuted V's columns inside every head, column d' of the V block = original column pi(d'), pi = the swap of bits [5:4]
     //   and [3:2] of d (arp_enc.hip::vperm64).  O^T = V^T.P^T leaves lane (fg, fr) with the d' = 16 dt + 4 fg + r of query fr -- a layout the MFMA fixes -- and
     //   those are then the ORIGINAL columns 16 fg + 4 dt + r: sixteen consecutive ones.  A query's head slice leaves as four 32-byte pieces (+ 8 + 8 bytes of
     //   e2m1) instead of sixteen 8-byte pieces (+ sixteen 2 + 2): 4 stores per lane and block where the unpermuted form issues 12.  Same values, same bits:
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
                 const float sc = inv * out8;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16 + fg * 4, o[dt][0] * sc, o[dt][1] * sc, o[dt][2] * sc, o[dt][3] * sc);
-            } else if (NT > 4 && outc == 2) {  // (compiled out of the 96-register instances, NT <= 4: the sixteen-value store made them spill 22-36 registers whatever outc is at run time)
+            } else if (NT > 4 && (outc & 3) == 2) {  // (compiled out of the 96-register instances, NT <= 4: the sixteen-value store made them spill 22-36 registers whatever outc is at run time)
                 if constexpr (__is_same(T, f16_t) && NT > 4) {
                     f16_t* orow = out + ((size_t)b * N + qidx) * 3 * D / 2;
                     float v16[16];
@@ -699,14 +700,20 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 5 : 2)) void attn_mfma_kernel(const
                     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v16[4 * dt + r] = o[dt][r] * inv;
-                    store_f16c16(orow, h * 64 + fg * 16, D, v16);
+                    store_f16c16(orow, h * 64 + fg * 16, D, v16, !(outc & 4));
                 }
             } else if (outc) {
                 if constexpr (__is_same(T, f16_t)) {
                     f16_t* orow = out + ((size_t)b * N + qidx) * 3 * D / 2;
+                    if (NT > 4 && (outc & 4)) {  // (the 96-register instances keep the one form: the second loop cost them 20 spilled registers)
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-                        store_f16c<true>(orow, h * 64 + dt * 16 + fg * 4, D, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+                        for (int dt = 0; dt < 4; ++dt)
+                            store_f16c<false>(orow, h * 64 + dt * 16 + fg * 4, D, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+                    } else {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+                            store_f16c<true>(orow, h * 64 + dt * 16 + fg * 4, D, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+                    }
                 }
             } else {
                 T* orow = out + ((size_t)b * N + qidx) * D + h * 64;

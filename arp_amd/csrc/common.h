@@ -219,7 +219,7 @@ template <bool WITH_DX> __device__ __forceinline__ void store_f16c(f16_t* row, i
 }
 // sixteen consecutive values at column c (a multiple of 16): the same three segments as whole 32- / 8- / 8-byte pieces (two 16-byte stores and two 8-byte
 // stores per lane where four calls of the form above issue twelve stores of 8, 2 and 2 bytes)
-__device__ __forceinline__ void store_f16c16(f16_t* row, int c, int K, const float (&a)[16]) {
+__device__ __forceinline__ void store_f16c16(f16_t* row, int c, int K, const float (&a)[16], bool with_dx = true) {
     float v[16], h[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -238,7 +238,7 @@ __device__ __forceinline__ void store_f16c16(f16_t* row, int c, int K, const flo
         d0[j] = (v[j] - h[j]) * sd; d1[j] = (v[8 + j] - h[8 + j]) * sd;
     }
     *reinterpret_cast<uint2*>(seg + (c >> 1)) = make_uint2(pack_fp4x8(x0), pack_fp4x8(x1));
-    *reinterpret_cast<uint2*>(seg + (K >> 1) + (c >> 1)) = make_uint2(pack_fp4x8(d0), pack_fp4x8(d1));
+    if (with_dx) *reinterpret_cast<uint2*>(seg + (K >> 1) + (c >> 1)) = make_uint2(pack_fp4x8(d0), pack_fp4x8(d1));  // (uniform: the consumer's plan)
 }
 
 __device__ __forceinline__ void load4(const f16_t* p, float (&v)[4]) {

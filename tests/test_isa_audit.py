@@ -16,7 +16,8 @@ BUDGET = [
     ("arp_enc.o", "attn_mfma_kernel<arp::f16_t, 18>", 0),
     ("arp_dt.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 2, false, 16, false, 1, false, false>", 0),
     ("arp_dt.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 0, false, 16, false, 1, false, false>", 0),
-    ("arp_dt.o", "iti_x3_kernel<1, arp::f16_t, arp::f16_t, true>", 0),
+    ("arp_dt.o", "iti_x3_kernel<1, arp::f16_t, arp::f16_t, true, false>", 0),
+    ("arp_dt.o", "iti_x3_kernel<1, arp::f16_t, arp::f16_t, true, true>", 0),  # the default since round 6: binary16 adapter output + its e2m1 error code
     ("arp_dt.o", "policy_fused_kernel<128, 512, true>", 0),
     ("arp_clip.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 1, false, 3, false, 1, false, false>", 3),   # c_fc: three dwords of prologue state
     ("arp_clip.o", "gemm256_nt_kernel<arp::f16_t, arp::f16_t, 1, false, 3, false, 1, false, true>", 3),    # ... and its clock-diagnostic twin (round 6): the same budget
