@@ -133,10 +133,12 @@ struct arp_dt {
     // output into Adx, decoded by iti_x3_kernel's mix).  Chosen with scripts/adapter_plan_emulate.py (fp64 emulation of every rounding, 8 + 8 seeds) and measured on
     // the GPU: profiles/r6_adapter_plans.txt.
     int ac_plan1 = 2, ac_plan2 = 2;
-    // 22d.  Per-seed maxima over 16 seeds of N(0,1) encodings / 8 seeds behind f32 encoder outputs / the seed of bench.py's own gate, and the policy step alone:
-    //   plain 8.7e-4 / 1.18e-3 / 8.3e-4, 0.77 ms;  22h 7.1e-4 / 6.4e-4 / 9.0e-4, 0.87;  22d 7.3e-4 / 4.6e-4 / 6.5e-4, 0.90;  22e 6.6e-4 / 4.8e-4 / 7.0e-4, 0.93
-    // (one box).  h leaves the hand-off's rounding as the one term that can land on the wrong side of a seed (the gate's); d takes it out to 2^-14 for 12.6 MB where
-    // e moves 50 MB more and puts fc2 on the f32 epilogue.
+    // 22d.  Per-seed maxima over 16 seeds of N(0,1) encodings / 8 seeds behind f32 encoder outputs / the seed of bench.py's own gate, and the policy step alone
+    // (one box; after the x4 segment written by fc1's epilogue was repaired, gemm256.h -- rounds 5 and 6 measured every plan with fc2's weight correction as noise):
+    //   plain 8.7e-4 / 1.18e-3 / 8.3e-4, 0.77 ms;  11h 1.18e-3 / 7.9e-4 / 8.9e-4, 0.85;  11d 9.3e-4 / 6.5e-4 / 5.6e-4, 0.86;  12h 7.1e-4 / 7.1e-4 / 6.7e-4, 0.87;
+    //   21h 6.0e-4 / 7.8e-4;  12d 6.4e-4 / 6.0e-4;  22h 4.9e-4 / 3.5e-4 / 5.9e-4, 0.875;  22d 1.6e-4 / 2.1e-4 / 1.2e-4, 0.90 (22e: the same errors, 0.925)
+    // Every one of the four corrections carries its share (fc1's activation rounding is the encodings' own); h leaves the hand-off's rounding, which is then the
+    // largest term left; d takes it out to 2^-14 for 12.6 MB where e moves 50 MB more and puts fc2 on the f32 epilogue.
     bool ac_a_dx = true;
     DevBuf Adx;            // d: [Mx, D / 2] bytes
     bool ac_a_exact = false;
@@ -1494,8 +1496,8 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
     if (const char* e = getenv("ARP_DT_ITI_X3")) c->iti_x3 = atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ITI_MIX")) c->iti_mix = atoi(e) != 0;
     // Round 6: ON by default where the corrected products exist (f16, adapter widths that are multiples of 256): the plain f16 adapter reads 8.7e-4 on the logits over
-    // 16 seeds of N(0,1) encodings and 1.18e-3 behind real encoder outputs (one seed of eight outside north_star's 1e-3); corrected (plan 22d) 7.3e-4 / 4.6e-4,
-    // for +0.13 ms per 32-sample step (profiles/r6_adapter_plans.txt).  ARP_DT_ADAPTER_C=0 / arp_dt_set_adapter_corrections(h, 0): the plain products.
+    // 16 seeds of N(0,1) encodings and 1.18e-3 behind real encoder outputs (one seed of eight outside north_star's 1e-3); corrected (plan 22d) 1.6e-4 / 2.1e-4,
+    // for +0.12 ms per 32-sample step (profiles/r6_adapter_plans.txt).  ARP_DT_ADAPTER_C=0 / arp_dt_set_adapter_corrections(h, 0): the plain products.
     c->adapter_c = k.mode == ARP_MODE_F16 && k.use_adapter && k.enc_dim % 256 == 0 && k.enc_dim >= 512;
     if (const char* e = getenv("ARP_DT_ADAPTER_C")) c->adapter_c = c->adapter_c && atoi(e) != 0;
     if (const char* e = getenv("ARP_DT_ADAPTER_PLAN")) {  // "<fc1><fc2><e|h|d>", e.g. 22e (round 5), 12h

@@ -72,7 +72,7 @@ def test_train_step_with_encoder_inside(gpu_lib):
     a.close(); b.close(); enc.close()
 
 
-def test_policy_logits_with_the_encoder_inside_full_geometry(gpu_lib):
+def test_policy_logits_with_the_encoder_inside_full_geometry(gpu_lib, monkeypatch):
     """Row N1 at the real geometry (VERDICT r3 next #1a): frames in, the frozen encoder (ViT-B/16 at 256 x 256, 257 tokens) in front of the policy,
     against oracle/m3ae_np -> oracle/arpdt_torch in fp64, EIGHT seeds.
     * f32 mode -- the mode `bench.py`'s `policy_with_encoder` line times, and the reference's own arithmetic type (its JAX model runs in float32):
@@ -80,7 +80,10 @@ def test_policy_logits_with_the_encoder_inside_full_geometry(gpu_lib):
     * f16x3 encoder (every GEMM operand an (hi, lo) binary16 pair, three 16-bit MFMAs per product, attention / LayerNorm in f32) in front of the f32
       policy: the 16-bit-MFMA mode VERDICT r3 asked for -- asserted at 1e-3 on every seed too (and at 1e-4: it is f32-accurate).
     * f16c encoder + f16 policy with adapter corrections (round 5): binary16 products whose operand roundings are corrected on the scaled
-      fp4 MFMA (1.5x the binary16 product instead of f16x3's 3x): asserted at 1e-3 on every seed (measured 4.2e-4 ... 6.7e-4).
+      fp4 MFMA: asserted at 1e-3 on every seed.  Round 6: the default plan corrects the WEIGHT roundings of in_proj / out_proj / fc1 (ARP_F16C_PLAN=1110,
+      1.25x the binary16 K loop on three of the four products): measured 3.0e-4 ... 7.0e-4; round 5's plan (1221: + the activation roundings of out_proj / fc1 and
+      fc2's weights, +0.7 ms per 32-sample step) runs beside it and is asserted at 5e-4 (measured 1.5e-4 ... 3.7e-4 -- it read 4.2e-4 ... 6.7e-4 in rounds 5 and 6
+      until the x4 segment that fc1's epilogue writes for fc2 was repaired, gemm256.h: this arm is what pins that repair in the encoder).
     * f16 mode -- a THROUGHPUT mode with a stated error, NOT a parity claim: measured over these eight seeds (scripts/n1_parity_probe.py,
       profiles/r4_n1_probe.txt) 0.74e-3 ... 1.54e-3, four seeds outside 1e-3.  The probe also separates the two sources: f16 encoder in front of an
       f32 policy 0.50 ... 1.31e-3, f32 encoder in front of the f16 policy 0.57 ... 1.23e-3 -- each about one f16 rounding step (2^-11) per operand
@@ -105,11 +108,14 @@ def test_policy_logits_with_the_encoder_inside_full_geometry(gpu_lib):
         codes = M.forward_representation(EP, eocfg, frames.reshape(-1, 256, 256, 3)).reshape(B, T, ecfg.tokens, ecfg.width)
         Pt = {k: torch.from_numpy(v).double() for k, v in P.items()}
         ref = O.forward(Pt, pocfg, torch.from_numpy(np.asarray(codes, np.float64)), torch.from_numpy(act).long(), torch.from_numpy(rtg).double())
-        for mode in ("f32", "f16x3", "f16c") + (("f16",) if seed < 4 else ()):
-            enc = m3ae.M3AEEncoder(ecfg, EP, mode=mode)
+        for mode in ("f32", "f16x3", "f16c", "f16c-1221") + (("f16",) if seed < 4 else ()):
+            if mode == "f16c-1221":
+                monkeypatch.setenv("ARP_F16C_PLAN", "1221")  # read by arp_enc_create
+            enc = m3ae.M3AEEncoder(ecfg, EP, mode=mode.split("-")[0])
+            monkeypatch.delenv("ARP_F16C_PLAN", raising=False)
             # f16x3 is an ENCODER mode: the policy behind it runs in f32.  f16c (round 5): the binary16 encoder AND the binary16 policy, each with the operand
             # roundings of its big products corrected on the fp4 MFMA -- the 16-bit configuration `bench.py`'s policy_with_encoder_f16c line times
-            tr = PolicyTrainer(pcfg, mode={"f16x3": "f32", "f16c": "f16"}.get(mode, mode), adapter_corrections=mode == "f16c")
+            tr = PolicyTrainer(pcfg, mode={"f16x3": "f32", "f16c": "f16", "f16c-1221": "f16"}.get(mode, mode), adapter_corrections=mode.startswith("f16c"))
             tr.set_params(P)
             tr.attach_encoder(enc)
             tr.set_batch_images(frames, act, rtg)
@@ -124,7 +130,9 @@ def test_policy_logits_with_the_encoder_inside_full_geometry(gpu_lib):
     x3 = [e for (m, s), e in errs.items() if m == "f16x3"]
     assert len(x3) == 8 and max(x3) < 1e-3 and max(x3) < 1e-4  # the 16-bit-MFMA mode that meets north_star (three MFMAs per product)
     fc = [e for (m, s), e in errs.items() if m == "f16c"]
-    assert len(fc) == 8 and max(fc) < 1e-3  # north_star on every seed at 16-bit speed (measured 4.2e-4 ... 6.7e-4; profiles/r5_n1_probe.txt)
+    assert len(fc) == 8 and max(fc) < 1e-3  # north_star on every seed at 16-bit speed (measured 3.0e-4 ... 7.0e-4; profiles/r6_n1_plan_sweep.txt)
+    fc2 = [e for (m, s), e in errs.items() if m == "f16c-1221"]
+    assert len(fc2) == 8 and max(fc2) < 5e-4  # (measured 1.5e-4 ... 3.7e-4)
     assert max(e for (m, s), e in errs.items() if m == "f16") < 2.5e-3  # NOT north_star's 1e-3: see the docstring
 
 
@@ -301,9 +309,9 @@ def _n1_trajectory_report(tag, res, lr, steps):
 def test_f16c_training_trajectory_tracks_f32_small(gpu_lib):
     """row N1's 16-bit configuration -- f16c encoder, f16 policy, adapter corrections -- against the f32 configuration over a TRAINING RUN with
     frames in, not one forward: 10 clipped Adam steps at the smallest geometry the f16c products exist at.  Loss within 1e-3 relative on every step (measured 1.7e-4;
-    2e-7 on the first step).  Gradient norms per tensor: on the FIRST step -- the same parameters on both sides, so the difference is arithmetic -- within 3 %, the
-    SCALAR residual_weight within 15 % (its gradient is one sum of 35 k products of opposite signs: a measure of how much of that sum cancels, not of a norm);
-    over all ten steps within 10 % / 50 %: Adam's first steps move every parameter by ~lr per step whatever its gradient's size, a flipped sign of a near-zero gradient
+    2e-7 on the first step).  Gradient norms per tensor: on the FIRST step -- the same parameters on both sides, so the difference is arithmetic -- within 0.5 %
+    (measured 0.05 %), the scalar residual_weight included; over all ten steps within 10 %, the SCALAR residual_weight within 50 % (its gradient is one sum of 35 k
+    products of opposite signs: once the parameters differ it measures how much of that sum cancels, not an error): Adam's first steps move every parameter by ~lr per step whatever its gradient's size, a flipped sign of a near-zero gradient
     entry costs 2 lr on that entry, and from there the two runs are different trajectories (measured at the worst step 5.8 % / 22 %; 512-wide contractions average
     the operand roundings less than the real 768 / 197 376-wide ones -- the full-geometry test below holds the 2 % the verdict asked for).  Parameters after the run
     within a tenth of the distance the run moved them (the bound is on the MEAN; measured 0.4 %)."""
@@ -313,23 +321,23 @@ def test_f16c_training_trajectory_tracks_f32_small(gpu_lib):
     res = _n1_trajectory(SMALL_C, pcfg, 4, steps, lr, (11, 12, 13, 14))
     rel, worst, dp, worst_scalar, first = _n1_trajectory_report("small", res, lr, steps)
     assert rel.max() < 1e-3, float(rel.max())
-    assert max(v for k, v in first.items() if k not in worst_scalar) < 3e-2, max(first.items(), key=lambda kv: kv[1])
-    assert max(first[k] for k in worst_scalar) < 0.15, {k: first[k] for k in worst_scalar}
+    assert max(first.values()) < 5e-3, max(first.items(), key=lambda kv: kv[1])  # measured 5.0e-4 (AdapterMLP_0/Dense_0/bias); the scalar 2.2e-4
     assert max(worst.values()) < 0.1, max(worst.items(), key=lambda kv: kv[1])
     assert max(worst_scalar.values()) < 0.5, worst_scalar
     assert max(dp.values()) < 0.1 * lr * steps, max(dp.items(), key=lambda kv: kv[1])
 
 
 def test_f16c_training_trajectory_tracks_f32_full_geometry(gpu_lib):
-    """... and two steps at the real geometry (ViT-B/16 at 256 x 256 in front of the 26.9 M-parameter policy, B = 2): loss within 1e-3 relative (measured 8.6e-5),
-    every gradient tensor's norm within 2 % (measured <= 1.6 %; the scalar residual_weight within 6 %, measured 3.4 %), parameters within a tenth of the distance moved
-    (measured 1.4 %)."""
+    """... and two steps at the real geometry (ViT-B/16 at 256 x 256 in front of the 26.9 M-parameter policy, B = 2): loss within 1e-3 relative (measured 2.6e-5; 2.2e-6 on the first step),
+    every gradient tensor's norm within 0.5 % on the first step (measured 0.07 %) and 2 % on the second (measured 1.1 %; the scalar residual_weight within 6 %, measured
+    2.7 %), parameters within a tenth of the distance moved (measured 0.7 %)."""
     from arp_amd.train import PolicyConfig
     pcfg = PolicyConfig(lambda_ret=0.01)
     lr, steps = 3e-4, 2
     res = _n1_trajectory(dict(), pcfg, 2, steps, lr, (50, 60, 70, 80))
-    rel, worst, dp, worst_scalar, _ = _n1_trajectory_report("full", res, lr, steps)
+    rel, worst, dp, worst_scalar, first = _n1_trajectory_report("full", res, lr, steps)
     assert rel.max() < 1e-3, float(rel.max())
+    assert max(first.values()) < 5e-3, max(first.items(), key=lambda kv: kv[1])  # the first step, arithmetic only: measured 6.5e-4 (residual_weight), 2.2e-4 the worst tensor
     assert max(worst.values()) < 2e-2, max(worst.items(), key=lambda kv: kv[1])
     assert max(worst_scalar.values()) < 6e-2, worst_scalar
     assert max(dp.values()) < 0.1 * lr * steps, max(dp.items(), key=lambda kv: kv[1])
@@ -382,8 +390,8 @@ def test_encode_ahead_gives_the_same_trajectory(gpu_lib):
 
 def test_default_f16_policy_behind_f32_encoder_outputs(gpu_lib):
     """the f16 policy behind REAL encoder outputs (the f32 encoder on the GPU: 5e-6 from the fp64 oracle) read 1.18e-3 on one seed of eight
-    (profiles/r5_n1_probe.txt) -- encodings are not N(0,1).  The round-6 default (adapter corrections on, plan 22e) must hold north_star's 1e-3 on all eight;
-    the plain products (adapter_corrections=False) are printed beside it."""
+    (profiles/r5_n1_probe.txt) -- encodings are not N(0,1).  The round-6 default (adapter corrections on, plan 22d) must hold north_star's 1e-3 on all eight
+    with room: measured 2.1e-4 (max) / 1.0e-4 (median), asserted at 4e-4; the plain products (adapter_corrections=False) are printed beside it."""
     import torch
     from arp_amd import m3ae, synth_policy as S
     from arp_amd.train import PolicyConfig, PolicyTrainer
@@ -411,4 +419,4 @@ def test_default_f16_policy_behind_f32_encoder_outputs(gpu_lib):
     for tr in trs.values():
         tr.close()
     print("f16 policy behind f32 encoder outputs, 8 seeds: " + "; ".join(f"{k}: max {max(v):.2e} median {np.median(v):.2e}" for k, v in errs.items()))
-    assert max(errs["default"]) < 1e-3, errs["default"]  # measured 4.8e-4
+    assert max(errs["default"]) < 4e-4, errs["default"]  # measured 2.1e-4 (4.8e-4 before the x4 segment of fc1's epilogue was repaired)

@@ -555,13 +555,15 @@ def test_f16_full_geometry_logits_over_sixteen_seeds(gpu_lib, monkeypatch):
         assert stats[name][1] < LOGIT_TOL_16BIT and stats[name][3] < LOGIT_TOL_16BIT, (name, stats[name])
     assert max(stats["all_f16"][0], stats["all_f16"][2]) < 1.2e-3, stats["all_f16"]
     assert max(stats["default"][0], stats["default"][2]) < LOGIT_TOL_16BIT, stats["default"]
-    # the corrected adapter: logits max 3.9e-4 against 6.0e-4, return prediction 6.6e-4 against 7.4e-4 on these synthetic encodings (behind REAL encoder
-    # outputs 4.8e-4 against 1.18e-3 over eight seeds: profiles/r5_n1_probe.txt) -- asserted: better on both heads, inside 1e-3
+    # the corrected adapter: logits max 1.3e-4 against 8.7e-4, return prediction 1.6e-4 against 7.4e-4 on these synthetic encodings (behind REAL encoder
+    # outputs 2.1e-4 against 1.18e-3 over eight seeds: profiles/r6_adapter_plans.txt; rounds 5 and 6 read 3.9e-4 / 6.6e-4 here until the x4 segment fc1's epilogue
+    # writes was repaired, gemm256.h) -- asserted: better on both heads, inside 1e-3
     assert stats["corrected"][0] < stats["default"][0] and stats["corrected"][2] < stats["default"][2], (stats["corrected"], stats["default"])
     assert max(stats["corrected"][0], stats["corrected"][2]) < LOGIT_TOL_16BIT
-    # round 6: the corrected adapter is what PolicyTrainer(mode="f16") runs unless told otherwise (plan 22e: both operand roundings of both products, f32 hand-off
-    # to the mix); VERDICT r5 next #2 asked for a 16-seed maximum of at most 7.5e-4 (measured 3.91e-4 logits / 6.55e-4 return)
-    assert max(stats["corrected"][0], stats["corrected"][2]) <= 7.5e-4, stats["corrected"]
+    # round 6: the corrected adapter is what PolicyTrainer(mode="f16") runs unless told otherwise (plan 22d: both operand roundings of both products, the output
+    # handed to the mix as binary16 + the e2m1 code of its rounding error); VERDICT r5 next #2 asked for a 16-seed maximum of at most 7.5e-4: measured
+    # 1.27e-4 logits / 1.63e-4 return, asserted at 3e-4
+    assert max(stats["corrected"][0], stats["corrected"][2]) <= 3e-4, stats["corrected"]
     tr = PolicyTrainer(cases[0][0], mode="f16")  # the default
     cfg, P, (enc, act, rtg), r_log, r_ret = cases[0]
     tr.set_params(P)
