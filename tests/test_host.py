@@ -386,6 +386,53 @@ def test_two_prefetchers_on_one_trainer_never_share_device_slots():
     last.close()
 
 
+def test_prefetcher_enqueues_the_next_batch_encoder_pass_behind_its_upload(monkeypatch):
+    """Round 6 (row N1): with a frozen encoder attached and FRAMES in the batches, the prefetch worker enqueues the slot's encoder pass (arp_dt_encode_ahead) right
+    behind that slot's upload -- never before it, never for encodings-in batches, and not at all with ARP_DT_ENCODE_AHEAD=0.  Stub trainer, no GPU."""
+    from arp_amd.train import DeviceBatch, PolicyConfig, prefetch_to_device
+
+    class Stub:
+        cfg = PolicyConfig(emb=8, depth=1, heads=2, window=2, enc_tokens=2, enc_dim=4)
+
+        def __init__(self, encoder):
+            self._encoder = encoder
+            self.log = []
+
+        def upload_async(self, slot, enc, act, rtg, images=False):
+            self.log.append(("upload", slot, bool(images)))
+
+        def encode_ahead(self, slot):
+            self.log.append(("encode", slot))
+
+    def frames(n):
+        for i in range(n):
+            yield {"image": {"ob": np.full((2, 2, 8, 8, 3), i, np.float32)}, "action": np.zeros((2, 2), np.int32), "rtg": {"ob": np.zeros((2, 2, 1), np.float32)}}
+
+    def encodings(n):
+        for i in range(n):
+            yield {"image": {"ob": np.full((2, 2, 2, 4), i, np.float32)}, "action": np.zeros((2, 2), np.int32), "rtg": {"ob": np.zeros((2, 2, 1), np.float32)}}
+
+    def drain(tr, gen):
+        it = prefetch_to_device(gen, 2, tr)
+        for b in it:
+            assert isinstance(b, DeviceBatch)
+            b.done()
+        it.close()
+        return tr.log
+
+    log = drain(Stub(encoder=object()), frames(4))
+    ups = [e for e in log if e[0] == "upload"]
+    assert len(ups) == 4 and all(e[2] for e in ups)
+    for i, e in enumerate(log):  # every upload of frames is followed IMMEDIATELY by the encoder pass of the same slot
+        if e[0] == "upload":
+            assert log[i + 1] == ("encode", e[1]), log
+    assert [e[1] for e in ups] == [0, 1, 0, 1]
+    assert not any(e[0] == "encode" for e in drain(Stub(encoder=object()), encodings(3)))  # encodings in: nothing to encode
+    assert not any(e[0] == "encode" for e in drain(Stub(encoder=None), frames(3)))        # no encoder attached
+    monkeypatch.setenv("ARP_DT_ENCODE_AHEAD", "0")
+    assert not any(e[0] == "encode" for e in drain(Stub(encoder=object()), frames(3)))     # switched off: the encoder runs at the head of its own step
+
+
 def test_alibi_slopes_known_answers():
     """_get_attention_slopes (arp_dt/layers.py:97-110) in the oracle: the published ALiBi slopes -- 1/2 ... 1/256 for 8 heads, 2^(-8 i / n) in general for a
     power of two, and for 12 heads the 8-head slopes followed by every other 16-head slope."""
