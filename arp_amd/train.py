@@ -553,7 +553,11 @@ def _stage(tr, batch, rank, world, device_axis):
     if isinstance(batch, DeviceBatch):
         tr.select(batch.slot)
         return batch
-    tr.set_batch(*_batch_arrays(shard_batch(batch, rank, world, device_axis), tr.cfg.use_symlog))
+    enc, act, rtg = _batch_arrays(shard_batch(batch, rank, world, device_axis), tr.cfg.use_symlog)
+    if getattr(tr, "_encoder", None) is not None and enc.ndim == 5 and enc.shape[-1] == 3:  # frames in, frozen encoder attached (row N1): the synchronous slot
+        tr.set_batch_images(enc, act, rtg)
+    else:
+        tr.set_batch(enc, act, rtg)
     return None
 
 

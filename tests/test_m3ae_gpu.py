@@ -152,8 +152,9 @@ def test_prefetched_frames_with_the_encoder_inside_equal_the_synchronous_path(gp
         frames = S.normalized_frames(4 * pcfg.window, ecfg.img_res, seed=20 + i).reshape(4, pcfg.window, ecfg.img_res, ecfg.img_res, 3)
         batches.append({"image": {"ob": frames}, "action": rng.integers(0, pcfg.n_actions, (4, pcfg.window)).astype(np.int32),
                         "rtg": {"ob": rng.random((4, pcfg.window, 1)).astype(np.float32)}})
+    from arp_amd.train import create_val_step
     out = {}
-    for name in ("sync", "prefetch"):
+    for name in ("sync", "host", "prefetch"):
         enc = m3ae.M3AEEncoder(ecfg, EP, mode="f32")
         state = TrainState.create(pcfg, P, mode="f32")
         state.trainer.attach_encoder(enc)
@@ -163,14 +164,22 @@ def test_prefetched_frames_with_the_encoder_inside_equal_the_synchronous_path(gp
             for b in batches:
                 state.trainer.set_batch_images(b["image"]["ob"], b["action"], b["rtg"]["ob"])
                 losses.append(state.trainer.train_step(1e-3)["loss"])
+        elif name == "host":  # round 6: HOST batches of frames straight through the step functions (no prefetcher): the synchronous slot, set_batch_images
+            vfn = create_val_step(pcfg)
+            for i, b in enumerate(batches):
+                state, aux, _ = fn(state, b, None)
+                losses.append(aux["loss"])
+                if i == 2:  # a validation step on frames in between leaves the training state alone
+                    vaux, _ = vfn(state, batches[0], None)
+                    assert np.isfinite(vaux["loss"])
         else:
             for b in prefetch_to_device(iter(batches), 2, state.trainer):
                 state, aux, _ = fn(state, b, None)
                 losses.append(aux["loss"])
         out[name] = (losses, state.trainer.get_params())
         state.trainer.close(); enc.close()
-    assert out["sync"][0] == out["prefetch"][0]
-    assert all(np.array_equal(out["sync"][1][k], out["prefetch"][1][k]) for k in out["sync"][1])
+    assert out["sync"][0] == out["prefetch"][0] == out["host"][0]
+    assert all(np.array_equal(out["sync"][1][k], out["prefetch"][1][k]) and np.array_equal(out["sync"][1][k], out["host"][1][k]) for k in out["sync"][1])
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
