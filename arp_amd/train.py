@@ -201,14 +201,21 @@ class PolicyTrainer:
     def backward(self):
         check(lib.arp_dt_backward(self._h))
 
+    def _set_batch_any(self, enc, action, rtg):
+        """encodings [B, T, tokens, dim], or -- with a frozen encoder attached -- normalised frames [B, T, H, W, 3] (row N1: what the rollout loop has)"""
+        if getattr(self, "_encoder", None) is not None and np.ndim(enc) == 5 and np.shape(enc)[-1] == 3:
+            self.set_batch_images(enc, action, rtg)
+        else:
+            self.set_batch(enc, action, rtg)
+
     def greedy_action(self, enc, action, rtg):
         """ARPDT.greedy_action (ARPDT.py:488-492): argmax of the LAST time step's action logits."""
-        self.set_batch(enc, action, rtg)
+        self._set_batch_any(enc, action, rtg)
         return self.forward()["action_pred"][:, -1, :].argmax(-1)
 
     def greedy_return(self, enc, action, rtg):
         """ARPDT.greedy_return (ARPDT.py:494-495): symexp(return_pred) (utils.py symexp = sign(x)(exp|x| - 1))."""
-        self.set_batch(enc, action, rtg)
+        self._set_batch_any(enc, action, rtg)
         r = self.forward()["return_pred"]
         return np.sign(r) * (np.exp(np.abs(r)) - 1.0)
 
@@ -554,10 +561,7 @@ def _stage(tr, batch, rank, world, device_axis):
         tr.select(batch.slot)
         return batch
     enc, act, rtg = _batch_arrays(shard_batch(batch, rank, world, device_axis), tr.cfg.use_symlog)
-    if getattr(tr, "_encoder", None) is not None and enc.ndim == 5 and enc.shape[-1] == 3:  # frames in, frozen encoder attached (row N1): the synchronous slot
-        tr.set_batch_images(enc, act, rtg)
-    else:
-        tr.set_batch(enc, act, rtg)
+    tr._set_batch_any(enc, act, rtg) if hasattr(tr, "_set_batch_any") else tr.set_batch(enc, act, rtg)  # frames in with a frozen encoder attached (row N1): set_batch_images
     return None
 
 

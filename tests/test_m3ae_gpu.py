@@ -169,9 +169,13 @@ def test_prefetched_frames_with_the_encoder_inside_equal_the_synchronous_path(gp
             for i, b in enumerate(batches):
                 state, aux, _ = fn(state, b, None)
                 losses.append(aux["loss"])
-                if i == 2:  # a validation step on frames in between leaves the training state alone
+                if i == 2:  # a validation step and a greedy action on frames in between leave the training state alone
                     vaux, _ = vfn(state, batches[0], None)
                     assert np.isfinite(vaux["loss"])
+                    b0 = batches[0]
+                    ga = state.trainer.greedy_action(b0["image"]["ob"], b0["action"], b0["rtg"]["ob"])
+                    state.trainer.set_batch_images(b0["image"]["ob"], b0["action"], b0["rtg"]["ob"])
+                    assert np.array_equal(ga, state.trainer.forward()["action_pred"][:, -1, :].argmax(-1)) and ga.shape == (4,)
         else:
             for b in prefetch_to_device(iter(batches), 2, state.trainer):
                 state, aux, _ = fn(state, b, None)
