@@ -138,7 +138,10 @@ struct arp_enc {
     Ws ws[MAX_PARTS];
     int n_parts = 2;          // arp_enc_set_streams / ARP_ENC_STREAMS
     int min_part_frames = 24; // a part of fewer frames does not fill the chip's GEMM grid (24 x 257 rows = 24 row tiles x 3..12 column tiles)
-    int first_part = 0;       // frames of part 0 when two parts are cut unevenly (0: equal parts; ARP_ENC_SPLIT)
+    // frames of part 0 of two (ARP_ENC_SPLIT); 0 = the default cut, 15/32 of the frames (60 + 68 of the step's 128); < 0 = equal parts.  Uneven parts end at different
+    // times, so that one part's GEMM grid tails and LayerNorms keep meeting the other's full rounds instead of its tails: 9.05-9.08 against 9.19-9.26 ms per 32-sample step
+    // (three boxes, three repetitions each: profiles/r6_n1_streams.txt, r6_plans_time.txt, r6_n1_split_final.txt); 56 + 72 the same, 43 + 43 + 42 slower
+    int first_part = 0;
     hipEvent_t ev_fork = nullptr;
     bool shared_chip = false; // the pass being enqueued runs beside another part's kernels (tower.h: out_proj's kernel choice)
     DevBuf img_in, out;
@@ -472,6 +475,7 @@ int enc_forward_on(arp_enc* c, hipStream_t stream, const float* images_dev, int 
         cut[0] = 0;
         for (int i = 1; i <= parts; ++i) cut[i] = (int)((long long)nb * i / parts);
         if (parts == 2 && c->first_part > 0 && c->first_part < nb) cut[1] = c->first_part;
+        else if (parts == 2 && c->first_part == 0 && nb >= 32) cut[1] = (int)(((long long)nb * 15 + 16) / 32);
         if (!c->ev_fork) ARP_HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int i = 1; i < parts; ++i) {
             if (!c->ws[i].stream) ARP_HIP_OK(hipStreamCreateWithFlags(&c->ws[i].stream, hipStreamNonBlocking));
@@ -527,7 +531,7 @@ int arp_enc_create(const arp_enc_cfg* cfg, arp_enc** out) {
     }
     if (const char* e = getenv("ARP_F16C_VPERM")) c->vperm = atoi(e) != 0;
     if (const char* e = getenv("ARP_ENC_STREAMS")) c->n_parts = std::max(1, std::min(atoi(e), (int)arp_enc::MAX_PARTS));
-    if (const char* e = getenv("ARP_ENC_SPLIT")) c->first_part = std::max(0, atoi(e));
+    if (const char* e = getenv("ARP_ENC_SPLIT")) c->first_part = std::max(-1, atoi(e));
     if (const char* e = getenv("ARP_ENC_MIN_PART")) c->min_part_frames = std::max(1, atoi(e));
     // fc1's plan-0 instance has no e2m1 side output, which fc2's correction K-tiles read: such a plan would run on stale operand segments
     if (c->plan[2] == 0 && c->plan[3] >= 1) {
@@ -682,10 +686,10 @@ int arp_enc_forward(arp_enc* c, const float* images, int n, float* out) {
     return 0;
 }
 
-// Part streams of a call (see arp_enc::Ws).  n_streams 1 = everything on the caller's stream (rounds 1-5); first_part_frames > 0 cuts two parts unevenly;
+// Part streams of a call (see arp_enc::Ws).  n_streams 1 = everything on the caller's stream (rounds 1-5); first_part_frames > 0: that many frames in part 0 of two, 0: the default cut (15/32), < 0: equal parts;
 // min_part_frames <= 0 keeps the default (a part of fewer frames runs with fewer parts).  Takes effect from the next call.
 int arp_enc_set_streams(arp_enc* c, int n_streams, int first_part_frames, int min_part_frames) {
-    if (!c || n_streams < 1 || n_streams > arp_enc::MAX_PARTS || first_part_frames < 0) return fail("n_streams must be 1..4");
+    if (!c || n_streams < 1 || n_streams > arp_enc::MAX_PARTS) return fail("n_streams must be 1..4");
     c->n_parts = n_streams;
     c->first_part = first_part_frames;
     if (min_part_frames > 0) c->min_part_frames = min_part_frames;

@@ -369,8 +369,8 @@ int arp_enc_finalize_weights(arp_enc* h);
 int arp_enc_forward(arp_enc* h, const float* images_host, int n, float* out_host);
 /* Part streams (round 6): a call's frames are encoded as `n_streams` contiguous parts (1..4, default 2), part 0 on the caller's stream and the others on
  * streams of their own, so that one part's memory-bound kernels and GEMM grid tails run beside another part's GEMMs -- as arp_clip_cfg.n_streams does
- * for the labelling pass.  first_part_frames > 0 cuts two parts unevenly; a part of fewer than min_part_frames frames (<= 0: keep the default, 24)
- * is not cut off.  Encodings are bit-identical for every setting. */
+ * for the labelling pass.  first_part_frames > 0: that many frames in part 0 of two; 0: the default cut (15/32 of the frames: parts that end at different times
+ * fill each other's grid tails better, -1.5 % per step); < 0: equal parts.  A part of fewer than min_part_frames frames (<= 0: keep the default, 24) is not cut off.  Encodings are bit-identical for every setting. */
 int arp_enc_set_streams(arp_enc* h, int n_streams, int first_part_frames, int min_part_frames);
 int arp_enc_profile_enable(arp_enc* h, int on);
 int arp_enc_profile_json(arp_enc* h, char* buf, int buf_len);
