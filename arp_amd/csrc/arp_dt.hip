@@ -145,7 +145,7 @@ struct arp_dt {
     bool ac_h1_inplace = true;  // the backward reads H1 out of the [hi | x4 | dx4] rows fc1 wrote (row stride 3 D / 2 halves) instead of a copy made by extract_hi_kernel
     const void* h1_ptr = nullptr;  // what the backward reads as H1 this step, and its row stride
     int h1_ld = 0;
-    DevBuf Xc, H1c, A32, W1c, W2c, wc_scal;  // operand rows [hi | x4 | dx4]; packed weights [W_hi | dW4 | W4]; wc_scal: 2 x {absmax pair (2 floats), scale pair (2 ints)}
+    DevBuf Xc, H1c, A32, W1c, W2c, wc_scal;  // operand rows [hi | x4 | dx4]; packed weights [W_hi | dW4 | W4]; wc_scal: 16 ints (sd, sw of W1 / W2 at 4, 5 / 12, 13) + 2 x 32 per-block (max |dw|, max |w|) pairs
     ncclComm_t comm = nullptr;
     bool has_comm = false;
     // data-parallel step: gradient all-reduce in two buckets on a communication stream, bucket 1 (image_text_input's kernel, 94 % of
@@ -436,14 +436,10 @@ template <typename T> int refresh_shadows(arp_dt* c) {
     if constexpr (__is_same(T, f16_t)) {
         if (k.use_adapter && c->adapter_c) {  // [W_hi | dW4 | W4] of the adapter's two kernels from the f32 parameters, scales chosen on the device
             ARP_TRY(c->W1c.ensure((size_t)D * 3 * D + 512)); ARP_TRY(c->W2c.ensure((size_t)D * 3 * D + 512));
-            {
-                const void* before = c->wc_scal.p;
-                ARP_TRY(c->wc_scal.ensure(64));
-                if (c->wc_scal.p != before) ARP_HIP_OK(hipMemsetAsync(c->wc_scal.p, 0, 64, c->stream));  // once: the pack launch leaves the accumulators at zero (dtops.h)
-            }
+            ARP_TRY(c->wc_scal.ensure(1024));  // 16 ints of scales (ints 4, 5 / 12, 13: sd, sw of W1 / W2) + 2 x 32 (max |dw|, max |w|) pairs
             unsigned int* mx = c->wc_scal.as<unsigned int>();
             hipLaunchKernelGGL(wc_absmax2_kernel, dim3(32, 2), dim3(256), 0, c->stream, c->p("AdapterMLP_0/Dense_0/kernel"), c->p("AdapterMLP_0/Dense_1/kernel"), (size_t)D * D, mx);
-            hipLaunchKernelGGL(wc_pack2_kernel, dim3(cdiv((size_t)D * D, 1024), 2), dim3(256), 0, c->stream, c->p("AdapterMLP_0/Dense_0/kernel"), c->p("AdapterMLP_0/Dense_1/kernel"), D, D, mx,
+            hipLaunchKernelGGL(wc_pack2_kernel, dim3(cdiv((size_t)D * D, 1024), 2), dim3(256), 0, c->stream, c->p("AdapterMLP_0/Dense_0/kernel"), c->p("AdapterMLP_0/Dense_1/kernel"), D, D, mx, 32,
                                c->W1c.as<f16_t>(), c->W2c.as<f16_t>());
             ARP_HIP_OK(hipGetLastError());
         }
@@ -1553,7 +1549,7 @@ int arp_dt_create(const arp_dt_cfg* cfg, arp_dt** out) {
 int arp_dt_destroy(arp_dt* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->cfg.device);
-    for (hipStream_t st : {c->stream, c->comm_stream, c->side_stream, c->copy_stream[0], c->copy_stream[1]})
+    for (hipStream_t st : {c->stream, c->comm_stream, c->side_stream, c->copy_stream[0], c->copy_stream[1], c->enc_stream})  // (an encode-ahead pass may still be in flight)
         if (st) (void)hipStreamSynchronize(st);
     for (auto& slot : c->graphs)
         for (auto& gr : slot)
@@ -1561,7 +1557,7 @@ int arp_dt_destroy(arp_dt* c) {
     if (c->has_comm && rccl_api()) (void)rccl_api()->CommDestroy(c->comm);
     for (hipEvent_t e : {c->ev_fork, c->ev_dapre, c->ev_side, c->ev_enc_go, c->bt[0].enc_done, c->bt[1].enc_done, c->bt[2].enc_done})
         if (e) (void)hipEventDestroy(e);
-    if (c->enc_stream) { (void)hipStreamSynchronize(c->enc_stream); (void)hipStreamDestroy(c->enc_stream); }
+    if (c->enc_stream) (void)hipStreamDestroy(c->enc_stream);
     c->part_side.release();
     for (hipEvent_t e : {c->ev_b1, c->ev_b2, c->ev_comm, c->bt[0].up, c->bt[0].use, c->bt[1].up, c->bt[1].use, c->bt[2].up, c->bt[2].use})
         if (e) (void)hipEventDestroy(e);
